@@ -1,0 +1,80 @@
+/* oracle/hobbit_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the reference's Our_PC / sumcheck hot path (see hobbit_oracle.c for
+ * the per-function reference citations).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the product path (libhobbit_hip.so) never does.
+ *
+ * Parity status: PINNED -- every function below is checked bit-exactly against the real reference
+ * (oracle/_ref/libhobbit_ref.so, built from /root/reference by oracle/Makefile) in
+ * tests/test_oracle_vs_ref.py (runs where /root/reference is present) and against the golden
+ * vectors that library produced (tests/golden/, tests/test_oracle_golden.py; runs everywhere).
+ *
+ * F = uint64_t[2] {real, img} in F_{p^2}, p = 2^61-1, i^2 = -1; hashes are uint8_t[32].
+ */
+#ifndef HOBBIT_ORACLE_H
+#define HOBBIT_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { uint64_t re, im; } oF;
+
+/* field */
+void orc_f_add(const oF *a, const oF *b, oF *o, size_t n);
+void orc_f_sub(const oF *a, const oF *b, oF *o, size_t n);
+void orc_f_mul(const oF *a, const oF *b, oF *o, size_t n);
+void orc_f_neg(const oF *a, oF *o, size_t n);
+void orc_f_inv(const oF *a, oF *o, size_t n);
+void orc_root_of_unity(int logn, oF *o);
+
+/* transcript hash */
+void orc_mimc(const oF *x, const oF *k, oF *o, size_t n);
+
+/* BLAKE3 64 B -> 32 B, Merkle-Damgard leaf, trees */
+void orc_blake3_64(const uint8_t *in, uint8_t *out, size_t n);
+void orc_hash_md(const oF *xyzw, const uint8_t *prev, uint8_t *out, size_t n);
+size_t orc_mt_commit_blake(const oF *leafs, size_t N, uint8_t *levels_out);
+size_t orc_create_tree_blake(const uint8_t *level0, size_t n, uint8_t *levels_out);
+/* levels = flat [level0 (n) | level1 (n/2) | ... | root]; returns depth = log2(n) */
+int orc_open_tree_blake(const uint8_t *levels, size_t n_leaves, size_t col, size_t row, size_t columns, uint8_t *path_out);
+
+/* libc RNG (shared glibc generator; default seed 1) */
+void orc_rng_reset(void);
+void orc_generate_randomness(int n, oF *out);
+
+/* expander graphs: drawn with libc rand()/random() in the reference's call order */
+long long orc_expander_init_store(long long n);
+long long orc_graph_dims(int dep, int kind, long long *R, int *degree);
+void orc_graph_edges(int dep, int kind, long long *nbr, oF *w);
+void orc_graph_set_weights(int dep, int kind, const oF *w);
+int orc_encode_monolithic(const oF *src, oF *dst, long long n);
+
+/* FFT / eq table / evaluation */
+void orc_fft(oF *arr, int logn, int inverse);          /* fresh twiddles (fft(vector&), utils.cpp:467) */
+void orc_fft_cached(oF *arr, int logn, int inverse);   /* _fft with the length-keyed twiddle cache (utils.cpp:605) */
+void orc_fft_cache_reset(void);
+void orc_precompute_beta(const oF *r, int k, oF *out);
+void orc_evaluate_vector(const oF *v, size_t n, const oF *r, int k, oF *out);
+
+/* tensor code + Our_PC commit */
+void orc_compute_tensorcode(const oF *msg, size_t M, int trs, int lin, oF *out);
+size_t orc_commit_standard(const oF *poly, size_t N, int K, int trs, int lin, uint8_t *levels_out, oF *tensor_out);
+void orc_aggregate(const oF *poly, size_t N, const oF *beta, int K, oF *aggr_out);
+
+/* sumchecks */
+void orc_sumcheck2(const oF *v1, const oF *v2, size_t n, const oF *prev_r, oF *qpoly, oF *r, oF *vr, oF *fin);
+void orc_sumcheck3(const oF *v1, const oF *v2, const oF *v3, size_t n, const oF *prev_r, oF *cpoly, oF *r, oF *vr, oF *fin);
+
+/* Elastic_PC streaming commit on the synthetic "test" stream */
+void orc_read_stream_pc(size_t B, oF *out);
+size_t orc_elastic_commit(size_t N, size_t B, int opt, uint8_t *levels_out);
+
+/* cpu_baseline helper: generate test_PC's inputs and time commit_standard (seconds) */
+double orc_time_commit_standard(size_t N, int K);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

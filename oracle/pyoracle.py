@@ -1,0 +1,313 @@
+"""oracle/pyoracle.py -- TEST INFRASTRUCTURE ONLY.
+
+ctypes/numpy front-ends for
+  * ``Oracle``  : oracle/libhobbit_oracle.so, our plain-C restatement (hobbit_oracle.c), and
+  * ``Ref``     : oracle/_ref/libhobbit_ref.so, the REAL reference compiled from /root/reference
+                  (present only where `make -C oracle ref` has run; travels to the GPU box as a
+                  prebuilt file).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+Field arrays are numpy uint64 of shape (..., 2) = (real, img); hashes are uint8 (..., 32).
+"""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "libhobbit_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libhobbit_ref.so")
+P = (1 << 61) - 1
+
+c_sz = ctypes.c_size_t
+c_vp = ctypes.c_void_p
+
+
+def _p(a):
+    return a.ctypes.data_as(c_vp)
+
+
+def F(a):
+    """contiguous uint64 (...,2) array"""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    assert a.shape[-1] == 2
+    return a
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
+
+
+def build_ref():
+    subprocess.check_call(["make", "-s", "-j8", "-C", HERE, "ref"])
+
+
+def ref_available():
+    return os.path.exists(REF_SO)
+
+
+def _dlopen_lazy(path):
+    # ctypes.CDLL always adds RTLD_NOW; the reference library keeps SHA3_256 (lib/libXKCP.a, a
+    # prebuilt binary we do not link) unresolved, so bind lazily through dlopen itself.
+    libdl = ctypes.CDLL(None)
+    libdl.dlopen.restype = c_vp
+    libdl.dlopen.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    h = libdl.dlopen(path.encode(), os.RTLD_LAZY | os.RTLD_LOCAL)
+    if not h:
+        raise OSError("dlopen failed: " + path)
+    return ctypes.CDLL(path, handle=h)
+
+
+class _Base:
+    """Common numpy wrappers; subclasses provide self.lib and self.pfx."""
+
+    def fn(self, name):
+        return getattr(self.lib, self.pfx + name)
+
+    # ---- field
+    def _bin(self, name, a, b):
+        a, b = F(a), F(b)
+        o = np.empty_like(a)
+        self.fn(name)(_p(a), _p(b), _p(o), c_sz(a.size // 2))
+        return o
+
+    def f_add(self, a, b): return self._bin("f_add", a, b)
+    def f_sub(self, a, b): return self._bin("f_sub", a, b)
+    def f_mul(self, a, b): return self._bin("f_mul", a, b)
+
+    def _un(self, name, a):
+        a = F(a)
+        o = np.empty_like(a)
+        self.fn(name)(_p(a), _p(o), c_sz(a.size // 2))
+        return o
+
+    def f_neg(self, a): return self._un("f_neg", a)
+    def f_inv(self, a): return self._un("f_inv", a)
+
+    def root_of_unity(self, logn):
+        o = np.zeros(2, np.uint64)
+        self.fn("root_of_unity")(ctypes.c_int(logn), _p(o))
+        return o
+
+    def mimc(self, x, k): return self._bin("mimc", x, k)
+
+    # ---- hashes
+    def blake3_64(self, blocks):
+        b = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(-1, 64)
+        o = np.empty((b.shape[0], 32), np.uint8)
+        self.fn("blake3_64")(_p(b), _p(o), c_sz(b.shape[0]))
+        return o
+
+    def hash_md(self, xyzw, prev):
+        x = F(xyzw).reshape(-1, 4, 2)
+        pv = np.ascontiguousarray(prev, dtype=np.uint8).reshape(-1, 32)
+        o = np.empty_like(pv)
+        self.fn("hash_md")(_p(x), _p(pv), _p(o), c_sz(x.shape[0]))
+        return o
+
+    def mt_commit_blake(self, leafs):
+        x = F(leafs).reshape(-1, 2)
+        n = x.shape[0]
+        o = np.zeros((2 * (n // 4), 32), np.uint8)
+        f = self.fn("mt_commit_blake"); f.restype = c_sz
+        cnt = f(_p(x), (c_sz if self.pfx == "orc_" else ctypes.c_int)(n), _p(o))
+        return o[:cnt]
+
+    def create_tree_blake(self, level0):
+        l0 = np.ascontiguousarray(level0, dtype=np.uint8).reshape(-1, 32)
+        n = l0.shape[0]
+        o = np.zeros((2 * n, 32), np.uint8)
+        f = self.fn("create_tree_blake"); f.restype = c_sz
+        cnt = f(_p(l0), (c_sz if self.pfx == "orc_" else ctypes.c_int)(n), _p(o))
+        return o[:cnt]
+
+    # ---- rng / graphs / encode
+    def rng_reset(self): self.fn("rng_reset")()
+
+    def generate_randomness(self, n):
+        o = np.zeros((n, 2), np.uint64)
+        self.fn("generate_randomness")(ctypes.c_int(n), _p(o))
+        return o
+
+    def expander_init_store(self, n):
+        f = self.fn("expander_init_store"); f.restype = ctypes.c_longlong
+        return f(ctypes.c_longlong(n))
+
+    def graph(self, dep, kind):
+        R = ctypes.c_longlong(); d = ctypes.c_int()
+        f = self.fn("graph_dims"); f.restype = ctypes.c_longlong
+        L = f(ctypes.c_int(dep), ctypes.c_int(kind), ctypes.byref(R), ctypes.byref(d))
+        nbr = np.zeros(L * d.value, np.int64); w = np.zeros((L * d.value, 2), np.uint64)
+        self.fn("graph_edges")(ctypes.c_int(dep), ctypes.c_int(kind), _p(nbr), _p(w))
+        return dict(L=L, R=R.value, degree=d.value, nbr=nbr, w=w)
+
+    def graph_set_weights(self, dep, kind, w):
+        w = F(w)
+        self.fn("graph_set_weights")(ctypes.c_int(dep), ctypes.c_int(kind), _p(w))
+
+    def encode_monolithic(self, src):
+        s = F(src).reshape(-1, 2)
+        n = s.shape[0]
+        d = np.zeros((2 * n, 2), np.uint64)
+        f = self.fn("encode_monolithic"); f.restype = ctypes.c_int
+        ln = f(_p(s), _p(d), ctypes.c_longlong(n))
+        return d, ln
+
+    # ---- fft & friends
+    def precompute_beta(self, r):
+        r = F(r).reshape(-1, 2)
+        k = r.shape[0]
+        o = np.zeros((1 << k, 2), np.uint64)
+        self.fn("precompute_beta")(_p(r), ctypes.c_int(k), _p(o))
+        return o
+
+    def evaluate_vector(self, v, r):
+        v = F(v).reshape(-1, 2); r = F(r).reshape(-1, 2)
+        o = np.zeros(2, np.uint64)
+        self.fn("evaluate_vector")(_p(v), c_sz(v.shape[0]), _p(r), ctypes.c_int(r.shape[0]), _p(o))
+        return o
+
+    def compute_tensorcode(self, msg, trs, lin):
+        m = F(msg).reshape(-1, 2)
+        M = m.shape[0]
+        o = np.zeros((2 * trs, 2 * M // trs, 2), np.uint64)
+        self.fn("compute_tensorcode")(_p(m), c_sz(M), ctypes.c_int(trs), ctypes.c_int(lin), _p(o))
+        return o
+
+    # ---- sumchecks
+    def sumcheck2(self, v1, v2, prev_r):
+        v1 = F(v1).reshape(-1, 2); v2 = F(v2).reshape(-1, 2); pr = F(prev_r).reshape(2)
+        n = v1.shape[0]; rounds = n.bit_length() - 1
+        q = np.zeros((rounds, 3, 2), np.uint64); r = np.zeros((rounds, 2), np.uint64)
+        vr = np.zeros((2, 2), np.uint64); fin = np.zeros(2, np.uint64)
+        self.fn("sumcheck2")(_p(v1), _p(v2), c_sz(n), _p(pr), _p(q), _p(r), _p(vr), _p(fin))
+        return dict(poly=q, r=r, vr=vr, fin=fin)
+
+    def sumcheck3(self, v1, v2, v3, prev_r):
+        v1 = F(v1).reshape(-1, 2); v2 = F(v2).reshape(-1, 2); v3 = F(v3).reshape(-1, 2); pr = F(prev_r).reshape(2)
+        n = v1.shape[0]; rounds = n.bit_length() - 1
+        q = np.zeros((rounds, 4, 2), np.uint64); r = np.zeros((rounds, 2), np.uint64)
+        vr = np.zeros((3, 2), np.uint64); fin = np.zeros(2, np.uint64)
+        self.fn("sumcheck3")(_p(v1), _p(v2), _p(v3), c_sz(n), _p(pr), _p(q), _p(r), _p(vr), _p(fin))
+        return dict(poly=q, r=r, vr=vr, fin=fin)
+
+    def elastic_commit(self, N, B, opt):
+        o = np.zeros((8 * B, 32), np.uint8)
+        f = self.fn("elastic_commit"); f.restype = c_sz
+        cnt = f(c_sz(N), c_sz(B), ctypes.c_int(opt), _p(o))
+        return o[:cnt]
+
+
+class Oracle(_Base):
+    pfx = "orc_"
+
+    def __init__(self, build=True):
+        if build and not os.path.exists(ORACLE_SO):
+            build_oracle()
+        self.lib = ctypes.CDLL(ORACLE_SO)
+
+    def fft(self, arr, inverse=False, cached=False):
+        a = F(arr).reshape(-1, 2).copy()
+        logn = a.shape[0].bit_length() - 1
+        self.fn("fft_cached" if cached else "fft")(_p(a), ctypes.c_int(logn), ctypes.c_int(int(inverse)))
+        return a
+
+    def fft_cache_reset(self): self.lib.orc_fft_cache_reset()
+
+    def commit_standard(self, poly, K, trs, lin, want_tensor=False):
+        p = F(poly).reshape(-1, 2)
+        N = p.shape[0]; M = N // K
+        lv = np.zeros((2 * M, 32), np.uint8)
+        t = np.zeros((K, 2 * trs, 2 * M // trs, 2), np.uint64) if want_tensor else None
+        f = self.lib.orc_commit_standard; f.restype = c_sz
+        cnt = f(_p(p), c_sz(N), ctypes.c_int(K), ctypes.c_int(trs), ctypes.c_int(lin), _p(lv), _p(t) if want_tensor else None)
+        return lv[:cnt], t
+
+    def open_tree_blake(self, levels, n_leaves, col, row, columns):
+        lv = np.ascontiguousarray(levels, dtype=np.uint8)
+        path = np.zeros((64, 32), np.uint8)
+        f = self.lib.orc_open_tree_blake; f.restype = ctypes.c_int
+        d = f(_p(lv), c_sz(n_leaves), c_sz(col), c_sz(row), c_sz(columns), _p(path))
+        return path[:d]
+
+    def aggregate(self, poly, beta):
+        p = F(poly).reshape(-1, 2); b = F(beta).reshape(-1, 2)
+        K = b.shape[0]
+        o = np.zeros((p.shape[0] // K, 2), np.uint64)
+        self.lib.orc_aggregate(_p(p), c_sz(p.shape[0]), _p(b), ctypes.c_int(K), _p(o))
+        return o
+
+    def read_stream_pc(self, B):
+        o = np.zeros((B, 2), np.uint64)
+        self.lib.orc_read_stream_pc(c_sz(B), _p(o))
+        return o
+
+    def time_commit_standard(self, N, K):
+        f = self.lib.orc_time_commit_standard; f.restype = ctypes.c_double
+        return f(c_sz(N), ctypes.c_int(K))
+
+
+class Ref(_Base):
+    pfx = "ref_"
+
+    def __init__(self):
+        self.lib = _dlopen_lazy(REF_SO)
+        self.lib.ref_init()
+
+    def fft(self, arr, inverse=False, cached=False):
+        a = F(arr).reshape(-1, 2).copy()
+        logn = a.shape[0].bit_length() - 1
+        self.fn("fft_raw" if cached else "fft_vec")(_p(a), ctypes.c_int(logn), ctypes.c_int(int(inverse)))
+        return a
+
+    def encode_reset_scratch(self): self.lib.ref_encode_reset_scratch()
+
+    def commit_standard(self, poly, K, trs, lin, want_tensor=False):
+        p = F(poly).reshape(-1, 2)
+        N = p.shape[0]; M = N // K
+        lv = np.zeros((2 * M, 32), np.uint8)
+        f = self.lib.ref_commit_standard; f.restype = c_sz
+        cnt = f(_p(p), c_sz(N), ctypes.c_int(K), ctypes.c_int(trs), ctypes.c_int(lin), _p(lv))
+        t = None
+        if want_tensor:
+            t = np.zeros((K, 2 * trs, 2 * M // trs, 2), np.uint64)
+            for i in range(K):
+                for r in range(2 * trs):
+                    self.lib.ref_tensor_row(ctypes.c_int(i), ctypes.c_int(r), _p(t[i, r]))
+        return lv[:cnt], t
+
+    def open_tree_blake(self, col, row, columns):
+        path = np.zeros((64, 32), np.uint8)
+        f = self.lib.ref_open_tree_blake; f.restype = ctypes.c_int
+        d = f(c_sz(col), c_sz(row), ctypes.c_int(columns), _p(path))
+        return path[:d]
+
+    def release_commit(self): self.lib.ref_release_commit()
+
+    def aggregate(self, poly, beta, trs=16, lin=0):
+        p = F(poly).reshape(-1, 2); b = F(beta).reshape(-1, 2)
+        K = b.shape[0]
+        o = np.zeros((p.shape[0] // K, 2), np.uint64)
+        self.lib.ref_aggregate(_p(p), c_sz(p.shape[0]), _p(b), ctypes.c_int(K), ctypes.c_int(trs), ctypes.c_int(lin), _p(o))
+        return o
+
+    def read_stream_pc(self, N, B, chunk_idx=0):
+        o = np.zeros((B, 2), np.uint64)
+        self.lib.ref_read_stream_pc(c_sz(N), c_sz(B), c_sz(chunk_idx), _p(o))
+        return o
+
+    def time_commit_standard(self, N, K):
+        f = self.lib.ref_time_commit_standard; f.restype = ctypes.c_double
+        return f(c_sz(N), ctypes.c_int(K))
+
+
+# ---- deterministic full-range test data (splitmix64, reduced mod p per limb) ------------------
+def splitmix_field(n, seed):
+    """n full-range F_{p^2} elements, SURVEY 8(d) C2 input generator (splitmix64 mod p)."""
+    idx = np.arange(1, 2 * n + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) * np.uint64(0x632BE59BD9B4E019) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z % np.uint64(P)).reshape(n, 2)

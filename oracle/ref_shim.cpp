@@ -1,0 +1,241 @@
+// oracle/ref_shim.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// extern "C" entry points over the REAL reference implementation (compiled from /root/reference
+// by oracle/Makefile `make ref` into oracle/_ref/libhobbit_ref.so).  Nothing here restates an
+// algorithm: every function only marshals plain buffers into the std::vector / F** arguments the
+// reference functions take and copies their results out.  Used (a) to generate the committed
+// golden vectors under tests/golden/ (oracle/gen_golden.py), (b) to cross-check the C
+// restatement in oracle/hobbit_oracle.c while /root/reference is present, and (c) as the
+// "reference" CPU baseline timed by bench.py.
+//
+// F buffers are uint64_t[2] = {real, img}, exactly virgo::fieldElement (src/fieldElement.hpp:96-97).
+// Hashes are uint8_t[32] = struct _hash (src/Blake3_hash.h:3-5).
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "config_pc.hpp"
+#include "mimc.h"
+#include "utils.hpp"
+#include "merkle_tree.h"
+#include "sumcheck.h"
+#include "PC_utils.h"
+#include "Our_PC.hpp"
+#include "Elastic_PC.hpp"
+#include "Virgo.h"
+#include "linear_code_encode.h"
+
+extern bool linear_time;                     // src/Our_PC.cpp:21
+extern int tensor_row_size;                  // src/main.cpp:31
+extern shockwave_data *C_f, *C_c;            // src/PC_utils.cpp:6-7
+void _aggregate(vector<F> &poly, vector<F> beta1, vector<F> random_points, vector<F> &aggregated_vector,
+                vector<vector<F>> &aggregated_tensor, bool linear_time, int K);   // src/Our_PC.cpp:258
+void _compute_aggregation_reply(vector<vector<size_t>> &I, vector<vector<F>> &reply,
+                                vector<vector<vector<F>>> &_tensor, int K);        // src/Our_PC.cpp:291
+
+static_assert(sizeof(F) == 16, "fieldElement must be 16 bytes");
+static_assert(sizeof(_hash) == 32, "_hash must be 32 bytes");
+
+static inline F ldF(const uint64_t *p) { F f; f.real = p[0]; f.img = p[1]; return f; }
+static inline void stF(uint64_t *p, const F &f) { p[0] = f.real; p[1] = f.img; }
+static vector<F> vecF(const uint64_t *p, size_t n) { vector<F> v(n); if (n) memcpy((void *)v.data(), p, 16 * n); return v; }
+
+// state kept between calls (one commitment at a time)
+static vector<vector<_hash>> g_MT;
+static vector<vector<vector<F>>> g_tensor;
+
+extern "C" {
+
+void ref_init(void) { init_hash(); }
+// glibc: rand() and random() share one generator whose default seed is 1 -> fresh-process state.
+void ref_rng_reset(void) { srandom(1); }
+void ref_rng_seed(unsigned s) { srandom(s); }
+long ref_libc_rand(void) { return rand(); }
+long ref_libc_random(void) { return random(); }
+
+// ---- field (src/fieldElement.cpp:34-96, 206-209) --------------------------------------------
+void ref_f_add(const uint64_t *a, const uint64_t *b, uint64_t *o, size_t n) { for (size_t i = 0; i < n; i++) stF(o + 2 * i, ldF(a + 2 * i) + ldF(b + 2 * i)); }
+void ref_f_sub(const uint64_t *a, const uint64_t *b, uint64_t *o, size_t n) { for (size_t i = 0; i < n; i++) stF(o + 2 * i, ldF(a + 2 * i) - ldF(b + 2 * i)); }
+void ref_f_mul(const uint64_t *a, const uint64_t *b, uint64_t *o, size_t n) { for (size_t i = 0; i < n; i++) stF(o + 2 * i, ldF(a + 2 * i) * ldF(b + 2 * i)); }
+void ref_f_neg(const uint64_t *a, uint64_t *o, size_t n) { for (size_t i = 0; i < n; i++) stF(o + 2 * i, -ldF(a + 2 * i)); }
+void ref_f_inv(const uint64_t *a, uint64_t *o, size_t n) { for (size_t i = 0; i < n; i++) stF(o + 2 * i, ldF(a + 2 * i).inv()); }
+void ref_root_of_unity(int logn, uint64_t *o) { stF(o, getRootOfUnity(logn)); }
+
+// ---- mimc (src/mimc.cpp:95-107) ---------------------------------------------------------------
+void ref_mimc(const uint64_t *x, const uint64_t *k, uint64_t *o, size_t n) { for (size_t i = 0; i < n; i++) stF(o + 2 * i, mimc_hash(ldF(x + 2 * i), ldF(k + 2 * i))); }
+
+// ---- BLAKE3 / Merkle (src/Blake3_hash.cpp:5-10, src/merkle_tree.cpp:62-87,193-221,255-287,308-324)
+void ref_blake3_64(const uint8_t *in, uint8_t *out, size_t n) { for (size_t i = 0; i < n; i++) blake3_hash((uint8_t *)in + 64 * i, out + 32 * i); }
+void ref_hash_md(const uint64_t *xyzw, const uint8_t *prev, uint8_t *out, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        _hash p; memcpy(p.arr, prev + 32 * i, 32);
+        _hash r = merkle_tree::hash_double_field_element_merkle_damgard_blake(ldF(xyzw + 8 * i), ldF(xyzw + 8 * i + 2), ldF(xyzw + 8 * i + 4), ldF(xyzw + 8 * i + 6), p);
+        memcpy(out + 32 * i, r.arr, 32);
+    }
+}
+static size_t flatten_levels(const vector<vector<_hash>> &h, uint8_t *out) {
+    size_t off = 0;
+    for (auto &lv : h) { memcpy(out + 32 * off, lv.data(), 32 * lv.size()); off += lv.size(); }
+    return off;
+}
+// leaves N/4 then levels; out must hold (2*(N/4)-1)*32 bytes. returns number of hashes written.
+size_t ref_mt_commit_blake(const uint64_t *leafs, int N, uint8_t *out) {
+    vector<F> v = vecF(leafs, N);
+    vector<vector<_hash>> h;
+    merkle_tree::merkle_tree_prover::MT_commit_Blake(v.data(), h, N);
+    return flatten_levels(h, out);
+}
+size_t ref_create_tree_blake(const uint8_t *level0, int n, uint8_t *out) {
+    vector<vector<_hash>> h((int)log2(n) + 1);
+    h[0].resize(n); memcpy(h[0].data(), level0, 32 * (size_t)n);
+    merkle_tree::merkle_tree_prover::create_tree_blake(n, h, 32, true);
+    return flatten_levels(h, out);
+}
+
+// ---- expander graphs + encode (src/expanders.h:20-47,78-92; src/linear_code_encode.h:62-119) ---
+long long ref_expander_init_store(long long n) { return expander_init_store(n); }
+// kind 0 = _C[dep], 1 = D[dep]; returns L, fills R,degree
+long long ref_graph_dims(int dep, int kind, long long *R, int *degree) {
+    graph &g = kind ? D[dep] : _C[dep];
+    *R = g.R; *degree = g.degree; return g.L;
+}
+void ref_graph_edges(int dep, int kind, long long *nbr, uint64_t *w) {
+    graph &g = kind ? D[dep] : _C[dep];
+    for (long long i = 0; i < g.L; i++)
+        for (int j = 0; j < g.degree; j++) { nbr[i * g.degree + j] = g.neighbor[i][j]; stF(w + 2 * (i * g.degree + j), g.weight[i][j]); }
+}
+// overwrite the stored weights of one level (used to test full-range F_{p^2} weights)
+void ref_graph_set_weights(int dep, int kind, const uint64_t *w) {
+    graph &g = kind ? D[dep] : _C[dep];
+    for (auto &rw : g.r_weight) rw.clear();
+    for (auto &rn : g.r_neighbor) rn.clear();
+    for (long long i = 0; i < g.L; i++)
+        for (int j = 0; j < g.degree; j++) {
+            g.weight[i][j] = ldF(w + 2 * (i * g.degree + j));
+            g.r_neighbor[g.neighbor[i][j]].push_back(i);
+            g.r_weight[g.neighbor[i][j]].push_back(g.weight[i][j]);
+        }
+}
+// dst must hold 2n F (zero-initialised by us, as the callers' vector<F>(2n, 0) is)
+int ref_encode_monolithic(const uint64_t *src, uint64_t *dst, long long n) {
+    vector<F> s = vecF(src, n), d(2 * n, F(0));
+    int len = encode_monolithic(s.data(), d.data(), n);
+    memcpy(dst, d.data(), 32 * n);
+    return len;
+}
+// the reference allocates its global scratch on first use only (linear_code_encode.h:64-72):
+// re-arm it when a larger n follows a smaller one.
+void ref_encode_reset_scratch(void) { __encode_initialized = false; }
+
+// ---- FFT / eq-table / evaluation (src/utils.cpp:605-673, 467-527, 251-296, 789-802, 873-883) ---
+void ref_fft_raw(uint64_t *arr, int logn, int inverse) { _fft((F *)arr, logn, inverse != 0); }
+void ref_fft_vec(uint64_t *arr, int logn, int inverse) {
+    vector<F> v = vecF(arr, (size_t)1 << logn); fft(v, logn, inverse != 0); memcpy(arr, v.data(), 16 * v.size());
+}
+void ref_precompute_beta(const uint64_t *r, int k, uint64_t *out) {
+    vector<F> B; precompute_beta(vecF(r, k), B); memcpy(out, B.data(), 16 * B.size());
+}
+void ref_evaluate_vector(const uint64_t *v, size_t n, const uint64_t *r, int k, uint64_t *out) { stF(out, evaluate_vector(vecF(v, n), vecF(r, k))); }
+void ref_generate_randomness(int n, uint64_t *out) { vector<F> x = generate_randomness(n); memcpy(out, x.data(), 16 * (size_t)n); }
+
+// ---- tensor code (src/PC_utils.cpp:66-123) ------------------------------------------------------
+// out: row-major (2*trs) x (2*M/trs)
+void ref_compute_tensorcode(const uint64_t *msg, size_t M, int trs, int lin, uint64_t *out) {
+    tensor_row_size = trs; linear_time = lin != 0;
+    vector<F> m = vecF(msg, M); vector<vector<F>> t;
+    compute_tensorcode(m, t);
+    size_t cols = t[0].size();
+    for (size_t i = 0; i < t.size(); i++) memcpy(out + 2 * i * cols, t[i].data(), 16 * cols);
+}
+
+// ---- Our_PC commit (src/Our_PC.cpp:146-171) -----------------------------------------------------
+// levels_out: (2*M-1)*32 bytes (level 0 = M leaves, ... root). tensor kept for ref_tensor_get.
+size_t ref_commit_standard(const uint64_t *poly, size_t N, int K, int trs, int lin, uint8_t *levels_out) {
+    tensor_row_size = trs; linear_time = lin != 0;
+    vector<F> p = vecF(poly, N);
+    _hash comm; g_MT.clear(); g_tensor.clear();
+    commit_standard(p, comm, g_MT, g_tensor, K);
+    return flatten_levels(g_MT, levels_out);
+}
+void ref_tensor_get(int chunk, const uint32_t *rows, const uint32_t *cols, size_t nq, uint64_t *out) {
+    for (size_t q = 0; q < nq; q++) stF(out + 2 * q, g_tensor[chunk][rows[q]][cols[q]]);
+}
+void ref_tensor_row(int chunk, int row, uint64_t *out) { memcpy(out, g_tensor[chunk][row].data(), 16 * g_tensor[chunk][row].size()); }
+// path for query (col=c0,row=c1) (src/merkle_tree.cpp:308-324); returns depth
+int ref_open_tree_blake(size_t c0, size_t c1, int columns, uint8_t *path_out) {
+    vector<size_t> c = {c0, c1};
+    vector<_hash> p = merkle_tree::merkle_tree_prover::open_tree_blake(g_MT, c, columns);
+    memcpy(path_out, p.data(), 32 * p.size());
+    return (int)p.size();
+}
+void ref_compute_aggregation_reply(const uint64_t *I, size_t nq, int K, uint64_t *reply) {
+    extern int aggregation_queries; aggregation_queries = (int)nq;
+    vector<vector<size_t>> II(nq); for (size_t q = 0; q < nq; q++) { II[q] = {(size_t)I[2 * q], (size_t)I[2 * q + 1]}; }
+    vector<vector<F>> r; _compute_aggregation_reply(II, r, g_tensor, K);
+    for (size_t q = 0; q < nq; q++) memcpy(reply + 2 * q * K, r[q].data(), 16 * (size_t)K);
+}
+void ref_release_commit(void) { g_MT.clear(); g_MT.shrink_to_fit(); g_tensor.clear(); g_tensor.shrink_to_fit(); }
+
+// aggregation axpy only (src/Our_PC.cpp:258-272): aggr[j] = sum_i beta[i]*poly[i*M+j].
+// The reference function continues into shockwave_commit; we call the real function and free
+// what it allocates.
+void ref_aggregate(const uint64_t *poly, size_t N, const uint64_t *beta, int K, int trs, int lin, uint64_t *aggr_out) {
+    tensor_row_size = trs; linear_time = lin != 0;
+    vector<F> p = vecF(poly, N), b = vecF(beta, K), rv(K, F(1)), aggr; vector<vector<F>> at;
+    _aggregate(p, b, rv, aggr, at, linear_time, K);
+    memcpy(aggr_out, aggr.data(), 16 * aggr.size());
+    delete C_f; C_f = nullptr;
+    if (linear_time) { delete C_c; C_c = nullptr; }
+}
+
+// ---- sumchecks (src/sumcheck.cpp:2391-2460, 1974-2058) ------------------------------------------
+// qpoly: rounds*3 F (a,b,c); r: rounds F; vr: 2 F; fin: 1 F
+void ref_sumcheck2(const uint64_t *v1, const uint64_t *v2, size_t n, const uint64_t *prev_r, uint64_t *qpoly, uint64_t *r, uint64_t *vr, uint64_t *fin) {
+    vector<F> a = vecF(v1, n), b = vecF(v2, n); double vt = 0, ps = 0;
+    proof P = generate_2product_sumcheck_proof(a, b, ldF(prev_r), vt, ps);
+    for (size_t i = 0; i < P.q_poly.size(); i++) { stF(qpoly + 6 * i, P.q_poly[i].a); stF(qpoly + 6 * i + 2, P.q_poly[i].b); stF(qpoly + 6 * i + 4, P.q_poly[i].c); }
+    for (size_t i = 0; i < P.randomness[0].size(); i++) stF(r + 2 * i, P.randomness[0][i]);
+    stF(vr, P.vr[0]); stF(vr + 2, P.vr[1]); stF(fin, P.final_rand);
+}
+// cpoly: rounds*4 F (a,b,c,d); vr: 3 F. Inputs are destroyed in place by the reference; we copy.
+void ref_sumcheck3(const uint64_t *v1, const uint64_t *v2, const uint64_t *v3, size_t n, const uint64_t *prev_r, uint64_t *cpoly, uint64_t *r, uint64_t *vr, uint64_t *fin) {
+    vector<F> a = vecF(v1, n), b = vecF(v2, n), c = vecF(v3, n); double vt = 0, ps = 0;
+    proof P = _generate_3product_sumcheck_proof(a, b, c, ldF(prev_r), vt, ps);
+    for (size_t i = 0; i < P.c_poly.size(); i++) { stF(cpoly + 8 * i, P.c_poly[i].a); stF(cpoly + 8 * i + 2, P.c_poly[i].b); stF(cpoly + 8 * i + 4, P.c_poly[i].c); stF(cpoly + 8 * i + 6, P.c_poly[i].d); }
+    for (size_t i = 0; i < P.randomness[0].size(); i++) stF(r + 2 * i, P.randomness[0][i]);
+    stF(vr, P.vr[0]); stF(vr + 2, P.vr[1]); stF(vr + 4, P.vr[2]); stF(fin, P.final_rand);
+}
+
+// ---- Elastic_PC streaming commit (src/Elastic_PC.cpp:174-285) on the synthetic "test" stream ----
+// opt 1: RSxRS (trs = B/2^11); opt 2: RS x expander (trs = B/2^14, graphs drawn here).
+size_t ref_elastic_commit(size_t N, size_t B, int opt, uint8_t *levels_out) {
+    BUFFER_SPACE = B;
+    if (opt == 1) { linear_time = false; tensor_row_size = (int)(B >> 11); }
+    else { linear_time = true; tensor_row_size = (int)(B >> 14); expander_init_store(tensor_row_size); }
+    stream_descriptor fd; fd.name = "test"; fd.size = N; fd.pos = 0;
+    _hash comm; vector<vector<_hash>> MT;
+    commit(fd, comm, MT);
+    return flatten_levels(MT, levels_out);
+}
+void ref_read_stream_pc(size_t N, size_t B, size_t chunk_idx, uint64_t *out) {
+    stream_descriptor fd; fd.name = "test"; fd.size = N; fd.pos = 0;
+    vector<F> buf(B);
+    for (size_t i = 0; i <= chunk_idx; i++) read_stream_PC(fd, buf.data(), (int)B);
+    memcpy(out, buf.data(), 16 * B);
+}
+
+// whole-driver timing hook for bench.py's cpu_baseline ("reference" kind): commit only.
+double ref_time_commit_standard(size_t N, int K) {
+    srandom(1);
+    vector<F> poly = generate_randomness((int)N);
+    linear_time = true; tensor_row_size = (int)(N / ((size_t)K << 11));
+    __encode_initialized = false;
+    expander_init_store(tensor_row_size);
+    vector<vector<_hash>> MT; vector<vector<vector<F>>> T; _hash comm;
+    struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+    commit_standard(poly, comm, MT, T, K);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+}
+
+}  // extern "C"

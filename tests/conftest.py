@@ -1,0 +1,32 @@
+import os
+import sys
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The plain-C CPU restatement (oracle/hobbit_oracle.c); built on demand with gcc."""
+    from oracle import pyoracle
+    pyoracle.build_oracle()
+    return pyoracle.Oracle()
+
+
+@pytest.fixture(scope="session")
+def ref():
+    """The real reference (oracle/_ref); only where it has been built (needs /root/reference)."""
+    from oracle import pyoracle
+    if not pyoracle.ref_available():
+        if os.path.isdir("/root/reference/src"):
+            pyoracle.build_ref()
+        else:
+            pytest.skip("oracle/_ref not built and /root/reference absent")
+    return pyoracle.Ref()

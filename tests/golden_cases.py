@@ -1,0 +1,243 @@
+"""Golden-vector case definitions (shared by oracle/gen_golden.py, which runs them against the
+REAL reference build oracle/_ref and writes tests/golden/*.npz, and by
+tests/test_oracle_golden.py, which runs them against the C restatement oracle/hobbit_oracle.c).
+
+Each case is ``fn(lib) -> dict[str, np.ndarray]``; ``lib`` is oracle.pyoracle.Ref or .Oracle (same
+method names).  Large outputs are stored as a SHA-256 digest plus sampled entries so that every
+fixture stays small (SURVEY.md 8c list, items 1-13).  Inputs are re-derived deterministically
+(splitmix64 full-range elements, or the libc generator from its default seed as the reference
+itself does), so fixtures hold expected OUTPUTS only.
+"""
+import hashlib
+import numpy as np
+from oracle.pyoracle import splitmix_field, P
+
+
+def dg(a):
+    """sha256 of the raw bytes -> uint8[32]"""
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8).copy()
+
+
+def samp(a, k=64, seed=5):
+    flat = np.ascontiguousarray(a).reshape(-1, a.shape[-1])
+    idx = np.random.default_rng(seed).integers(0, flat.shape[0], k)
+    return flat[idx].copy()
+
+
+EDGE = np.array([[0, 0], [1, 0], [P - 1, 0], [0, P - 1], [P - 1, P - 1], [0, 1], [1, 1], [2, P - 2]], dtype=np.uint64)
+
+
+def field_inputs(n):
+    a = splitmix_field(n, 1); b = splitmix_field(n, 2)
+    a[:8] = EDGE; b[:8] = EDGE[::-1]
+    a[8:16] = EDGE; b[8:16] = EDGE           # squares of the edge set
+    return a, b
+
+
+def case_field(lib):
+    a, b = field_inputs(1024)
+    A, B = field_inputs(4096)
+    return dict(add=lib.f_add(a, b), sub=lib.f_sub(a, b), mul=lib.f_mul(a, b), neg=lib.f_neg(a),
+                inv=lib.f_inv(a[1:65]), mul4k=dg(lib.f_mul(A, B)), add4k=dg(lib.f_add(A, B)), sub4k=dg(lib.f_sub(A, B)),
+                rou=np.stack([lib.root_of_unity(l) for l in (1, 2, 4, 12, 13, 20, 61)]))
+
+
+def case_mimc(lib):
+    a, b = field_inputs(256)
+    out = lib.mimc(a, b)
+    # 64-step chained transcript: r <- mimc(r, x_i)
+    r = np.array([[33, 0]], dtype=np.uint64); chain = []
+    for i in range(64):
+        r = lib.mimc(r, a[i:i + 1]); chain.append(r[0].copy())
+    kat = lib.mimc(np.array([[5, 7]], dtype=np.uint64), np.array([[11, 13]], dtype=np.uint64))
+    return dict(out=out, chain=np.stack(chain), kat=kat)
+
+
+def case_blake(lib):
+    blk = np.random.default_rng(0).integers(0, 256, (256, 64), dtype=np.uint8)
+    blk[0] = [(7 * i + 3) % 256 for i in range(64)]
+    a, _ = field_inputs(256)
+    prev = np.random.default_rng(1).integers(0, 256, (64, 32), dtype=np.uint8)
+    prev[:8] = 0
+    return dict(h64=lib.blake3_64(blk), md=lib.hash_md(a, prev))
+
+
+def case_merkle(lib):
+    a, _ = field_inputs(1024)
+    l0 = np.random.default_rng(2).integers(0, 256, (1024, 32), dtype=np.uint8)
+    return dict(mt4=lib.mt_commit_blake(a[:4]), mt32=lib.mt_commit_blake(a[:32]), mt1024=lib.mt_commit_blake(a),
+                tree1024=lib.create_tree_blake(l0), tree2=lib.create_tree_blake(l0[:2]), tree1=lib.create_tree_blake(l0[:1]))
+
+
+def _graph_dump(lib, n, full):
+    out = {}
+    dep, m = 0, n
+    while m > 13:
+        for kind in (0, 1):
+            g = lib.graph(dep, kind)
+            key = "n%d_d%d_k%d_" % (n, dep, kind)
+            out[key + "dims"] = np.array([g["L"], g["R"], g["degree"]], dtype=np.int64)
+            if full:
+                out[key + "nbr"] = g["nbr"]; out[key + "w"] = g["w"]
+            else:
+                out[key + "nbr_dg"] = dg(g["nbr"]); out[key + "w_dg"] = dg(g["w"])
+        m = int(0.211 * m); dep += 1
+    return out
+
+
+def case_graph_encode(lib):
+    out = {}
+    for n in (4, 13, 14, 16, 64, 100, 256, 1024, 4096):
+        lib.rng_reset()
+        out["len_%d" % n] = np.array([lib.expander_init_store(n)], dtype=np.int64)
+        out.update(_graph_dump(lib, n, full=(n <= 64)))
+        if hasattr(lib, "encode_reset_scratch"):
+            lib.encode_reset_scratch()
+        for tag, src in (("small", (splitmix_field(n, 40 + n) % np.uint64(1 << 32)) * np.array([1, 0], dtype=np.uint64)),
+                         ("full", splitmix_field(n, 41 + n))):
+            d, ln = lib.encode_monolithic(src)
+            out["enc_%s_%d_len" % (tag, n)] = np.array([ln], dtype=np.int64)
+            if n <= 256 and tag == "full":
+                out["enc_%s_%d" % (tag, n)] = d
+            else:
+                out["enc_%s_%d_dg" % (tag, n)] = dg(d)
+    # full-range F_{p^2} weights on the n=64 graph (the reference only ever draws 31-bit weights)
+    lib.rng_reset(); lib.expander_init_store(64)
+    if hasattr(lib, "encode_reset_scratch"):
+        lib.encode_reset_scratch()
+    for kind in (0, 1):
+        g = lib.graph(0, kind)
+        lib.graph_set_weights(0, kind, splitmix_field(g["L"] * g["degree"], 100 + kind))
+    d, ln = lib.encode_monolithic(splitmix_field(64, 5))
+    out["enc_fullw_64"] = d
+    return out
+
+
+def case_fft(lib):
+    out = {}
+    for logn in (1, 4, 8, 12):
+        x = splitmix_field(1 << logn, 7 + logn)
+        for inv in (0, 1):
+            y = lib.fft(x, bool(inv))
+            if logn <= 8:
+                out["fft_%d_%d" % (logn, inv)] = y
+            else:
+                out["fft_%d_%d_dg" % (logn, inv)] = dg(y); out["fft_%d_%d_s" % (logn, inv)] = samp(y)
+    # zero-padded message rows, as compute_tensorcode feeds them
+    x = splitmix_field(4096, 3); x[2048:] = 0
+    out["fft_pad_dg"] = dg(lib.fft(x, False)); out["fft_pad_s"] = samp(lib.fft(x, False))
+    for k in (1, 5, 10):
+        b = lib.precompute_beta(splitmix_field(k, 3))
+        out["beta_%d" % k] = b if k <= 5 else dg(b)
+    out["eval"] = lib.evaluate_vector(splitmix_field(1024, 4), splitmix_field(12, 5))
+    lib.rng_reset()
+    out["genrand"] = lib.generate_randomness(1000)
+    return out
+
+
+def case_tensorcode(lib):
+    out = {}
+    for (M, trs) in ((1 << 13, 4), (1 << 15, 16), (1 << 17, 64)):
+        for lin in (0, 1):
+            lib.rng_reset(); lib.expander_init_store(trs)
+            if hasattr(lib, "encode_reset_scratch"):
+                lib.encode_reset_scratch()
+            t = lib.compute_tensorcode(splitmix_field(M, 11), trs, lin)
+            key = "tc_%d_%d_%d" % (M, trs, lin)
+            out[key + "_dg"] = dg(t); out[key + "_s"] = samp(t)
+    return out
+
+
+COMMIT_CASES = ((1 << 18, 32), (1 << 20, 32), (1 << 20, 16))
+QUERIES = ((0, 0), (5, 3), (4095, -1), (100, -2), (2048, 7))   # (col,row); row<0 -> 2*trs+row, -2 -> trs
+
+
+def test_pc_inputs(lib, N, K):
+    """test_PC(N,4,K) input sequence (src/Our_PC.cpp:757-813): poly, then graphs, from a fresh RNG."""
+    trs = N // (K << 11)
+    lib.rng_reset()
+    poly = lib.generate_randomness(N)
+    lib.expander_init_store(trs)
+    if hasattr(lib, "encode_reset_scratch"):
+        lib.encode_reset_scratch()
+    return poly, trs
+
+
+def case_commit(lib):
+    out = {}
+    for (N, K) in COMMIT_CASES:
+        poly, trs = test_pc_inputs(lib, N, K)
+        M = N // K
+        lv, T = lib.commit_standard(poly, K, trs, 1, want_tensor=True)
+        key = "c_%d_%d_" % (N, K)
+        out[key + "root"] = lv[-1].copy()
+        off, sz, lvl = 0, M, 0
+        dgs = []
+        while sz >= 1:
+            dgs.append(dg(lv[off:off + sz])); off += sz; sz //= 2; lvl += 1
+        out[key + "level_dg"] = np.stack(dgs)
+        out[key + "tensor_dg"] = dg(T); out[key + "tensor_s"] = samp(T)
+        paths = []
+        for (c, rw) in QUERIES:
+            row = rw if rw >= 0 else (2 * trs - 1 if rw == -1 else trs)
+            row = min(row, 2 * trs - 1)
+            if lib.__class__.__name__ == "Ref":
+                paths.append(lib.open_tree_blake(c, row, 4096))
+            else:
+                paths.append(lib.open_tree_blake(lv, M, c, row, 4096))
+        out[key + "paths"] = np.stack(paths)
+        if lib.__class__.__name__ == "Ref":
+            lib.release_commit()
+    # full-range polynomial (img != 0 everywhere), 2^18 / K=32 and RSxRS (linear_time=false, trs=4)
+    poly = splitmix_field(1 << 18, 77)
+    for lin in (0, 1):
+        lv, T = lib.commit_standard(poly, 32, 4, lin, want_tensor=True)
+        out["cfull_%d_root" % lin] = lv[-1].copy(); out["cfull_%d_lv_dg" % lin] = dg(lv); out["cfull_%d_t_dg" % lin] = dg(T)
+    if lib.__class__.__name__ == "Ref":
+        lib.release_commit()
+    pb = splitmix_field(1 << 14, 77); beta = splitmix_field(16, 78)
+    out["aggr"] = lib.aggregate(pb, beta)
+    return out
+
+
+def sumcheck_inputs(n):
+    v1 = splitmix_field(n, 1); v2 = splitmix_field(n, 2); v3 = splitmix_field(n, 3)
+    v2z = v2.copy(); v2z[0:n // 2] = 0
+    v1z = v1.copy(); v1z[n // 4:n // 2] = 0
+    return v1, v2, v3, v1z, v2z
+
+
+def case_sumcheck(lib):
+    out = {}
+    pr = np.array([33, 0], dtype=np.uint64)
+    for n in (2, 4, 32, 1024, 1 << 16):
+        v1, v2, v3, v1z, v2z = sumcheck_inputs(n)
+        for tag, res in (("s2", lib.sumcheck2(v1, v2, pr)), ("s3", lib.sumcheck3(v1, v2, v3, pr)), ("s3z", lib.sumcheck3(v1z, v2z, v3, pr))):
+            for k, v in res.items():
+                out["%s_%d_%s" % (tag, n, k)] = v
+    # table 2 = eq-table of full-range challenges (the C2 benchmark shape, at 2^12)
+    v1 = splitmix_field(1 << 12, 1); v2 = lib.precompute_beta(splitmix_field(12, 9))
+    for k, v in lib.sumcheck2(v1, v2, pr).items():
+        out["s2beta_%s" % k] = v
+    return out
+
+
+def case_elastic(lib):
+    out = {}
+    B = 1 << 14
+    for opt in (1, 2):
+        lib.rng_reset()
+        if hasattr(lib, "encode_reset_scratch"):
+            lib.encode_reset_scratch()
+        lv = lib.elastic_commit(1 << 18, B, opt)
+        T = 4 * B
+        # leaf T-1 is undefined in the reference (out-of-bounds read, see hobbit_oracle.c); it is an
+        # odd leaf and never feeds a parent (left|left quirk), so everything else is pinned.
+        out["el_%d_root" % opt] = lv[-1].copy()
+        out["el_%d_leaves_dg" % opt] = dg(lv[:T - 1])
+        out["el_%d_upper_dg" % opt] = dg(lv[T:])
+    return out
+
+
+CASES = dict(field=case_field, mimc=case_mimc, blake=case_blake, merkle=case_merkle, graph_encode=case_graph_encode,
+             fft=case_fft, tensorcode=case_tensorcode, commit=case_commit, sumcheck=case_sumcheck, elastic=case_elastic)
