@@ -1,0 +1,438 @@
+"""hobbit_amd -- Python harness over libhobbit_hip.so (the C ABI in include/hobbit_hip.h).
+
+This module is plumbing for tests and bench.py: it loads the in-tree shared library, owns device
+buffers through the ABI's own allocator, and mirrors the reference's function names for the hot
+path (commit_standard, generate_2product_sumcheck_proof, expander_init_store, ...; reference
+src/Our_PC.cpp, src/sumcheck.cpp, src/expanders.h) so the parity tests read like calls into the
+reference.  The product itself is the HIP library; the C++ host mirror with the reference's exact
+C++ signatures lives in host/.
+
+There is NO CPU fallback: if the library is missing, or no HIP device is present, construction
+raises.  Nothing under oracle/ is imported here.
+"""
+import ctypes
+import os
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libhobbit_hip.so")
+P = (1 << 61) - 1
+
+c_sz = ctypes.c_size_t
+c_vp = ctypes.c_void_p
+c_int = ctypes.c_int
+c_ll = ctypes.c_longlong
+
+# every symbol include/hobbit_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "hobbit_ctx_create", "hobbit_ctx_create_on_stream", "hobbit_ctx_destroy", "hobbit_last_error", "hobbit_version", "hobbit_sync",
+    "hobbit_malloc", "hobbit_free", "hobbit_memcpy_h2d", "hobbit_memcpy_d2h", "hobbit_memset", "hobbit_timer_begin", "hobbit_timer_end_ms",
+    "hobbit_profile_enable", "hobbit_profile_reset", "hobbit_profile_get", "hobbit_profile_names",
+    "hobbit_mimc", "hobbit_f_mul_host", "hobbit_f_inv_host", "hobbit_f_binop",
+    "hobbit_graph_reset", "hobbit_graph_upload", "hobbit_graph_finalize", "hobbit_encode_batch", "hobbit_fft_batch",
+    "hobbit_blake3_64", "hobbit_hash_md", "hobbit_mt_commit_blake", "hobbit_merkle_levels", "hobbit_merkle_path", "hobbit_merkle_paths",
+    "hobbit_eq_table", "hobbit_eval_vector", "hobbit_tensorcode",
+    "hobbit_commit_standard", "hobbit_commitment_free", "hobbit_commitment_num_leaves", "hobbit_commitment_levels_dev",
+    "hobbit_commitment_tensor_dev", "hobbit_commitment_levels", "hobbit_commitment_root", "hobbit_commitment_tensor_row",
+    "hobbit_commitment_gather", "hobbit_commitment_path", "hobbit_commitment_paths",
+    "hobbit_aggregate", "hobbit_sumcheck2", "hobbit_sumcheck3", "hobbit_fill_splitmix",
+]
+
+
+class HobbitError(RuntimeError):
+    pass
+
+
+def load_library(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise HobbitError("libhobbit_hip.so is not built (run __graft_entry__.build()): " + path)
+    lib = ctypes.CDLL(path)
+    lib.hobbit_last_error.restype = ctypes.c_char_p
+    lib.hobbit_version.restype = ctypes.c_char_p
+    lib.hobbit_commitment_num_leaves.restype = c_sz
+    lib.hobbit_commitment_levels_dev.restype = c_vp
+    lib.hobbit_commitment_tensor_dev.restype = c_vp
+    # explicit prototypes: a bare Python int would otherwise be passed as a 32-bit C int and
+    # truncate device pointers / sizes
+    V, S, I, L, U64 = c_vp, c_sz, c_int, c_ll, ctypes.c_uint64
+    protos = {
+        "hobbit_ctx_create": [I, V], "hobbit_ctx_create_on_stream": [I, V, V], "hobbit_ctx_destroy": [V], "hobbit_last_error": [V],
+        "hobbit_sync": [V], "hobbit_malloc": [V, S, V], "hobbit_free": [V, V], "hobbit_memcpy_h2d": [V, V, V, S],
+        "hobbit_memcpy_d2h": [V, V, V, S], "hobbit_memset": [V, V, I, S], "hobbit_timer_begin": [V], "hobbit_timer_end_ms": [V, V],
+        "hobbit_profile_enable": [V, I], "hobbit_profile_reset": [V], "hobbit_profile_get": [V, ctypes.c_char_p, V, V],
+        "hobbit_profile_names": [V, V, S], "hobbit_mimc": [V, V, V], "hobbit_f_mul_host": [V, V, V, S], "hobbit_f_inv_host": [V, V, S],
+        "hobbit_f_binop": [V, I, V, V, V, S], "hobbit_graph_reset": [V], "hobbit_graph_upload": [V, I, I, L, L, I, V, V],
+        "hobbit_graph_finalize": [V, L, V], "hobbit_encode_batch": [V, V, V, L, S, S, S], "hobbit_fft_batch": [V, V, I, S, S, I],
+        "hobbit_blake3_64": [V, V, V, S], "hobbit_hash_md": [V, V, V, V, S], "hobbit_mt_commit_blake": [V, V, S, V],
+        "hobbit_merkle_levels": [V, V, S, I], "hobbit_merkle_path": [V, V, S, S, V], "hobbit_merkle_paths": [V, V, S, V, S, V],
+        "hobbit_eq_table": [V, V, I, V], "hobbit_eval_vector": [V, V, S, V, V], "hobbit_tensorcode": [V, V, S, I, I, V],
+        "hobbit_commit_standard": [V, V, S, I, I, I, V], "hobbit_commitment_free": [V], "hobbit_commitment_num_leaves": [V],
+        "hobbit_commitment_levels_dev": [V], "hobbit_commitment_tensor_dev": [V], "hobbit_commitment_levels": [V, V, V],
+        "hobbit_commitment_root": [V, V, V], "hobbit_commitment_tensor_row": [V, V, I, I, V], "hobbit_commitment_gather": [V, V, V, V, S, V],
+        "hobbit_commitment_path": [V, V, S, S, V], "hobbit_commitment_paths": [V, V, V, V, S, V], "hobbit_aggregate": [V, V, S, V, I, V],
+        "hobbit_sumcheck2": [V, V, V, S, V, V, V, V, V], "hobbit_sumcheck3": [V, V, V, V, S, V, V, V, V, V],
+        "hobbit_fill_splitmix": [V, V, S, U64],
+    }
+    for name, args in protos.items():
+        getattr(lib, name).argtypes = args
+    return lib
+
+
+def _hp(a):
+    return a.ctypes.data_as(c_vp)
+
+
+def Fh(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    assert a.shape[-1] == 2
+    return a
+
+
+class DeviceBuffer:
+    """Device allocation owned through the C ABI (hobbit_malloc / hobbit_free)."""
+
+    def __init__(self, hb, nbytes):
+        self.hb = hb
+        self.nbytes = int(nbytes)
+        p = c_vp()
+        hb._chk(hb.lib.hobbit_malloc(hb.ctx, c_sz(self.nbytes), ctypes.byref(p)))
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr and self.hb.ctx:          # after Hobbit.close() the context (and its memory) is gone
+            self.hb.lib.hobbit_free(self.hb.ctx, c_vp(self.ptr))
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Commitment:
+    """Handle on a device-resident Our_PC commitment (tensor + Merkle levels)."""
+
+    def __init__(self, hb, handle, N, K, trs):
+        self.hb, self.h, self.N, self.K, self.trs = hb, handle, N, K, trs
+        self.M = N // K
+        self.cols = 2 * self.M // trs
+
+    def levels(self):
+        out = np.zeros((2 * self.M - 1, 32), np.uint8)
+        self.hb._chk(self.hb.lib.hobbit_commitment_levels(self.hb.ctx, self.h, _hp(out)))
+        return out
+
+    def root(self):
+        out = np.zeros(32, np.uint8)
+        self.hb._chk(self.hb.lib.hobbit_commitment_root(self.hb.ctx, self.h, _hp(out)))
+        return out
+
+    def tensor_row(self, chunk, row):
+        out = np.zeros((self.cols, 2), np.uint64)
+        self.hb._chk(self.hb.lib.hobbit_commitment_tensor_row(self.hb.ctx, self.h, c_int(chunk), c_int(row), _hp(out)))
+        return out
+
+    def tensor(self):
+        """whole _tensor[K][2trs][cols] in the reference's layout (small cases only)"""
+        return np.stack([np.stack([self.tensor_row(i, r) for r in range(2 * self.trs)]) for i in range(self.K)])
+
+    def gather(self, rows, cols):
+        """_compute_aggregation_reply: reply[q][i] = _tensor[i][rows[q]][cols[q]]"""
+        rows = np.ascontiguousarray(rows, np.uint32); cols = np.ascontiguousarray(cols, np.uint32)
+        out = np.zeros((len(rows), self.K, 2), np.uint64)
+        self.hb._chk(self.hb.lib.hobbit_commitment_gather(self.hb.ctx, self.h, _hp(rows), _hp(cols), c_sz(len(rows)), _hp(out)))
+        return out
+
+    def open_tree_blake(self, col, row):
+        depth = self.M.bit_length() - 1
+        out = np.zeros((depth, 32), np.uint8)
+        self.hb._chk(self.hb.lib.hobbit_commitment_path(self.hb.ctx, self.h, c_sz(col), c_sz(row), _hp(out)))
+        return out
+
+    def paths(self, cols, rows):
+        cols = np.ascontiguousarray(cols, np.uint32); rows = np.ascontiguousarray(rows, np.uint32)
+        depth = self.M.bit_length() - 1
+        out = np.zeros((len(cols), depth, 32), np.uint8)
+        self.hb._chk(self.hb.lib.hobbit_commitment_paths(self.hb.ctx, self.h, _hp(cols), _hp(rows), c_sz(len(cols)), _hp(out)))
+        return out
+
+    def free(self):
+        if self.h and self.hb.ctx:
+            self.hb.lib.hobbit_commitment_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Hobbit:
+    """One context on one GPU.  Raises HobbitError when the library or the device is missing."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        ctx = c_vp()
+        rc = self.lib.hobbit_ctx_create_on_stream(c_int(device), c_vp(stream) if stream else None, ctypes.byref(ctx))
+        if rc != 0:
+            raise HobbitError("hobbit_ctx_create failed (rc=%d): no usable HIP device -- there is no CPU fallback" % rc)
+        self.ctx = ctx
+        self._libc = ctypes.CDLL(None)
+        self._libc.random.restype = ctypes.c_long
+
+    def close(self):
+        if self.ctx:
+            self.lib.hobbit_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise HobbitError("rc=%d: %s" % (rc, self.lib.hobbit_last_error(self.ctx).decode()))
+
+    # ---- memory
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        b = DeviceBuffer(self, max(arr.nbytes, 16))
+        if arr.nbytes:
+            self._chk(self.lib.hobbit_memcpy_h2d(self.ctx, c_vp(b.ptr), _hp(arr), c_sz(arr.nbytes)))
+        return b
+
+    def to_host(self, buf, shape, dtype, offset=0):
+        out = np.zeros(shape, dtype)
+        ptr = buf.ptr if isinstance(buf, DeviceBuffer) else int(buf)
+        if out.nbytes:
+            self._chk(self.lib.hobbit_memcpy_d2h(self.ctx, _hp(out), c_vp(ptr + offset), c_sz(out.nbytes)))
+        return out
+
+    def sync(self):
+        self._chk(self.lib.hobbit_sync(self.ctx))
+
+    # ---- timing / profiling
+    def timer_begin(self):
+        self._chk(self.lib.hobbit_timer_begin(self.ctx))
+
+    def timer_end_ms(self):
+        ms = ctypes.c_float()
+        self._chk(self.lib.hobbit_timer_end_ms(self.ctx, ctypes.byref(ms)))
+        return ms.value
+
+    def profile(self, on=True):
+        self._chk(self.lib.hobbit_profile_enable(self.ctx, c_int(int(on))))
+
+    def profile_reset(self):
+        self._chk(self.lib.hobbit_profile_reset(self.ctx))
+
+    def profile_report(self):
+        buf = ctypes.create_string_buffer(8192)
+        self._chk(self.lib.hobbit_profile_names(self.ctx, buf, c_sz(8192)))
+        out = {}
+        for name in [s for s in buf.value.decode().split(";") if s]:
+            ms = ctypes.c_double(); cnt = c_ll()
+            self._chk(self.lib.hobbit_profile_get(self.ctx, name.encode(), ctypes.byref(ms), ctypes.byref(cnt)))
+            out[name] = (ms.value, cnt.value)
+        return out
+
+    # ---- field
+    def f_binop(self, op, a, b):
+        a, b = Fh(a), Fh(b)
+        da, db = self.to_device(a), self.to_device(b)
+        do = self.alloc(a.nbytes)
+        self._chk(self.lib.hobbit_f_binop(self.ctx, c_int(op), c_vp(da.ptr), c_vp(db.ptr), c_vp(do.ptr), c_sz(a.size // 2)))
+        return self.to_host(do, a.shape, np.uint64)
+
+    def mimc_hash(self, x, k):
+        x, k = Fh(x).reshape(2), Fh(k).reshape(2)
+        o = np.zeros(2, np.uint64)
+        self.lib.hobbit_mimc(_hp(x), _hp(k), _hp(o))
+        return o
+
+    def fill_splitmix(self, n, seed):
+        b = self.alloc(16 * n)
+        self._chk(self.lib.hobbit_fill_splitmix(self.ctx, c_vp(b.ptr), c_sz(n), ctypes.c_uint64(seed)))
+        return b
+
+    # ---- expander graphs: drawn on the host with libc rand()/random() in the reference's order
+    def rng_reset(self):
+        self._libc.srandom(1)
+
+    def generate_randomness(self, n):
+        """src/utils.cpp:873-883 (host-side, libc)"""
+        out = np.zeros((n, 2), np.uint64)
+        c = 0
+        for i in range(n):
+            if i % 100 == 0:
+                c = self._libc.random()
+            out[i, 0] = (c + self._libc.rand()) % P
+        return out
+
+    def _draw(self, L, R, d):
+        nbr = np.zeros(L * d, np.int64); w = np.zeros((L * d, 2), np.uint64)
+        rnd, rdm = self._libc.rand, self._libc.random
+        for e in range(L * d):
+            nbr[e] = rnd() % R          # src/expanders.h:36
+            w[e, 0] = rdm()             # src/expanders.h:37
+        return nbr, w
+
+    def expander_init_store(self, n, weights=None):
+        """src/expanders.h:78-92: draw _C[dep], recurse, draw D[dep]; upload every level.
+        `weights`: optional dict {(dep,kind): F array} overriding the drawn weights (tests)."""
+        self._chk(self.lib.hobbit_graph_reset(self.ctx))
+        self._graph_levels = {}
+
+        def rec(m, dep):
+            if m <= 13:
+                return m
+            R = int(0.211 * m)
+            self._graph_levels[(dep, 0)] = (m, R, 9) + self._draw(m, R, 9)
+            L = rec(R, dep + 1)
+            R2 = int(m * (1.72 - 1) - L)
+            self._graph_levels[(dep, 1)] = (L, R2, 12) + self._draw(L, R2, 12)
+            return m + L + R2
+
+        total = rec(n, 0)
+        for (dep, kind), (L, R, d, nbr, w) in self._graph_levels.items():
+            if weights and (dep, kind) in weights:
+                w = Fh(weights[(dep, kind)])
+            self._chk(self.lib.hobbit_graph_upload(self.ctx, c_int(dep), c_int(kind), c_ll(L), c_ll(R), c_int(d), _hp(nbr), _hp(w)))
+        ln = c_ll()
+        self._chk(self.lib.hobbit_graph_finalize(self.ctx, c_ll(n), ctypes.byref(ln)))
+        assert ln.value == total
+        return total
+
+    def upload_graphs(self, n, levels):
+        """levels: {(dep,kind): dict(L,R,degree,nbr,w)} (e.g. taken from the oracle in tests)"""
+        self._chk(self.lib.hobbit_graph_reset(self.ctx))
+        for (dep, kind), g in levels.items():
+            nbr = np.ascontiguousarray(g["nbr"], np.int64); w = Fh(g["w"])
+            self._chk(self.lib.hobbit_graph_upload(self.ctx, c_int(dep), c_int(kind), c_ll(g["L"]), c_ll(g["R"]), c_int(g["degree"]), _hp(nbr), _hp(w)))
+        ln = c_ll()
+        self._chk(self.lib.hobbit_graph_finalize(self.ctx, c_ll(n), ctypes.byref(ln)))
+        return ln.value
+
+    def encode_monolithic(self, src):
+        """src: (batch, n, 2) or (n, 2) -> (batch, 2n, 2)"""
+        s = Fh(src)
+        single = s.ndim == 2
+        if single:
+            s = s[None]
+        batch, n = s.shape[0], s.shape[1]
+        ds = self.to_device(s); dd = self.alloc(batch * 2 * n * 16)
+        self._chk(self.lib.hobbit_encode_batch(self.ctx, c_vp(ds.ptr), c_vp(dd.ptr), c_ll(n), c_sz(batch), c_sz(n), c_sz(2 * n)))
+        out = self.to_host(dd, (batch, 2 * n, 2), np.uint64)
+        return out[0] if single else out
+
+    # ---- FFT
+    def fft(self, arr, inverse=False):
+        a = Fh(arr)
+        single = a.ndim == 2
+        if single:
+            a = a[None]
+        batch, ln = a.shape[0], a.shape[1]
+        d = self.to_device(a)
+        self._chk(self.lib.hobbit_fft_batch(self.ctx, c_vp(d.ptr), c_int(ln.bit_length() - 1), c_sz(batch), c_sz(ln), c_int(int(inverse))))
+        out = self.to_host(d, a.shape, np.uint64)
+        return out[0] if single else out
+
+    # ---- hashes / Merkle
+    def blake3_64(self, blocks):
+        b = np.ascontiguousarray(blocks, np.uint8).reshape(-1, 64)
+        d = self.to_device(b); o = self.alloc(32 * b.shape[0])
+        self._chk(self.lib.hobbit_blake3_64(self.ctx, c_vp(d.ptr), c_vp(o.ptr), c_sz(b.shape[0])))
+        return self.to_host(o, (b.shape[0], 32), np.uint8)
+
+    def hash_md(self, xyzw, prev):
+        x = Fh(xyzw).reshape(-1, 4, 2); p = np.ascontiguousarray(prev, np.uint8).reshape(-1, 32)
+        dx, dp = self.to_device(x), self.to_device(p)
+        self._chk(self.lib.hobbit_hash_md(self.ctx, c_vp(dx.ptr), c_vp(dp.ptr), c_vp(dp.ptr), c_sz(x.shape[0])))
+        return self.to_host(dp, p.shape, np.uint8)
+
+    def mt_commit_blake(self, leafs):
+        x = Fh(leafs).reshape(-1, 2)
+        n = x.shape[0] // 4
+        d = self.to_device(x); lv = self.alloc(64 * n)
+        self._chk(self.lib.hobbit_mt_commit_blake(self.ctx, c_vp(d.ptr), c_sz(x.shape[0]), c_vp(lv.ptr)))
+        return self.to_host(lv, (2 * n - 1, 32), np.uint8)
+
+    def create_tree_blake(self, level0, quirk=1):
+        l0 = np.ascontiguousarray(level0, np.uint8).reshape(-1, 32)
+        n = l0.shape[0]
+        lv = self.alloc(64 * n)
+        self._chk(self.lib.hobbit_memcpy_h2d(self.ctx, c_vp(lv.ptr), _hp(l0), c_sz(l0.nbytes)))
+        self._chk(self.lib.hobbit_merkle_levels(self.ctx, c_vp(lv.ptr), c_sz(n), c_int(quirk)))
+        return self.to_host(lv, (2 * n - 1, 32), np.uint8)
+
+    # ---- multilinear
+    def precompute_beta(self, r, keep_on_device=False):
+        r = Fh(r).reshape(-1, 2)
+        k = r.shape[0]
+        d = self.alloc(16 << k)
+        self._chk(self.lib.hobbit_eq_table(self.ctx, _hp(r), c_int(k), c_vp(d.ptr)))
+        return d if keep_on_device else self.to_host(d, (1 << k, 2), np.uint64)
+
+    def evaluate_vector(self, v, r):
+        v = Fh(v).reshape(-1, 2); r = Fh(r).reshape(-1, 2)
+        d = self.to_device(v); o = np.zeros(2, np.uint64)
+        self._chk(self.lib.hobbit_eval_vector(self.ctx, c_vp(d.ptr), c_sz(v.shape[0]), _hp(r), _hp(o)))
+        return o
+
+    # ---- tensor code / commit
+    def compute_tensorcode(self, msg, trs, lin):
+        """returns the tensor in the reference's row-major (2trs, cols) layout"""
+        m = Fh(msg).reshape(-1, 2)
+        M = m.shape[0]; cols = 2 * M // trs
+        d = self.to_device(m); o = self.alloc(16 * 4 * M)
+        self._chk(self.lib.hobbit_tensorcode(self.ctx, c_vp(d.ptr), c_sz(M), c_int(trs), c_int(lin), c_vp(o.ptr)))
+        t = self.to_host(o, (cols, 2 * trs, 2), np.uint64)      # codeword-major on the device
+        return np.ascontiguousarray(t.transpose(1, 0, 2))
+
+    def commit_standard(self, poly, K, trs, lin=1):
+        """poly: host array (N,2) or a DeviceBuffer/int pointer with N given as tuple (ptr, N)"""
+        if isinstance(poly, tuple):
+            ptr, N = poly
+            ptr = ptr.ptr if isinstance(ptr, DeviceBuffer) else int(ptr)
+            keep = None
+        else:
+            p = Fh(poly).reshape(-1, 2)
+            N = p.shape[0]
+            keep = self.to_device(p); ptr = keep.ptr
+        h = c_vp()
+        self._chk(self.lib.hobbit_commit_standard(self.ctx, c_vp(ptr), c_sz(N), c_int(K), c_int(trs), c_int(lin), ctypes.byref(h)))
+        self.sync()
+        return Commitment(self, h, N, K, trs)
+
+    def aggregate(self, poly, beta):
+        p = Fh(poly).reshape(-1, 2); b = Fh(beta).reshape(-1, 2)
+        K = b.shape[0]
+        d = self.to_device(p); o = self.alloc(16 * (p.shape[0] // K))
+        self._chk(self.lib.hobbit_aggregate(self.ctx, c_vp(d.ptr), c_sz(p.shape[0]), _hp(b), c_int(K), c_vp(o.ptr)))
+        return self.to_host(o, (p.shape[0] // K, 2), np.uint64)
+
+    # ---- sumchecks (reference names: src/sumcheck.cpp:2391, 1974)
+    def _dev_table(self, v):
+        if isinstance(v, tuple):
+            return (v[0].ptr if isinstance(v[0], DeviceBuffer) else int(v[0])), v[1], None
+        a = Fh(v).reshape(-1, 2)
+        b = self.to_device(a)
+        return b.ptr, a.shape[0], b
+
+    def generate_2product_sumcheck_proof(self, v1, v2, previous_r):
+        p1, n, k1 = self._dev_table(v1); p2, n2, k2 = self._dev_table(v2)
+        assert n == n2
+        rounds = n.bit_length() - 1
+        pr = Fh(previous_r).reshape(2)
+        q = np.zeros((rounds, 3, 2), np.uint64); r = np.zeros((rounds, 2), np.uint64); vr = np.zeros((2, 2), np.uint64); fin = np.zeros(2, np.uint64)
+        self._chk(self.lib.hobbit_sumcheck2(self.ctx, c_vp(p1), c_vp(p2), c_sz(n), _hp(pr), _hp(q), _hp(r), _hp(vr), _hp(fin)))
+        return dict(poly=q, r=r, vr=vr, fin=fin)
+
+    def generate_3product_sumcheck_proof(self, v1, v2, v3, previous_r):
+        p1, n, k1 = self._dev_table(v1); p2, _, k2 = self._dev_table(v2); p3, _, k3 = self._dev_table(v3)
+        rounds = n.bit_length() - 1
+        pr = Fh(previous_r).reshape(2)
+        q = np.zeros((rounds, 4, 2), np.uint64); r = np.zeros((rounds, 2), np.uint64); vr = np.zeros((3, 2), np.uint64); fin = np.zeros(2, np.uint64)
+        self._chk(self.lib.hobbit_sumcheck3(self.ctx, c_vp(p1), c_vp(p2), c_vp(p3), c_sz(n), _hp(pr), _hp(q), _hp(r), _hp(vr), _hp(fin)))
+        return dict(poly=q, r=r, vr=vr, fin=fin)

@@ -1,0 +1,396 @@
+// hobbit_capi.hip -- the extern "C" boundary declared in include/hobbit_hip.h.
+// Host orchestration only: argument checks, graph preprocessing (reverse adjacency in sliced-ELL
+// form), twiddle tables, and the launch sequences of tensor code / commit / open building blocks.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include "hobbit_kernels.hpp"
+
+using namespace hobbit;
+
+static inline const F *cF(const hobbit_F *p) { return reinterpret_cast<const F *>(p); }
+static inline F *mF(hobbit_F *p) { return reinterpret_cast<F *>(p); }
+static_assert(sizeof(hobbit_F) == sizeof(F), "ABI field element must be 16 bytes");
+
+struct hobbit_commitment {
+    hobbit_ctx *ctx;
+    size_t N, M; int K, trs, lin; uint32_t cols, rows2;
+    F *d_tensor; uint8_t *d_levels;
+    size_t tensor_bytes, levels_bytes;
+};
+
+static int ilog2_exact(size_t n) { int l = 0; while (((size_t)1 << l) < n) l++; return ((size_t)1 << l) == n ? l : -1; }
+
+static int get_twiddles(hobbit_ctx *ctx, int logn, bool inverse, const F **out) {
+    auto &m = inverse ? ctx->tw_inv : ctx->tw_fwd;
+    auto it = m.find(logn);
+    if (it != m.end()) { *out = it->second; return 0; }
+    size_t half = logn >= 1 ? ((size_t)1 << (logn - 1)) : 1;
+    std::vector<F> w(half);
+    w[0] = fmake(1);
+    if (half > 1) {   // src/utils.cpp:646-653: w[1] = rou (or its inverse), w[i] = w[i-1]*w[1]
+        F w1 = root_of_unity(logn); if (inverse) w1 = finv(w1);
+        w[1] = w1;
+        for (size_t i = 2; i < half; i++) w[i] = fmul(w[i - 1], w1);
+    }
+    F *d = nullptr;
+    if (hipMalloc((void **)&d, half * sizeof(F)) != hipSuccess) return ctx->fail(HOBBIT_ENOMEM, "twiddle alloc failed");
+    HB_CHECK(ctx, hipMemcpy(d, w.data(), half * sizeof(F), hipMemcpyHostToDevice));
+    m[logn] = d; *out = d; return 0;
+}
+
+static void free_code(DeviceCode &c) {
+    if (c.d_steps) hipFree(c.d_steps);
+    if (c.d_slice_ptr) hipFree(c.d_slice_ptr);
+    if (c.d_slice_width) hipFree(c.d_slice_width);
+    if (c.d_edges32) hipFree(c.d_edges32);
+    if (c.d_eidx) hipFree(c.d_eidx);
+    if (c.d_ew) hipFree(c.d_ew);
+    c = DeviceCode();
+}
+
+extern "C" {
+
+const char *hobbit_version(void) { return "hobbit-hip 0.1 (gfx950)"; }
+
+int hobbit_ctx_create_on_stream(int device, void *hip_stream, hobbit_ctx **out) {
+    if (!out) return HOBBIT_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HOBBIT_ENODEV;   // no CPU fallback, by design
+    if (device < 0 || device >= ndev) return HOBBIT_ENODEV;
+    if (hipSetDevice(device) != hipSuccess) return HOBBIT_ENODEV;
+    hobbit_ctx *c = new hobbit_ctx();
+    c->device = device;
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->owns_stream = false; }
+    else { if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return HOBBIT_EHIP; } c->owns_stream = true; }
+    hipEventCreate(&c->t0); hipEventCreate(&c->t1);
+    *out = c;
+    return 0;
+}
+int hobbit_ctx_create(int device, hobbit_ctx **out) { return hobbit_ctx_create_on_stream(device, nullptr, out); }
+
+void hobbit_ctx_destroy(hobbit_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    ctx->prof_collect();
+    for (auto &kv : ctx->tw_fwd) hipFree(kv.second);
+    for (auto &kv : ctx->tw_inv) hipFree(kv.second);
+    free_code(ctx->code);
+    if (ctx->ws) hipFree(ctx->ws);
+    if (ctx->spare_tensor) hipFree(ctx->spare_tensor);
+    if (ctx->spare_levels) hipFree(ctx->spare_levels);
+    hipEventDestroy(ctx->t0); hipEventDestroy(ctx->t1);
+    if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+const char *hobbit_last_error(const hobbit_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+int hobbit_sync(hobbit_ctx *ctx) { HB_CHECK(ctx, hipStreamSynchronize(ctx->stream)); return 0; }
+int hobbit_malloc(hobbit_ctx *ctx, size_t bytes, void **d_ptr) {
+    hipSetDevice(ctx->device);
+    if (hipMalloc(d_ptr, bytes ? bytes : 16) != hipSuccess) return ctx->fail(HOBBIT_ENOMEM, "hipMalloc failed");
+    return 0;
+}
+int hobbit_free(hobbit_ctx *ctx, void *d_ptr) { HB_CHECK(ctx, hipStreamSynchronize(ctx->stream)); HB_CHECK(ctx, hipFree(d_ptr)); return 0; }
+int hobbit_memcpy_h2d(hobbit_ctx *ctx, void *d, const void *h, size_t bytes) {
+    HB_CHECK(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream)); HB_CHECK(ctx, hipStreamSynchronize(ctx->stream)); return 0;
+}
+int hobbit_memcpy_d2h(hobbit_ctx *ctx, void *h, const void *d, size_t bytes) {
+    HB_CHECK(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream)); HB_CHECK(ctx, hipStreamSynchronize(ctx->stream)); return 0;
+}
+int hobbit_memset(hobbit_ctx *ctx, void *d, int value, size_t bytes) { HB_CHECK(ctx, hipMemsetAsync(d, value, bytes, ctx->stream)); return 0; }
+int hobbit_timer_begin(hobbit_ctx *ctx) { HB_CHECK(ctx, hipEventRecord(ctx->t0, ctx->stream)); return 0; }
+int hobbit_timer_end_ms(hobbit_ctx *ctx, float *ms) {
+    HB_CHECK(ctx, hipEventRecord(ctx->t1, ctx->stream)); HB_CHECK(ctx, hipEventSynchronize(ctx->t1));
+    HB_CHECK(ctx, hipEventElapsedTime(ms, ctx->t0, ctx->t1)); return 0;
+}
+int hobbit_profile_enable(hobbit_ctx *ctx, int on) { ctx->prof_on = on != 0; return 0; }
+int hobbit_profile_reset(hobbit_ctx *ctx) { hipStreamSynchronize(ctx->stream); ctx->prof_collect(); ctx->prof.clear(); return 0; }
+int hobbit_profile_get(hobbit_ctx *ctx, const char *kernel, double *total_ms, long long *launches) {
+    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->prof_collect();
+    auto it = ctx->prof.find(kernel);
+    if (it == ctx->prof.end()) { *total_ms = 0; *launches = 0; return 0; }
+    *total_ms = it->second.ms; *launches = it->second.launches; return 0;
+}
+int hobbit_profile_names(hobbit_ctx *ctx, char *buf, size_t buflen) {
+    std::string s;
+    for (auto &kv : ctx->prof) { if (!s.empty()) s += ";"; s += kv.first; }
+    if (s.size() + 1 > buflen) return ctx->fail(HOBBIT_EINVAL, "profile_names: buffer too small");
+    memcpy(buf, s.c_str(), s.size() + 1); return 0;
+}
+
+// ---- host-side field helpers ------------------------------------------------------------------
+void hobbit_mimc(const hobbit_F *x, const hobbit_F *k, hobbit_F *out) { *mF(out) = mimc_hash(*cF(x), *cF(k)); }
+void hobbit_f_mul_host(const hobbit_F *a, const hobbit_F *b, hobbit_F *o, size_t n) { for (size_t i = 0; i < n; i++) mF(o)[i] = fmul(cF(a)[i], cF(b)[i]); }
+void hobbit_f_inv_host(const hobbit_F *a, hobbit_F *o, size_t n) { for (size_t i = 0; i < n; i++) mF(o)[i] = finv(cF(a)[i]); }
+int hobbit_f_binop(hobbit_ctx *ctx, int op, const hobbit_F *a, const hobbit_F *b, hobbit_F *o, size_t n) {
+    if (op < 0 || op > 2) return ctx->fail(HOBBIT_EINVAL, "f_binop: op must be 0,1,2");
+    if (!n) return 0;
+    return launch_f_binop(ctx, op, cF(a), cF(b), mF(o), n);
+}
+int hobbit_fill_splitmix(hobbit_ctx *ctx, hobbit_F *o, size_t n, uint64_t seed) { if (!n) return 0; return launch_fill_splitmix(ctx, mF(o), n, seed); }
+
+// ---- expander graphs --------------------------------------------------------------------------
+int hobbit_graph_reset(hobbit_ctx *ctx) { ctx->graphs.clear(); hipStreamSynchronize(ctx->stream); free_code(ctx->code); return 0; }
+int hobbit_graph_upload(hobbit_ctx *ctx, int dep, int kind, long long L, long long R, int degree, const long long *nbr, const hobbit_F *w) {
+    if (dep < 0 || dep >= 100 || (kind != 0 && kind != 1) || L <= 0 || R <= 0 || degree <= 0) return ctx->fail(HOBBIT_EINVAL, "graph_upload: bad dims");
+    HostGraph g; g.L = L; g.R = R; g.degree = degree;
+    g.nbr.assign(nbr, nbr + L * degree);
+    g.w.assign(cF(w), cF(w) + L * degree);
+    for (long long t : g.nbr) if (t < 0 || t >= R) return ctx->fail(HOBBIT_EINVAL, "graph_upload: neighbour out of range");
+    ctx->graphs[{dep, kind}] = std::move(g);
+    return 0;
+}
+int hobbit_graph_finalize(hobbit_ctx *ctx, long long n, long long *len_out) {
+    hipStreamSynchronize(ctx->stream);
+    free_code(ctx->code);
+    DeviceCode &c = ctx->code;
+    const long long thr = 13;   // distance_threshold, src/parameter.h:5
+    if (n <= 0 || n > (1 << 20)) return ctx->fail(HOBBIT_EINVAL, "graph_finalize: bad n");
+    // level sizes and offsets
+    std::vector<long long> nd{n}, off{0};
+    int D = 0;
+    while (nd[D] > thr) {
+        auto it = ctx->graphs.find({D, 0});
+        if (it == ctx->graphs.end() || it->second.L != nd[D]) return ctx->fail(HOBBIT_ESTATE, "graph_finalize: missing or mismatched _C level");
+        off.push_back(off[D] + nd[D]); nd.push_back(it->second.R); D++;
+    }
+    std::vector<long long> cwlen(D + 1); cwlen[D] = nd[D];
+    for (int d = D - 1; d >= 0; d--) {
+        auto it = ctx->graphs.find({d, 1});
+        if (it == ctx->graphs.end() || it->second.L != cwlen[d + 1]) return ctx->fail(HOBBIT_ESTATE, "graph_finalize: missing or mismatched D level");
+        cwlen[d] = nd[d] + cwlen[d + 1] + it->second.R;
+    }
+    c.n = n; c.len = cwlen[0];
+    if (c.len > 2 * n) return ctx->fail(HOBBIT_EINVAL, "graph_finalize: codeword longer than 2n");
+    struct Plan { const HostGraph *g; long long in_off, out_off; };
+    std::vector<Plan> plan;
+    for (int d = 0; d < D; d++) plan.push_back({&ctx->graphs[{d, 0}], off[d], off[d] + nd[d]});
+    for (int d = D - 1; d >= 0; d--) plan.push_back({&ctx->graphs[{d, 1}], off[d + 1], off[d + 1] + cwlen[d + 1]});
+    c.small_weights = true;
+    for (auto &p : plan) for (auto &w : p.g->w) if (w.im != 0 || w.re >> 32) { c.small_weights = false; break; }
+    std::vector<uint32_t> slice_ptr, slice_width, eidx; std::vector<uint2> e32; std::vector<F> ew;
+    size_t pos = 0;
+    for (auto &p : plan) {
+        const HostGraph &g = *p.g;
+        std::vector<std::vector<std::pair<uint32_t, F>>> rows(g.R);
+        for (long long i = 0; i < g.L; i++)
+            for (int j = 0; j < g.degree; j++) rows[g.nbr[i * g.degree + j]].push_back({(uint32_t)i, g.w[i * g.degree + j]});
+        EncStep s; s.in_off = (uint32_t)p.in_off; s.out_off = (uint32_t)p.out_off; s.out_len = (uint32_t)g.R;
+        s.n_slices = (uint32_t)((g.R + 63) / 64); s.slice_base = (uint32_t)slice_ptr.size();
+        for (uint32_t sl = 0; sl < s.n_slices; sl++) {
+            size_t width = 0;
+            for (uint32_t l = 0; l < 64; l++) { size_t t = (size_t)sl * 64 + l; if (t < (size_t)g.R) width = std::max(width, rows[t].size()); }
+            slice_ptr.push_back((uint32_t)pos); slice_width.push_back((uint32_t)width);
+            for (size_t k = 0; k < width; k++)
+                for (uint32_t l = 0; l < 64; l++) {
+                    size_t t = (size_t)sl * 64 + l;
+                    uint32_t id = 0; F w = fmake(0);
+                    if (t < (size_t)g.R && k < rows[t].size()) { id = rows[t][k].first; w = rows[t][k].second; c.n_edges++; }
+                    if (c.small_weights) e32.push_back(make_uint2(id, (uint32_t)w.re)); else { eidx.push_back(id); ew.push_back(w); }
+                }
+            pos += width * 64;
+        }
+        c.steps.push_back(s);
+    }
+    c.n_edges_padded = pos;
+    auto up = [&](void **d, const void *h, size_t bytes) -> int {
+        if (hipMalloc(d, bytes ? bytes : 16) != hipSuccess) return ctx->fail(HOBBIT_ENOMEM, "graph alloc failed");
+        if (bytes) HB_CHECK(ctx, hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+        return 0;
+    };
+    HB_TRY(up((void **)&c.d_steps, c.steps.data(), c.steps.size() * sizeof(EncStep)));
+    HB_TRY(up((void **)&c.d_slice_ptr, slice_ptr.data(), slice_ptr.size() * 4));
+    HB_TRY(up((void **)&c.d_slice_width, slice_width.data(), slice_width.size() * 4));
+    if (c.small_weights) HB_TRY(up((void **)&c.d_edges32, e32.data(), e32.size() * sizeof(uint2)));
+    else { HB_TRY(up((void **)&c.d_eidx, eidx.data(), eidx.size() * 4)); HB_TRY(up((void **)&c.d_ew, ew.data(), ew.size() * sizeof(F))); }
+    if (len_out) *len_out = c.len;
+    return 0;
+}
+int hobbit_encode_batch(hobbit_ctx *ctx, const hobbit_F *d_src, hobbit_F *d_dst, long long n, size_t batch, size_t ld_src, size_t ld_dst) {
+    if (n <= 0 || ld_src < (size_t)n || ld_dst < (size_t)(2 * n)) return ctx->fail(HOBBIT_EINVAL, "encode_batch: bad n / leading dimensions");
+    return launch_encode(ctx, cF(d_src), ld_src, mF(d_dst), ld_dst, n, batch, 1);
+}
+
+// ---- FFT --------------------------------------------------------------------------------------
+int hobbit_fft_batch(hobbit_ctx *ctx, hobbit_F *d_data, int logn, size_t batch, size_t ld, int inverse) {
+    if (logn < 0 || logn > 12) return ctx->fail(HOBBIT_EINVAL, "fft_batch: logn must be in [0,12]");
+    if (logn == 0 || batch == 0) return 0;
+    if (ld < ((size_t)1 << logn)) return ctx->fail(HOBBIT_EINVAL, "fft_batch: ld < 2^logn");
+    const F *tw; HB_TRY(get_twiddles(ctx, logn, inverse != 0, &tw));
+    F scale = fmake(1);
+    if (inverse) scale = finv(fmake((uint64_t)1 << logn));          // src/utils.cpp:663-671
+    return launch_fft_rows(ctx, cF(d_data), ld, 1u << logn, mF(d_data), ld, 1, logn, tw, scale, inverse != 0, 1, (uint32_t)batch, 0, 0);
+}
+
+// ---- BLAKE3 / Merkle --------------------------------------------------------------------------
+int hobbit_blake3_64(hobbit_ctx *ctx, const uint8_t *d_in, uint8_t *d_out, size_t n) { return launch_blake3_64(ctx, d_in, d_out, n); }
+int hobbit_hash_md(hobbit_ctx *ctx, const hobbit_F *d_xyzw, const uint8_t *d_prev, uint8_t *d_out, size_t n) { return launch_hash_md(ctx, cF(d_xyzw), d_prev, d_out, n); }
+int hobbit_merkle_levels(hobbit_ctx *ctx, uint8_t *d_levels, size_t n, int quirk) {
+    if (ilog2_exact(n) < 0) return ctx->fail(HOBBIT_EINVAL, "merkle_levels: n must be a power of two");
+    return launch_merkle_levels(ctx, d_levels, n, quirk);
+}
+int hobbit_mt_commit_blake(hobbit_ctx *ctx, const hobbit_F *d_leafs, size_t N, uint8_t *d_levels) {
+    if (N < 4 || ilog2_exact(N / 4) < 0 || N % 4) return ctx->fail(HOBBIT_EINVAL, "mt_commit_blake: N/4 must be a power of two");
+    HB_TRY(launch_blake3_64(ctx, reinterpret_cast<const uint8_t *>(d_leafs), d_levels, N / 4));
+    return launch_merkle_levels(ctx, d_levels, N / 4, 1);
+}
+static int paths_common(hobbit_ctx *ctx, const uint8_t *d_levels, size_t n, const uint64_t *h_pos, size_t nq, uint8_t *h_paths) {
+    int depth = ilog2_exact(n);
+    if (depth < 0) return ctx->fail(HOBBIT_EINVAL, "merkle_path: n must be a power of two");
+    for (size_t q = 0; q < nq; q++) if (h_pos[q] >= n) return ctx->fail(HOBBIT_EINVAL, "merkle_path: position out of range");   // src/merkle_tree.cpp:310-313
+    if (depth == 0 || nq == 0) return 0;
+    uint8_t *buf; size_t pbytes = nq * 8, obytes = nq * depth * 32;
+    HB_TRY(ctx->workspace(pbytes + obytes + 64, (void **)&buf));
+    uint8_t *d_paths = buf; uint64_t *d_pos = reinterpret_cast<uint64_t *>(buf + ((obytes + 15) / 16) * 16);
+    HB_CHECK(ctx, hipMemcpyAsync(d_pos, h_pos, pbytes, hipMemcpyHostToDevice, ctx->stream));
+    HB_TRY(launch_merkle_paths(ctx, d_levels, n, d_pos, nq, depth, d_paths));
+    HB_CHECK(ctx, hipMemcpyAsync(h_paths, d_paths, obytes, hipMemcpyDeviceToHost, ctx->stream));
+    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int hobbit_merkle_path(hobbit_ctx *ctx, const uint8_t *d_levels, size_t n, size_t pos, uint8_t *h_path) {
+    uint64_t p = pos; return paths_common(ctx, d_levels, n, &p, 1, h_path);
+}
+int hobbit_merkle_paths(hobbit_ctx *ctx, const uint8_t *d_levels, size_t n, const uint64_t *h_pos, size_t nq, uint8_t *h_paths) {
+    return paths_common(ctx, d_levels, n, h_pos, nq, h_paths);
+}
+
+// ---- multilinear utilities --------------------------------------------------------------------
+int hobbit_eq_table(hobbit_ctx *ctx, const hobbit_F *h_r, int k, hobbit_F *d_out) {
+    if (k < 0 || k > 34) return ctx->fail(HOBBIT_EINVAL, "eq_table: bad k");
+    return launch_eq_table(ctx, cF(h_r), k, mF(d_out));
+}
+int hobbit_eval_vector(hobbit_ctx *ctx, const hobbit_F *d_v, size_t n, const hobbit_F *h_r, hobbit_F *h_out) {
+    int lg = ilog2_exact(n);
+    if (lg < 0) return ctx->fail(HOBBIT_EINVAL, "eval_vector: n must be a power of two");
+    if (lg == 0) return hobbit_memcpy_d2h(ctx, h_out, d_v, sizeof(F));
+    F *ws; HB_TRY(ctx->workspace((n / 2 + n / 4 + 2) * sizeof(F), (void **)&ws));
+    F *a = ws, *b = ws + n / 2;
+    const F *src = cF(d_v);
+    F *dst = a;
+    for (int i = 0; i < lg; i++) {
+        size_t L = n >> (i + 1);
+        HB_TRY(launch_eval_fold(ctx, src, dst, L, cF(h_r)[i]));
+        src = dst; dst = dst == a ? b : a;
+    }
+    return hobbit_memcpy_d2h(ctx, h_out, src, sizeof(F));
+}
+
+// ---- tensor code / commit ---------------------------------------------------------------------
+static int tensorcode_chunks(hobbit_ctx *ctx, const F *d_msg, size_t M, int K, int trs, int lin, F *d_out) {
+    if (trs <= 0 || M % (size_t)trs) return ctx->fail(HOBBIT_EINVAL, "tensorcode: trs must divide M");
+    size_t half = M / trs, cols = 2 * half, rows2 = 2 * (size_t)trs;
+    int logc = ilog2_exact(cols), logr = ilog2_exact(rows2);
+    if (logc < 1 || logc > 12) return ctx->fail(HOBBIT_EINVAL, "tensorcode: row length 2M/trs must be a power of two <= 4096");
+    if (logr < 1) return ctx->fail(HOBBIT_EINVAL, "tensorcode: trs must be a power of two");
+    const F *tw; HB_TRY(get_twiddles(ctx, logc, false, &tw));
+    // rows: RS encode = zero-padded FFT (src/PC_utils.cpp:75-84,105-107), written transposed into
+    // the codeword-major tensor: element (r, c) of chunk i at i*cols*rows2 + c*rows2 + r
+    HB_TRY(launch_fft_rows(ctx, d_msg, half, (uint32_t)half, d_out, 1, rows2, logc, tw, fmake(1), 0, (uint32_t)K, (uint32_t)trs, M, cols * rows2));
+    if (lin) {     // columns: expander code, in place on contiguous codewords (src/PC_utils.cpp:110-121)
+        if (trs > 13 && ctx->code.n != trs) return ctx->fail(HOBBIT_ESTATE, "tensorcode: expander graphs for n = trs not finalized");
+        if (trs <= 13 && ctx->code.n != trs) { long long l; HB_TRY(hobbit_graph_finalize(ctx, trs, &l)); }
+        return launch_encode(ctx, d_out, rows2, d_out, rows2, trs, (size_t)K * cols, 0);
+    }
+    if (logr > 12) return ctx->fail(HOBBIT_EINVAL, "tensorcode: RSxRS needs 2*trs <= 4096");
+    const F *tw2; HB_TRY(get_twiddles(ctx, logr, false, &tw2));   // columns: RS (src/PC_utils.cpp:92-101)
+    return launch_fft_rows(ctx, d_out, rows2, (uint32_t)trs, d_out, rows2, 1, logr, tw2, fmake(1), 0, 1, (uint32_t)((size_t)K * cols), 0, 0);
+}
+int hobbit_tensorcode(hobbit_ctx *ctx, const hobbit_F *d_msg, size_t M, int trs, int linear_time, hobbit_F *d_out) {
+    return tensorcode_chunks(ctx, cF(d_msg), M, 1, trs, linear_time, mF(d_out));
+}
+
+int hobbit_commit_standard(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, int K, int trs, int linear_time, hobbit_commitment **out) {
+    if (!out) return HOBBIT_EINVAL;
+    *out = nullptr;
+    if (K <= 0 || N % (size_t)K) return ctx->fail(HOBBIT_EINVAL, "commit_standard: K must divide N");
+    size_t M = N / K;
+    if (trs < 4 || trs % 4 || M % (size_t)trs) return ctx->fail(HOBBIT_EINVAL, "commit_standard: trs must be a multiple of 4 dividing N/K");
+    if (ilog2_exact(M) < 0) return ctx->fail(HOBBIT_EINVAL, "commit_standard: N/K must be a power of two");
+    size_t cols = 2 * M / trs, rows2 = 2 * (size_t)trs;
+    hobbit_commitment *c = new hobbit_commitment();
+    c->ctx = ctx; c->N = N; c->M = M; c->K = K; c->trs = trs; c->lin = linear_time; c->cols = (uint32_t)cols; c->rows2 = (uint32_t)rows2;
+    c->d_tensor = nullptr; c->d_levels = nullptr;
+    size_t tbytes = (size_t)K * cols * rows2 * sizeof(F);
+    c->tensor_bytes = tbytes; c->levels_bytes = 64 * M;
+    if (ctx->spare_tensor && ctx->spare_tensor_bytes == tbytes && ctx->spare_levels_bytes == 64 * M) {
+        c->d_tensor = (F *)ctx->spare_tensor; c->d_levels = (uint8_t *)ctx->spare_levels;
+        ctx->spare_tensor = nullptr; ctx->spare_levels = nullptr;
+    } else if (hipMalloc((void **)&c->d_tensor, tbytes) != hipSuccess || hipMalloc((void **)&c->d_levels, 64 * M) != hipSuccess) {
+        hobbit_commitment_free(c); return ctx->fail(HOBBIT_ENOMEM, "commit_standard: tensor allocation failed");
+    }
+    int r = tensorcode_chunks(ctx, cF(d_poly), M, K, trs, linear_time, c->d_tensor);
+    // leaf chain over the K chunks (src/Our_PC.cpp:155-167), then the tree (src/Our_PC.cpp:169)
+    if (!r) r = launch_leaf_chain(ctx, c->d_tensor, cols * rows2, K, (uint32_t)cols, (uint32_t)(trs / 2), c->d_levels);
+    if (!r) r = launch_merkle_levels(ctx, c->d_levels, M, 1);
+    if (r) { hobbit_commitment_free(c); return r; }
+    *out = c;
+    return 0;
+}
+void hobbit_commitment_free(hobbit_commitment *c) {
+    if (!c) return;
+    hobbit_ctx *ctx = c->ctx;
+    hipStreamSynchronize(ctx->stream);
+    if (c->d_tensor && c->d_levels && !ctx->spare_tensor) {      // park the buffers for the next commit
+        ctx->spare_tensor = c->d_tensor; ctx->spare_tensor_bytes = c->tensor_bytes;
+        ctx->spare_levels = c->d_levels; ctx->spare_levels_bytes = c->levels_bytes;
+    } else {
+        if (c->d_tensor) hipFree(c->d_tensor);
+        if (c->d_levels) hipFree(c->d_levels);
+    }
+    delete c;
+}
+size_t hobbit_commitment_num_leaves(const hobbit_commitment *c) { return c->M; }
+const uint8_t *hobbit_commitment_levels_dev(const hobbit_commitment *c) { return c->d_levels; }
+const hobbit_F *hobbit_commitment_tensor_dev(const hobbit_commitment *c) { return reinterpret_cast<const hobbit_F *>(c->d_tensor); }
+int hobbit_commitment_levels(hobbit_ctx *ctx, const hobbit_commitment *c, uint8_t *h_levels) { return hobbit_memcpy_d2h(ctx, h_levels, c->d_levels, 32 * (2 * c->M - 1)); }
+int hobbit_commitment_root(hobbit_ctx *ctx, const hobbit_commitment *c, uint8_t *h_root) { return hobbit_memcpy_d2h(ctx, h_root, c->d_levels + 32 * (2 * c->M - 2), 32); }
+int hobbit_commitment_tensor_row(hobbit_ctx *ctx, const hobbit_commitment *c, int chunk, int row, hobbit_F *h_out) {
+    if (chunk < 0 || chunk >= c->K || row < 0 || (uint32_t)row >= c->rows2) return ctx->fail(HOBBIT_EINVAL, "tensor_row: index out of range");
+    F *tmp; HB_TRY(ctx->workspace((size_t)c->cols * sizeof(F), (void **)&tmp));
+    HB_TRY(launch_tensor_row(ctx, c->d_tensor + (size_t)chunk * c->cols * c->rows2, c->rows2, c->cols, (uint32_t)row, tmp));
+    return hobbit_memcpy_d2h(ctx, h_out, tmp, (size_t)c->cols * sizeof(F));
+}
+int hobbit_commitment_gather(hobbit_ctx *ctx, const hobbit_commitment *c, const uint32_t *h_rows, const uint32_t *h_cols, size_t nq, hobbit_F *h_reply) {
+    for (size_t q = 0; q < nq; q++) if (h_rows[q] >= c->rows2 || h_cols[q] >= c->cols) return ctx->fail(HOBBIT_EINVAL, "gather: query out of range");
+    if (!nq) return 0;
+    uint8_t *buf; size_t rb = ((nq * c->K * sizeof(F) + 15) / 16) * 16;
+    HB_TRY(ctx->workspace(rb + 8 * nq + 64, (void **)&buf));
+    F *d_reply = reinterpret_cast<F *>(buf); uint32_t *d_rows = reinterpret_cast<uint32_t *>(buf + rb), *d_cols = d_rows + nq;
+    HB_CHECK(ctx, hipMemcpyAsync(d_rows, h_rows, 4 * nq, hipMemcpyHostToDevice, ctx->stream));
+    HB_CHECK(ctx, hipMemcpyAsync(d_cols, h_cols, 4 * nq, hipMemcpyHostToDevice, ctx->stream));
+    HB_TRY(launch_gather(ctx, c->d_tensor, (size_t)c->cols * c->rows2, c->rows2, c->K, d_rows, d_cols, nq, d_reply));
+    return hobbit_memcpy_d2h(ctx, h_reply, d_reply, nq * c->K * sizeof(F));
+}
+int hobbit_commitment_paths(hobbit_ctx *ctx, const hobbit_commitment *c, const uint32_t *h_cols, const uint32_t *h_rows, size_t nq, uint8_t *h_paths) {
+    std::vector<uint64_t> pos(nq);
+    for (size_t q = 0; q < nq; q++) pos[q] = (uint64_t)(h_rows[q] / 4) * c->cols + h_cols[q];   // src/merkle_tree.cpp:309
+    return paths_common(ctx, c->d_levels, c->M, pos.data(), nq, h_paths);
+}
+int hobbit_commitment_path(hobbit_ctx *ctx, const hobbit_commitment *c, size_t col, size_t row, uint8_t *h_path) {
+    uint32_t cc = (uint32_t)col, rr = (uint32_t)row;
+    return hobbit_commitment_paths(ctx, c, &cc, &rr, 1, h_path);
+}
+
+// ---- open building blocks ---------------------------------------------------------------------
+int hobbit_aggregate(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_F *h_beta, int K, hobbit_F *d_aggr) {
+    if (K <= 0 || N % (size_t)K) return ctx->fail(HOBBIT_EINVAL, "aggregate: K must divide N");
+    F *d_beta; HB_TRY(ctx->workspace((size_t)K * sizeof(F), (void **)&d_beta));
+    HB_CHECK(ctx, hipMemcpyAsync(d_beta, h_beta, (size_t)K * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return launch_aggregate(ctx, cF(d_poly), N / K, K, d_beta, mF(d_aggr));
+}
+
+int hobbit_sumcheck2(hobbit_ctx *ctx, const hobbit_F *d_v1, const hobbit_F *d_v2, size_t n, const hobbit_F *prev_r, hobbit_F *h_qpoly,
+                     hobbit_F *h_r, hobbit_F *h_vr, hobbit_F *h_final) {
+    return launch_sumcheck2(ctx, cF(d_v1), cF(d_v2), n, *cF(prev_r), mF(h_qpoly), mF(h_r), mF(h_vr), mF(h_final));
+}
+int hobbit_sumcheck3(hobbit_ctx *ctx, const hobbit_F *d_v1, const hobbit_F *d_v2, const hobbit_F *d_v3, size_t n, const hobbit_F *prev_r,
+                     hobbit_F *h_cpoly, hobbit_F *h_r, hobbit_F *h_vr, hobbit_F *h_final) {
+    return launch_sumcheck3(ctx, cF(d_v1), cF(d_v2), cF(d_v3), n, *cF(prev_r), mF(h_cpoly), mF(h_r), mF(h_vr), mF(h_final));
+}
+
+}  // extern "C"

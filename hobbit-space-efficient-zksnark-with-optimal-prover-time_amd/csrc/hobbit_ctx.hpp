@@ -1,0 +1,114 @@
+// hobbit_ctx.hpp -- context object behind the C ABI (include/hobbit_hip.h): device, stream,
+// error string, per-kernel HIP-event profiler, cached twiddle tables and the uploaded expander
+// graphs in their device (gather / sliced-ELL) form.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <map>
+#include <string>
+#include <vector>
+#include "hobbit_field.hpp"
+#include "../../include/hobbit_hip.h"
+
+namespace hobbit {
+
+// One SpMV step of the recursive expander encode, in gather form over the codeword buffer:
+//   cw[out_off + t] = sum_e w_e * cw[in_off + idx_e],  t in [0, out_len)
+// Edges of 64 consecutive outputs form a slice stored k-major (edge k of output t at
+// slice_ptr[t/64] + k*64 + t%64) and padded with zero-weight edges to the slice's widest row, so
+// a wavefront reads its edges with fully coalesced loads and needs no per-lane bounds.
+struct EncStep {
+    uint32_t in_off, out_off, out_len, n_slices;
+    uint32_t slice_base;   // index of this step's first slice in slice_ptr/slice_width
+};
+
+struct HostGraph {          // one uploaded level (src/expanders.h:7-16)
+    long long L = 0, R = 0;
+    int degree = 0;
+    std::vector<long long> nbr;
+    std::vector<F> w;
+};
+
+struct DeviceCode {         // finalized code for one message length n
+    long long n = 0, len = 0;
+    bool small_weights = true;               // all weights real and < 2^32
+    std::vector<EncStep> steps;
+    EncStep *d_steps = nullptr;
+    uint32_t *d_slice_ptr = nullptr, *d_slice_width = nullptr;
+    uint2 *d_edges32 = nullptr;              // {idx, w32}          (small_weights)
+    uint32_t *d_eidx = nullptr; F *d_ew = nullptr;   // general weights
+    size_t n_edges_padded = 0, n_edges = 0;
+};
+
+struct ProfEntry { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double ms = 0; long long launches = 0; };
+
+}  // namespace hobbit
+
+struct hobbit_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    std::string err;
+    // profiler
+    bool prof_on = false;
+    std::map<std::string, hobbit::ProfEntry> prof;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    // twiddles: logn -> device table of 2^(logn-1) forward (and inverse) roots
+    std::map<int, hobbit::F *> tw_fwd, tw_inv;
+    // graphs
+    std::map<std::pair<int, int>, hobbit::HostGraph> graphs;   // (dep, kind)
+    hobbit::DeviceCode code;
+    // scratch
+    void *ws = nullptr; size_t ws_bytes = 0;
+    // one retired commitment's buffers, kept for the next commit of the same shape (a 2^28 commit
+    // owns 16.5 GiB; re-allocating it per call would dominate a repeated-commit loop)
+    void *spare_tensor = nullptr; size_t spare_tensor_bytes = 0;
+    void *spare_levels = nullptr; size_t spare_levels_bytes = 0;
+
+    int fail(int code, const std::string &msg) { err = msg; return code; }
+    int hip(hipError_t e, const char *what) {
+        if (e == hipSuccess) return 0;
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return HOBBIT_EHIP;
+    }
+    void prof_begin(const char *name) {
+        if (!prof_on) return;
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        hipEventRecord(a, stream);
+        prof[name].ev.emplace_back(a, b);
+    }
+    void prof_end(const char *name) {
+        if (!prof_on) return;
+        auto &e = prof[name]; hipEventRecord(e.ev.back().second, stream); e.launches++;
+    }
+    void prof_collect() {
+        for (auto &kv : prof) {
+            for (auto &p : kv.second.ev) {
+                hipEventSynchronize(p.second);
+                float ms = 0; hipEventElapsedTime(&ms, p.first, p.second);
+                kv.second.ms += ms; hipEventDestroy(p.first); hipEventDestroy(p.second);
+            }
+            kv.second.ev.clear();
+        }
+    }
+    int workspace(size_t bytes, void **p) {
+        if (bytes > ws_bytes) {
+            if (ws) { hipStreamSynchronize(stream); hipFree(ws); ws = nullptr; ws_bytes = 0; }
+            hipError_t e = hipMalloc(&ws, bytes);
+            if (e != hipSuccess) { err = "workspace hipMalloc failed"; return HOBBIT_ENOMEM; }
+            ws_bytes = bytes;
+        }
+        *p = ws; return 0;
+    }
+};
+
+// launch + optional per-kernel event bracket; checks the launch error
+#define HB_LAUNCH(ctx, name, kern, grid, block, lds, ...)                                   \
+    do {                                                                                     \
+        (ctx)->prof_begin(name);                                                             \
+        hipLaunchKernelGGL(kern, grid, block, lds, (ctx)->stream, __VA_ARGS__);              \
+        (ctx)->prof_end(name);                                                               \
+        hipError_t e__ = hipGetLastError();                                                  \
+        if (e__ != hipSuccess) return (ctx)->hip(e__, name);                                 \
+    } while (0)
+#define HB_CHECK(ctx, call) do { int r__ = (ctx)->hip((call), #call); if (r__) return r__; } while (0)
+#define HB_TRY(expr) do { int r__ = (expr); if (r__) return r__; } while (0)

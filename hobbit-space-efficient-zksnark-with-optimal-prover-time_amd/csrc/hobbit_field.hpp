@@ -1,0 +1,91 @@
+// hobbit_field.hpp -- F_{p^2} arithmetic, p = 2^61-1, i^2 = -1, for gfx950 device code and the
+// host-side transcript/orchestration code of libhobbit_hip.so.
+//
+// Semantics follow the reference's virgo::fieldElement (src/fieldElement.cpp:34-96, 336-360):
+// 16-byte elements {real, img}, canonical outputs 0 <= x < p for canonical inputs.  Because + and *
+// are exact ring operations with canonical results, any evaluation order is bit-identical to the
+// reference's sequential loops -- that is what lets the kernels use tree /
+// wavefront reductions and lazy 128-bit accumulation.
+//
+// gfx950 notes: a 64x64->128 product lowers to 4 v_mad_u64_u32; one F_{p^2} product is 3 such
+// products (Karatsuba) folded with two Mersenne reductions = 12 v_mad_u64_u32 + ~60 VALU.  A
+// product with a 32-bit real scalar (the expander weights, src/expanders.h:37) is 4 v_mad_u64_u32.
+#pragma once
+#include <stdint.h>
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define HB_HD __host__ __device__ __forceinline__
+#else
+#define HB_HD inline
+#endif
+
+namespace hobbit {
+
+typedef unsigned __int128 u128;
+static constexpr uint64_t P61 = 2305843009213693951ULL;
+
+struct __attribute__((aligned(16))) F {
+    uint64_t re, im;
+};
+
+HB_HD F fmake(uint64_t re, uint64_t im = 0) { F r; r.re = re; r.im = im; return r; }
+HB_HD bool fis0(const F &a) { return (a.re | a.im) == 0; }
+HB_HD bool feq(const F &a, const F &b) { return a.re == b.re && a.im == b.im; }
+
+HB_HD uint64_t addp(uint64_t a, uint64_t b) { uint64_t s = a + b; return s >= P61 ? s - P61 : s; }
+HB_HD uint64_t subp(uint64_t a, uint64_t b) { return a >= b ? a - b : a + P61 - b; }
+// x < 2^124 -> canonical
+HB_HD uint64_t red124(u128 x) {
+    uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+    uint64_t s = (lo & P61) + ((hi << 3) | (lo >> 61));   // x>>61 < 2^63: no overflow
+    uint64_t t = (s & P61) + (s >> 61);
+    return t >= P61 ? t - P61 : t;
+}
+// canonical a,b -> canonical a*b
+HB_HD uint64_t mulp(uint64_t a, uint64_t b) {
+    u128 x = (u128)a * b;
+    uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+    uint64_t s = (lo & P61) + ((hi << 3) | (lo >> 61));
+    return s >= P61 ? s - P61 : s;
+}
+// canonical a (< 2^61) times a 32-bit scalar
+HB_HD uint64_t mulp32(uint64_t a, uint32_t w) {
+    u128 x = (u128)a * (uint64_t)w;                        // < 2^93
+    uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+    uint64_t s = (lo & P61) + ((hi << 3) | (lo >> 61));   // < 2^61 + 2^32
+    return s >= P61 ? s - P61 : s;
+}
+
+HB_HD F fadd(const F &a, const F &b) { return fmake(addp(a.re, b.re), addp(a.im, b.im)); }
+HB_HD F fsub(const F &a, const F &b) { return fmake(subp(a.re, b.re), subp(a.im, b.im)); }
+HB_HD F fneg(const F &a) { return fmake(a.re ? P61 - a.re : 0, a.im ? P61 - a.im : 0); }
+// (a+bi)(c+di) = (ac - bd) + ((a+b)(c+d) - ac - bd) i, all three products kept 128-bit wide and
+// folded once per component.  C = p*2^61 >= (p-1)^2 keeps ac + C - bd non-negative.
+HB_HD F fmul(const F &a, const F &b) {
+    u128 ac = (u128)a.re * b.re, bd = (u128)a.im * b.im;
+    u128 all = (u128)(a.re + a.im) * (b.re + b.im);        // operands < 2^62
+    const u128 C = ((u128)P61) << 61;
+    return fmake(red124(ac + C - bd), red124(all - ac - bd));
+}
+HB_HD F fsqr(const F &a) { return fmul(a, a); }
+HB_HD F fmul32(const F &a, uint32_t w) { return fmake(mulp32(a.re, w), mulp32(a.im, w)); }
+// multiply by i: (a+bi) i = -b + a i
+HB_HD F fmul_i(const F &a) { return fmake(a.im ? P61 - a.im : 0, a.re); }
+
+inline F fpow(F x, u128 e) { F r = fmake(1); while (e) { if (e & 1) r = fmul(r, x); x = fmul(x, x); e >>= 1; } return r; }
+inline F finv(const F &x) { return fpow(x, (u128)P61 * P61 - 2); }              // src/fieldElement.cpp:206-209
+// order-2^logn root of unity (src/utils.cpp:452-463 / src/fieldElement.cpp:237-249)
+inline F root_of_unity(int logn) { F r = fmake(2147483648ULL, 1033321771269002680ULL); for (int i = 0; i < 62 - logn; i++) r = fmul(r, r); return r; }
+
+// MiMC transcript hash (src/mimc.cpp:95-107; constants Common[i] = F(i), src/mimc.cpp:11-19):
+// 161 rounds t <- (h + k + c_{i-1})^3 (round 0: t = x + k), result h + k.  Strictly sequential.
+HB_HD F mimc_hash(const F &x, const F &k) {
+    F h = fmake(0), t;
+    for (int i = 0; i < 161; i++) {
+        t = i == 0 ? fadd(x, k) : fadd(fadd(h, k), fmake((uint64_t)(i - 1)));
+        h = fmul(fmul(t, t), t);
+    }
+    return fadd(h, k);
+}
+
+}  // namespace hobbit

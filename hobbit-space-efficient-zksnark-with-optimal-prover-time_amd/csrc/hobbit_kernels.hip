@@ -1,0 +1,576 @@
+// hobbit_kernels.hip -- gfx950 kernels of the HOBBIT prover hot path and their launchers.
+//
+// All kernels are integer (F_{p^2}, p = 2^61-1) or hash work: no MFMA.  The streaming kernels
+// (fold, aggregate, leaf chain, tree levels) are HBM-bound and use 16-byte-per-lane coalesced
+// accesses; the FFT and the expander encode keep a whole row / codeword in LDS (64 KB / <=110 KB
+// of the CU's 160 KB) and are bound by the v_mad_u64_u32 rate.
+#include "hobbit_kernels.hpp"
+#include "hobbit_blake3.hpp"
+
+namespace hobbit {
+
+// ============================================================================================
+// small utilities
+// ============================================================================================
+__device__ __forceinline__ F ldF(const F *p) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(p);     // one global_load_dwordx4 / ds_read_b128
+    F r; r.re = (uint64_t)v.x | ((uint64_t)v.y << 32); r.im = (uint64_t)v.z | ((uint64_t)v.w << 32); return r;
+}
+__device__ __forceinline__ void stF(F *p, const F &a) {
+    uint4 v; v.x = (uint32_t)a.re; v.y = (uint32_t)(a.re >> 32); v.z = (uint32_t)a.im; v.w = (uint32_t)(a.im >> 32);
+    *reinterpret_cast<uint4 *>(p) = v;
+}
+__device__ __forceinline__ F shfl_down_F(const F &a, int d) {
+    F r;
+    r.re = __shfl_down((unsigned long long)a.re, d, 64);
+    r.im = __shfl_down((unsigned long long)a.im, d, 64);
+    return r;
+}
+// sum over the 64 lanes of a wavefront; result valid in lane 0
+__device__ __forceinline__ F wave_sum(F a) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) a = fadd(a, shfl_down_F(a, d));
+    return a;
+}
+
+__global__ void k_f_binop(int op, const F *a, const F *b, F *o, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        F x = ldF(a + i), y = ldF(b + i);
+        stF(o + i, op == 0 ? fadd(x, y) : op == 1 ? fsub(x, y) : fmul(x, y));
+    }
+}
+__device__ __forceinline__ uint64_t splitmix(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed * 0x632BE59BD9B4E019ULL + idx * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__global__ void k_fill_splitmix(F *o, size_t n, uint64_t seed) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        stF(o + i, fmake(splitmix(seed, 2 * i + 1) % P61, splitmix(seed, 2 * i + 2) % P61));
+}
+
+static inline int grid_for(size_t n, int block, int cap = 4096) {
+    size_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > (size_t)cap) g = cap;
+    return (int)g;
+}
+
+int launch_f_binop(hobbit_ctx *ctx, int op, const F *a, const F *b, F *o, size_t n) {
+    HB_LAUNCH(ctx, "k_f_binop", k_f_binop, dim3(grid_for(n, 256)), dim3(256), 0, op, a, b, o, n);
+    return 0;
+}
+int launch_fill_splitmix(hobbit_ctx *ctx, F *o, size_t n, uint64_t seed) {
+    HB_LAUNCH(ctx, "k_fill_splitmix", k_fill_splitmix, dim3(grid_for(n, 256)), dim3(256), 0, o, n, seed);
+    return 0;
+}
+
+// ============================================================================================
+// FFT: one workgroup per row, the whole row (<= 4096 x 16 B = 64 KB) in LDS.
+// Radix-2 DIT on bit-reversed input == the reference's _fft (src/utils.cpp:605-673): same DFT,
+// natural order in and out.  Two radix-2 stages are fused per barrier (radix-4 in registers).
+// The source row may be shorter than the transform (zero padding, src/PC_utils.cpp:75-84) and the
+// destination may be strided (dst_es = element stride), which is how the row FFT of the tensor
+// code writes straight into the codeword-major tensor.
+// ============================================================================================
+__global__ void __launch_bounds__(256)
+k_fft_rows(const F *__restrict__ src, size_t src_ld, uint32_t src_len, F *__restrict__ dst, size_t dst_ld, size_t dst_es,
+           int logn, const F *__restrict__ tw, F scale, int do_scale, uint32_t rows_per_group, size_t src_gs, size_t dst_gs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    F *s = reinterpret_cast<F *>(lds_raw);
+    const uint32_t len = 1u << logn;
+    // row = (group, r): lets one launch cover K chunks x trs rows with per-chunk base strides
+    const uint32_t grp = blockIdx.x / rows_per_group, r = blockIdx.x % rows_per_group;
+    const F *in = src + (size_t)grp * src_gs + (size_t)r * src_ld;
+    F *out = dst + (size_t)grp * dst_gs + (size_t)r * dst_ld;
+    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+        F v = i < src_len ? ldF(in + i) : fmake(0);
+        stF(&s[__brev(i) >> (32 - logn)], v);
+    }
+    __syncthreads();
+    uint32_t h = 1;
+    int st = 0;
+    if (logn & 1) {   // single radix-2 stage first when the stage count is odd
+        for (uint32_t b = threadIdx.x; b < len / 2; b += blockDim.x) {
+            F u = ldF(&s[2 * b]), v = ldF(&s[2 * b + 1]);   // twiddle w^0 = 1
+            stF(&s[2 * b], fadd(u, v)); stF(&s[2 * b + 1], fsub(u, v));
+        }
+        __syncthreads();
+        h = 2; st = 1;
+    }
+    for (; st < logn; st += 2, h <<= 2) {
+        const uint32_t sA = len / (2 * h), sB = len / (4 * h);   // twiddle strides of the two stages
+        for (uint32_t b = threadIdx.x; b < len / 4; b += blockDim.x) {
+            const uint32_t k = b & (h - 1), j = b / h;
+            const uint32_t i0 = j * 4 * h + k;
+            F a0 = ldF(&s[i0]), a1 = ldF(&s[i0 + h]), a2 = ldF(&s[i0 + 2 * h]), a3 = ldF(&s[i0 + 3 * h]);
+            const F wA = ldF(tw + (size_t)k * sA);
+            F t1 = fmul(a1, wA), t3 = fmul(a3, wA);
+            F b0 = fadd(a0, t1), b1 = fsub(a0, t1), b2 = fadd(a2, t3), b3 = fsub(a2, t3);
+            const F wB0 = ldF(tw + (size_t)k * sB), wB1 = ldF(tw + (size_t)(k + h) * sB);
+            F u2 = fmul(b2, wB0), u3 = fmul(b3, wB1);
+            stF(&s[i0], fadd(b0, u2)); stF(&s[i0 + 2 * h], fsub(b0, u2));
+            stF(&s[i0 + h], fadd(b1, u3)); stF(&s[i0 + 3 * h], fsub(b1, u3));
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+        F v = ldF(&s[i]);
+        if (do_scale) v = fmul(v, scale);
+        stF(out + (size_t)i * dst_es, v);
+    }
+}
+
+int launch_fft_rows(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_len, F *dst, size_t dst_ld, size_t dst_es,
+                    int logn, const F *tw, F scale, int do_scale, uint32_t groups, uint32_t rows_per_group, size_t src_gs, size_t dst_gs) {
+    if (logn < 1 || logn > 12) return ctx->fail(HOBBIT_EINVAL, "fft: logn must be in [1,12] for the LDS-resident kernel");
+    size_t lds = (size_t)16 << logn;
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void *)k_fft_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_set = true; }
+    size_t blocks = (size_t)groups * rows_per_group;
+    if (blocks == 0) return 0;
+    HB_LAUNCH(ctx, "k_fft_rows", k_fft_rows, dim3((unsigned)blocks), dim3(256), lds, src, src_ld, src_len, dst, dst_ld, dst_es, logn, tw,
+              scale, do_scale, rows_per_group, src_gs, dst_gs);
+    return 0;
+}
+
+// ============================================================================================
+// Expander encode (src/linear_code_encode.h:62-119), one workgroup per message, the whole
+// codeword in LDS.  The recursion unrolls into a straight sequence of SpMV steps over one buffer
+//   [x_0 | x_1 = C_0 x_0 | ... | x_D | z_{D-1} = D_{D-1} cw_D | ... | z_0 = D_0 cw_1]
+// (the reference places the child codeword at dst+n and the D output behind it), executed in
+// gather form (reverse adjacency: no atomics, deterministic, one writer per output).
+// ============================================================================================
+template <bool SMALLW>
+__global__ void k_encode(const F *__restrict__ src, size_t ld_src, F *__restrict__ dst, size_t ld_dst, uint32_t n, uint32_t len,
+                         const EncStep *__restrict__ steps, int nsteps, const uint32_t *__restrict__ slice_ptr,
+                         const uint32_t *__restrict__ slice_width, const uint2 *__restrict__ e32, const uint32_t *__restrict__ eidx,
+                         const F *__restrict__ ew, int write_msg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    F *cw = reinterpret_cast<F *>(lds_raw);
+    const F *in = src + (size_t)blockIdx.x * ld_src;
+    F *out = dst + (size_t)blockIdx.x * ld_dst;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) stF(&cw[i], ldF(in + i));
+    __syncthreads();
+    for (int s = 0; s < nsteps; s++) {
+        const EncStep sp = steps[s];
+        const F *cin = cw + sp.in_off;
+        for (uint32_t t = threadIdx.x; t < sp.n_slices * 64; t += blockDim.x) {   // blockDim % 64 == 0: whole slices per wave
+            const uint32_t sl = sp.slice_base + (t >> 6), lane = t & 63;
+            const uint32_t base = slice_ptr[sl] + lane, width = slice_width[sl];
+            F acc = fmake(0);
+            for (uint32_t k = 0; k < width; k++) {
+                if (SMALLW) {
+                    const uint2 e = e32[base + k * 64];
+                    acc = fadd(acc, fmul32(ldF(cin + e.x), e.y));
+                } else {
+                    const uint32_t id = eidx[base + k * 64];
+                    acc = fadd(acc, fmul(ldF(cin + id), ldF(ew + base + k * 64)));
+                }
+            }
+            if (t < sp.out_len) stF(&cw[sp.out_off + t], acc);
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = write_msg ? threadIdx.x : n + threadIdx.x; i < 2 * n; i += blockDim.x) stF(out + i, i < len ? ldF(&cw[i]) : fmake(0));
+}
+
+int launch_encode(hobbit_ctx *ctx, const F *src, size_t ld_src, F *dst, size_t ld_dst, long long n, size_t batch, int write_msg) {
+    DeviceCode &c = ctx->code;
+    if (c.n != n) return ctx->fail(HOBBIT_ESTATE, "encode: graphs for this n are not finalized (hobbit_graph_finalize)");
+    if (batch == 0) return 0;
+    size_t lds = (size_t)c.len * 16;
+    if (lds > 160 * 1024) return ctx->fail(HOBBIT_EINVAL, "encode: codeword does not fit in 160 KB of LDS (n <= 4096 supported)");
+    // threads: enough for the widest step (C_0: 0.211 n outputs), a multiple of 64
+    uint32_t widest = 64;
+    for (auto &s : c.steps) widest = s.n_slices * 64 > widest ? s.n_slices * 64 : widest;
+    uint32_t block = widest > 1024 ? 1024 : widest;
+    if (n >= 64 && block < 256) block = 256;
+    if (c.small_weights) {
+        hipFuncSetAttribute((const void *)k_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        HB_LAUNCH(ctx, "k_encode", k_encode<true>, dim3((unsigned)batch), dim3(block), lds, src, ld_src, dst, ld_dst, (uint32_t)n, (uint32_t)c.len,
+                  c.d_steps, (int)c.steps.size(), c.d_slice_ptr, c.d_slice_width, c.d_edges32, c.d_eidx, c.d_ew, write_msg);
+    } else {
+        hipFuncSetAttribute((const void *)k_encode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        HB_LAUNCH(ctx, "k_encode_fullw", k_encode<false>, dim3((unsigned)batch), dim3(block), lds, src, ld_src, dst, ld_dst, (uint32_t)n,
+                  (uint32_t)c.len, c.d_steps, (int)c.steps.size(), c.d_slice_ptr, c.d_slice_width, c.d_edges32, c.d_eidx, c.d_ew, write_msg);
+    }
+    return 0;
+}
+
+// ============================================================================================
+// BLAKE3 / Merkle
+// ============================================================================================
+__device__ __forceinline__ void load16w(const void *p, uint32_t m[16]) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { uint4 v = q[i]; m[4 * i] = v.x; m[4 * i + 1] = v.y; m[4 * i + 2] = v.z; m[4 * i + 3] = v.w; }
+}
+__device__ __forceinline__ void load8w(const void *p, uint32_t m[8]) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+    for (int i = 0; i < 2; i++) { uint4 v = q[i]; m[4 * i] = v.x; m[4 * i + 1] = v.y; m[4 * i + 2] = v.z; m[4 * i + 3] = v.w; }
+}
+__device__ __forceinline__ void store8w(void *p, const uint32_t h[8]) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(h[0], h[1], h[2], h[3]); q[1] = make_uint4(h[4], h[5], h[6], h[7]);
+}
+
+__global__ void k_blake3_64(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t m[16], h[8];
+        load16w(in + 64 * i, m); blake3_compress64(m, h); store8w(out + 32 * i, h);
+    }
+}
+// out[i] = H( H(xyzw[i]) | prev[i] )   (src/merkle_tree.cpp:62-87)
+__global__ void k_hash_md(const F *__restrict__ xyzw, const uint8_t *__restrict__ prev, uint8_t *__restrict__ out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t m[16], h[8];
+        load16w(xyzw + 4 * i, m); blake3_compress64(m, h);
+#pragma unroll
+        for (int j = 0; j < 8; j++) m[j] = h[j];
+        load8w(prev + 32 * i, m + 8);
+        blake3_compress64(m, h); store8w(out + 32 * i, h);
+    }
+}
+// level kernel: cur[i] = H(prev[2i] | prev[2i + (quirk ? 0 : 1)])   (src/merkle_tree.cpp:255-287)
+__global__ void k_merkle_level(const uint8_t *__restrict__ prev, uint8_t *__restrict__ cur, size_t n_cur, int quirk) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_cur; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t m[16], h[8];
+        load8w(prev + 64 * i, m);
+        if (quirk) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) m[8 + j] = m[j];
+        } else load8w(prev + 64 * i + 32, m + 8);
+        blake3_compress64(m, h); store8w(cur + 32 * i, h);
+    }
+}
+// Our_PC leaf chain over all K chunks (src/Our_PC.cpp:162-166).  The tensor is codeword-major
+// ([chunk][col][2 trs]), so the 4 field elements of leaf (j, col) are 64 contiguous bytes.  One
+// thread owns one leaf and keeps its Merkle-Damgard state in registers across the chunk loop:
+// the tensor is read exactly once and the leaf array is written exactly once.
+__global__ void k_leaf_chain(const F *__restrict__ tensor, size_t chunk_stride, int K, uint32_t cols, uint32_t half_trs,
+                             uint8_t *__restrict__ leaves) {
+    const size_t total = (size_t)cols * half_trs;
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t c = (uint32_t)(g / half_trs), j = (uint32_t)(g % half_trs);
+        uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const F *p = tensor + ((size_t)c * half_trs + j) * 4;     // (c * 2trs + 4j)
+        for (int i = 0; i < K; i++) {
+            uint32_t m[16], h[8];
+            load16w(p + (size_t)i * chunk_stride, m);
+            blake3_compress64(m, h);
+#pragma unroll
+            for (int q = 0; q < 8; q++) { m[q] = h[q]; m[8 + q] = st[q]; }
+            blake3_compress64(m, st);
+        }
+        store8w(leaves + 32 * ((size_t)j * cols + c), st);
+    }
+}
+// paths[q][l] = levels[off_l + (pos_q >> l) ^ 1]   (src/merkle_tree.cpp:308-324)
+__global__ void k_merkle_paths(const uint8_t *__restrict__ levels, size_t n, const uint64_t *__restrict__ pos, size_t nq, int depth,
+                               uint8_t *__restrict__ paths) {
+    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (g >= nq * depth) return;
+    size_t q = g / depth; int l = (int)(g % depth);
+    size_t off = 0, sz = n;
+    for (int t = 0; t < l; t++) { off += sz; sz >>= 1; }
+    size_t p = (pos[q] >> l) ^ 1;
+    const uint4 *s = reinterpret_cast<const uint4 *>(levels + 32 * (off + p));
+    uint4 *d = reinterpret_cast<uint4 *>(paths + 32 * g);
+    d[0] = s[0]; d[1] = s[1];
+}
+
+int launch_blake3_64(hobbit_ctx *ctx, const uint8_t *in, uint8_t *out, size_t n) {
+    if (!n) return 0;
+    HB_LAUNCH(ctx, "k_blake3_64", k_blake3_64, dim3(grid_for(n, 256)), dim3(256), 0, in, out, n);
+    return 0;
+}
+int launch_hash_md(hobbit_ctx *ctx, const F *xyzw, const uint8_t *prev, uint8_t *out, size_t n) {
+    if (!n) return 0;
+    HB_LAUNCH(ctx, "k_hash_md", k_hash_md, dim3(grid_for(n, 256)), dim3(256), 0, xyzw, prev, out, n);
+    return 0;
+}
+int launch_merkle_levels(hobbit_ctx *ctx, uint8_t *levels, size_t n, int quirk) {
+    size_t off = 0, tot = n;
+    for (size_t sz = n / 2; sz >= 1; sz /= 2) {
+        HB_LAUNCH(ctx, "k_merkle_level", k_merkle_level, dim3(grid_for(sz, 256)), dim3(256), 0, levels + 32 * off, levels + 32 * tot, sz, quirk);
+        off = tot; tot += sz;
+    }
+    return 0;
+}
+int launch_leaf_chain(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, int K, uint32_t cols, uint32_t half_trs, uint8_t *leaves) {
+    size_t total = (size_t)cols * half_trs;
+    HB_LAUNCH(ctx, "k_leaf_chain", k_leaf_chain, dim3(grid_for(total, 256, 1 << 20)), dim3(256), 0, tensor, chunk_stride, K, cols, half_trs, leaves);
+    return 0;
+}
+int launch_merkle_paths(hobbit_ctx *ctx, const uint8_t *levels, size_t n, const uint64_t *d_pos, size_t nq, int depth, uint8_t *d_paths) {
+    size_t total = nq * depth;
+    if (!total) return 0;
+    HB_LAUNCH(ctx, "k_merkle_paths", k_merkle_paths, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, levels, n, d_pos, nq, depth, d_paths);
+    return 0;
+}
+
+// ============================================================================================
+// eq table / aggregate / gather
+// ============================================================================================
+// one doubling step of precompute_beta (src/utils.cpp:251-296): new[2j] = old[j] - r*old[j]; new[2j+1] = r*old[j]
+__global__ void k_eq_step(const F *__restrict__ old, F *__restrict__ nw, size_t m, F r) {
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < m; j += (size_t)gridDim.x * blockDim.x) {
+        F o = ldF(old + j), t = fmul(r, o);
+        stF(nw + 2 * j, fsub(o, t)); stF(nw + 2 * j + 1, t);
+    }
+}
+int launch_eq_table(hobbit_ctx *ctx, const F *h_r, int k, F *d_out) {
+    // ping-pong between d_out (final) and workspace so that the last step lands in d_out
+    size_t n = (size_t)1 << k;
+    F *tmp = nullptr;
+    if (k > 0) HB_TRY(ctx->workspace(n / 2 * sizeof(F), (void **)&tmp));
+    F one = fmake(1);
+    F *cur = (k % 2 == 0) ? d_out : tmp;
+    HB_CHECK(ctx, hipMemcpyAsync(cur, &one, sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // `one` is a stack temporary
+    for (int i = 0; i < k; i++) {
+        F *nxt = cur == d_out ? tmp : d_out;
+        size_t m = (size_t)1 << i;
+        HB_LAUNCH(ctx, "k_eq_step", k_eq_step, dim3(grid_for(m, 256)), dim3(256), 0, cur, nxt, m, h_r[k - 1 - i]);
+        cur = nxt;
+    }
+    return 0;
+}
+// aggr[j] = sum_i beta[i] * poly[i*M + j]   (src/Our_PC.cpp:258-272)
+__global__ void k_aggregate(const F *__restrict__ poly, size_t M, int K, const F *__restrict__ beta, F *__restrict__ aggr) {
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < M; j += (size_t)gridDim.x * blockDim.x) {
+        F acc = fmake(0);
+        for (int i = 0; i < K; i++) acc = fadd(acc, fmul(ldF(beta + i), ldF(poly + (size_t)i * M + j)));
+        stF(aggr + j, acc);
+    }
+}
+int launch_aggregate(hobbit_ctx *ctx, const F *poly, size_t M, int K, const F *d_beta, F *aggr) {
+    HB_LAUNCH(ctx, "k_aggregate", k_aggregate, dim3(grid_for(M, 256)), dim3(256), 0, poly, M, K, d_beta, aggr);
+    return 0;
+}
+// reply[q*K + i] = tensor[i][col_q][row_q]   (src/Our_PC.cpp:291-305, codeword-major tensor)
+__global__ void k_gather(const F *__restrict__ tensor, size_t chunk_stride, uint32_t rows2, int K, const uint32_t *__restrict__ rows,
+                         const uint32_t *__restrict__ cols, size_t nq, F *__restrict__ reply) {
+    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (g >= nq * K) return;
+    size_t q = g / K; int i = (int)(g % K);
+    stF(reply + g, ldF(tensor + (size_t)i * chunk_stride + (size_t)cols[q] * rows2 + rows[q]));
+}
+int launch_gather(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, uint32_t rows2, int K, const uint32_t *d_rows, const uint32_t *d_cols,
+                  size_t nq, F *d_reply) {
+    size_t total = nq * K;
+    if (!total) return 0;
+    HB_LAUNCH(ctx, "k_gather", k_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, tensor, chunk_stride, rows2, K, d_rows, d_cols, nq, d_reply);
+    return 0;
+}
+// row `row` of one chunk in the reference's row-major order: out[c] = tensor[c*rows2 + row]
+__global__ void k_tensor_row(const F *__restrict__ chunk, uint32_t rows2, uint32_t cols, uint32_t row, F *__restrict__ out) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < cols) stF(out + c, ldF(chunk + (size_t)c * rows2 + row));
+}
+int launch_tensor_row(hobbit_ctx *ctx, const F *chunk, uint32_t rows2, uint32_t cols, uint32_t row, F *d_out) {
+    HB_LAUNCH(ctx, "k_tensor_row", k_tensor_row, dim3((cols + 255) / 256), dim3(256), 0, chunk, rows2, cols, row, d_out);
+    return 0;
+}
+// multilinear evaluation fold step of evaluate_vector (src/utils.cpp:789-802): v'[j] = (1-r) v[2j] + r v[2j+1]
+__global__ void k_eval_fold(const F *__restrict__ v, F *__restrict__ o, size_t L, F r) {
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < L; j += (size_t)gridDim.x * blockDim.x) {
+        F a = ldF(v + 2 * j), b = ldF(v + 2 * j + 1);
+        stF(o + j, fadd(a, fmul(r, fsub(b, a))));
+    }
+}
+int launch_eval_fold(hobbit_ctx *ctx, const F *v, F *o, size_t L, F r) {
+    HB_LAUNCH(ctx, "k_eval_fold", k_eval_fold, dim3(grid_for(L, 256)), dim3(256), 0, v, o, L, r);
+    return 0;
+}
+
+// ============================================================================================
+// Sumcheck (src/sumcheck.cpp:2391-2460 two-product, 1974-2058 three-product)
+//
+// Per round: one streaming kernel over the tables that produces per-workgroup partial sums of the
+// round polynomial's coefficients, then a one-workgroup finishing kernel that reduces them and
+// runs the MiMC transcript (3-4 x 161 sequential cubings) ON THE DEVICE, leaving the next
+// challenge in device memory for the next launch: no host round trip inside the round loop.
+// Coefficient sums are exact field sums, so any reduction tree is bit-identical to the
+// reference's sequential accumulation.
+// ============================================================================================
+struct SC2State { F rand; };
+
+template <int NC>
+__device__ __forceinline__ void block_reduce_store(F (&c)[NC], F *partials) {
+    __shared__ F red[NC][16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NC; q++) { F s = wave_sum(c[q]); if (lane == 0) red[q][wv] = s; }
+    __syncthreads();
+    if (threadIdx.x < NC) {
+        F s = red[threadIdx.x][0];
+        for (int w = 1; w < nw; w++) s = fadd(s, red[threadIdx.x][w]);
+        stF(partials + (size_t)blockIdx.x * NC + threadIdx.x, s);
+    }
+}
+__device__ __forceinline__ void acc_quad(F (&c)[3], const F &x0, const F &x1, const F &y0, const F &y1) {
+    // (dx t + x0)(dy t + y0): a = dx dy, b = dx y0 + x0 dy, c = x0 y0   (src/polynomial.cpp:133-135)
+    F dx = fsub(x1, x0), dy = fsub(y1, y0);
+    c[0] = fadd(c[0], fmul(dx, dy));
+    c[1] = fadd(c[1], fadd(fmul(dx, y0), fmul(x0, dy)));
+    c[2] = fadd(c[2], fmul(x0, y0));
+}
+// round 0 of the 2-product sumcheck: polynomial only (inputs are preserved)
+__global__ void __launch_bounds__(256) k_sc2_poly(const F *__restrict__ v1, const F *__restrict__ v2, size_t L, F *__restrict__ partials) {
+    F c[3] = {fmake(0), fmake(0), fmake(0)};
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < L; j += (size_t)gridDim.x * blockDim.x)
+        acc_quad(c, ldF(v1 + 2 * j), ldF(v1 + 2 * j + 1), ldF(v2 + 2 * j), ldF(v2 + 2 * j + 1));
+    block_reduce_store<3>(c, partials);
+}
+// rounds >= 1: fold the previous tables with the challenge just derived (4 -> 2 elements per
+// thread and table) and accumulate this round's polynomial from the folded pair in registers.
+__global__ void __launch_bounds__(256) k_sc2_fold_poly(const F *__restrict__ s1, const F *__restrict__ s2, F *__restrict__ d1, F *__restrict__ d2,
+                                                       size_t L, const F *__restrict__ rand_p, F *__restrict__ partials) {
+    const F r = ldF(rand_p);
+    F c[3] = {fmake(0), fmake(0), fmake(0)};
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < L; j += (size_t)gridDim.x * blockDim.x) {
+        F a0 = ldF(s1 + 4 * j), a1 = ldF(s1 + 4 * j + 1), a2 = ldF(s1 + 4 * j + 2), a3 = ldF(s1 + 4 * j + 3);
+        F b0 = ldF(s2 + 4 * j), b1 = ldF(s2 + 4 * j + 1), b2 = ldF(s2 + 4 * j + 2), b3 = ldF(s2 + 4 * j + 3);
+        F x0 = fadd(a0, fmul(r, fsub(a1, a0))), x1 = fadd(a2, fmul(r, fsub(a3, a2)));
+        F y0 = fadd(b0, fmul(r, fsub(b1, b0))), y1 = fadd(b2, fmul(r, fsub(b3, b2)));
+        stF(d1 + 2 * j, x0); stF(d1 + 2 * j + 1, x1); stF(d2 + 2 * j, y0); stF(d2 + 2 * j + 1, y1);
+        acc_quad(c, x0, x1, y0, y1);
+    }
+    block_reduce_store<3>(c, partials);
+}
+// last fold (tables of 2 -> 1) + closing transcript steps
+__global__ void k_sc2_final(const F *__restrict__ s1, const F *__restrict__ s2, F *__restrict__ state, F *__restrict__ out_vr_fin) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        F r = ldF(state);
+        F a0 = ldF(s1), a1 = ldF(s1 + 1), b0 = ldF(s2), b1 = ldF(s2 + 1);
+        F x = fadd(a0, fmul(r, fsub(a1, a0))), y = fadd(b0, fmul(r, fsub(b1, b0)));
+        r = mimc_hash(r, x); r = mimc_hash(r, y);
+        stF(out_vr_fin, x); stF(out_vr_fin + 1, y); stF(out_vr_fin + 2, r);
+    }
+}
+// reduce partials, hash the coefficients into the transcript, publish challenge + proof data
+template <int NC>
+__global__ void __launch_bounds__(256) k_sc_finish(const F *__restrict__ partials, int nblocks, F *__restrict__ state, F *__restrict__ poly_out,
+                                                   F *__restrict__ r_out, int round, int record_before) {
+    F c[NC];
+#pragma unroll
+    for (int q = 0; q < NC; q++) c[q] = fmake(0);
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
+#pragma unroll
+        for (int q = 0; q < NC; q++) c[q] = fadd(c[q], ldF(partials + (size_t)b * NC + q));
+    __shared__ F red[NC][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NC; q++) { F s = wave_sum(c[q]); if (lane == 0) red[q][wv] = s; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        F r = ldF(state);
+        if (record_before) stF(r_out + round, r);          // 3-product: randomness[i] = pre-round challenge
+        for (int q = 0; q < NC; q++) {
+            F s = fadd(fadd(red[q][0], red[q][1]), fadd(red[q][2], red[q][3]));
+            stF(poly_out + (size_t)round * NC + q, s);
+            r = mimc_hash(r, s);
+        }
+        if (!record_before) stF(r_out + round, r);         // 2-product: randomness[i] = post-hash challenge
+        stF(state, r);
+    }
+}
+
+int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev_r, F *h_qpoly, F *h_r, F *h_vr, F *h_final) {
+    int rounds = 0; while (((size_t)1 << rounds) < n) rounds++;
+    if (((size_t)1 << rounds) != n || n < 2) return ctx->fail(HOBBIT_EINVAL, "sumcheck2: n must be a power of two >= 2");
+    const int MAXB = 1024;
+    // workspace: tables A (2 x n/2), B (2 x n/4), partials, state, outputs
+    size_t szA = n / 2, szB = n / 4 ? n / 4 : 1;
+    size_t elems = 2 * szA + 2 * szB + (size_t)MAXB * 3 + 1 + (size_t)rounds * 4 + 3;
+    F *ws; HB_TRY(ctx->workspace(elems * sizeof(F), (void **)&ws));
+    F *A1 = ws, *A2 = A1 + szA, *B1 = A2 + szA, *B2 = B1 + szB, *part = B2 + szB, *state = part + (size_t)MAXB * 3;
+    F *d_q = state + 1, *d_r = d_q + (size_t)rounds * 3, *d_fin = d_r + rounds;
+    HB_CHECK(ctx, hipMemcpyAsync(state, &prev_r, sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const F *s1 = v1, *s2 = v2;
+    size_t L = n / 2;
+    int nb = grid_for(L, 256, MAXB);
+    HB_LAUNCH(ctx, "k_sc2_poly", k_sc2_poly, dim3(nb), dim3(256), 0, s1, s2, L, part);
+    HB_LAUNCH(ctx, "k_sc_finish", k_sc_finish<3>, dim3(1), dim3(256), 0, part, nb, state, d_q, d_r, 0, 0);
+    F *d1 = A1, *d2 = A2;
+    for (int i = 1; i < rounds; i++) {
+        L = n >> (i + 1);
+        nb = grid_for(L, 256, MAXB);
+        HB_LAUNCH(ctx, "k_sc2_fold_poly", k_sc2_fold_poly, dim3(nb), dim3(256), 0, s1, s2, d1, d2, L, state, part);
+        HB_LAUNCH(ctx, "k_sc_finish", k_sc_finish<3>, dim3(1), dim3(256), 0, part, nb, state, d_q, d_r, i, 0);
+        s1 = d1; s2 = d2;
+        if (d1 == A1) { d1 = B1; d2 = B2; } else { d1 = A1; d2 = A2; }
+    }
+    HB_LAUNCH(ctx, "k_sc2_final", k_sc2_final, dim3(1), dim3(64), 0, s1, s2, state, d_fin);
+    HB_CHECK(ctx, hipMemcpyAsync(h_qpoly, d_q, sizeof(F) * rounds * 3, hipMemcpyDeviceToHost, ctx->stream));
+    HB_CHECK(ctx, hipMemcpyAsync(h_r, d_r, sizeof(F) * rounds, hipMemcpyDeviceToHost, ctx->stream));
+    F fin[3];
+    HB_CHECK(ctx, hipMemcpyAsync(fin, d_fin, sizeof(F) * 3, hipMemcpyDeviceToHost, ctx->stream));
+    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    h_vr[0] = fin[0]; h_vr[1] = fin[1]; *h_final = fin[2];
+    return 0;
+}
+
+// 3-product: polynomial of the current tables and fold with the PRE-round challenge in one pass
+__global__ void __launch_bounds__(256) k_sc3_poly_fold(const F *__restrict__ s1, const F *__restrict__ s2, const F *__restrict__ s3,
+                                                       F *__restrict__ d1, F *__restrict__ d2, F *__restrict__ d3, size_t L,
+                                                       const F *__restrict__ rand_p, F *__restrict__ partials) {
+    const F r = ldF(rand_p);
+    F c[4] = {fmake(0), fmake(0), fmake(0), fmake(0)};
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < L; j += (size_t)gridDim.x * blockDim.x) {
+        F x0 = ldF(s1 + 2 * j), x1 = ldF(s1 + 2 * j + 1), y0 = ldF(s2 + 2 * j), y1 = ldF(s2 + 2 * j + 1), z0 = ldF(s3 + 2 * j), z1 = ldF(s3 + 2 * j + 1);
+        F dx = fsub(x1, x0), dy = fsub(y1, y0), dz = fsub(z1, z0);
+        // (l1*l2)*l3 with the reference's operator grouping (src/polynomial.cpp:91-93,133-135)
+        F qa = fmul(dx, dy), qb = fadd(fmul(dx, y0), fmul(x0, dy)), qc = fmul(x0, y0);
+        c[0] = fadd(c[0], fmul(qa, dz));
+        c[1] = fadd(c[1], fadd(fmul(qa, z0), fmul(qb, dz)));
+        c[2] = fadd(c[2], fadd(fmul(qb, z0), fmul(qc, dz)));
+        c[3] = fadd(c[3], fmul(qc, z0));
+        stF(d1 + j, fadd(x0, fmul(r, dx))); stF(d2 + j, fadd(y0, fmul(r, dy))); stF(d3 + j, fadd(z0, fmul(r, dz)));
+    }
+    block_reduce_store<4>(c, partials);
+}
+__global__ void k_sc3_final(const F *__restrict__ s1, const F *__restrict__ s2, const F *__restrict__ s3, F *__restrict__ state, F *__restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        F r = ldF(state), x = ldF(s1), y = ldF(s2), z = ldF(s3);
+        r = mimc_hash(r, x); r = mimc_hash(r, y);        // v3[0] is not hashed (src/sumcheck.cpp:2043-2046)
+        stF(out, x); stF(out + 1, y); stF(out + 2, z); stF(out + 3, r);
+    }
+}
+int launch_sumcheck3(hobbit_ctx *ctx, const F *v1, const F *v2, const F *v3, size_t n, F prev_r, F *h_cpoly, F *h_r, F *h_vr, F *h_final) {
+    int rounds = 0; while (((size_t)1 << rounds) < n) rounds++;
+    if (((size_t)1 << rounds) != n || n < 2) return ctx->fail(HOBBIT_EINVAL, "sumcheck3: n must be a power of two >= 2");
+    const int MAXB = 1024;
+    size_t szA = n / 2, szB = n / 4 ? n / 4 : 1;
+    size_t elems = 3 * szA + 3 * szB + (size_t)MAXB * 4 + 1 + (size_t)rounds * 5 + 4;
+    F *ws; HB_TRY(ctx->workspace(elems * sizeof(F), (void **)&ws));
+    F *A = ws, *B = A + 3 * szA, *part = B + 3 * szB, *state = part + (size_t)MAXB * 4;
+    F *d_c = state + 1, *d_r = d_c + (size_t)rounds * 4, *d_fin = d_r + rounds;
+    HB_CHECK(ctx, hipMemcpyAsync(state, &prev_r, sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const F *s1 = v1, *s2 = v2, *s3 = v3;
+    F *dst = A; size_t dsz = szA;
+    for (int i = 0; i < rounds; i++) {
+        size_t L = n >> (i + 1);
+        int nb = grid_for(L, 256, MAXB);
+        HB_LAUNCH(ctx, "k_sc3_poly_fold", k_sc3_poly_fold, dim3(nb), dim3(256), 0, s1, s2, s3, dst, dst + dsz, dst + 2 * dsz, L, state, part);
+        HB_LAUNCH(ctx, "k_sc_finish4", k_sc_finish<4>, dim3(1), dim3(256), 0, part, nb, state, d_c, d_r, i, 1);
+        s1 = dst; s2 = dst + dsz; s3 = dst + 2 * dsz;
+        if (dst == A) { dst = B; dsz = szB; } else { dst = A; dsz = szA; }
+    }
+    HB_LAUNCH(ctx, "k_sc3_final", k_sc3_final, dim3(1), dim3(64), 0, s1, s2, s3, state, d_fin);
+    HB_CHECK(ctx, hipMemcpyAsync(h_cpoly, d_c, sizeof(F) * rounds * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HB_CHECK(ctx, hipMemcpyAsync(h_r, d_r, sizeof(F) * rounds, hipMemcpyDeviceToHost, ctx->stream));
+    F fin[4];
+    HB_CHECK(ctx, hipMemcpyAsync(fin, d_fin, sizeof(F) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    h_vr[0] = fin[0]; h_vr[1] = fin[1]; h_vr[2] = fin[2]; *h_final = fin[3];
+    return 0;
+}
+
+}  // namespace hobbit

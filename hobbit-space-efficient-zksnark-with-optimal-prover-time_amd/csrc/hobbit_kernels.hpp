@@ -1,0 +1,24 @@
+// hobbit_kernels.hpp -- launcher prototypes (definitions in hobbit_kernels.hip)
+#pragma once
+#include "hobbit_ctx.hpp"
+
+namespace hobbit {
+int launch_f_binop(hobbit_ctx *ctx, int op, const F *a, const F *b, F *o, size_t n);
+int launch_fill_splitmix(hobbit_ctx *ctx, F *o, size_t n, uint64_t seed);
+int launch_fft_rows(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_len, F *dst, size_t dst_ld, size_t dst_es, int logn,
+                    const F *tw, F scale, int do_scale, uint32_t groups, uint32_t rows_per_group, size_t src_gs, size_t dst_gs);
+int launch_encode(hobbit_ctx *ctx, const F *src, size_t ld_src, F *dst, size_t ld_dst, long long n, size_t batch, int write_msg);
+int launch_blake3_64(hobbit_ctx *ctx, const uint8_t *in, uint8_t *out, size_t n);
+int launch_hash_md(hobbit_ctx *ctx, const F *xyzw, const uint8_t *prev, uint8_t *out, size_t n);
+int launch_merkle_levels(hobbit_ctx *ctx, uint8_t *levels, size_t n, int quirk);
+int launch_leaf_chain(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, int K, uint32_t cols, uint32_t half_trs, uint8_t *leaves);
+int launch_merkle_paths(hobbit_ctx *ctx, const uint8_t *levels, size_t n, const uint64_t *d_pos, size_t nq, int depth, uint8_t *d_paths);
+int launch_eq_table(hobbit_ctx *ctx, const F *h_r, int k, F *d_out);
+int launch_aggregate(hobbit_ctx *ctx, const F *poly, size_t M, int K, const F *d_beta, F *aggr);
+int launch_gather(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, uint32_t rows2, int K, const uint32_t *d_rows, const uint32_t *d_cols,
+                  size_t nq, F *d_reply);
+int launch_tensor_row(hobbit_ctx *ctx, const F *chunk, uint32_t rows2, uint32_t cols, uint32_t row, F *d_out);
+int launch_eval_fold(hobbit_ctx *ctx, const F *v, F *o, size_t L, F r);
+int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev_r, F *h_qpoly, F *h_r, F *h_vr, F *h_final);
+int launch_sumcheck3(hobbit_ctx *ctx, const F *v1, const F *v2, const F *v3, size_t n, F prev_r, F *h_cpoly, F *h_r, F *h_vr, F *h_final);
+}  // namespace hobbit

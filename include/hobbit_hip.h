@@ -1,0 +1,160 @@
+/* hobbit_hip.h -- C ABI of libhobbit_hip.so, the MI355X (gfx950) implementation of the HOBBIT
+ * prover hot path: Our_PC commit/open building blocks and the in-memory sumchecks.
+ *
+ * This is the drop-in boundary: every entry point names the reference function (file:line under
+ * the reference's src/) whose body it replaces.  The reference has no FFI of its own (one C++
+ * executable); the C++ host mirror in <package>/host/hobbit_host.hpp keeps the reference's
+ * signatures (commit_standard, generate_2product_sumcheck_proof, ...) and calls this ABI.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or torch types.
+ *   - field elements: uint64_t[2] = {real, img}, canonical, exactly virgo::fieldElement
+ *     (src/fieldElement.hpp:96-97).  Hashes: uint8_t[32] = struct _hash (src/Blake3_hash.h:3-5).
+ *   - pointers named d_* are DEVICE pointers (hipMalloc / hobbit_malloc / torch data_ptr on the
+ *     context's device); pointers named h_* are HOST pointers.
+ *   - every call returns 0 on success, a negative HOBBIT_E* code otherwise; hobbit_last_error()
+ *     describes the most recent failure on the context.  Nothing falls back to the CPU: without
+ *     a HIP device hobbit_ctx_create fails with HOBBIT_ENODEV.
+ *   - work is enqueued on the context's stream; calls that return data to h_* pointers
+ *     synchronise that stream, all others are asynchronous.
+ *   - not re-entrant per context (like the reference: global scratch, global RNG); use one context
+ *     per thread / per GPU.
+ */
+#ifndef HOBBIT_HIP_H
+#define HOBBIT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HOBBIT_OK 0
+#define HOBBIT_ENODEV (-1)   /* no usable HIP device */
+#define HOBBIT_EINVAL (-2)   /* bad argument / unsupported shape */
+#define HOBBIT_ENOMEM (-3)   /* device allocation failed */
+#define HOBBIT_EHIP (-4)     /* HIP runtime error (see hobbit_last_error) */
+#define HOBBIT_ESTATE (-5)   /* call order violated (e.g. encode before graph upload) */
+
+typedef struct hobbit_ctx hobbit_ctx;
+typedef struct hobbit_commitment hobbit_commitment;
+typedef struct { uint64_t re, im; } hobbit_F;
+
+/* ---- context, memory, timing ------------------------------------------------------------- */
+int hobbit_ctx_create(int device, hobbit_ctx **out);
+/* share an existing hipStream_t (e.g. torch's current stream); stream==NULL creates one */
+int hobbit_ctx_create_on_stream(int device, void *hip_stream, hobbit_ctx **out);
+void hobbit_ctx_destroy(hobbit_ctx *ctx);
+const char *hobbit_last_error(const hobbit_ctx *ctx);
+const char *hobbit_version(void);
+int hobbit_sync(hobbit_ctx *ctx);
+int hobbit_malloc(hobbit_ctx *ctx, size_t bytes, void **d_ptr);
+int hobbit_free(hobbit_ctx *ctx, void *d_ptr);
+int hobbit_memcpy_h2d(hobbit_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int hobbit_memcpy_d2h(hobbit_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int hobbit_memset(hobbit_ctx *ctx, void *d_dst, int value, size_t bytes);
+/* HIP-event timing on the context's stream (bench.py's timed region / roofline) */
+int hobbit_timer_begin(hobbit_ctx *ctx);
+int hobbit_timer_end_ms(hobbit_ctx *ctx, float *ms);
+/* per-kernel profiling: when enabled every kernel launch is bracketed by HIP events on the
+ * context's stream; hobbit_profile_get returns total ms and launch count by kernel name. */
+int hobbit_profile_enable(hobbit_ctx *ctx, int on);
+int hobbit_profile_reset(hobbit_ctx *ctx);
+int hobbit_profile_get(hobbit_ctx *ctx, const char *kernel, double *total_ms, long long *launches);
+int hobbit_profile_names(hobbit_ctx *ctx, char *buf, size_t buflen); /* ';'-separated */
+
+/* ---- field / transcript (host-side helpers; src/fieldElement.cpp, src/mimc.cpp:95-107) ---- */
+void hobbit_mimc(const hobbit_F *x, const hobbit_F *k, hobbit_F *out);           /* mimc_hash */
+void hobbit_f_mul_host(const hobbit_F *a, const hobbit_F *b, hobbit_F *out, size_t n);
+void hobbit_f_inv_host(const hobbit_F *a, hobbit_F *out, size_t n);
+/* element-wise device ops (test surface for the device field arithmetic): op 0 add, 1 sub, 2 mul */
+int hobbit_f_binop(hobbit_ctx *ctx, int op, const hobbit_F *d_a, const hobbit_F *d_b, hobbit_F *d_out, size_t n);
+
+/* ---- expander code (src/expanders.h:20-47,78-92; src/linear_code_encode.h:62-119) ---------- */
+/* The host keeps drawing the graphs with libc rand()/random() in the reference's order
+ * (expander_init_store); it uploads each level here.  kind 0 = _C[dep], 1 = D[dep].
+ * nbr[i*degree+j] in [0,R), w[i*degree+j] any canonical F (32-bit real weights take a fast path). */
+int hobbit_graph_reset(hobbit_ctx *ctx);
+int hobbit_graph_upload(hobbit_ctx *ctx, int dep, int kind, long long L, long long R, int degree,
+                        const long long *h_nbr, const hobbit_F *h_w);
+/* call after all levels for code length n are uploaded; returns codeword length via *len */
+int hobbit_graph_finalize(hobbit_ctx *ctx, long long n, long long *len);
+/* encode_monolithic on `batch` messages; message b at d_src + b*ld_src (n F, contiguous), its
+ * codeword written to d_dst + b*ld_dst (2n F: codeword then zeros).  d_src may alias d_dst. */
+int hobbit_encode_batch(hobbit_ctx *ctx, const hobbit_F *d_src, hobbit_F *d_dst, long long n,
+                        size_t batch, size_t ld_src, size_t ld_dst);
+
+/* ---- FFT (src/utils.cpp:605-673 _fft; natural order in and out) ---------------------------- */
+/* in place on `batch` rows of 2^logn F, row b at d_data + b*ld.  inverse!=0 scales by 1/len.
+ * Twiddles are always those of the requested direction (the reference's length-keyed cache quirk,
+ * SURVEY.md 1, is NOT reproduced here; the host mirror documents where it matters). */
+int hobbit_fft_batch(hobbit_ctx *ctx, hobbit_F *d_data, int logn, size_t batch, size_t ld, int inverse);
+
+/* ---- BLAKE3 / Merkle (src/Blake3_hash.cpp:5-10; src/merkle_tree.cpp:62-87,193-221,255-324) -- */
+int hobbit_blake3_64(hobbit_ctx *ctx, const uint8_t *d_in, uint8_t *d_out, size_t n);      /* blake3_hash x n */
+/* hash_double_field_element_merkle_damgard_blake x n: out[i] = H(H(xyzw[i]) | prev[i]); in place ok */
+int hobbit_hash_md(hobbit_ctx *ctx, const hobbit_F *d_xyzw, const uint8_t *d_prev, uint8_t *d_out, size_t n);
+/* MT_commit_Blake: leaves H(4 consecutive F) into d_levels[0..N/4), then the tree */
+int hobbit_mt_commit_blake(hobbit_ctx *ctx, const hobbit_F *d_leafs, size_t N, uint8_t *d_levels);
+/* create_tree_blake: d_levels holds level 0 (n hashes) and receives levels 1.. behind it
+ * ((2n-1)*32 bytes in all).  left_left_quirk=1 reproduces the reference (parent = H(left|left),
+ * src/merkle_tree.cpp:275-280); 0 builds the conventional H(left|right) tree. */
+int hobbit_merkle_levels(hobbit_ctx *ctx, uint8_t *d_levels, size_t n, int left_left_quirk);
+/* open_tree_blake: sibling path of leaf pos from flat levels; h_path receives log2(n) hashes */
+int hobbit_merkle_path(hobbit_ctx *ctx, const uint8_t *d_levels, size_t n, size_t pos, uint8_t *h_path);
+/* batched: h_paths receives nq x log2(n) hashes */
+int hobbit_merkle_paths(hobbit_ctx *ctx, const uint8_t *d_levels, size_t n, const uint64_t *h_pos, size_t nq, uint8_t *h_paths);
+
+/* ---- multilinear utilities (src/utils.cpp:251-296 precompute_beta, 789-802 evaluate_vector) -- */
+int hobbit_eq_table(hobbit_ctx *ctx, const hobbit_F *h_r, int k, hobbit_F *d_out);
+int hobbit_eval_vector(hobbit_ctx *ctx, const hobbit_F *d_v, size_t n, const hobbit_F *h_r, hobbit_F *h_out);
+
+/* ---- tensor code (src/PC_utils.cpp:66-123 compute_tensorcode) ------------------------------ */
+/* message M F (row-major trs x M/trs) -> tensor (2 trs) x (2M/trs), stored CODEWORD-MAJOR on the
+ * device: element (row, col) at d_out[col*(2*trs) + row].  linear_time!=0: RS rows x expander
+ * columns (graphs for n = trs must be finalized); 0: RS x RS. */
+int hobbit_tensorcode(hobbit_ctx *ctx, const hobbit_F *d_msg, size_t M, int trs, int linear_time, hobbit_F *d_out);
+
+/* ---- Our_PC commit (src/Our_PC.cpp:146-171 commit_standard) -------------------------------- */
+/* poly: N F on the device.  The commitment object owns the device-resident tensor (K chunks,
+ * codeword-major) and Merkle levels. */
+int hobbit_commit_standard(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, int K, int trs, int linear_time,
+                           hobbit_commitment **out);
+void hobbit_commitment_free(hobbit_commitment *c);
+size_t hobbit_commitment_num_leaves(const hobbit_commitment *c);
+const uint8_t *hobbit_commitment_levels_dev(const hobbit_commitment *c);   /* flat levels, device */
+const hobbit_F *hobbit_commitment_tensor_dev(const hobbit_commitment *c);  /* K x cols x 2trs, device */
+int hobbit_commitment_levels(hobbit_ctx *ctx, const hobbit_commitment *c, uint8_t *h_levels); /* (2M-1)*32 B */
+int hobbit_commitment_root(hobbit_ctx *ctx, const hobbit_commitment *c, uint8_t *h_root);
+/* _tensor[chunk][row][0..cols) in the reference's row-major order (lazy materialisation) */
+int hobbit_commitment_tensor_row(hobbit_ctx *ctx, const hobbit_commitment *c, int chunk, int row, hobbit_F *h_out);
+/* _compute_aggregation_reply (src/Our_PC.cpp:291-305): reply[q*K + i] = _tensor[i][rows[q]][cols[q]] */
+int hobbit_commitment_gather(hobbit_ctx *ctx, const hobbit_commitment *c, const uint32_t *h_rows, const uint32_t *h_cols,
+                             size_t nq, hobbit_F *h_reply);
+/* open_tree_blake for query (col,row): pos = (row/4)*cols + col (src/merkle_tree.cpp:308-324) */
+int hobbit_commitment_path(hobbit_ctx *ctx, const hobbit_commitment *c, size_t col, size_t row, uint8_t *h_path);
+int hobbit_commitment_paths(hobbit_ctx *ctx, const hobbit_commitment *c, const uint32_t *h_cols, const uint32_t *h_rows, size_t nq,
+                            uint8_t *h_paths);
+
+/* ---- Our_PC open building blocks ----------------------------------------------------------- */
+/* _aggregate axpy (src/Our_PC.cpp:258-272): d_aggr[j] = sum_i beta[i] * poly[i*M + j], M = N/K */
+int hobbit_aggregate(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_F *h_beta, int K, hobbit_F *d_aggr);
+
+/* ---- sumchecks ----------------------------------------------------------------------------- */
+/* generate_2product_sumcheck_proof (src/sumcheck.cpp:2391-2460).  Inputs preserved.
+ * h_qpoly: rounds x 3 F (a,b,c highest degree first); h_r: rounds F; h_vr: 2 F; h_final: 1 F. */
+int hobbit_sumcheck2(hobbit_ctx *ctx, const hobbit_F *d_v1, const hobbit_F *d_v2, size_t n, const hobbit_F *prev_r,
+                     hobbit_F *h_qpoly, hobbit_F *h_r, hobbit_F *h_vr, hobbit_F *h_final);
+/* _generate_3product_sumcheck_proof (src/sumcheck.cpp:1974-2058): pre-round-challenge fold order
+ * kept.  The reference destroys its inputs in place; here d_v1..3 are preserved (the folded
+ * values are returned in h_vr).  h_cpoly: rounds x 4 F; h_vr: 3 F. */
+int hobbit_sumcheck3(hobbit_ctx *ctx, const hobbit_F *d_v1, const hobbit_F *d_v2, const hobbit_F *d_v3, size_t n,
+                     const hobbit_F *prev_r, hobbit_F *h_cpoly, hobbit_F *h_r, hobbit_F *h_vr, hobbit_F *h_final);
+
+/* ---- synthetic inputs on the device (bench / tests) ---------------------------------------- */
+/* splitmix64-derived full-range elements: element i = (sm(seed,2i+1) mod p, sm(seed,2i+2) mod p) */
+int hobbit_fill_splitmix(hobbit_ctx *ctx, hobbit_F *d_out, size_t n, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
