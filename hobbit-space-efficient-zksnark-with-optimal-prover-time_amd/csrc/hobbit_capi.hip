@@ -179,19 +179,21 @@ int hobbit_graph_finalize(hobbit_ctx *ctx, long long n, long long *len_out) {
         for (long long i = 0; i < g.L; i++)
             for (int j = 0; j < g.degree; j++) rows[g.nbr[i * g.degree + j]].push_back({(uint32_t)i, g.w[i * g.degree + j]});
         EncStep s; s.in_off = (uint32_t)p.in_off; s.out_off = (uint32_t)p.out_off; s.out_len = (uint32_t)g.R;
-        s.n_slices = (uint32_t)((g.R + 63) / 64); s.slice_base = (uint32_t)slice_ptr.size();
+        s.n_slices = (uint32_t)((g.R + ENC_SW - 1) / ENC_SW); s.slice_base = (uint32_t)slice_ptr.size();
         for (uint32_t sl = 0; sl < s.n_slices; sl++) {
             size_t width = 0;
-            for (uint32_t l = 0; l < 64; l++) { size_t t = (size_t)sl * 64 + l; if (t < (size_t)g.R) width = std::max(width, rows[t].size()); }
+            for (uint32_t l = 0; l < ENC_SW; l++) { size_t t = (size_t)sl * ENC_SW + l; if (t < (size_t)g.R) width = std::max(width, rows[t].size()); }
+            const size_t q = ENC_SPLIT * ENC_UNROLL;
+            width = (width + q - 1) / q * q;
             slice_ptr.push_back((uint32_t)pos); slice_width.push_back((uint32_t)width);
             for (size_t k = 0; k < width; k++)
-                for (uint32_t l = 0; l < 64; l++) {
-                    size_t t = (size_t)sl * 64 + l;
+                for (uint32_t l = 0; l < ENC_SW; l++) {
+                    size_t t = (size_t)sl * ENC_SW + l;
                     uint32_t id = 0; F w = fmake(0);
                     if (t < (size_t)g.R && k < rows[t].size()) { id = rows[t][k].first; w = rows[t][k].second; c.n_edges++; }
                     if (c.small_weights) e32.push_back(make_uint2(id, (uint32_t)w.re)); else { eidx.push_back(id); ew.push_back(w); }
                 }
-            pos += width * 64;
+            pos += width * ENC_SW;
         }
         c.steps.push_back(s);
     }

@@ -13,9 +13,15 @@ namespace hobbit {
 
 // One SpMV step of the recursive expander encode, in gather form over the codeword buffer:
 //   cw[out_off + t] = sum_e w_e * cw[in_off + idx_e],  t in [0, out_len)
-// Edges of 64 consecutive outputs form a slice stored k-major (edge k of output t at
-// slice_ptr[t/64] + k*64 + t%64) and padded with zero-weight edges to the slice's widest row, so
-// a wavefront reads its edges with fully coalesced loads and needs no per-lane bounds.
+// Edges of ENC_SW consecutive outputs form a slice stored k-major (edge k of output t at
+// slice_ptr[t/ENC_SW] + k*ENC_SW + t%ENC_SW) and padded with zero-weight edges to a multiple of
+// ENC_SPLIT*ENC_UNROLL past the slice's widest row, so a wavefront reads 64 consecutive records
+// per instruction and needs no per-lane bounds.
+// slice geometry shared by the host preprocessing and k_encode (see hobbit_kernels.hip)
+static constexpr uint32_t ENC_SW = 16;                 // outputs per slice
+static constexpr uint32_t ENC_SPLIT = 64 / ENC_SW;     // lane groups sharing one output's edges
+static constexpr uint32_t ENC_UNROLL = 4;              // edge records in flight per lane
+
 struct EncStep {
     uint32_t in_off, out_off, out_len, n_slices;
     uint32_t slice_base;   // index of this step's first slice in slice_ptr/slice_width

@@ -142,61 +142,146 @@ int launch_fft_rows(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_l
 // (the reference places the child codeword at dst+n and the D output behind it), executed in
 // gather form (reverse adjacency: no atomics, deterministic, one writer per output).
 // ============================================================================================
+// Sliced-ELL geometry of one SpMV step: a slice is ENC_SW consecutive outputs; a wavefront owns a
+// slice and splits each output's in-edges over ENC_SPLIT = 64/ENC_SW lane groups (lane l works on
+// output l % ENC_SW, edges k = l / ENC_SW (mod ENC_SPLIT)), so one wave-instruction reads 64
+// consecutive edge records (fully coalesced) and the per-lane dependent chain is ENC_SPLIT x
+// shorter than one-lane-per-output.  The host pads every slice to a multiple of
+// ENC_SPLIT*ENC_UNROLL edges per output with zero-weight records.
+//
+// SMALLW (all weights real and < 2^32, the only kind the reference ever draws, src/expanders.h:37):
+// products are accumulated UNREDUCED in four 96-bit sums per output,
+//     S_lo = sum w * lo32(a),  S_hi = sum w * hi32(a)        (for a = re and a = im)
+// i.e. 4 v_mad_u64_u32 + 4 carry adds per edge and ONE Mersenne fold per output -- exact integer
+// arithmetic, so the result is the same canonical element the reference's per-edge mod-p loop gives.
+struct Acc96 { uint64_t lo; uint32_t hi; };
+// a += w * x (32x32 -> 64 product into a 96-bit sum): one v_mad_u64_u32 whose carry-out feeds one
+// v_addc (hipcc does not use the instruction's own carry output, hence the two-line asm).
+__device__ __forceinline__ void acc96_mad(Acc96 &a, uint32_t w, uint32_t x) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc" : "+v"(a.lo), "+v"(a.hi) : "v"(w), "v"(x) : "vcc");
+}
+__device__ __forceinline__ uint64_t acc_fold(const Acc96 &lo, const Acc96 &hi) {
+    // value = lo + hi * 2^32 < 2^(96+33)... bounded by (#edges) * 2^93 < 2^124 for any in-degree < 2^31
+    const u128 v = (((u128)lo.hi << 64) | lo.lo) + ((((u128)hi.hi << 64) | hi.lo) << 32);
+    return red124(v);
+}
+__device__ __forceinline__ F shfl_xor_F(const F &a, int m) {
+    F r;
+    r.re = __shfl_xor((unsigned long long)a.re, m, 64);
+    r.im = __shfl_xor((unsigned long long)a.im, m, 64);
+    return r;
+}
+
+// A launch executes steps [s_lo, s_hi) of the encode on codeword indices [base, base + LDS extent):
+// it loads [ld_lo, ld_hi) from the column in global memory, runs the steps (an output that falls
+// outside the LDS window goes straight to global memory), and stores [st_lo, st_hi) (zeros past
+// the codeword).  Small codes run as ONE pass; for n = 4096 (110 KB codeword, one workgroup per
+// CU) the launcher splits the work into pass A = C_0 alone (64 KB message window, 2 workgroups per
+// CU) and pass B = everything else (46 KB window, 3 per CU) so that one workgroup's global
+// load/store overlaps another's gather loop.
+struct EncPass { uint32_t base, ld_lo, ld_hi, s_lo, s_hi, st_lo, st_hi, direct_out; };
+
 template <bool SMALLW>
-__global__ void k_encode(const F *__restrict__ src, size_t ld_src, F *__restrict__ dst, size_t ld_dst, uint32_t n, uint32_t len,
-                         const EncStep *__restrict__ steps, int nsteps, const uint32_t *__restrict__ slice_ptr,
-                         const uint32_t *__restrict__ slice_width, const uint2 *__restrict__ e32, const uint32_t *__restrict__ eidx,
-                         const F *__restrict__ ew, int write_msg) {
+__global__ void __launch_bounds__(1024)
+k_encode(const F *__restrict__ src, size_t ld_src, F *__restrict__ dst, size_t ld_dst, uint32_t len, EncPass ps,
+         const EncStep *__restrict__ steps, const uint32_t *__restrict__ slice_ptr,
+         const uint32_t *__restrict__ slice_width, const uint2 *__restrict__ e32, const uint32_t *__restrict__ eidx,
+         const F *__restrict__ ew) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    F *cw = reinterpret_cast<F *>(lds_raw);
+    F *cw = reinterpret_cast<F *>(lds_raw) - ps.base;          // cw[i] addresses codeword index i
     const F *in = src + (size_t)blockIdx.x * ld_src;
     F *out = dst + (size_t)blockIdx.x * ld_dst;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) stF(&cw[i], ldF(in + i));
+    for (uint32_t i = ps.ld_lo + threadIdx.x; i < ps.ld_hi; i += blockDim.x) stF(&cw[i], ldF(in + i));
     __syncthreads();
-    for (int s = 0; s < nsteps; s++) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const uint32_t tl = lane % ENC_SW;
+    for (uint32_t s = ps.s_lo; s < ps.s_hi; s++) {
         const EncStep sp = steps[s];
         const F *cin = cw + sp.in_off;
-        for (uint32_t t = threadIdx.x; t < sp.n_slices * 64; t += blockDim.x) {   // blockDim % 64 == 0: whole slices per wave
-            const uint32_t sl = sp.slice_base + (t >> 6), lane = t & 63;
-            const uint32_t base = slice_ptr[sl] + lane, width = slice_width[sl];
-            F acc = fmake(0);
-            for (uint32_t k = 0; k < width; k++) {
-                if (SMALLW) {
-                    const uint2 e = e32[base + k * 64];
-                    acc = fadd(acc, fmul32(ldF(cin + e.x), e.y));
-                } else {
-                    const uint32_t id = eidx[base + k * 64];
-                    acc = fadd(acc, fmul(ldF(cin + id), ldF(ew + base + k * 64)));
+        for (uint32_t sl = wave; sl < sp.n_slices; sl += nwaves) {
+            const uint32_t base = slice_ptr[sp.slice_base + sl] + lane;
+            const uint32_t iters = slice_width[sp.slice_base + sl] / ENC_SPLIT;    // multiple of ENC_UNROLL
+            F acc;
+            if (SMALLW) {
+                Acc96 rl = {0, 0}, rh = {0, 0}, il = {0, 0}, ih = {0, 0};
+                uint2 en[ENC_UNROLL];
+#pragma unroll
+                for (int u = 0; u < ENC_UNROLL; u++) en[u] = e32[base + u * 64];
+                for (uint32_t j = 0; j < iters; j += ENC_UNROLL) {
+                    uint2 e[ENC_UNROLL]; uint4 x[ENC_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < ENC_UNROLL; u++) e[u] = en[u];
+                    if (j + ENC_UNROLL < iters) {          // prefetch the next group of edge records
+#pragma unroll
+                        for (int u = 0; u < ENC_UNROLL; u++) en[u] = e32[base + (j + ENC_UNROLL + u) * 64];
+                    }
+#pragma unroll
+                    for (int u = 0; u < ENC_UNROLL; u++) x[u] = *reinterpret_cast<const uint4 *>(cin + e[u].x);
+#pragma unroll
+                    for (int u = 0; u < ENC_UNROLL; u++) {
+                        acc96_mad(rl, e[u].y, x[u].x); acc96_mad(rh, e[u].y, x[u].y);
+                        acc96_mad(il, e[u].y, x[u].z); acc96_mad(ih, e[u].y, x[u].w);
+                    }
+                }
+                acc = fmake(acc_fold(rl, rh), acc_fold(il, ih));
+            } else {
+                acc = fmake(0);
+                for (uint32_t j = 0; j < iters; j++) {
+                    const uint32_t id = eidx[base + j * 64];
+                    acc = fadd(acc, fmul(ldF(cin + id), ldF(ew + base + j * 64)));
                 }
             }
-            if (t < sp.out_len) stF(&cw[sp.out_off + t], acc);
+#pragma unroll
+            for (int m = ENC_SW; m < 64; m <<= 1) acc = fadd(acc, shfl_xor_F(acc, m));   // combine the lane groups
+            const uint32_t t = sl * ENC_SW + tl;
+            if (lane < ENC_SW && t < sp.out_len) {
+                if (ps.direct_out) stF(out + sp.out_off + t, acc); else stF(&cw[sp.out_off + t], acc);
+            }
         }
         __syncthreads();
     }
-    for (uint32_t i = write_msg ? threadIdx.x : n + threadIdx.x; i < 2 * n; i += blockDim.x) stF(out + i, i < len ? ldF(&cw[i]) : fmake(0));
+    for (uint32_t i = ps.st_lo + threadIdx.x; i < ps.st_hi; i += blockDim.x) stF(out + i, i < len ? ldF(&cw[i]) : fmake(0));
+}
+
+template <bool SMALLW>
+static int launch_encode_pass(hobbit_ctx *ctx, const char *name, const F *src, size_t ld_src, F *dst, size_t ld_dst, size_t batch, EncPass ps,
+                              uint32_t lds_elems, uint32_t block) {
+    DeviceCode &c = ctx->code;
+    hipFuncSetAttribute((const void *)k_encode<SMALLW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    HB_LAUNCH(ctx, name, k_encode<SMALLW>, dim3((unsigned)batch), dim3(block), (size_t)lds_elems * 16, src, ld_src, dst, ld_dst, (uint32_t)c.len, ps,
+              c.d_steps, c.d_slice_ptr, c.d_slice_width, c.d_edges32, c.d_eidx, c.d_ew);
+    return 0;
+}
+static uint32_t block_for(const DeviceCode &c, uint32_t s_lo, uint32_t s_hi, uint32_t max_waves) {
+    uint32_t widest = 1;
+    for (uint32_t s = s_lo; s < s_hi; s++) widest = c.steps[s].n_slices > widest ? c.steps[s].n_slices : widest;
+    return (widest >= max_waves ? max_waves : widest) * 64;
 }
 
 int launch_encode(hobbit_ctx *ctx, const F *src, size_t ld_src, F *dst, size_t ld_dst, long long n, size_t batch, int write_msg) {
     DeviceCode &c = ctx->code;
     if (c.n != n) return ctx->fail(HOBBIT_ESTATE, "encode: graphs for this n are not finalized (hobbit_graph_finalize)");
     if (batch == 0) return 0;
-    size_t lds = (size_t)c.len * 16;
-    if (lds > 160 * 1024) return ctx->fail(HOBBIT_EINVAL, "encode: codeword does not fit in 160 KB of LDS (n <= 4096 supported)");
-    // threads: enough for the widest step (C_0: 0.211 n outputs), a multiple of 64
-    uint32_t widest = 64;
-    for (auto &s : c.steps) widest = s.n_slices * 64 > widest ? s.n_slices * 64 : widest;
-    uint32_t block = widest > 1024 ? 1024 : widest;
-    if (n >= 64 && block < 256) block = 256;
-    if (c.small_weights) {
-        hipFuncSetAttribute((const void *)k_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        HB_LAUNCH(ctx, "k_encode", k_encode<true>, dim3((unsigned)batch), dim3(block), lds, src, ld_src, dst, ld_dst, (uint32_t)n, (uint32_t)c.len,
-                  c.d_steps, (int)c.steps.size(), c.d_slice_ptr, c.d_slice_width, c.d_edges32, c.d_eidx, c.d_ew, write_msg);
-    } else {
-        hipFuncSetAttribute((const void *)k_encode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        HB_LAUNCH(ctx, "k_encode_fullw", k_encode<false>, dim3((unsigned)batch), dim3(block), lds, src, ld_src, dst, ld_dst, (uint32_t)n,
-                  (uint32_t)c.len, c.d_steps, (int)c.steps.size(), c.d_slice_ptr, c.d_slice_width, c.d_edges32, c.d_eidx, c.d_ew, write_msg);
+    if ((size_t)c.len * 16 > 160 * 1024) return ctx->fail(HOBBIT_EINVAL, "encode: codeword does not fit in 160 KB of LDS (n <= 4096 supported)");
+    const uint32_t nn = (uint32_t)n, nsteps = (uint32_t)c.steps.size();
+    const bool split = nsteps >= 2 && (size_t)c.len * 16 > 80 * 1024;     // cannot co-schedule two workgroups per CU otherwise
+    if (!split) {
+        EncPass ps = {0, 0, nn, 0, nsteps, write_msg ? 0u : nn, 2 * nn, 0};
+        uint32_t block = block_for(c, 0, nsteps, 16);
+        return c.small_weights ? launch_encode_pass<true>(ctx, "k_encode", src, ld_src, dst, ld_dst, batch, ps, (uint32_t)c.len, block)
+                               : launch_encode_pass<false>(ctx, "k_encode_fullw", src, ld_src, dst, ld_dst, batch, ps, (uint32_t)c.len, block);
     }
-    return 0;
+    // pass A: x_1 = C_0 x_0, outputs straight to the column in global memory
+    const uint32_t r0 = c.steps[0].out_len;
+    EncPass pa = {0, 0, nn, 0, 1, write_msg ? 0u : nn, write_msg ? nn : nn, 1};
+    // pass B: the remaining steps on the window [n, len)
+    EncPass pb = {nn, nn, nn + r0, 1, nsteps, nn + r0, 2 * nn, 0};
+    if (c.small_weights) {
+        HB_TRY(launch_encode_pass<true>(ctx, "k_encode_A", src, ld_src, dst, ld_dst, batch, pa, nn, block_for(c, 0, 1, 8)));
+        return launch_encode_pass<true>(ctx, "k_encode_B", dst, ld_dst, dst, ld_dst, batch, pb, (uint32_t)c.len - nn, block_for(c, 1, nsteps, 8));
+    }
+    HB_TRY(launch_encode_pass<false>(ctx, "k_encode_fullw_A", src, ld_src, dst, ld_dst, batch, pa, nn, block_for(c, 0, 1, 8)));
+    return launch_encode_pass<false>(ctx, "k_encode_fullw_B", dst, ld_dst, dst, ld_dst, batch, pb, (uint32_t)c.len - nn, block_for(c, 1, nsteps, 8));
 }
 
 // ============================================================================================
