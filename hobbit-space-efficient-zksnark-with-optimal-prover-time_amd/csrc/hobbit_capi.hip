@@ -39,6 +39,36 @@ static int get_twiddles(hobbit_ctx *ctx, int logn, bool inverse, const F **out) 
     m[logn] = d; *out = d; return 0;
 }
 
+// per-pass twiddle tables of k_fft4096: pass with butterfly stride h stores, for k < h,
+//   [wA(k) | wB0(k) | wB1(k) | wC0(k) | wC1(k) | wC2(k) | wC3(k)],  w*(k) = w^((k + s h) * len / (2h,4h,8h))
+static int get_tw8(hobbit_ctx *ctx, bool inverse) {
+    const int d = inverse ? 1 : 0;
+    if (ctx->tw8[d]) return 0;
+    const uint32_t len = 4096;
+    std::vector<F> w(len / 2);
+    w[0] = fmake(1);
+    F w1 = root_of_unity(12); if (inverse) w1 = finv(w1);
+    for (uint32_t i = 1; i < len / 2; i++) w[i] = fmul(w[i - 1], w1);
+    std::vector<F> t;
+    for (uint32_t h : {8u, 64u, 512u}) {
+        for (uint32_t k = 0; k < h; k++) t.push_back(w[k * (len / (2 * h))]);
+        for (uint32_t s2 = 0; s2 < 2; s2++) for (uint32_t k = 0; k < h; k++) t.push_back(w[(k + s2 * h) * (len / (4 * h))]);
+        for (uint32_t s4 = 0; s4 < 4; s4++) for (uint32_t k = 0; k < h; k++) t.push_back(w[(k + s4 * h) * (len / (8 * h))]);
+    }
+    F *dptr = nullptr;
+    if (hipMalloc((void **)&dptr, t.size() * sizeof(F)) != hipSuccess) return ctx->fail(HOBBIT_ENOMEM, "twiddle alloc failed");
+    HB_CHECK(ctx, hipMemcpy(dptr, t.data(), t.size() * sizeof(F), hipMemcpyHostToDevice));
+    ctx->tw8[d] = dptr;
+    ctx->tw8_w8[d] = w[512]; ctx->tw8_w83[d] = w[1536];
+    const F w4 = w[1024];
+    if (w4.re != 0 || (w4.im != 1 && w4.im != P61 - 1)) return ctx->fail(HOBBIT_EINVAL, "unexpected 4th root of unity");
+    ctx->tw8_w4_plus_i[d] = w4.im == 1;
+    return 0;
+}
+// FFT dispatch: the 4096-point kernel when it applies, the generic LDS kernel otherwise
+static int fft_rows(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_len, F *dst, size_t dst_ld, size_t dst_es, int logn, bool inverse,
+                    uint32_t groups, uint32_t rows_per_group, size_t src_gs, size_t dst_gs);
+
 static void free_code(DeviceCode &c) {
     if (c.d_steps) hipFree(c.d_steps);
     if (c.d_slice_ptr) hipFree(c.d_slice_ptr);
@@ -47,6 +77,21 @@ static void free_code(DeviceCode &c) {
     if (c.d_eidx) hipFree(c.d_eidx);
     if (c.d_ew) hipFree(c.d_ew);
     c = DeviceCode();
+}
+
+static int fft_rows(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_len, F *dst, size_t dst_ld, size_t dst_es, int logn, bool inverse,
+                    uint32_t groups, uint32_t rows_per_group, size_t src_gs, size_t dst_gs) {
+    F scale = fmake(1);
+    if (inverse) scale = finv(fmake((uint64_t)1 << logn));          // src/utils.cpp:663-671
+    if (logn == 12 && (src_len == 2048 || src_len == 4096)) {
+        HB_TRY(get_tw8(ctx, inverse));
+        const int d = inverse ? 1 : 0;
+        const F *t = ctx->tw8[d];
+        return launch_fft4096(ctx, src, src_ld, src_len, dst, dst_ld, dst_es, t, t + 7 * 8, t + 7 * 8 + 7 * 64, ctx->tw8_w8[d], ctx->tw8_w83[d],
+                              ctx->tw8_w4_plus_i[d], scale, inverse ? 1 : 0, groups, rows_per_group, src_gs, dst_gs);
+    }
+    const F *tw; HB_TRY(get_twiddles(ctx, logn, inverse, &tw));
+    return launch_fft_rows(ctx, src, src_ld, src_len, dst, dst_ld, dst_es, logn, tw, scale, inverse ? 1 : 0, groups, rows_per_group, src_gs, dst_gs);
 }
 
 extern "C" {
@@ -77,8 +122,10 @@ void hobbit_ctx_destroy(hobbit_ctx *ctx) {
     ctx->prof_collect();
     for (auto &kv : ctx->tw_fwd) hipFree(kv.second);
     for (auto &kv : ctx->tw_inv) hipFree(kv.second);
+    for (int d = 0; d < 2; d++) if (ctx->tw8[d]) hipFree(ctx->tw8[d]);
     free_code(ctx->code);
     if (ctx->ws) hipFree(ctx->ws);
+    if (ctx->ws2) hipFree(ctx->ws2);
     if (ctx->spare_tensor) hipFree(ctx->spare_tensor);
     if (ctx->spare_levels) hipFree(ctx->spare_levels);
     hipEventDestroy(ctx->t0); hipEventDestroy(ctx->t1);
@@ -221,10 +268,7 @@ int hobbit_fft_batch(hobbit_ctx *ctx, hobbit_F *d_data, int logn, size_t batch, 
     if (logn < 0 || logn > 12) return ctx->fail(HOBBIT_EINVAL, "fft_batch: logn must be in [0,12]");
     if (logn == 0 || batch == 0) return 0;
     if (ld < ((size_t)1 << logn)) return ctx->fail(HOBBIT_EINVAL, "fft_batch: ld < 2^logn");
-    const F *tw; HB_TRY(get_twiddles(ctx, logn, inverse != 0, &tw));
-    F scale = fmake(1);
-    if (inverse) scale = finv(fmake((uint64_t)1 << logn));          // src/utils.cpp:663-671
-    return launch_fft_rows(ctx, cF(d_data), ld, 1u << logn, mF(d_data), ld, 1, logn, tw, scale, inverse != 0, 1, (uint32_t)batch, 0, 0);
+    return fft_rows(ctx, cF(d_data), ld, 1u << logn, mF(d_data), ld, 1, logn, inverse != 0, 1, (uint32_t)batch, 0, 0);
 }
 
 // ---- BLAKE3 / Merkle --------------------------------------------------------------------------
@@ -288,18 +332,24 @@ static int tensorcode_chunks(hobbit_ctx *ctx, const F *d_msg, size_t M, int K, i
     int logc = ilog2_exact(cols), logr = ilog2_exact(rows2);
     if (logc < 1 || logc > 12) return ctx->fail(HOBBIT_EINVAL, "tensorcode: row length 2M/trs must be a power of two <= 4096");
     if (logr < 1) return ctx->fail(HOBBIT_EINVAL, "tensorcode: trs must be a power of two");
-    const F *tw; HB_TRY(get_twiddles(ctx, logc, false, &tw));
     // rows: RS encode = zero-padded FFT (src/PC_utils.cpp:75-84,105-107), written transposed into
     // the codeword-major tensor: element (r, c) of chunk i at i*cols*rows2 + c*rows2 + r
-    HB_TRY(launch_fft_rows(ctx, d_msg, half, (uint32_t)half, d_out, 1, rows2, logc, tw, fmake(1), 0, (uint32_t)K, (uint32_t)trs, M, cols * rows2));
+    // Large tensors: FFT to a row-major scratch (coalesced stores) + tiled transpose; small ones write the
+    // transposed layout directly (one launch less, the scattered stores stay in L2).
+    if ((size_t)K * trs * cols * sizeof(F) >= ((size_t)64 << 20)) {
+        F *rm; HB_TRY(ctx->workspace2((size_t)K * trs * cols * sizeof(F), (void **)&rm));
+        HB_TRY(fft_rows(ctx, d_msg, half, (uint32_t)half, rm, cols, 1, logc, false, (uint32_t)K, (uint32_t)trs, M, (size_t)trs * cols));
+        HB_TRY(launch_transpose(ctx, rm, (size_t)trs * cols, (uint32_t)trs, (uint32_t)cols, d_out, cols * rows2, rows2, (uint32_t)K));
+    } else
+        HB_TRY(fft_rows(ctx, d_msg, half, (uint32_t)half, d_out, 1, rows2, logc, false, (uint32_t)K, (uint32_t)trs, M, cols * rows2));
     if (lin) {     // columns: expander code, in place on contiguous codewords (src/PC_utils.cpp:110-121)
         if (trs > 13 && ctx->code.n != trs) return ctx->fail(HOBBIT_ESTATE, "tensorcode: expander graphs for n = trs not finalized");
         if (trs <= 13 && ctx->code.n != trs) { long long l; HB_TRY(hobbit_graph_finalize(ctx, trs, &l)); }
         return launch_encode(ctx, d_out, rows2, d_out, rows2, trs, (size_t)K * cols, 0);
     }
     if (logr > 12) return ctx->fail(HOBBIT_EINVAL, "tensorcode: RSxRS needs 2*trs <= 4096");
-    const F *tw2; HB_TRY(get_twiddles(ctx, logr, false, &tw2));   // columns: RS (src/PC_utils.cpp:92-101)
-    return launch_fft_rows(ctx, d_out, rows2, (uint32_t)trs, d_out, rows2, 1, logr, tw2, fmake(1), 0, 1, (uint32_t)((size_t)K * cols), 0, 0);
+    // columns: RS (src/PC_utils.cpp:92-101)
+    return fft_rows(ctx, d_out, rows2, (uint32_t)trs, d_out, rows2, 1, logr, false, 1, (uint32_t)((size_t)K * cols), 0, 0);
 }
 int hobbit_tensorcode(hobbit_ctx *ctx, const hobbit_F *d_msg, size_t M, int trs, int linear_time, hobbit_F *d_out) {
     return tensorcode_chunks(ctx, cF(d_msg), M, 1, trs, linear_time, mF(d_out));

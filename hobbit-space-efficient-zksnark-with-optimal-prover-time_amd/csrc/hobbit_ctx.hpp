@@ -60,11 +60,24 @@ struct hobbit_ctx {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // twiddles: logn -> device table of 2^(logn-1) forward (and inverse) roots
     std::map<int, hobbit::F *> tw_fwd, tw_inv;
+    // radix-8 per-pass tables of the FFT-4096 kernel ([7][8] | [7][64] | [7][512]), fwd / inv
+    hobbit::F *tw8[2] = {nullptr, nullptr};
+    hobbit::F tw8_w8[2], tw8_w83[2]; int tw8_w4_plus_i[2] = {0, 0};
     // graphs
     std::map<std::pair<int, int>, hobbit::HostGraph> graphs;   // (dep, kind)
     hobbit::DeviceCode code;
     // scratch
     void *ws = nullptr; size_t ws_bytes = 0;
+    // second scratch: the row-major FFT output of a tensor code before its transpose
+    void *ws2 = nullptr; size_t ws2_bytes = 0;
+    int workspace2(size_t bytes, void **p) {
+        if (bytes > ws2_bytes) {
+            if (ws2) { hipStreamSynchronize(stream); hipFree(ws2); ws2 = nullptr; ws2_bytes = 0; }
+            if (hipMalloc(&ws2, bytes) != hipSuccess) { err = "workspace2 hipMalloc failed"; return HOBBIT_ENOMEM; }
+            ws2_bytes = bytes;
+        }
+        *p = ws2; return 0;
+    }
     // one retired commitment's buffers, kept for the next commit of the same shape (a 2^28 commit
     // owns 16.5 GiB; re-allocating it per call would dominate a repeated-commit loop)
     void *spare_tensor = nullptr; size_t spare_tensor_bytes = 0;

@@ -135,6 +135,145 @@ int launch_fft_rows(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_l
     return 0;
 }
 
+// --------------------------------------------------------------------------------------------
+// FFT-4096, the hot size (row RS-encode of every tensor code): 512 threads, radix-8 DIT in
+// registers, four passes, LDS padded by one slot per eight (phys(i) = i + i/8) so that the
+// stride-8 / stride-64 / stride-512 butterflies and the bit-reversed first-pass gather are all
+// bank-conflict-free; 73.7 KB of LDS -> two workgroups per CU.
+//   load     global -> LDS in natural order (coalesced, contiguous LDS writes)
+//   pass 0   butterfly b reads x[rev9(b) + 512 u]  (= DIT positions 8b+t), writes positions 8b+t.
+//            Its twiddles are the 8th roots of unity: 1, w4 = +-i (free), w8, w8^3; with the
+//            zero-padded message rows (upper half 0) the first stage has no arithmetic at all.
+//   pass 1,2 in place, twiddle tables stored per pass as [7][h] (contiguous in k)
+//   pass 3   results go straight to global memory (row-major or codeword-major/transposed)
+// Same DFT as the reference's _fft (src/utils.cpp:605-673): bit-exact by exactness of F_{p^2}.
+// --------------------------------------------------------------------------------------------
+struct Fft4kConst { F w8, w8_3; int w4_plus_i; };
+
+__device__ __forceinline__ F fmul_w4(const F &a, int plus_i) {   // a * (+i) or a * (-i)
+    return plus_i ? fmake(a.im ? P61 - a.im : 0, a.re) : fmake(a.im, a.re ? P61 - a.re : 0);
+}
+__device__ __forceinline__ uint32_t fft_phys(uint32_t i) { return i + (i >> 3); }
+#define HB_BFLY(x, y, w) do { F v__ = fmul(y, w); y = fsub(x, v__); x = fadd(x, v__); } while (0)
+
+template <bool PADDED>
+__global__ void __launch_bounds__(512)
+k_fft4096(const F *__restrict__ src, size_t src_ld, F *__restrict__ dst, size_t dst_ld, size_t dst_es, const F *__restrict__ tw1,
+          const F *__restrict__ tw2, const F *__restrict__ tw3, Fft4kConst cst, F scale, int do_scale, uint32_t rows_per_group, size_t src_gs,
+          size_t dst_gs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    F *s = reinterpret_cast<F *>(lds_raw);
+    const uint32_t grp = blockIdx.x / rows_per_group, r = blockIdx.x % rows_per_group;
+    const F *in = src + (size_t)grp * src_gs + (size_t)r * src_ld;
+    F *out = dst + (size_t)grp * dst_gs + (size_t)r * dst_ld;
+    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t NLOAD = PADDED ? 2048 : 4096;
+#pragma unroll
+    for (uint32_t i = 0; i < NLOAD; i += 512) stF(&s[fft_phys(i + tid)], ldF(in + i + tid));
+    __syncthreads();
+    F a[8];
+    {   // ---- pass 0 (h = 1)
+        const uint32_t m = __brev(tid) >> 23;                       // rev9(b), b = tid
+        a[0] = ldF(&s[fft_phys(m)]); a[2] = ldF(&s[fft_phys(m + 1024)]); a[4] = ldF(&s[fft_phys(m + 512)]); a[6] = ldF(&s[fft_phys(m + 1536)]);
+        if (PADDED) { a[1] = a[0]; a[3] = a[2]; a[5] = a[4]; a[7] = a[6]; }       // (u, 0) -> (u, u)
+        else {
+            a[1] = ldF(&s[fft_phys(m + 2048)]); a[3] = ldF(&s[fft_phys(m + 3072)]); a[5] = ldF(&s[fft_phys(m + 2560)]); a[7] = ldF(&s[fft_phys(m + 3584)]);
+            F t;
+            t = a[1]; a[1] = fsub(a[0], t); a[0] = fadd(a[0], t);
+            t = a[3]; a[3] = fsub(a[2], t); a[2] = fadd(a[2], t);
+            t = a[5]; a[5] = fsub(a[4], t); a[4] = fadd(a[4], t);
+            t = a[7]; a[7] = fsub(a[6], t); a[6] = fadd(a[6], t);
+        }
+        F t;
+        t = a[2]; a[2] = fsub(a[0], t); a[0] = fadd(a[0], t);                      // twiddle 1
+        t = fmul_w4(a[3], cst.w4_plus_i); a[3] = fsub(a[1], t); a[1] = fadd(a[1], t);
+        t = a[6]; a[6] = fsub(a[4], t); a[4] = fadd(a[4], t);
+        t = fmul_w4(a[7], cst.w4_plus_i); a[7] = fsub(a[5], t); a[5] = fadd(a[5], t);
+        t = a[4]; a[4] = fsub(a[0], t); a[0] = fadd(a[0], t);
+        HB_BFLY(a[1], a[5], cst.w8);
+        t = fmul_w4(a[6], cst.w4_plus_i); a[6] = fsub(a[2], t); a[2] = fadd(a[2], t);
+        HB_BFLY(a[3], a[7], cst.w8_3);
+        __syncthreads();                                            // every input has been read
+        const uint32_t o = fft_phys(8 * tid);                       // 9*tid: positions 8b..8b+7 are contiguous
+#pragma unroll
+        for (int t8 = 0; t8 < 8; t8++) stF(&s[o + t8], a[t8]);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int pass = 1; pass <= 3; pass++) {
+        const uint32_t h = pass == 1 ? 8u : pass == 2 ? 64u : 512u;
+        const F *tw = pass == 1 ? tw1 : pass == 2 ? tw2 : tw3;
+        const uint32_t k = tid & (h - 1), j = tid / h, i0 = j * 8 * h + k;
+#pragma unroll
+        for (int t8 = 0; t8 < 8; t8++) a[t8] = ldF(&s[fft_phys(i0 + t8 * h)]);
+        const F wA = ldF(tw + k), wB0 = ldF(tw + h + k), wB1 = ldF(tw + 2 * h + k);
+        HB_BFLY(a[0], a[1], wA); HB_BFLY(a[2], a[3], wA); HB_BFLY(a[4], a[5], wA); HB_BFLY(a[6], a[7], wA);
+        HB_BFLY(a[0], a[2], wB0); HB_BFLY(a[1], a[3], wB1); HB_BFLY(a[4], a[6], wB0); HB_BFLY(a[5], a[7], wB1);
+        const F wC0 = ldF(tw + 3 * h + k), wC1 = ldF(tw + 4 * h + k), wC2 = ldF(tw + 5 * h + k), wC3 = ldF(tw + 6 * h + k);
+        HB_BFLY(a[0], a[4], wC0); HB_BFLY(a[1], a[5], wC1); HB_BFLY(a[2], a[6], wC2); HB_BFLY(a[3], a[7], wC3);
+        if (pass < 3) {
+#pragma unroll
+            for (int t8 = 0; t8 < 8; t8++) stF(&s[fft_phys(i0 + t8 * h)], a[t8]);
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int t8 = 0; t8 < 8; t8++) {
+                F v = a[t8];
+                if (do_scale) v = fmul(v, scale);
+                stF(out + (size_t)(i0 + t8 * h) * dst_es, v);
+            }
+        }
+    }
+}
+
+int launch_fft4096(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_len, F *dst, size_t dst_ld, size_t dst_es, const F *tw1,
+                   const F *tw2, const F *tw3, F w8, F w8_3, int w4_plus_i, F scale, int do_scale, uint32_t groups, uint32_t rows_per_group,
+                   size_t src_gs, size_t dst_gs) {
+    size_t blocks = (size_t)groups * rows_per_group;
+    if (blocks == 0) return 0;
+    const size_t lds = (size_t)(4096 + 512) * 16;
+    Fft4kConst cst; cst.w8 = w8; cst.w8_3 = w8_3; cst.w4_plus_i = w4_plus_i;
+    if (src_len == 2048) {
+        hipFuncSetAttribute((const void *)k_fft4096<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        HB_LAUNCH(ctx, "k_fft4096", k_fft4096<true>, dim3((unsigned)blocks), dim3(512), lds, src, src_ld, dst, dst_ld, dst_es, tw1, tw2, tw3, cst,
+                  scale, do_scale, rows_per_group, src_gs, dst_gs);
+    } else {
+        hipFuncSetAttribute((const void *)k_fft4096<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        HB_LAUNCH(ctx, "k_fft4096_full", k_fft4096<false>, dim3((unsigned)blocks), dim3(512), lds, src, src_ld, dst, dst_ld, dst_es, tw1, tw2, tw3,
+                  cst, scale, do_scale, rows_per_group, src_gs, dst_gs);
+    }
+    return 0;
+}
+
+// Row-major (rows x cols) -> codeword-major (cols x ld_out) tiled transpose through LDS: both the
+// global reads and the global writes are 512-byte contiguous runs.  (Writing the FFT output
+// transposed directly costs a 16-byte scattered store per element: measured 22 ms vs 8 ms for the
+// 2^28 commit's row pass, hence this separate, HBM-bound pass.)
+__global__ void __launch_bounds__(256)
+k_transpose(const F *__restrict__ in, size_t in_gs, uint32_t rows, uint32_t cols, F *__restrict__ out, size_t out_gs, size_t ld_out) {
+    __shared__ F tile[32][33];
+    const F *src = in + (size_t)blockIdx.z * in_gs;
+    F *dst = out + (size_t)blockIdx.z * out_gs;
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    const uint32_t c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t r = r0 + ty + 8 * i;
+        if (r < rows && c0 + tx < cols) stF(&tile[ty + 8 * i][tx], ldF(src + (size_t)r * cols + c0 + tx));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t c = c0 + ty + 8 * i;
+        if (c < cols && r0 + tx < rows) stF(dst + (size_t)c * ld_out + r0 + tx, ldF(&tile[tx][ty + 8 * i]));
+    }
+}
+int launch_transpose(hobbit_ctx *ctx, const F *in, size_t in_gs, uint32_t rows, uint32_t cols, F *out, size_t out_gs, size_t ld_out, uint32_t groups) {
+    if (!rows || !cols || !groups) return 0;
+    HB_LAUNCH(ctx, "k_transpose", k_transpose, dim3((cols + 31) / 32, (rows + 31) / 32, groups), dim3(256), 0, in, in_gs, rows, cols, out, out_gs, ld_out);
+    return 0;
+}
+
 // ============================================================================================
 // Expander encode (src/linear_code_encode.h:62-119), one workgroup per message, the whole
 // codeword in LDS.  The recursion unrolls into a straight sequence of SpMV steps over one buffer
