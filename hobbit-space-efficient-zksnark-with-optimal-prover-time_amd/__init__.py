@@ -11,7 +11,9 @@ There is NO CPU fallback: if the library is missing, or no HIP device is present
 raises.  Nothing under oracle/ is imported here.
 """
 import ctypes
+import importlib.util
 import os
+import sys
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -35,6 +37,7 @@ ABI_SYMBOLS = [
     "hobbit_commit_standard", "hobbit_commitment_free", "hobbit_commitment_num_leaves", "hobbit_commitment_levels_dev",
     "hobbit_commitment_tensor_dev", "hobbit_commitment_levels", "hobbit_commitment_root", "hobbit_commitment_tensor_row",
     "hobbit_commitment_gather", "hobbit_commitment_path", "hobbit_commitment_paths",
+    "hobbit_tensorcode_chunks", "hobbit_inner_digests", "hobbit_chain_digests", "hobbit_blake3_64_host",
     "hobbit_aggregate", "hobbit_sumcheck2", "hobbit_sumcheck3", "hobbit_fill_splitmix",
 ]
 
@@ -72,6 +75,8 @@ def load_library(path=LIB_PATH):
         "hobbit_commitment_path": [V, V, S, S, V], "hobbit_commitment_paths": [V, V, V, V, S, V], "hobbit_aggregate": [V, V, S, V, I, V],
         "hobbit_sumcheck2": [V, V, V, S, V, V, V, V, V], "hobbit_sumcheck3": [V, V, V, V, S, V, V, V, V, V],
         "hobbit_fill_splitmix": [V, V, S, U64],
+        "hobbit_tensorcode_chunks": [V, V, S, I, I, I, V], "hobbit_inner_digests": [V, V, S, I, I, V],
+        "hobbit_chain_digests": [V, V, S, I, S, V], "hobbit_blake3_64_host": [V, V, S],
     }
     for name, args in protos.items():
         getattr(lib, name).argtypes = args
@@ -436,3 +441,19 @@ class Hobbit:
         q = np.zeros((rounds, 4, 2), np.uint64); r = np.zeros((rounds, 2), np.uint64); vr = np.zeros((3, 2), np.uint64); fin = np.zeros(2, np.uint64)
         self._chk(self.lib.hobbit_sumcheck3(self.ctx, c_vp(p1), c_vp(p2), c_vp(p3), c_sz(n), _hp(pr), _hp(q), _hp(r), _hp(vr), _hp(fin)))
         return dict(poly=q, r=r, vr=vr, fin=fin)
+
+
+# ---- submodule: chunk-sharded multi-GPU commit orchestration --------------------------------
+def _load_parallel():
+    name = __name__ + ".parallel"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(PKG_DIR, "parallel.py"))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+parallel = _load_parallel()
+parallel_tree_top = parallel.tree_top_host

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include "hobbit_kernels.hpp"
+#include "hobbit_blake3.hpp"
 
 using namespace hobbit;
 
@@ -425,6 +426,24 @@ int hobbit_commitment_paths(hobbit_ctx *ctx, const hobbit_commitment *c, const u
 int hobbit_commitment_path(hobbit_ctx *ctx, const hobbit_commitment *c, size_t col, size_t row, uint8_t *h_path) {
     uint32_t cc = (uint32_t)col, rr = (uint32_t)row;
     return hobbit_commitment_paths(ctx, c, &cc, &rr, 1, h_path);
+}
+
+// ---- multi-GPU commit building blocks -------------------------------------------
+int hobbit_tensorcode_chunks(hobbit_ctx *ctx, const hobbit_F *d_msg, size_t M, int nchunks, int trs, int linear_time, hobbit_F *d_out) {
+    if (nchunks <= 0) return ctx->fail(HOBBIT_EINVAL, "tensorcode_chunks: nchunks must be positive");
+    return tensorcode_chunks(ctx, cF(d_msg), M, nchunks, trs, linear_time, mF(d_out));
+}
+int hobbit_inner_digests(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M, int nchunks, int trs, uint8_t *d_out) {
+    if (trs < 4 || trs % 4 || M % (size_t)trs) return ctx->fail(HOBBIT_EINVAL, "inner_digests: trs must be a multiple of 4 dividing M");
+    size_t cols = 2 * M / trs;
+    return launch_inner_digests(ctx, cF(d_tensor), cols * 2 * (size_t)trs, nchunks, (uint32_t)cols, (uint32_t)(trs / 2), d_out);
+}
+int hobbit_chain_digests(hobbit_ctx *ctx, const uint8_t *d_digests, size_t stride_bytes, int K, size_t m, uint8_t *d_leaves) {
+    if (K < 0 || stride_bytes % 16) return ctx->fail(HOBBIT_EINVAL, "chain_digests: bad K / stride");
+    return launch_chain_digests(ctx, d_digests, stride_bytes, K, m, d_leaves);
+}
+void hobbit_blake3_64_host(const uint8_t *in, uint8_t *out, size_t n) {
+    for (size_t i = 0; i < n; i++) { uint32_t m[16], h[8]; memcpy(m, in + 64 * i, 64); blake3_compress64(m, h); memcpy(out + 32 * i, h, 32); }
 }
 
 // ---- open building blocks ---------------------------------------------------------------------

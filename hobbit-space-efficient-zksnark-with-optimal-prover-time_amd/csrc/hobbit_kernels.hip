@@ -492,6 +492,47 @@ __global__ void k_leaf_chain(const F *__restrict__ tensor, size_t chunk_stride, 
         store8w(leaves + 32 * ((size_t)j * cols + c), st);
     }
 }
+// Multi-GPU commit, step 1: inner digests H(t[4j..4j+3][c]) of the chunks a rank
+// owns, written in the reference's LEAF ORDER (leaf = j*cols + c) so that a contiguous leaf range
+// is a contiguous byte range to send: out[(i*M + j*cols + c)*32].
+__global__ void k_inner_digests(const F *__restrict__ tensor, size_t chunk_stride, int nchunks, uint32_t cols, uint32_t half_trs,
+                                uint8_t *__restrict__ out) {
+    const size_t M = (size_t)cols * half_trs, total = M * nchunks;
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = g / M, rem = g % M;
+        const uint32_t c = (uint32_t)(rem / half_trs), j = (uint32_t)(rem % half_trs);
+        uint32_t m[16], h[8];
+        load16w(tensor + i * chunk_stride + ((size_t)c * half_trs + j) * 4, m);
+        blake3_compress64(m, h);
+        store8w(out + 32 * (i * M + (size_t)j * cols + c), h);
+    }
+}
+// step 2: Merkle-Damgard chain over the K chunks for a leaf range held in leaf order:
+// leaf[p] = H(dig[K-1][p] | ... H(dig[0][p] | leaf[p]) ...), dig[i] at digests + i*stride
+__global__ void k_chain_digests(const uint8_t *__restrict__ digests, size_t stride_bytes, int K, size_t m, uint8_t *__restrict__ leaves) {
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < m; p += (size_t)gridDim.x * blockDim.x) {
+        uint32_t st[8], mm[16];
+        load8w(leaves + 32 * p, st);
+        for (int i = 0; i < K; i++) {
+            load8w(digests + (size_t)i * stride_bytes + 32 * p, mm);
+#pragma unroll
+            for (int q = 0; q < 8; q++) mm[8 + q] = st[q];
+            blake3_compress64(mm, st);
+        }
+        store8w(leaves + 32 * p, st);
+    }
+}
+int launch_inner_digests(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, int nchunks, uint32_t cols, uint32_t half_trs, uint8_t *out) {
+    size_t total = (size_t)cols * half_trs * nchunks;
+    if (!total) return 0;
+    HB_LAUNCH(ctx, "k_inner_digests", k_inner_digests, dim3(grid_for(total, 256, 1 << 20)), dim3(256), 0, tensor, chunk_stride, nchunks, cols, half_trs, out);
+    return 0;
+}
+int launch_chain_digests(hobbit_ctx *ctx, const uint8_t *digests, size_t stride_bytes, int K, size_t m, uint8_t *leaves) {
+    if (!m) return 0;
+    HB_LAUNCH(ctx, "k_chain_digests", k_chain_digests, dim3(grid_for(m, 256, 1 << 20)), dim3(256), 0, digests, stride_bytes, K, m, leaves);
+    return 0;
+}
 // paths[q][l] = levels[off_l + (pos_q >> l) ^ 1]   (src/merkle_tree.cpp:308-324)
 __global__ void k_merkle_paths(const uint8_t *__restrict__ levels, size_t n, const uint64_t *__restrict__ pos, size_t nq, int depth,
                                uint8_t *__restrict__ paths) {

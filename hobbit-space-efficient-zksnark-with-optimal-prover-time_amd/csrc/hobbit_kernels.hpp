@@ -16,6 +16,8 @@ int launch_blake3_64(hobbit_ctx *ctx, const uint8_t *in, uint8_t *out, size_t n)
 int launch_hash_md(hobbit_ctx *ctx, const F *xyzw, const uint8_t *prev, uint8_t *out, size_t n);
 int launch_merkle_levels(hobbit_ctx *ctx, uint8_t *levels, size_t n, int quirk);
 int launch_leaf_chain(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, int K, uint32_t cols, uint32_t half_trs, uint8_t *leaves);
+int launch_inner_digests(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, int nchunks, uint32_t cols, uint32_t half_trs, uint8_t *out);
+int launch_chain_digests(hobbit_ctx *ctx, const uint8_t *digests, size_t stride_bytes, int K, size_t m, uint8_t *leaves);
 int launch_merkle_paths(hobbit_ctx *ctx, const uint8_t *levels, size_t n, const uint64_t *d_pos, size_t nq, int depth, uint8_t *d_paths);
 int launch_eq_table(hobbit_ctx *ctx, const F *h_r, int k, F *d_out);
 int launch_aggregate(hobbit_ctx *ctx, const F *poly, size_t M, int K, const F *d_beta, F *aggr);

@@ -1,0 +1,315 @@
+// hobbit_host.cpp -- bodies of the reference-shaped host interface (hobbit_host.hpp): marshal
+// std::vector arguments to device buffers and call the C ABI.  See the header for the mapping.
+#include "hobbit_host.hpp"
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+
+int tensor_row_size = 128;        /* src/main.cpp:31 */
+size_t BUFFER_SPACE = 0;          /* src/main.cpp:38 */
+bool linear_time = false;         /* src/Our_PC.cpp:21 */
+int aggregation_queries = 1900;   /* src/Elastic_PC.cpp:10 */
+graph _C[100], D[100];
+
+static hobbit_ctx *g_ctx = nullptr;
+static hobbit_commitment *g_commit = nullptr;
+static int g_commit_K = 0, g_commit_trs = 0; static size_t g_commit_cols = 0;
+
+#define HCHK(call) do { int rc__ = (call); if (rc__ != 0) { printf("Error in %s: %s\n", #call, hobbit_last_error(g_ctx)); exit(-1); } } while (0)
+
+hobbit_ctx *hobbit_host_ctx() {
+    if (!g_ctx) {
+        const char *d = getenv("HOBBIT_DEVICE");
+        int rc = hobbit_ctx_create(d ? atoi(d) : 0, &g_ctx);
+        if (rc != 0) { printf("Error: no usable MI355X / HIP device (rc=%d); libhobbit_hip has no CPU fallback\n", rc); exit(-1); }
+    }
+    return g_ctx;
+}
+void hobbit_host_shutdown() {
+    if (g_commit) { hobbit_commitment_free(g_commit); g_commit = nullptr; }
+    if (g_ctx) { hobbit_ctx_destroy(g_ctx); g_ctx = nullptr; }
+}
+hobbit_commitment *hobbit_host_last_commitment() { return g_commit; }
+
+static inline const hobbit_F *hF(const F *p) { return reinterpret_cast<const hobbit_F *>(p); }
+static inline hobbit_F *hF(F *p) { return reinterpret_cast<hobbit_F *>(p); }
+static_assert(sizeof(F) == sizeof(hobbit_F), "fieldElement layout");
+
+struct DevBuf {   // RAII device buffer
+    void *p = nullptr;
+    DevBuf(size_t bytes) { HCHK(hobbit_malloc(hobbit_host_ctx(), bytes, &p)); }
+    DevBuf(const void *h, size_t bytes) : DevBuf(bytes) { if (bytes) HCHK(hobbit_memcpy_h2d(g_ctx, p, h, bytes)); }
+    ~DevBuf() { if (p) hobbit_free(g_ctx, p); }
+    void to_host(void *h, size_t bytes, size_t off = 0) { if (bytes) HCHK(hobbit_memcpy_d2h(g_ctx, h, (char *)p + off, bytes)); }
+};
+
+// ---- field (src/fieldElement.cpp:24-96, 206-209) ---------------------------------------------------
+namespace virgo {
+static const unsigned long long MODP = 2305843009213693951ULL;
+fieldElement::fieldElement(long long x) { real = x >= 0 ? x : MODP + x; img = 0; }
+fieldElement::fieldElement(long long x, long long y) { real = x >= 0 ? x : MODP + x; img = y >= 0 ? y : MODP + y; }
+fieldElement fieldElement::operator+(const fieldElement &o) const { fieldElement r; r.real = real + o.real; if (r.real >= MODP) r.real -= MODP; r.img = img + o.img; if (r.img >= MODP) r.img -= MODP; return r; }
+fieldElement fieldElement::operator-(const fieldElement &o) const { fieldElement r; r.real = real >= o.real ? real - o.real : real + MODP - o.real; r.img = img >= o.img ? img - o.img : img + MODP - o.img; return r; }
+fieldElement fieldElement::operator-() const { return zero() - *this; }
+fieldElement fieldElement::operator*(const fieldElement &o) const { fieldElement r; hobbit_f_mul_host(hF(this), hF(&o), hF(&r), 1); return r; }
+fieldElement fieldElement::inv() const { fieldElement r; hobbit_f_inv_host(hF(this), hF(&r), 1); return r; }
+}  // namespace virgo
+
+// ---- transcript -----------------------------------------------------------------------------------
+void init_hash() {}                                                 // constants are compiled in (src/mimc.cpp:11-19)
+F mimc_hash(F input, F k) { F r; hobbit_mimc(hF(&input), hF(&k), hF(&r)); return r; }
+
+// ---- utils ----------------------------------------------------------------------------------------
+vector<F> generate_randomness(int size) {                           // src/utils.cpp:873-883 (host, libc)
+    vector<F> x; x.reserve(size);
+    F c;
+    for (int i = 0; i < size; i++) { if (i % 100 == 0) c = F(random()); x.push_back(c + F(rand())); }
+    return x;
+}
+void precompute_beta(vector<F> r, vector<F> &B) {                   // src/utils.cpp:251-296
+    B.resize((size_t)1 << r.size());
+    DevBuf d(B.size() * sizeof(F));
+    HCHK(hobbit_eq_table(hobbit_host_ctx(), hF(r.data()), (int)r.size(), (hobbit_F *)d.p));
+    d.to_host(B.data(), B.size() * sizeof(F));
+}
+F evaluate_vector(vector<F> v, vector<F> r) {                       // src/utils.cpp:789-802
+    DevBuf d(v.data(), v.size() * sizeof(F));
+    F out;
+    HCHK(hobbit_eval_vector(hobbit_host_ctx(), (const hobbit_F *)d.p, v.size(), hF(r.data()), hF(&out)));
+    return out;
+}
+void _fft(F *arr, int logn, bool flag) {                            // src/utils.cpp:605-673
+    // NOTE: the reference caches twiddles by length only, so an inverse call right after a forward call
+    // of the same length reuses FORWARD twiddles.  This mirror always uses the twiddles of
+    // the requested direction; the commit path only ever calls the forward transform.
+    size_t len = (size_t)1 << logn;
+    if (logn > 12) { printf("Error: _fft length 2^%d not supported on the device yet\n", logn); exit(-1); }
+    DevBuf d(arr, len * sizeof(F));
+    HCHK(hobbit_fft_batch(hobbit_host_ctx(), (hobbit_F *)d.p, logn, 1, len, flag ? 1 : 0));
+    d.to_host(arr, len * sizeof(F));
+}
+void fft(vector<F> &arr, int logn, bool flag) { _fft(arr.data(), logn, flag); }   // src/utils.cpp:467-527
+
+// ---- expander code --------------------------------------------------------------------------------
+static graph generate_random_expander_store(long long L, long long R, long long d) {   // src/expanders.h:20-47
+    graph ret; ret.degree = (int)d;
+    ret.neighbor.resize(L); ret.weight.resize(L); ret.r_neighbor.resize(R); ret.r_weight.resize(R);
+    for (long long i = 0; i < L; ++i) {
+        ret.neighbor[i].resize(d); ret.weight[i].resize(d);
+        for (long long j = 0; j < d; ++j) {
+            long long target = rand() % R;
+            F weight = random();
+            ret.neighbor[i][j] = target; ret.weight[i][j] = weight;
+            ret.r_neighbor[target].push_back(i); ret.r_weight[target].push_back(weight);
+        }
+    }
+    ret.L = L; ret.R = R;
+    return ret;
+}
+static void upload_graph(int dep, int kind, const graph &g) {
+    vector<long long> nbr((size_t)g.L * g.degree); vector<F> w((size_t)g.L * g.degree);
+    for (long long i = 0; i < g.L; i++) for (int j = 0; j < g.degree; j++) { nbr[i * g.degree + j] = g.neighbor[i][j]; w[i * g.degree + j] = g.weight[i][j]; }
+    HCHK(hobbit_graph_upload(hobbit_host_ctx(), dep, kind, g.L, g.R, g.degree, nbr.data(), hF(w.data())));
+}
+static const double k_alpha = 0.211, k_r = 1.72;                    // src/parameter.h:4-8
+static const int k_cn = 9, k_dn = 12, k_distance_threshold = (int)(1.0 / 0.07) - 1;
+static long long expander_rec(long long n, int dep) {               // src/expanders.h:78-92
+    if (n <= k_distance_threshold) return n;
+    _C[dep] = generate_random_expander_store(n, (long long)(k_alpha * n), k_cn);
+    long long L = expander_rec((long long)(k_alpha * n), dep + 1);
+    D[dep] = generate_random_expander_store(L, (long long)(n * (k_r - 1) - L), k_dn);
+    upload_graph(dep, 0, _C[dep]); upload_graph(dep, 1, D[dep]);
+    return n + L + (long long)(n * (k_r - 1) - L);
+}
+long long expander_init_store(long long n, int dep) {
+    if (dep == 0) HCHK(hobbit_graph_reset(hobbit_host_ctx()));
+    long long total = expander_rec(n, dep);
+    if (dep == 0) { long long len = 0; HCHK(hobbit_graph_finalize(g_ctx, n, &len)); if (len != total) { printf("Error in expander_init_store\n"); exit(-1); } }
+    return total;
+}
+int encode_monolithic(const F *src, F *dst, long long n, int dep) {  // src/linear_code_encode.h:62-119
+    if (dep != 0) { printf("Error: encode_monolithic recursion is internal to the device kernel\n"); exit(-1); }
+    DevBuf s(src, (size_t)n * sizeof(F)), d((size_t)2 * n * sizeof(F));
+    long long len = n;
+    HCHK(hobbit_graph_finalize(hobbit_host_ctx(), n, &len));         // (re)binds the uploaded levels to this n; returns n+L+R
+    HCHK(hobbit_encode_batch(g_ctx, (const hobbit_F *)s.p, (hobbit_F *)d.p, n, 1, (size_t)n, (size_t)2 * n));
+    d.to_host(dst, (size_t)len * sizeof(F));                        // the reference writes n+L+R elements of dst
+    return (int)len;
+}
+
+// ---- hashes / Merkle ------------------------------------------------------------------------------
+void blake3_hash(uint8_t *src, uint8_t *dst) {                      // src/Blake3_hash.cpp:5-10
+    DevBuf s(src, 64), d(32);
+    HCHK(hobbit_blake3_64(hobbit_host_ctx(), (const uint8_t *)s.p, (uint8_t *)d.p, 1));
+    d.to_host(dst, 32);
+}
+namespace merkle_tree {
+_hash hash_double_field_element_merkle_damgard_blake(virgo::fieldElement x, virgo::fieldElement y, virgo::fieldElement z, virgo::fieldElement w, _hash &prev_hash) {
+    F e[4] = {x, y, z, w};                                          // src/merkle_tree.cpp:62-87
+    DevBuf s(e, 64), p(prev_hash.arr, 32);
+    HCHK(hobbit_hash_md(hobbit_host_ctx(), (const hobbit_F *)s.p, (const uint8_t *)p.p, (uint8_t *)p.p, 1));
+    _hash r; p.to_host(r.arr, 32); return r;
+}
+namespace merkle_tree_prover {
+static void unflatten(DevBuf &lv, size_t n, vector<vector<_hash>> &hashes) {
+    size_t levels = (size_t)log2((double)n) + 1;
+    if (hashes.size() < levels) hashes.resize(levels);
+    size_t off = 0;
+    for (size_t l = 0, sz = n; l < levels; l++, sz /= 2) { hashes[l].resize(sz); lv.to_host(hashes[l].data(), 32 * sz, 32 * off); off += sz; }
+}
+void MT_commit_Blake(F *leafs, vector<vector<_hash>> &hashes, int N) {   // src/merkle_tree.cpp:193-221
+    DevBuf s(leafs, (size_t)N * sizeof(F)), lv((size_t)64 * (N / 4));
+    HCHK(hobbit_mt_commit_blake(hobbit_host_ctx(), (const hobbit_F *)s.p, (size_t)N, (uint8_t *)lv.p));
+    unflatten(lv, (size_t)N / 4, hashes);
+}
+void create_tree_blake(int ele_num, vector<vector<_hash>> &hashes, const int, bool) {   // src/merkle_tree.cpp:255-287 (left|left kept)
+    DevBuf lv((size_t)64 * ele_num);
+    HCHK(hobbit_memcpy_h2d(hobbit_host_ctx(), lv.p, hashes[0].data(), (size_t)32 * ele_num));
+    HCHK(hobbit_merkle_levels(g_ctx, (uint8_t *)lv.p, (size_t)ele_num, 1));
+    unflatten(lv, (size_t)ele_num, hashes);
+}
+vector<_hash> open_tree_blake(vector<vector<_hash>> &MT_hashes, vector<size_t> c, int collumns) {   // src/merkle_tree.cpp:308-324
+    int pos = (int)((c[1] / 4) * collumns + c[0]);
+    if ((size_t)pos >= MT_hashes[0].size()) { printf("Error %d,%d\n", pos, (int)MT_hashes[0].size()); exit(-1); }
+    vector<_hash> path;
+    for (size_t i = 0; i + 1 < MT_hashes.size(); i++) { path.push_back(MT_hashes[i][2 * (pos / 2) + (1 - (pos % 2))]); pos = pos / 2; }
+    return path;
+}
+}  // namespace merkle_tree_prover
+}  // namespace merkle_tree
+
+// ---- tensor code / commit -------------------------------------------------------------------------
+void compute_tensorcode(vector<F> &message, vector<vector<F>> &tensor) {       // src/PC_utils.cpp:66-123
+    size_t M = message.size(), cols = 2 * M / tensor_row_size, rows2 = 2 * (size_t)tensor_row_size;
+    DevBuf m(message.data(), M * sizeof(F)), t(cols * rows2 * sizeof(F));
+    HCHK(hobbit_tensorcode(hobbit_host_ctx(), (const hobbit_F *)m.p, M, tensor_row_size, linear_time ? 1 : 0, (hobbit_F *)t.p));
+    vector<F> cm(cols * rows2);                                     // codeword-major on the device
+    t.to_host(cm.data(), cm.size() * sizeof(F));
+    tensor.resize(rows2);
+    for (size_t r = 0; r < rows2; r++) { tensor[r].resize(cols); for (size_t c = 0; c < cols; c++) tensor[r][c] = cm[c * rows2 + r]; }
+}
+void hobbit_host_materialize_tensor(vector<vector<vector<F>>> &_tensor) {
+    if (!g_commit) return;
+    _tensor.resize(g_commit_K);
+    for (int i = 0; i < g_commit_K; i++) {
+        _tensor[i].resize(2 * (size_t)g_commit_trs);
+        for (int r = 0; r < 2 * g_commit_trs; r++) { _tensor[i][r].resize(g_commit_cols); HCHK(hobbit_commitment_tensor_row(g_ctx, g_commit, i, r, hF(_tensor[i][r].data()))); }
+    }
+}
+void commit_standard(vector<F> &poly, _hash &comm, vector<vector<_hash>> &MT_hashes, vector<vector<vector<F>>> &_tensor, int K) {   // src/Our_PC.cpp:146-171
+    (void)comm;                                                     // the reference never writes it either
+    size_t N = poly.size(), M = N / K;
+    if (g_commit) { hobbit_commitment_free(g_commit); g_commit = nullptr; }
+    {
+        DevBuf p(poly.data(), N * sizeof(F));
+        HCHK(hobbit_commit_standard(hobbit_host_ctx(), (const hobbit_F *)p.p, N, K, tensor_row_size, linear_time ? 1 : 0, &g_commit));
+        HCHK(hobbit_sync(g_ctx));
+    }
+    g_commit_K = K; g_commit_trs = tensor_row_size; g_commit_cols = 2 * M / tensor_row_size;
+    vector<uint8_t> flat(32 * (2 * M - 1));
+    HCHK(hobbit_commitment_levels(g_ctx, g_commit, flat.data()));
+    size_t levels = (size_t)log2((double)M) + 1, off = 0;
+    MT_hashes.resize(levels);
+    for (size_t l = 0, sz = M; l < levels; l++, sz /= 2) { MT_hashes[l].resize(sz); memcpy(MT_hashes[l].data(), flat.data() + 32 * off, 32 * sz); off += sz; }
+    _tensor.clear(); _tensor.resize(K);
+    const char *mat = getenv("HOBBIT_MATERIALIZE_TENSOR");
+    if ((mat && atoi(mat)) || (size_t)4 * N * sizeof(F) <= ((size_t)256 << 20)) hobbit_host_materialize_tensor(_tensor);
+}
+void _aggregate_axpy(vector<F> &poly, vector<F> beta1, vector<F> &aggregated_vector, int K) {    // src/Our_PC.cpp:258-272
+    size_t M = poly.size() / K;
+    DevBuf p(poly.data(), poly.size() * sizeof(F)), a(M * sizeof(F));
+    HCHK(hobbit_aggregate(hobbit_host_ctx(), (const hobbit_F *)p.p, poly.size(), hF(beta1.data()), K, (hobbit_F *)a.p));
+    aggregated_vector.resize(M);
+    a.to_host(aggregated_vector.data(), M * sizeof(F));
+}
+void _compute_aggregation_reply(vector<vector<size_t>> &I, vector<vector<F>> &reply, vector<vector<vector<F>>> &_tensor, int K) {   // src/Our_PC.cpp:291-305
+    reply.resize(aggregation_queries);
+    for (auto &r : reply) r.resize(K);
+    if (!_tensor.empty() && !_tensor[0].empty()) {                  // materialised: the reference's own loop
+        for (int i = 0; i < K; i++) for (size_t k = 0; k < I.size(); k++) reply[k][i] = _tensor[i][I[k][1]][I[k][0]];
+        return;
+    }
+    vector<uint32_t> rows(I.size()), cols(I.size());
+    for (size_t k = 0; k < I.size(); k++) { cols[k] = (uint32_t)I[k][0]; rows[k] = (uint32_t)I[k][1]; }
+    vector<F> flat(I.size() * K);
+    HCHK(hobbit_commitment_gather(hobbit_host_ctx(), g_commit, rows.data(), cols.data(), I.size(), hF(flat.data())));
+    for (size_t k = 0; k < I.size(); k++) for (int i = 0; i < K; i++) reply[k][i] = flat[k * K + i];
+}
+
+// ---- sumchecks ------------------------------------------------------------------------------------
+struct proof generate_2product_sumcheck_proof(vector<F> &_v1, vector<F> &_v2, F previous_r, double &vt, double &ps) {   // src/sumcheck.cpp:2391-2460
+    size_t n = _v1.size();
+    int rounds = (int)log2((double)n);
+    DevBuf a(_v1.data(), n * sizeof(F)), b(_v2.data(), n * sizeof(F));
+    vector<F> q(3 * (size_t)rounds), r(rounds); F vr[2], fin;
+    HCHK(hobbit_sumcheck2(hobbit_host_ctx(), (const hobbit_F *)a.p, (const hobbit_F *)b.p, n, hF(&previous_r), hF(q.data()), hF(r.data()), hF(vr), hF(&fin)));
+    struct proof Pr;
+    for (int i = 0; i < rounds; i++) Pr.q_poly.push_back(quadratic_poly(q[3 * i], q[3 * i + 1], q[3 * i + 2]));
+    Pr.randomness.push_back(r); Pr.vr = {vr[0], vr[1]}; Pr.final_rand = fin;
+    ps += rounds * 3 * sizeof(F) / 1024.0 + 2 * sizeof(F) / 1024.0;       // same proof-size accounting (src/sumcheck.cpp:2431,2449)
+    (void)vt;
+    return Pr;
+}
+struct proof _generate_3product_sumcheck_proof(vector<F> &v1, vector<F> &v2, vector<F> &v3, F previous_r, double &vt, double &ps) {   // src/sumcheck.cpp:1974-2058
+    size_t n = v1.size();
+    int rounds = (int)log2((double)n);
+    DevBuf a(v1.data(), n * sizeof(F)), b(v2.data(), n * sizeof(F)), c(v3.data(), n * sizeof(F));
+    vector<F> q(4 * (size_t)rounds), r(rounds); F vr[3], fin;
+    HCHK(hobbit_sumcheck3(hobbit_host_ctx(), (const hobbit_F *)a.p, (const hobbit_F *)b.p, (const hobbit_F *)c.p, n, hF(&previous_r), hF(q.data()), hF(r.data()), hF(vr), hF(&fin)));
+    struct proof Pr;
+    for (int i = 0; i < rounds; i++) Pr.c_poly.push_back(cubic_poly(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]));
+    Pr.randomness.push_back(r); Pr.vr = {vr[0], vr[1], vr[2]}; Pr.final_rand = fin;
+    // the reference folds v1..v3 in place; callers only rely on element 0 afterwards
+    v1[0] = vr[0]; v2[0] = vr[1]; v3[0] = vr[2];
+    ps += rounds * 5 * sizeof(F) / 1024.0 + 3 * sizeof(F) / 1024.0;       // src/sumcheck.cpp:2029,2047
+    (void)vt;
+    return Pr;
+}
+
+// ---- driver (src/Our_PC.cpp:757-826, option 4, commit phase) ---------------------------------------
+void test_PC(size_t N, int option, int K) {
+    if (option != 4) { printf("Error: only option 4 (RS x expander Our_PC) is built on the device path\n"); exit(-1); }
+    vector<F> poly = generate_randomness((int)N);
+    _hash comm; vector<vector<_hash>> MT_hashes;
+    linear_time = true;
+    tensor_row_size = (int)(N / (K * 1ULL << (11)));
+    printf("%d\n", tensor_row_size);
+    expander_init_store(tensor_row_size);
+    vector<vector<vector<F>>> _tensor;
+    auto start = std::chrono::steady_clock::now();
+    commit_standard(poly, comm, MT_hashes, _tensor, K);
+    auto end = std::chrono::steady_clock::now();
+    double commit_time = std::chrono::duration_cast<std::chrono::duration<double>>(end - start).count();
+    std::cout << "Commit time: " << commit_time << " seconds" << std::endl;
+    printf("root ");
+    for (int i = 0; i < 32; i++) printf("%02x", MT_hashes.back()[0].arr[i]);
+    printf("\n");
+}
+
+// ---- extern "C" hooks so tests can drive the C++ mirror through ctypes -------------------------------
+extern "C" {
+int hobbit_host_test_pc_root(size_t N, int K, uint8_t *root_out) {
+    srandom(1);
+    vector<F> poly = generate_randomness((int)N);
+    linear_time = true; tensor_row_size = (int)(N / (K * 1ULL << 11));
+    expander_init_store(tensor_row_size);
+    _hash comm; vector<vector<_hash>> MT; vector<vector<vector<F>>> T;
+    commit_standard(poly, comm, MT, T, K);
+    memcpy(root_out, MT.back()[0].arr, 32);
+    return (int)MT.size();
+}
+int hobbit_host_sumcheck2(const uint64_t *v1, const uint64_t *v2, size_t n, const uint64_t *prev, uint64_t *qpoly, uint64_t *r, uint64_t *vr, uint64_t *fin) {
+    vector<F> a(n), b(n); memcpy((void *)a.data(), v1, 16 * n); memcpy((void *)b.data(), v2, 16 * n);
+    F p; memcpy((void *)&p, prev, 16);
+    double vt = 0, ps = 0;
+    proof P = generate_2product_sumcheck_proof(a, b, p, vt, ps);
+    for (size_t i = 0; i < P.q_poly.size(); i++) { memcpy(qpoly + 6 * i, &P.q_poly[i].a, 16); memcpy(qpoly + 6 * i + 2, &P.q_poly[i].b, 16); memcpy(qpoly + 6 * i + 4, &P.q_poly[i].c, 16); }
+    memcpy(r, P.randomness[0].data(), 16 * P.randomness[0].size());
+    memcpy(vr, P.vr.data(), 32); memcpy(fin, &P.final_rand, 16);
+    return (int)P.q_poly.size();
+}
+void hobbit_host_close(void) { hobbit_host_shutdown(); }
+}

@@ -1,0 +1,128 @@
+// hobbit_host.hpp -- C++ host mirror of the reference's hot-path interface.
+//
+// The reference is one C++ executable whose "plugin API" for this path is a set of free functions
+// and globals.  This header re-declares exactly those names with the reference's
+// signatures so that a reference-shaped driver (src/main.cpp, test_PC) compiles against it
+// unchanged; every body in hobbit_host.cpp is a thin call into the C ABI (include/hobbit_hip.h).
+// Host-only pieces stay on the host exactly as in the reference: the libc rand()/random() draws
+// (graphs, generate_randomness, queries) and the printf/exit self-check convention.
+//
+// Each declaration cites the reference declaration it mirrors.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <string>
+#include <vector>
+#include "hobbit_hip.h"
+
+using std::vector;
+
+namespace virgo {
+// src/fieldElement.hpp:20-108 -- same 16-byte layout {real, img}, same operators; the arithmetic is
+// the library's (canonical results identical to the reference's, see hobbit_field.hpp)
+class fieldElement {
+public:
+    fieldElement() : real(0), img(0) {}
+    fieldElement(long long x);
+    fieldElement(long long x, long long y);
+    fieldElement operator+(const fieldElement &o) const;
+    fieldElement operator-(const fieldElement &o) const;
+    fieldElement operator-() const;
+    fieldElement operator*(const fieldElement &o) const;
+    bool operator==(const fieldElement &o) const { return real == o.real && img == o.img; }
+    bool operator!=(const fieldElement &o) const { return !(*this == o); }
+    fieldElement &operator+=(const fieldElement &o) { *this = *this + o; return *this; }
+    fieldElement &operator-=(const fieldElement &o) { *this = *this - o; return *this; }
+    fieldElement &operator*=(const fieldElement &o) { *this = *this * o; return *this; }
+    fieldElement inv() const;
+    static fieldElement zero() { return fieldElement(0); }
+    static fieldElement one() { return fieldElement(1); }
+    unsigned long long real, img;
+};
+}  // namespace virgo
+#define F virgo::fieldElement          /* src/config_pc.hpp:10-12 */
+#define F_ONE virgo::fieldElement::one()
+#define F_ZERO virgo::fieldElement::zero()
+
+struct _hash { uint8_t arr[32]; };     /* src/Blake3_hash.h:3-5 */
+
+/* globals that are part of the reference ABI (src/main.cpp:31,38; src/Our_PC.cpp:21; src/Elastic_PC.cpp:10,14) */
+extern int tensor_row_size;
+extern size_t BUFFER_SPACE;
+extern bool linear_time;
+extern int aggregation_queries;
+
+/* src/polynomial.h:18-70 (coefficients highest degree first) */
+class linear_poly { public: F a, b; linear_poly() {} linear_poly(const F &aa, const F &bb) : a(aa), b(bb) {} F eval(const F &x) const { return a * x + b; } };
+class quadratic_poly { public: F a, b, c; quadratic_poly() {} quadratic_poly(const F &aa, const F &bb, const F &cc) : a(aa), b(bb), c(cc) {}
+    F eval(const F &x) const { return ((a * x) + b) * x + c; } };
+class cubic_poly { public: F a, b, c, d; cubic_poly() {} cubic_poly(const F &aa, const F &bb, const F &cc, const F &dd) : a(aa), b(bb), c(cc), d(dd) {}
+    F eval(const F &x) const { return (((a * x) + b) * x + c) * x + d; } };
+
+/* src/sumcheck.h:21-43 (the members the hot-path functions fill) */
+struct proof {
+    int type = 0;
+    vector<vector<F>> randomness;
+    vector<quadratic_poly> q_poly;
+    vector<cubic_poly> c_poly;
+    vector<F> vr;
+    F final_rand;
+};
+
+/* src/expanders.h:7-16 */
+class graph {
+public:
+    int degree = 0;
+    vector<vector<long long>> neighbor, r_neighbor;
+    vector<vector<F>> weight, r_weight;
+    long long L = 0, R = 0;
+};
+extern graph _C[100], D[100];                                   /* src/expander.cpp:2 */
+
+/* device context used by every call below; created on first use on HOBBIT_DEVICE (default 0).
+ * Creation failure (no GPU / library) prints the reason and exits(-1), the reference's own error
+ * convention -- there is no CPU fallback. */
+hobbit_ctx *hobbit_host_ctx();
+void hobbit_host_shutdown();
+
+/* src/mimc.h:5-6 */
+void init_hash();
+F mimc_hash(F input, F k);
+/* src/utils.hpp:13,18,23,39,57 */
+void precompute_beta(vector<F> r, vector<F> &B);
+vector<F> generate_randomness(int size);
+F evaluate_vector(vector<F> v, vector<F> r);
+void fft(vector<F> &arr, int logn, bool flag);
+void _fft(F *arr, int logn, bool flag);
+/* src/expanders.h:78 ; src/linear_code_encode.h:62 */
+long long expander_init_store(long long n, int dep = 0);
+int encode_monolithic(const F *src, F *dst, long long n, int dep = 0);
+/* src/Blake3_hash.h:9 */
+void blake3_hash(uint8_t *src, uint8_t *dst);
+/* src/merkle_tree.h:25,33,36,38 */
+namespace merkle_tree {
+_hash hash_double_field_element_merkle_damgard_blake(virgo::fieldElement x, virgo::fieldElement y, virgo::fieldElement z, virgo::fieldElement w, _hash &prev_hash);
+namespace merkle_tree_prover {
+void MT_commit_Blake(F *leafs, vector<vector<_hash>> &hashes, int N);
+void create_tree_blake(int ele_num, vector<vector<_hash>> &hashes, const int element_size = 256 / 8, bool alloc_required = false);
+vector<_hash> open_tree_blake(vector<vector<_hash>> &MT_hashes, vector<size_t> c, int collumns);
+}  // namespace merkle_tree_prover
+}  // namespace merkle_tree
+/* src/PC_utils.h:6 */
+void compute_tensorcode(vector<F> &message, vector<vector<F>> &tensor);
+/* src/Our_PC.hpp:11-15 */
+void commit_standard(vector<F> &poly, _hash &comm, vector<vector<_hash>> &MT_hashes, vector<vector<vector<F>>> &_tensor, int K);
+void test_PC(size_t N, int option, int K);
+/* src/Our_PC.cpp:258-272, 291-305 (file-local helpers of open_standard) */
+void _aggregate_axpy(vector<F> &poly, vector<F> beta1, vector<F> &aggregated_vector, int K);
+void _compute_aggregation_reply(vector<vector<size_t>> &I, vector<vector<F>> &reply, vector<vector<vector<F>>> &_tensor, int K);
+/* src/sumcheck.h:70,78 */
+struct proof generate_2product_sumcheck_proof(vector<F> &_v1, vector<F> &_v2, F previous_r, double &vt, double &ps);
+struct proof _generate_3product_sumcheck_proof(vector<F> &v1, vector<F> &v2, vector<F> &v3, F previous_r, double &vt, double &ps);
+
+/* Not in the reference: the 16 GiB `_tensor` of a 2^28 commit stays on the device.
+ * commit_standard leaves `_tensor[i]` empty unless HOBBIT_MATERIALIZE_TENSOR=1 (or the tensor is
+ * under 256 MiB); the device-resident commitment of the last commit_standard is reachable here
+ * and is what _compute_aggregation_reply / open_tree_blake read when `_tensor[i]` is empty. */
+hobbit_commitment *hobbit_host_last_commitment();
+void hobbit_host_materialize_tensor(vector<vector<vector<F>>> &_tensor);

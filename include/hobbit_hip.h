@@ -135,6 +135,19 @@ int hobbit_commitment_path(hobbit_ctx *ctx, const hobbit_commitment *c, size_t c
 int hobbit_commitment_paths(hobbit_ctx *ctx, const hobbit_commitment *c, const uint32_t *h_cols, const uint32_t *h_rows, size_t nq,
                             uint8_t *h_paths);
 
+/* ---- multi-GPU commit building blocks (chunk-sharded commit) ------------------ */
+/* tensor codes of `nchunks` consecutive messages of M F each (chunk i at d_msg + i*M), outputs
+ * codeword-major per chunk at d_out + i*4M */
+int hobbit_tensorcode_chunks(hobbit_ctx *ctx, const hobbit_F *d_msg, size_t M, int nchunks, int trs, int linear_time, hobbit_F *d_out);
+/* inner leaf digests H(t[4j..4j+3][c]) (src/merkle_tree.cpp:70-75) of nchunks tensors, in leaf
+ * order: d_out[(i*M + j*cols + c)*32] */
+int hobbit_inner_digests(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M, int nchunks, int trs, uint8_t *d_out);
+/* Merkle-Damgard chain (src/merkle_tree.cpp:76-86) over K digests per leaf, in place on m leaves:
+ * leaf[p] = H(dig_i[p] | leaf[p]) for i = 0..K-1, dig_i at d_digests + i*stride_bytes */
+int hobbit_chain_digests(hobbit_ctx *ctx, const uint8_t *d_digests, size_t stride_bytes, int K, size_t m, uint8_t *d_leaves);
+/* host-side blake3_hash x n (tree tops of a handful of nodes) */
+void hobbit_blake3_64_host(const uint8_t *h_in, uint8_t *h_out, size_t n);
+
 /* ---- Our_PC open building blocks ----------------------------------------------------------- */
 /* _aggregate axpy (src/Our_PC.cpp:258-272): d_aggr[j] = sum_i beta[i] * poly[i*M + j], M = N/K */
 int hobbit_aggregate(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_F *h_beta, int K, hobbit_F *d_aggr);

@@ -307,3 +307,62 @@ def test_sumcheck2_2e24_claim_consistency(hb, oracle):
         for t in range(3):
             rr = oracle.mimc(rr, q[i, t:t + 1])
         assert np.array_equal(rr[0], res["r"][i])
+
+
+# ---- the C++ host mirror (reference signatures over the C ABI) -------------------------------
+def test_cpp_host_mirror_test_pc_and_sumcheck(oracle):
+    """libhobbit_host.so keeps the reference's C++ signatures (commit_standard, expander_init_store,
+    generate_2product_sumcheck_proof, ...); drive them through its extern-C hooks."""
+    import ctypes
+    from __graft_entry__ import PKG, build_host
+    build_host()
+    lib = ctypes.CDLL(os.path.join(PKG, "libhobbit_host.so"))
+    g = gold("commit")
+    root = np.zeros(32, np.uint8)
+    lib.hobbit_host_test_pc_root.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    levels = lib.hobbit_host_test_pc_root(1 << 20, 32, root.ctypes.data_as(ctypes.c_void_p))   # test_PC(2^20,4,32) input sequence
+    assert levels == 16 and np.array_equal(root, g["c_1048576_32_root"])
+    n = 1 << 10
+    v1, v2, _, _, _ = golden_cases.sumcheck_inputs(n)
+    pr = np.array([33, 0], np.uint64)
+    q = np.zeros((10, 3, 2), np.uint64); r = np.zeros((10, 2), np.uint64); vr = np.zeros((2, 2), np.uint64); fin = np.zeros(2, np.uint64)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.hobbit_host_sumcheck2.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t] + [ctypes.c_void_p] * 5
+    assert lib.hobbit_host_sumcheck2(P(v1), P(v2), n, P(pr), P(q), P(r), P(vr), P(fin)) == 10
+    gs = gold("sumcheck")
+    assert np.array_equal(q, gs["s2_1024_poly"]) and np.array_equal(r, gs["s2_1024_r"])
+    assert np.array_equal(vr, gs["s2_1024_vr"]) and np.array_equal(fin, gs["s2_1024_fin"])
+    lib.hobbit_host_close()
+
+
+# ---- multi-GPU building blocks on one GPU ------------------------------------------------------
+def test_sharded_commit_hip_ops_world1(hb, oracle):
+    """The per-rank GPU operations of the chunk-sharded commit (tensor codes of the local chunks,
+    inner digests in leaf order, Merkle-Damgard chain, subtree) at world size 1 must reproduce
+    commit_standard; the collective pattern itself is covered by tests/test_dist_gloo.py."""
+    import torch
+    from __graft_entry__ import load_package
+    mod = load_package()
+    N, K = 1 << 20, 32
+    trs = N // (K << 11)
+    oracle.rng_reset(); poly = oracle.generate_randomness(N); oracle.expander_init_store(trs)
+    hb.upload_graphs(trs, graphs_from(oracle, trs))
+    want, _ = oracle.commit_standard(poly, K, trs, 1)
+    plan = mod.parallel.ShardPlan(N, K, trs, 1)
+    d = hb.to_device(poly)
+    res = mod.parallel.sharded_commit(mod.parallel.HipOps(hb, torch.device("cuda", 0)), None, plan, 0, (d.ptr, K))
+    levels = mod.parallel.assemble_levels(plan, [res["subtree"].cpu().numpy()], res["top"])
+    assert np.array_equal(levels, want)
+    # emulate two ranks on the one GPU: digests of the odd/even chunks chained in global order
+    plan2 = mod.parallel.ShardPlan(N, K, trs, 2)
+    M = plan2.M
+    digs = {}
+    for r in range(2):
+        loc = np.concatenate([poly[i * M:(i + 1) * M] for i in plan2.chunks_of(r)])
+        dl = hb.to_device(loc)
+        digs[r] = mod.parallel.HipOps(hb, torch.device("cuda", 0)).inner_digests((dl.ptr, K // 2), plan2).cpu().numpy()
+    full = np.stack([digs[i % 2][i // 2] for i in range(K)])          # [K, M, 32] in global chunk order
+    leaves = np.zeros((M, 32), np.uint8)
+    for i in range(K):
+        leaves = oracle.blake3_64(np.concatenate([full[i], leaves], axis=1))
+    assert np.array_equal(leaves, want[:M])
