@@ -127,6 +127,7 @@ void hobbit_ctx_destroy(hobbit_ctx *ctx) {
     free_code(ctx->code);
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->ws2) hipFree(ctx->ws2);
+    if (ctx->pin) hipHostFree(ctx->pin);
     if (ctx->spare_tensor) hipFree(ctx->spare_tensor);
     if (ctx->spare_levels) hipFree(ctx->spare_levels);
     hipEventDestroy(ctx->t0); hipEventDestroy(ctx->t1);

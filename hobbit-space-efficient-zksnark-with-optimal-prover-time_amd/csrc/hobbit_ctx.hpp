@@ -78,6 +78,16 @@ struct hobbit_ctx {
         }
         *p = ws2; return 0;
     }
+    // small pinned host buffer for the per-round coefficient read-back of the sumchecks
+    void *pin = nullptr; size_t pin_bytes = 0;
+    int pinned(size_t bytes, void **p) {
+        if (bytes > pin_bytes) {
+            if (pin) hipHostFree(pin);
+            if (hipHostMalloc(&pin, bytes < 4096 ? 4096 : bytes) != hipSuccess) { pin = nullptr; pin_bytes = 0; err = "hipHostMalloc failed"; return HOBBIT_ENOMEM; }
+            pin_bytes = bytes < 4096 ? 4096 : bytes;
+        }
+        *p = pin; return 0;
+    }
     // one retired commitment's buffers, kept for the next commit of the same shape (a 2^28 commit
     // owns 16.5 GiB; re-allocating it per call would dominate a repeated-commit loop)
     void *spare_tensor = nullptr; size_t spare_tensor_bytes = 0;

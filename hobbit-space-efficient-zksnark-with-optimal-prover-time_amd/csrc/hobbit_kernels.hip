@@ -6,6 +6,7 @@
 // of the CU's 160 KB) and are bound by the v_mad_u64_u32 rate.
 #include "hobbit_kernels.hpp"
 #include "hobbit_blake3.hpp"
+#include <vector>
 
 namespace hobbit {
 
@@ -655,14 +656,16 @@ int launch_eval_fold(hobbit_ctx *ctx, const F *v, F *o, size_t L, F r) {
 // ============================================================================================
 // Sumcheck (src/sumcheck.cpp:2391-2460 two-product, 1974-2058 three-product)
 //
-// Per round: one streaming kernel over the tables that produces per-workgroup partial sums of the
-// round polynomial's coefficients, then a one-workgroup finishing kernel that reduces them and
-// runs the MiMC transcript (3-4 x 161 sequential cubings) ON THE DEVICE, leaving the next
-// challenge in device memory for the next launch: no host round trip inside the round loop.
-// Coefficient sums are exact field sums, so any reduction tree is bit-identical to the
-// reference's sequential accumulation.
+// Per round: one streaming kernel over the tables produces per-workgroup partial sums of the round
+// polynomial's coefficients, a one-workgroup kernel reduces them to 3-4 field elements, and those
+// 48-64 bytes go to the HOST, which runs the MiMC transcript (3-4 x 161 strictly sequential
+// cubings: ~4 us on a CPU core, ~80 us on a GPU scalar unit -- measured 5.7 of 6.7 ms at n = 2^24
+// with the transcript on the device) and passes the next challenge to the next launch as a kernel
+// argument.  Once the tables are down to SC_TAIL elements they are copied out and the last rounds
+// run on the host.  Coefficient sums are exact field sums, so any reduction tree is bit-identical
+// to the reference's sequential accumulation.
 // ============================================================================================
-struct SC2State { F rand; };
+static constexpr size_t SC_TAIL = 1024;      // table size at which the remaining rounds go to the host
 
 template <int NC>
 __device__ __forceinline__ void block_reduce_store(F (&c)[NC], F *partials) {
@@ -694,8 +697,7 @@ __global__ void __launch_bounds__(256) k_sc2_poly(const F *__restrict__ v1, cons
 // rounds >= 1: fold the previous tables with the challenge just derived (4 -> 2 elements per
 // thread and table) and accumulate this round's polynomial from the folded pair in registers.
 __global__ void __launch_bounds__(256) k_sc2_fold_poly(const F *__restrict__ s1, const F *__restrict__ s2, F *__restrict__ d1, F *__restrict__ d2,
-                                                       size_t L, const F *__restrict__ rand_p, F *__restrict__ partials) {
-    const F r = ldF(rand_p);
+                                                       size_t L, F r, F *__restrict__ partials) {
     F c[3] = {fmake(0), fmake(0), fmake(0)};
     for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < L; j += (size_t)gridDim.x * blockDim.x) {
         F a0 = ldF(s1 + 4 * j), a1 = ldF(s1 + 4 * j + 1), a2 = ldF(s1 + 4 * j + 2), a3 = ldF(s1 + 4 * j + 3);
@@ -707,41 +709,33 @@ __global__ void __launch_bounds__(256) k_sc2_fold_poly(const F *__restrict__ s1,
     }
     block_reduce_store<3>(c, partials);
 }
-// last fold (tables of 2 -> 1) + closing transcript steps
-__global__ void k_sc2_final(const F *__restrict__ s1, const F *__restrict__ s2, F *__restrict__ state, F *__restrict__ out_vr_fin) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        F r = ldF(state);
-        F a0 = ldF(s1), a1 = ldF(s1 + 1), b0 = ldF(s2), b1 = ldF(s2 + 1);
-        F x = fadd(a0, fmul(r, fsub(a1, a0))), y = fadd(b0, fmul(r, fsub(b1, b0)));
-        r = mimc_hash(r, x); r = mimc_hash(r, y);
-        stF(out_vr_fin, x); stF(out_vr_fin + 1, y); stF(out_vr_fin + 2, r);
-    }
-}
-// reduce partials, hash the coefficients into the transcript, publish challenge + proof data
+// reduce the per-workgroup partials to NC coefficients
 template <int NC>
-__global__ void __launch_bounds__(256) k_sc_finish(const F *__restrict__ partials, int nblocks, F *__restrict__ state, F *__restrict__ poly_out,
-                                                   F *__restrict__ r_out, int round, int record_before) {
+__global__ void __launch_bounds__(256) k_sc_reduce(const F *__restrict__ partials, int nblocks, F *__restrict__ out) {
     F c[NC];
 #pragma unroll
     for (int q = 0; q < NC; q++) c[q] = fmake(0);
     for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
 #pragma unroll
         for (int q = 0; q < NC; q++) c[q] = fadd(c[q], ldF(partials + (size_t)b * NC + q));
-    __shared__ F red[NC][4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int q = 0; q < NC; q++) { F s = wave_sum(c[q]); if (lane == 0) red[q][wv] = s; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        F r = ldF(state);
-        if (record_before) stF(r_out + round, r);          // 3-product: randomness[i] = pre-round challenge
-        for (int q = 0; q < NC; q++) {
-            F s = fadd(fadd(red[q][0], red[q][1]), fadd(red[q][2], red[q][3]));
-            stF(poly_out + (size_t)round * NC + q, s);
-            r = mimc_hash(r, s);
+    block_reduce_store<NC>(c, out);
+}
+
+// host tail of the 2-product sumcheck: tables a,b of size sz (not yet folded with `rnd` when
+// pending_fold), continuing at round `round` exactly as src/sumcheck.cpp:2401-2452
+static void sc2_host_tail(std::vector<F> &a, std::vector<F> &b, F &rnd, bool pending_fold, int round, int rounds, F *h_qpoly, F *h_r) {
+    size_t sz = a.size();
+    auto fold = [&](std::vector<F> &v) { for (size_t j = 0; j < sz / 2; j++) v[j] = fadd(v[2 * j], fmul(rnd, fsub(v[2 * j + 1], v[2 * j]))); };
+    if (pending_fold) { fold(a); fold(b); sz /= 2; }
+    for (int i = round; i < rounds; i++) {
+        F pa = fmake(0), pb = fmake(0), pc = fmake(0);
+        for (size_t j = 0; j < sz / 2; j++) {
+            F dx = fsub(a[2 * j + 1], a[2 * j]), dy = fsub(b[2 * j + 1], b[2 * j]);
+            pa = fadd(pa, fmul(dx, dy)); pb = fadd(pb, fadd(fmul(dx, b[2 * j]), fmul(a[2 * j], dy))); pc = fadd(pc, fmul(a[2 * j], b[2 * j]));
         }
-        if (!record_before) stF(r_out + round, r);         // 2-product: randomness[i] = post-hash challenge
-        stF(state, r);
+        rnd = mimc_hash(rnd, pa); rnd = mimc_hash(rnd, pb); rnd = mimc_hash(rnd, pc);
+        h_r[i] = rnd; h_qpoly[3 * i] = pa; h_qpoly[3 * i + 1] = pb; h_qpoly[3 * i + 2] = pc;
+        fold(a); fold(b); sz /= 2;
     }
 }
 
@@ -749,43 +743,54 @@ int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev
     int rounds = 0; while (((size_t)1 << rounds) < n) rounds++;
     if (((size_t)1 << rounds) != n || n < 2) return ctx->fail(HOBBIT_EINVAL, "sumcheck2: n must be a power of two >= 2");
     const int MAXB = 1024;
-    // workspace: tables A (2 x n/2), B (2 x n/4), partials, state, outputs
-    size_t szA = n / 2, szB = n / 4 ? n / 4 : 1;
-    size_t elems = 2 * szA + 2 * szB + (size_t)MAXB * 3 + 1 + (size_t)rounds * 4 + 3;
-    F *ws; HB_TRY(ctx->workspace(elems * sizeof(F), (void **)&ws));
-    F *A1 = ws, *A2 = A1 + szA, *B1 = A2 + szA, *B2 = B1 + szB, *part = B2 + szB, *state = part + (size_t)MAXB * 3;
-    F *d_q = state + 1, *d_r = d_q + (size_t)rounds * 3, *d_fin = d_r + rounds;
-    HB_CHECK(ctx, hipMemcpyAsync(state, &prev_r, sizeof(F), hipMemcpyHostToDevice, ctx->stream));
-    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    const F *s1 = v1, *s2 = v2;
-    size_t L = n / 2;
-    int nb = grid_for(L, 256, MAXB);
-    HB_LAUNCH(ctx, "k_sc2_poly", k_sc2_poly, dim3(nb), dim3(256), 0, s1, s2, L, part);
-    HB_LAUNCH(ctx, "k_sc_finish", k_sc_finish<3>, dim3(1), dim3(256), 0, part, nb, state, d_q, d_r, 0, 0);
-    F *d1 = A1, *d2 = A2;
-    for (int i = 1; i < rounds; i++) {
-        L = n >> (i + 1);
-        nb = grid_for(L, 256, MAXB);
-        HB_LAUNCH(ctx, "k_sc2_fold_poly", k_sc2_fold_poly, dim3(nb), dim3(256), 0, s1, s2, d1, d2, L, state, part);
-        HB_LAUNCH(ctx, "k_sc_finish", k_sc_finish<3>, dim3(1), dim3(256), 0, part, nb, state, d_q, d_r, i, 0);
-        s1 = d1; s2 = d2;
-        if (d1 == A1) { d1 = B1; d2 = B2; } else { d1 = A1; d2 = A2; }
+    F rnd = prev_r;
+    std::vector<F> ta, tb;
+    if (n <= SC_TAIL) {                       // small instance: all rounds on the host
+        ta.resize(n); tb.resize(n);
+        HB_CHECK(ctx, hipMemcpyAsync(ta.data(), v1, n * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+        HB_CHECK(ctx, hipMemcpyAsync(tb.data(), v2, n * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        sc2_host_tail(ta, tb, rnd, false, 0, rounds, h_qpoly, h_r);
+    } else {
+        size_t szA = n / 2, szB = n / 4;
+        F *ws; HB_TRY(ctx->workspace((2 * szA + 2 * szB + (size_t)MAXB * 3 + 4) * sizeof(F), (void **)&ws));
+        F *A1 = ws, *A2 = A1 + szA, *B1 = A2 + szA, *B2 = B1 + szB, *part = B2 + szB, *coef = part + (size_t)MAXB * 3;
+        F *pin; HB_TRY(ctx->pinned(4 * sizeof(F), (void **)&pin));
+        const F *s1 = v1, *s2 = v2;
+        F *d1 = A1, *d2 = A2;
+        int i = 0;
+        size_t cur = n;                       // size of the tables s1/s2 point at
+        for (;; i++) {
+            size_t L = n >> (i + 1);          // pairs of the round-i tables
+            int nb = grid_for(L, 256, MAXB);
+            if (i == 0) HB_LAUNCH(ctx, "k_sc2_poly", k_sc2_poly, dim3(nb), dim3(256), 0, s1, s2, L, part);
+            else {
+                HB_LAUNCH(ctx, "k_sc2_fold_poly", k_sc2_fold_poly, dim3(nb), dim3(256), 0, s1, s2, d1, d2, L, rnd, part);
+                s1 = d1; s2 = d2; cur = 2 * L;
+                if (d1 == A1) { d1 = B1; d2 = B2; } else { d1 = A1; d2 = A2; }
+            }
+            HB_LAUNCH(ctx, "k_sc_reduce", k_sc_reduce<3>, dim3(1), dim3(256), 0, part, nb, coef);
+            HB_CHECK(ctx, hipMemcpyAsync(pin, coef, 3 * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+            HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            for (int q = 0; q < 3; q++) { rnd = mimc_hash(rnd, pin[q]); h_qpoly[3 * i + q] = pin[q]; }
+            h_r[i] = rnd;
+            if (cur <= 2 * SC_TAIL || i == rounds - 1) break;   // hand the (unfolded) round-i tables to the host
+        }
+        ta.resize(cur); tb.resize(cur);
+        HB_CHECK(ctx, hipMemcpyAsync(ta.data(), s1, cur * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+        HB_CHECK(ctx, hipMemcpyAsync(tb.data(), s2, cur * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        sc2_host_tail(ta, tb, rnd, true, i + 1, rounds, h_qpoly, h_r);
     }
-    HB_LAUNCH(ctx, "k_sc2_final", k_sc2_final, dim3(1), dim3(64), 0, s1, s2, state, d_fin);
-    HB_CHECK(ctx, hipMemcpyAsync(h_qpoly, d_q, sizeof(F) * rounds * 3, hipMemcpyDeviceToHost, ctx->stream));
-    HB_CHECK(ctx, hipMemcpyAsync(h_r, d_r, sizeof(F) * rounds, hipMemcpyDeviceToHost, ctx->stream));
-    F fin[3];
-    HB_CHECK(ctx, hipMemcpyAsync(fin, d_fin, sizeof(F) * 3, hipMemcpyDeviceToHost, ctx->stream));
-    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    h_vr[0] = fin[0]; h_vr[1] = fin[1]; *h_final = fin[2];
+    rnd = mimc_hash(rnd, ta[0]); rnd = mimc_hash(rnd, tb[0]);          // src/sumcheck.cpp:2444-2446
+    h_vr[0] = ta[0]; h_vr[1] = tb[0]; *h_final = rnd;
     return 0;
 }
 
 // 3-product: polynomial of the current tables and fold with the PRE-round challenge in one pass
 __global__ void __launch_bounds__(256) k_sc3_poly_fold(const F *__restrict__ s1, const F *__restrict__ s2, const F *__restrict__ s3,
                                                        F *__restrict__ d1, F *__restrict__ d2, F *__restrict__ d3, size_t L,
-                                                       const F *__restrict__ rand_p, F *__restrict__ partials) {
-    const F r = ldF(rand_p);
+                                                       F r, F *__restrict__ partials) {
     F c[4] = {fmake(0), fmake(0), fmake(0), fmake(0)};
     for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < L; j += (size_t)gridDim.x * blockDim.x) {
         F x0 = ldF(s1 + 2 * j), x1 = ldF(s1 + 2 * j + 1), y0 = ldF(s2 + 2 * j), y1 = ldF(s2 + 2 * j + 1), z0 = ldF(s3 + 2 * j), z1 = ldF(s3 + 2 * j + 1);
@@ -800,41 +805,60 @@ __global__ void __launch_bounds__(256) k_sc3_poly_fold(const F *__restrict__ s1,
     }
     block_reduce_store<4>(c, partials);
 }
-__global__ void k_sc3_final(const F *__restrict__ s1, const F *__restrict__ s2, const F *__restrict__ s3, F *__restrict__ state, F *__restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        F r = ldF(state), x = ldF(s1), y = ldF(s2), z = ldF(s3);
-        r = mimc_hash(r, x); r = mimc_hash(r, y);        // v3[0] is not hashed (src/sumcheck.cpp:2043-2046)
-        stF(out, x); stF(out + 1, y); stF(out + 2, z); stF(out + 3, r);
+// host rounds of the 3-product sumcheck on tables of size sz (src/sumcheck.cpp:1981-2037)
+static void sc3_host_tail(std::vector<F> &a, std::vector<F> &b, std::vector<F> &c3, F &rnd, int round, int rounds, F *h_cpoly, F *h_r) {
+    size_t sz = a.size();
+    for (int i = round; i < rounds; i++) {
+        F pa = fmake(0), pb = fmake(0), pc = fmake(0), pd = fmake(0);
+        for (size_t j = 0; j < sz / 2; j++) {
+            F x0 = a[2 * j], y0 = b[2 * j], z0 = c3[2 * j];
+            F dx = fsub(a[2 * j + 1], x0), dy = fsub(b[2 * j + 1], y0), dz = fsub(c3[2 * j + 1], z0);
+            F qa = fmul(dx, dy), qb = fadd(fmul(dx, y0), fmul(x0, dy)), qc = fmul(x0, y0);
+            pa = fadd(pa, fmul(qa, dz)); pb = fadd(pb, fadd(fmul(qa, z0), fmul(qb, dz)));
+            pc = fadd(pc, fadd(fmul(qb, z0), fmul(qc, dz))); pd = fadd(pd, fmul(qc, z0));
+            a[j] = fadd(x0, fmul(rnd, dx)); b[j] = fadd(y0, fmul(rnd, dy)); c3[j] = fadd(z0, fmul(rnd, dz));
+        }
+        h_r[i] = rnd;
+        rnd = mimc_hash(rnd, pa); rnd = mimc_hash(rnd, pb); rnd = mimc_hash(rnd, pc); rnd = mimc_hash(rnd, pd);
+        h_cpoly[4 * i] = pa; h_cpoly[4 * i + 1] = pb; h_cpoly[4 * i + 2] = pc; h_cpoly[4 * i + 3] = pd;
+        sz /= 2;
     }
 }
 int launch_sumcheck3(hobbit_ctx *ctx, const F *v1, const F *v2, const F *v3, size_t n, F prev_r, F *h_cpoly, F *h_r, F *h_vr, F *h_final) {
     int rounds = 0; while (((size_t)1 << rounds) < n) rounds++;
     if (((size_t)1 << rounds) != n || n < 2) return ctx->fail(HOBBIT_EINVAL, "sumcheck3: n must be a power of two >= 2");
     const int MAXB = 1024;
-    size_t szA = n / 2, szB = n / 4 ? n / 4 : 1;
-    size_t elems = 3 * szA + 3 * szB + (size_t)MAXB * 4 + 1 + (size_t)rounds * 5 + 4;
-    F *ws; HB_TRY(ctx->workspace(elems * sizeof(F), (void **)&ws));
-    F *A = ws, *B = A + 3 * szA, *part = B + 3 * szB, *state = part + (size_t)MAXB * 4;
-    F *d_c = state + 1, *d_r = d_c + (size_t)rounds * 4, *d_fin = d_r + rounds;
-    HB_CHECK(ctx, hipMemcpyAsync(state, &prev_r, sizeof(F), hipMemcpyHostToDevice, ctx->stream));
-    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    F rnd = prev_r;
     const F *s1 = v1, *s2 = v2, *s3 = v3;
-    F *dst = A; size_t dsz = szA;
-    for (int i = 0; i < rounds; i++) {
-        size_t L = n >> (i + 1);
-        int nb = grid_for(L, 256, MAXB);
-        HB_LAUNCH(ctx, "k_sc3_poly_fold", k_sc3_poly_fold, dim3(nb), dim3(256), 0, s1, s2, s3, dst, dst + dsz, dst + 2 * dsz, L, state, part);
-        HB_LAUNCH(ctx, "k_sc_finish4", k_sc_finish<4>, dim3(1), dim3(256), 0, part, nb, state, d_c, d_r, i, 1);
-        s1 = dst; s2 = dst + dsz; s3 = dst + 2 * dsz;
-        if (dst == A) { dst = B; dsz = szB; } else { dst = A; dsz = szA; }
+    size_t cur = n;
+    int i = 0;
+    if (n > SC_TAIL) {
+        size_t szA = n / 2, szB = n / 4;
+        F *ws; HB_TRY(ctx->workspace((3 * szA + 3 * szB + (size_t)MAXB * 4 + 4) * sizeof(F), (void **)&ws));
+        F *A = ws, *B = A + 3 * szA, *part = B + 3 * szB, *coef = part + (size_t)MAXB * 4;
+        F *pin; HB_TRY(ctx->pinned(4 * sizeof(F), (void **)&pin));
+        F *dst = A; size_t dsz = szA;
+        for (; cur > SC_TAIL; i++) {
+            size_t L = cur / 2;
+            int nb = grid_for(L, 256, MAXB);
+            HB_LAUNCH(ctx, "k_sc3_poly_fold", k_sc3_poly_fold, dim3(nb), dim3(256), 0, s1, s2, s3, dst, dst + dsz, dst + 2 * dsz, L, rnd, part);
+            HB_LAUNCH(ctx, "k_sc_reduce4", k_sc_reduce<4>, dim3(1), dim3(256), 0, part, nb, coef);
+            HB_CHECK(ctx, hipMemcpyAsync(pin, coef, 4 * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+            HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            h_r[i] = rnd;                                           // randomness[i] = pre-round challenge
+            for (int q = 0; q < 4; q++) { rnd = mimc_hash(rnd, pin[q]); h_cpoly[4 * i + q] = pin[q]; }
+            s1 = dst; s2 = dst + dsz; s3 = dst + 2 * dsz; cur = L;
+            if (dst == A) { dst = B; dsz = szB; } else { dst = A; dsz = szA; }
+        }
     }
-    HB_LAUNCH(ctx, "k_sc3_final", k_sc3_final, dim3(1), dim3(64), 0, s1, s2, s3, state, d_fin);
-    HB_CHECK(ctx, hipMemcpyAsync(h_cpoly, d_c, sizeof(F) * rounds * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HB_CHECK(ctx, hipMemcpyAsync(h_r, d_r, sizeof(F) * rounds, hipMemcpyDeviceToHost, ctx->stream));
-    F fin[4];
-    HB_CHECK(ctx, hipMemcpyAsync(fin, d_fin, sizeof(F) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<F> ta(cur), tb(cur), tc(cur);
+    HB_CHECK(ctx, hipMemcpyAsync(ta.data(), s1, cur * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+    HB_CHECK(ctx, hipMemcpyAsync(tb.data(), s2, cur * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+    HB_CHECK(ctx, hipMemcpyAsync(tc.data(), s3, cur * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
     HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    h_vr[0] = fin[0]; h_vr[1] = fin[1]; h_vr[2] = fin[2]; *h_final = fin[3];
+    sc3_host_tail(ta, tb, tc, rnd, i, rounds, h_cpoly, h_r);
+    rnd = mimc_hash(rnd, ta[0]); rnd = mimc_hash(rnd, tb[0]);      // v3[0] is not hashed (src/sumcheck.cpp:2043-2046)
+    h_vr[0] = ta[0]; h_vr[1] = tb[0]; h_vr[2] = tc[0]; *h_final = rnd;
     return 0;
 }
 
