@@ -37,6 +37,7 @@ ABI_SYMBOLS = [
     "hobbit_commit_standard", "hobbit_commitment_free", "hobbit_commitment_num_leaves", "hobbit_commitment_levels_dev",
     "hobbit_commitment_tensor_dev", "hobbit_commitment_levels", "hobbit_commitment_root", "hobbit_commitment_tensor_row",
     "hobbit_commitment_gather", "hobbit_commitment_path", "hobbit_commitment_paths",
+    "hobbit_elastic_begin", "hobbit_elastic_push", "hobbit_elastic_finish", "hobbit_elastic_free",
     "hobbit_tensorcode_chunks", "hobbit_inner_digests", "hobbit_chain_digests", "hobbit_blake3_64_host",
     "hobbit_aggregate", "hobbit_sumcheck2", "hobbit_sumcheck3", "hobbit_fill_splitmix",
 ]
@@ -75,6 +76,8 @@ def load_library(path=LIB_PATH):
         "hobbit_commitment_path": [V, V, S, S, V], "hobbit_commitment_paths": [V, V, V, V, S, V], "hobbit_aggregate": [V, V, S, V, I, V],
         "hobbit_sumcheck2": [V, V, V, S, V, V, V, V, V], "hobbit_sumcheck3": [V, V, V, V, S, V, V, V, V, V],
         "hobbit_fill_splitmix": [V, V, S, U64],
+        "hobbit_elastic_begin": [V, S, I, I, I, V], "hobbit_elastic_push": [V, V, V], "hobbit_elastic_finish": [V, V, V],
+        "hobbit_elastic_free": [V],
         "hobbit_tensorcode_chunks": [V, V, S, I, I, I, V], "hobbit_inner_digests": [V, V, S, I, I, V],
         "hobbit_chain_digests": [V, V, S, I, S, V], "hobbit_blake3_64_host": [V, V, S],
     }
@@ -416,6 +419,41 @@ class Hobbit:
         d = self.to_device(p); o = self.alloc(16 * (p.shape[0] // K))
         self._chk(self.lib.hobbit_aggregate(self.ctx, c_vp(d.ptr), c_sz(p.shape[0]), _hp(b), c_int(K), c_vp(o.ptr)))
         return self.to_host(o, (p.shape[0] // K, 2), np.uint64)
+
+    # ---- Elastic_PC streaming commit (src/Elastic_PC.cpp:174-285) on the synthetic "test" stream
+    def read_stream_PC(self, B):
+        """default branch of read_stream_PC (src/witness_stream.cpp:2405-2411): n = 322322; v[i] = n; n = n*n + i.
+        Host-side and sequential, as in the reference; every chunk of the "test" stream is identical."""
+        out = np.zeros((B, 2), np.uint64)
+        n = np.array([[322322, 0]], np.uint64)
+        one = np.zeros((1, 2), np.uint64)
+        lib = self.lib
+        tmp = np.zeros((1, 2), np.uint64)
+        for i in range(B):
+            out[i] = n[0]
+            lib.hobbit_f_mul_host(_hp(n), _hp(n), _hp(tmp), 1)
+            one[0, 0] = i
+            r = (int(tmp[0, 0]) + i) % P
+            n[0, 0] = r; n[0, 1] = tmp[0, 1]
+        return out
+
+    def elastic_commit(self, N, B, opt, gcc_arg_order=1):
+        """test_Elastic_PC's commit (src/Elastic_PC.cpp:736-771): opt 1 RSxRS trs=B/2^11, opt 2 RSxexpander trs=B/2^14"""
+        if opt == 1:
+            lin, trs = 0, B >> 11
+        else:
+            lin, trs = 1, B >> 14
+            self.expander_init_store(trs)
+        e = c_vp()
+        self._chk(self.lib.hobbit_elastic_begin(self.ctx, B, trs, lin, gcc_arg_order, ctypes.byref(e)))
+        chunk = self.to_device(self.read_stream_PC(B))
+        for _ in range(N // B):
+            self._chk(self.lib.hobbit_elastic_push(self.ctx, e, chunk.ptr))
+        lv = self.alloc(32 * 8 * B)
+        self._chk(self.lib.hobbit_elastic_finish(self.ctx, e, lv.ptr))
+        out = self.to_host(lv, (8 * B - 1, 32), np.uint8)
+        self.lib.hobbit_elastic_free(e)
+        return out
 
     # ---- sumchecks (reference names: src/sumcheck.cpp:2391, 1974)
     def _dev_table(self, v):

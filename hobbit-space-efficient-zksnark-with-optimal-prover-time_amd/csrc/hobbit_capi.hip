@@ -88,7 +88,7 @@ static int fft_rows(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_l
         HB_TRY(get_tw8(ctx, inverse));
         const int d = inverse ? 1 : 0;
         const F *t = ctx->tw8[d];
-        return launch_fft4096(ctx, src, src_ld, src_len, dst, dst_ld, dst_es, t, t + 7 * 8, t + 7 * 8 + 7 * 64, ctx->tw8_w8[d], ctx->tw8_w83[d],
+        return launch_fft4096(ctx, src, src_ld, 1, src_len, dst, dst_ld, dst_es, t, t + 7 * 8, t + 7 * 8 + 7 * 64, ctx->tw8_w8[d], ctx->tw8_w83[d],
                               ctx->tw8_w4_plus_i[d], scale, inverse ? 1 : 0, groups, rows_per_group, src_gs, dst_gs);
     }
     const F *tw; HB_TRY(get_twiddles(ctx, logn, inverse, &tw));
@@ -332,10 +332,23 @@ static int tensorcode_chunks(hobbit_ctx *ctx, const F *d_msg, size_t M, int K, i
     if (trs <= 0 || M % (size_t)trs) return ctx->fail(HOBBIT_EINVAL, "tensorcode: trs must divide M");
     size_t half = M / trs, cols = 2 * half, rows2 = 2 * (size_t)trs;
     int logc = ilog2_exact(cols), logr = ilog2_exact(rows2);
-    if (logc < 1 || logc > 12) return ctx->fail(HOBBIT_EINVAL, "tensorcode: row length 2M/trs must be a power of two <= 4096");
+    if (logc < 1 || logc > 15) return ctx->fail(HOBBIT_EINVAL, "tensorcode: row length 2M/trs must be a power of two <= 32768");
     if (logr < 1) return ctx->fail(HOBBIT_EINVAL, "tensorcode: trs must be a power of two");
-    // rows: RS encode = zero-padded FFT (src/PC_utils.cpp:75-84,105-107), written transposed into
-    // the codeword-major tensor: element (r, c) of chunk i at i*cols*rows2 + c*rows2 + r
+    // rows: RS encode = zero-padded FFT (src/PC_utils.cpp:75-84,105-107)
+    if (logc > 12) {
+        // long rows (Elastic_PC opt 2: 32768): R strided FFT-4096 per row + twiddle/R-point combine, then transpose
+        const int lr = logc - 12; const uint32_t R = 1u << lr; const size_t nrows = (size_t)K * trs;
+        F *Y, *rm;
+        HB_TRY(ctx->workspace(nrows * cols * sizeof(F), (void **)&Y));
+        HB_TRY(ctx->workspace2(nrows * cols * sizeof(F), (void **)&rm));
+        HB_TRY(get_tw8(ctx, false));
+        const F *t8 = ctx->tw8[0];
+        HB_TRY(launch_fft4096(ctx, d_msg, 1, R, 2048, Y, 4096, 1, t8, t8 + 7 * 8, t8 + 7 * 8 + 7 * 64, ctx->tw8_w8[0], ctx->tw8_w83[0], ctx->tw8_w4_plus_i[0],
+                              fmake(1), 0, (uint32_t)nrows, R, half, cols));
+        const F *twl; HB_TRY(get_twiddles(ctx, logc, false, &twl));
+        HB_TRY(launch_fft_combine(ctx, lr, Y, rm, cols, twl, (uint32_t)nrows));
+        HB_TRY(launch_transpose(ctx, rm, (size_t)trs * cols, (uint32_t)trs, (uint32_t)cols, d_out, cols * rows2, rows2, (uint32_t)K));
+    } else
     // Large tensors: FFT to a row-major scratch (coalesced stores) + tiled transpose; small ones write the
     // transposed layout directly (one launch less, the scattered stores stay in L2).
     if ((size_t)K * trs * cols * sizeof(F) >= ((size_t)64 << 20)) {
@@ -427,6 +440,47 @@ int hobbit_commitment_paths(hobbit_ctx *ctx, const hobbit_commitment *c, const u
 int hobbit_commitment_path(hobbit_ctx *ctx, const hobbit_commitment *c, size_t col, size_t row, uint8_t *h_path) {
     uint32_t cc = (uint32_t)col, rr = (uint32_t)row;
     return hobbit_commitment_paths(ctx, c, &cc, &rr, 1, h_path);
+}
+
+// ---- Elastic_PC streaming commit (src/Elastic_PC.cpp:174-285) ----------------------------------
+struct hobbit_elastic {
+    hobbit_ctx *ctx; size_t B; int trs, lin, shift; uint32_t cols, rows2; size_t count;
+    F *t[4]; uint8_t *state;
+};
+int hobbit_elastic_begin(hobbit_ctx *ctx, size_t B, int trs, int linear_time, int gcc_arg_order, hobbit_elastic **out) {
+    if (!out) return HOBBIT_EINVAL;
+    *out = nullptr;
+    if (trs <= 0 || B % (size_t)trs || ilog2_exact(B) < 0) return ctx->fail(HOBBIT_EINVAL, "elastic_begin: B must be a power of two and trs divide it");
+    hobbit_elastic *e = new hobbit_elastic();
+    e->ctx = ctx; e->B = B; e->trs = trs; e->lin = linear_time; e->shift = gcc_arg_order ? 1 : 0; e->count = 0;
+    e->cols = (uint32_t)(2 * B / trs); e->rows2 = (uint32_t)(2 * trs);
+    for (int i = 0; i < 4; i++) e->t[i] = nullptr;
+    e->state = nullptr;
+    bool ok = true;
+    for (int i = 0; i < 4 && ok; i++) ok = hipMalloc((void **)&e->t[i], 4 * B * sizeof(F)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->state, 4 * B * 32) == hipSuccess;
+    if (!ok) { hobbit_elastic_free(e); return ctx->fail(HOBBIT_ENOMEM, "elastic_begin: allocation failed"); }
+    HB_CHECK(ctx, hipMemsetAsync(e->state, 0, 4 * B * 32, ctx->stream));       // buff_hash starts at zero (:186-193)
+    *out = e;
+    return 0;
+}
+int hobbit_elastic_push(hobbit_ctx *ctx, hobbit_elastic *e, const hobbit_F *d_chunk) {
+    const int slot = (int)(e->count % 4);
+    HB_TRY(tensorcode_chunks(ctx, cF(d_chunk), e->B, 1, e->trs, e->lin, e->t[slot]));   // an all-zero chunk encodes to zeros (:206-226)
+    if (slot == 3) HB_TRY(launch_elastic_leaf(ctx, e->t[0], e->t[1], e->t[2], e->t[3], e->rows2, e->cols, e->shift, e->state));
+    e->count++;
+    return 0;
+}
+int hobbit_elastic_finish(hobbit_ctx *ctx, hobbit_elastic *e, uint8_t *d_levels) {
+    HB_TRY(launch_elastic_finish(ctx, e->state, e->rows2, e->cols, d_levels));
+    return launch_merkle_levels(ctx, d_levels, 4 * e->B, 1);                    // :277-283
+}
+void hobbit_elastic_free(hobbit_elastic *e) {
+    if (!e) return;
+    hipStreamSynchronize(e->ctx->stream);
+    for (int i = 0; i < 4; i++) if (e->t[i]) hipFree(e->t[i]);
+    if (e->state) hipFree(e->state);
+    delete e;
 }
 
 // ---- multi-GPU commit building blocks -------------------------------------------

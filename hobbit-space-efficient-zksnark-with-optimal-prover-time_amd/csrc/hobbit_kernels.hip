@@ -159,7 +159,7 @@ __device__ __forceinline__ uint32_t fft_phys(uint32_t i) { return i + (i >> 3); 
 
 template <bool PADDED>
 __global__ void __launch_bounds__(512)
-k_fft4096(const F *__restrict__ src, size_t src_ld, F *__restrict__ dst, size_t dst_ld, size_t dst_es, const F *__restrict__ tw1,
+k_fft4096(const F *__restrict__ src, size_t src_ld, size_t src_es, F *__restrict__ dst, size_t dst_ld, size_t dst_es, const F *__restrict__ tw1,
           const F *__restrict__ tw2, const F *__restrict__ tw3, Fft4kConst cst, F scale, int do_scale, uint32_t rows_per_group, size_t src_gs,
           size_t dst_gs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -170,7 +170,7 @@ k_fft4096(const F *__restrict__ src, size_t src_ld, F *__restrict__ dst, size_t 
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t NLOAD = PADDED ? 2048 : 4096;
 #pragma unroll
-    for (uint32_t i = 0; i < NLOAD; i += 512) stF(&s[fft_phys(i + tid)], ldF(in + i + tid));
+    for (uint32_t i = 0; i < NLOAD; i += 512) stF(&s[fft_phys(i + tid)], ldF(in + (size_t)(i + tid) * src_es));
     __syncthreads();
     F a[8];
     {   // ---- pass 0 (h = 1)
@@ -227,7 +227,7 @@ k_fft4096(const F *__restrict__ src, size_t src_ld, F *__restrict__ dst, size_t 
     }
 }
 
-int launch_fft4096(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_len, F *dst, size_t dst_ld, size_t dst_es, const F *tw1,
+int launch_fft4096(hobbit_ctx *ctx, const F *src, size_t src_ld, size_t src_es, uint32_t src_len, F *dst, size_t dst_ld, size_t dst_es, const F *tw1,
                    const F *tw2, const F *tw3, F w8, F w8_3, int w4_plus_i, F scale, int do_scale, uint32_t groups, uint32_t rows_per_group,
                    size_t src_gs, size_t dst_gs) {
     size_t blocks = (size_t)groups * rows_per_group;
@@ -236,13 +236,63 @@ int launch_fft4096(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_le
     Fft4kConst cst; cst.w8 = w8; cst.w8_3 = w8_3; cst.w4_plus_i = w4_plus_i;
     if (src_len == 2048) {
         hipFuncSetAttribute((const void *)k_fft4096<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        HB_LAUNCH(ctx, "k_fft4096", k_fft4096<true>, dim3((unsigned)blocks), dim3(512), lds, src, src_ld, dst, dst_ld, dst_es, tw1, tw2, tw3, cst,
+        HB_LAUNCH(ctx, "k_fft4096", k_fft4096<true>, dim3((unsigned)blocks), dim3(512), lds, src, src_ld, src_es, dst, dst_ld, dst_es, tw1, tw2, tw3, cst,
                   scale, do_scale, rows_per_group, src_gs, dst_gs);
     } else {
         hipFuncSetAttribute((const void *)k_fft4096<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        HB_LAUNCH(ctx, "k_fft4096_full", k_fft4096<false>, dim3((unsigned)blocks), dim3(512), lds, src, src_ld, dst, dst_ld, dst_es, tw1, tw2, tw3,
+        HB_LAUNCH(ctx, "k_fft4096_full", k_fft4096<false>, dim3((unsigned)blocks), dim3(512), lds, src, src_ld, src_es, dst, dst_ld, dst_es, tw1, tw2, tw3,
                   cst, scale, do_scale, rows_per_group, src_gs, dst_gs);
     }
+    return 0;
+}
+
+// Long rows (len = R * 4096, R = 2, 4, 8; Elastic_PC opt 2 uses 32768-point row codes,
+// src/Elastic_PC.cpp:737-771) by one Cooley-Tukey split:
+//   X[4096 k1 + k2] = sum_{n1 < R} W_R^{n1 k1} * W_len^{n1 k2} * Y_{n1}[k2],   Y_{n1} = FFT_4096(x[R n2 + n1])
+// The R sub-transforms run in k_fft4096 (strided source); this kernel applies the twiddles and
+// the R-point DFT across n1, one lane per k2 (coalesced on both sides).  tw[m] = W_len^m, m < len/2.
+template <int LOGR>
+__global__ void __launch_bounds__(256)
+k_fft_combine(const F *__restrict__ Y, F *__restrict__ dst, size_t dst_ld, const F *__restrict__ tw, uint32_t rows) {
+    constexpr uint32_t R = 1u << LOGR, len = R * 4096, half = len / 2;
+    const size_t total = (size_t)rows * 4096;
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t row = (uint32_t)(g >> 12), k2 = (uint32_t)(g & 4095);
+        const F *y = Y + (size_t)row * len + k2;
+        F a[R];
+#pragma unroll
+        for (uint32_t n1 = 0; n1 < R; n1++) {
+            F v = ldF(y + (size_t)n1 * 4096);
+            if (n1) {
+                const uint32_t m = n1 * k2;                 // < len
+                F w = ldF(tw + (m & (half - 1)));
+                v = fmul(v, w);
+                if (m >= half) v = fneg(v);                  // W^(m) = -W^(m - len/2)
+            }
+            a[__brev(n1) >> (32 - LOGR)] = v;               // bit-reversed order for the in-register DIT
+        }
+#pragma unroll
+        for (uint32_t h = 1; h < R; h <<= 1)
+#pragma unroll
+            for (uint32_t b = 0; b < R / 2; b++) {
+                const uint32_t k = b & (h - 1), i0 = (b / h) * 2 * h + k;
+                F v = a[i0 + h];
+                if (k) v = fmul(v, ldF(tw + (size_t)k * (len / (2 * h))));   // W_{2h}^k = W_len^(k len/2h)
+                a[i0 + h] = fsub(a[i0], v); a[i0] = fadd(a[i0], v);
+            }
+        F *o = dst + (size_t)row * dst_ld + k2;
+#pragma unroll
+        for (uint32_t k1 = 0; k1 < R; k1++) stF(o + (size_t)k1 * 4096, a[k1]);
+    }
+}
+int launch_fft_combine(hobbit_ctx *ctx, int logr, const F *Y, F *dst, size_t dst_ld, const F *tw, uint32_t rows) {
+    size_t total = (size_t)rows * 4096;
+    if (!total) return 0;
+    dim3 g(grid_for(total, 256, 1 << 16)), b(256);
+    if (logr == 1) HB_LAUNCH(ctx, "k_fft_combine", k_fft_combine<1>, g, b, 0, Y, dst, dst_ld, tw, rows);
+    else if (logr == 2) HB_LAUNCH(ctx, "k_fft_combine", k_fft_combine<2>, g, b, 0, Y, dst, dst_ld, tw, rows);
+    else if (logr == 3) HB_LAUNCH(ctx, "k_fft_combine", k_fft_combine<3>, g, b, 0, Y, dst, dst_ld, tw, rows);
+    else return ctx->fail(HOBBIT_EINVAL, "fft_combine: row length must be 8192, 16384 or 32768");
     return 0;
 }
 
@@ -475,22 +525,43 @@ __global__ void k_merkle_level(const uint8_t *__restrict__ prev, uint8_t *__rest
 // ([chunk][col][2 trs]), so the 4 field elements of leaf (j, col) are 64 contiguous bytes.  One
 // thread owns one leaf and keeps its Merkle-Damgard state in registers across the chunk loop:
 // the tensor is read exactly once and the leaf array is written exactly once.
-__global__ void k_leaf_chain(const F *__restrict__ tensor, size_t chunk_stride, int K, uint32_t cols, uint32_t half_trs,
-                             uint8_t *__restrict__ leaves) {
-    const size_t total = (size_t)cols * half_trs;
-    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t c = (uint32_t)(g / half_trs), j = (uint32_t)(g % half_trs);
-        uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const F *p = tensor + ((size_t)c * half_trs + j) * 4;     // (c * 2trs + 4j)
-        for (int i = 0; i < K; i++) {
-            uint32_t m[16], h[8];
-            load16w(p + (size_t)i * chunk_stride, m);
-            blake3_compress64(m, h);
+template <int NL>
+__global__ void __launch_bounds__(256)
+k_leaf_chain(const F *__restrict__ tensor, size_t chunk_stride, int K, uint32_t cols, uint32_t half_trs, uint8_t *__restrict__ leaves) {
+    // NL leaves per thread (independent hash chains interleaved for instruction-level parallelism)
+    const size_t total = (size_t)cols * half_trs, per = (total + NL - 1) / NL;
+    for (size_t g0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g0 < per; g0 += (size_t)gridDim.x * blockDim.x) {
+        uint32_t st[NL][8];
+        const F *p[NL];
+        size_t g[NL];
 #pragma unroll
-            for (int q = 0; q < 8; q++) { m[q] = h[q]; m[8 + q] = st[q]; }
-            blake3_compress64(m, st);
+        for (int l = 0; l < NL; l++) {
+            g[l] = g0 + (size_t)l * per;
+            const size_t gg = g[l] < total ? g[l] : total - 1;      // tail lanes recompute the last leaf (not stored)
+#pragma unroll
+            for (int q = 0; q < 8; q++) st[l][q] = 0;
+            p[l] = tensor + gg * 4;                                   // (c * 2trs + 4j) with gg = c*half_trs + j
         }
-        store8w(leaves + 32 * ((size_t)j * cols + c), st);
+        for (int i = 0; i < K; i++) {
+            uint32_t m[NL][16], h[NL][8];
+#pragma unroll
+            for (int l = 0; l < NL; l++) load16w(p[l] + (size_t)i * chunk_stride, m[l]);
+#pragma unroll
+            for (int l = 0; l < NL; l++) blake3_compress64(m[l], h[l]);
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) { m[l][q] = h[l][q]; m[l][8 + q] = st[l][q]; }
+            }
+#pragma unroll
+            for (int l = 0; l < NL; l++) blake3_compress64(m[l], st[l]);
+        }
+#pragma unroll
+        for (int l = 0; l < NL; l++)
+            if (g[l] < total) {
+                const uint32_t c = (uint32_t)(g[l] / half_trs), j = (uint32_t)(g[l] % half_trs);
+                store8w(leaves + 32 * ((size_t)j * cols + c), st[l]);
+            }
     }
 }
 // Multi-GPU commit, step 1: inner digests H(t[4j..4j+3][c]) of the chunks a rank
@@ -534,6 +605,55 @@ int launch_chain_digests(hobbit_ctx *ctx, const uint8_t *digests, size_t stride_
     HB_LAUNCH(ctx, "k_chain_digests", k_chain_digests, dim3(grid_for(m, 256, 1 << 20)), dim3(256), 0, digests, stride_bytes, K, m, leaves);
     return 0;
 }
+// Elastic_PC streaming commit (src/Elastic_PC.cpp:228-243): every 4th chunk the four stored tensors
+// are hashed position-wise into the running leaves, leaf[p] = H( H(a|b|c|d) | leaf[p] ), p = row*cols+col.
+// The call passes (ci0[counter], ci1[counter], ci2[counter++], tensor[j][k]) as arguments of ONE call;
+// as built by GCC the first two are read at counter+1 -- `shift` = 1 reproduces that
+// (a, b taken at p+1, zero past the end), 0 reads all four at p.  Tensors and the running leaf state
+// are codeword-major (index g = col*rows2 + row) so every access is coalesced; k_elastic_finish
+// permutes the state into the reference's leaf order once at the end.
+__global__ void __launch_bounds__(256)
+k_elastic_leaf(const F *__restrict__ t0, const F *__restrict__ t1, const F *__restrict__ t2, const F *__restrict__ t3, uint32_t rows2, uint32_t cols,
+               int shift, uint8_t *__restrict__ state) {
+    const size_t T = (size_t)rows2 * cols;
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < T; g += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t k = (uint32_t)(g / rows2), j = (uint32_t)(g % rows2);
+        size_t gs = g; bool zero = false;
+        if (shift) {
+            if (k + 1 < cols) gs = g + rows2;                       // (j, k+1)
+            else if (j + 1 < rows2) gs = (size_t)j + 1;             // wraps to (j+1, 0)
+            else zero = true;                                       // p+1 == 4B: past the end
+        }
+        const F a = zero ? fmake(0) : ldF(t0 + gs), b = zero ? fmake(0) : ldF(t1 + gs), c = ldF(t2 + g), d = ldF(t3 + g);
+        uint32_t m[16], h[8];
+        m[0] = (uint32_t)a.re; m[1] = (uint32_t)(a.re >> 32); m[2] = (uint32_t)a.im; m[3] = (uint32_t)(a.im >> 32);
+        m[4] = (uint32_t)b.re; m[5] = (uint32_t)(b.re >> 32); m[6] = (uint32_t)b.im; m[7] = (uint32_t)(b.im >> 32);
+        m[8] = (uint32_t)c.re; m[9] = (uint32_t)(c.re >> 32); m[10] = (uint32_t)c.im; m[11] = (uint32_t)(c.im >> 32);
+        m[12] = (uint32_t)d.re; m[13] = (uint32_t)(d.re >> 32); m[14] = (uint32_t)d.im; m[15] = (uint32_t)(d.im >> 32);
+        blake3_compress64(m, h);
+#pragma unroll
+        for (int q = 0; q < 8; q++) m[q] = h[q];
+        load8w(state + 32 * g, m + 8);
+        blake3_compress64(m, h);
+        store8w(state + 32 * g, h);
+    }
+}
+__global__ void k_elastic_finish(const uint8_t *__restrict__ state, uint32_t rows2, uint32_t cols, uint8_t *__restrict__ leaves) {
+    const size_t T = (size_t)rows2 * cols;
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < T; g += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t k = (uint32_t)(g / rows2), j = (uint32_t)(g % rows2);
+        uint32_t h[8]; load8w(state + 32 * g, h);
+        store8w(leaves + 32 * ((size_t)j * cols + k), h);
+    }
+}
+int launch_elastic_leaf(hobbit_ctx *ctx, const F *t0, const F *t1, const F *t2, const F *t3, uint32_t rows2, uint32_t cols, int shift, uint8_t *state) {
+    HB_LAUNCH(ctx, "k_elastic_leaf", k_elastic_leaf, dim3(grid_for((size_t)rows2 * cols, 256, 1 << 16)), dim3(256), 0, t0, t1, t2, t3, rows2, cols, shift, state);
+    return 0;
+}
+int launch_elastic_finish(hobbit_ctx *ctx, const uint8_t *state, uint32_t rows2, uint32_t cols, uint8_t *leaves) {
+    HB_LAUNCH(ctx, "k_elastic_finish", k_elastic_finish, dim3(grid_for((size_t)rows2 * cols, 256, 1 << 16)), dim3(256), 0, state, rows2, cols, leaves);
+    return 0;
+}
 // paths[q][l] = levels[off_l + (pos_q >> l) ^ 1]   (src/merkle_tree.cpp:308-324)
 __global__ void k_merkle_paths(const uint8_t *__restrict__ levels, size_t n, const uint64_t *__restrict__ pos, size_t nq, int depth,
                                uint8_t *__restrict__ paths) {
@@ -568,7 +688,9 @@ int launch_merkle_levels(hobbit_ctx *ctx, uint8_t *levels, size_t n, int quirk) 
 }
 int launch_leaf_chain(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, int K, uint32_t cols, uint32_t half_trs, uint8_t *leaves) {
     size_t total = (size_t)cols * half_trs;
-    HB_LAUNCH(ctx, "k_leaf_chain", k_leaf_chain, dim3(grid_for(total, 256, 1 << 20)), dim3(256), 0, tensor, chunk_stride, K, cols, half_trs, leaves);
+    constexpr int NL = 1;   // 2 interleaved chains measured no faster: the kernel sits at the VALU issue limit (profiles/r01_microbench.txt)
+    HB_LAUNCH(ctx, "k_leaf_chain", k_leaf_chain<NL>, dim3(grid_for((total + NL - 1) / NL, 256, 1 << 20)), dim3(256), 0, tensor, chunk_stride, K, cols,
+              half_trs, leaves);
     return 0;
 }
 int launch_merkle_paths(hobbit_ctx *ctx, const uint8_t *levels, size_t n, const uint64_t *d_pos, size_t nq, int depth, uint8_t *d_paths) {

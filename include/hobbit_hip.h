@@ -37,6 +37,7 @@ extern "C" {
 
 typedef struct hobbit_ctx hobbit_ctx;
 typedef struct hobbit_commitment hobbit_commitment;
+typedef struct hobbit_elastic hobbit_elastic;
 typedef struct { uint64_t re, im; } hobbit_F;
 
 /* ---- context, memory, timing ------------------------------------------------------------- */
@@ -111,7 +112,7 @@ int hobbit_eval_vector(hobbit_ctx *ctx, const hobbit_F *d_v, size_t n, const hob
 /* ---- tensor code (src/PC_utils.cpp:66-123 compute_tensorcode) ------------------------------ */
 /* message M F (row-major trs x M/trs) -> tensor (2 trs) x (2M/trs), stored CODEWORD-MAJOR on the
  * device: element (row, col) at d_out[col*(2*trs) + row].  linear_time!=0: RS rows x expander
- * columns (graphs for n = trs must be finalized); 0: RS x RS. */
+ * columns (graphs for n = trs must be finalized); 0: RS x RS.  Row length 2M/trs <= 32768. */
 int hobbit_tensorcode(hobbit_ctx *ctx, const hobbit_F *d_msg, size_t M, int trs, int linear_time, hobbit_F *d_out);
 
 /* ---- Our_PC commit (src/Our_PC.cpp:146-171 commit_standard) -------------------------------- */
@@ -134,6 +135,18 @@ int hobbit_commitment_gather(hobbit_ctx *ctx, const hobbit_commitment *c, const 
 int hobbit_commitment_path(hobbit_ctx *ctx, const hobbit_commitment *c, size_t col, size_t row, uint8_t *h_path);
 int hobbit_commitment_paths(hobbit_ctx *ctx, const hobbit_commitment *c, const uint32_t *h_cols, const uint32_t *h_rows, size_t nq,
                             uint8_t *h_paths);
+
+/* ---- Elastic_PC streaming commit (src/Elastic_PC.cpp:174-285 commit) ------------------------- */
+/* The stream stays with the host (read_stream_PC); each B-element chunk is pushed as a device
+ * buffer.  Every 4th chunk the 4 stored tensor codes are hashed into the 4B running leaves;
+ * finish builds the tree: d_levels receives (8B-1)*32 bytes (4B leaves ... root).
+ * gcc_arg_order=1 reproduces the reference as built by GCC (Elastic_PC.cpp:238-239 evaluates its
+ * call arguments right to left: the first two hash inputs are taken at position+1); 0 takes all
+ * four at the same position.  trs = B/2^11 with linear_time=0 (opt 1), B/2^14 with 1 (opt 2). */
+int hobbit_elastic_begin(hobbit_ctx *ctx, size_t B, int trs, int linear_time, int gcc_arg_order, hobbit_elastic **out);
+int hobbit_elastic_push(hobbit_ctx *ctx, hobbit_elastic *e, const hobbit_F *d_chunk);
+int hobbit_elastic_finish(hobbit_ctx *ctx, hobbit_elastic *e, uint8_t *d_levels);
+void hobbit_elastic_free(hobbit_elastic *e);
 
 /* ---- multi-GPU commit building blocks (chunk-sharded commit) ------------------ */
 /* tensor codes of `nchunks` consecutive messages of M F each (chunk i at d_msg + i*M), outputs

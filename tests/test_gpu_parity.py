@@ -366,3 +366,51 @@ def test_sharded_commit_hip_ops_world1(hb, oracle):
     for i in range(K):
         leaves = oracle.blake3_64(np.concatenate([full[i], leaves], axis=1))
     assert np.array_equal(leaves, want[:M])
+
+
+# ---- Elastic_PC streaming commit + long-row tensor codes ---------------------------------------
+@pytest.mark.parametrize("opt", [1, 2])
+def test_elastic_commit_vs_golden(hb, opt):
+    g = gold("elastic")
+    B = 1 << 14
+    hb.rng_reset()
+    lv = hb.elastic_commit(1 << 18, B, opt)
+    T = 4 * B
+    assert np.array_equal(lv[-1], g["el_%d_root" % opt])
+    assert np.array_equal(dg(lv[:T - 1]), g["el_%d_leaves_dg" % opt])      # leaf T-1 is undefined in the reference
+    assert np.array_equal(dg(lv[T:]), g["el_%d_upper_dg" % opt])
+
+
+def test_elastic_stream_generator_matches_oracle(hb, oracle):
+    assert np.array_equal(hb.read_stream_PC(4096), oracle.read_stream_pc(4096))
+
+
+@pytest.mark.parametrize("logc,trs,lin", [(13, 16, 1), (14, 16, 0), (15, 64, 1), (15, 4, 1)])
+def test_tensorcode_long_rows_vs_oracle(hb, oracle, logc, trs, lin):
+    """row codes longer than 4096 (Elastic_PC opt 2 uses 32768): split FFT = R strided FFT-4096 + combine"""
+    M = trs << (logc - 1)
+    oracle.rng_reset(); oracle.expander_init_store(trs)
+    hb.upload_graphs(trs, graphs_from(oracle, trs)) if trs > 13 else hb.expander_init_store(trs)
+    msg = splitmix_field(M, 500 + logc)
+    assert np.array_equal(hb.compute_tensorcode(msg, trs, lin), oracle.compute_tensorcode(msg, trs, lin))
+
+
+def test_elastic_commit_2e22_opt2_vs_oracle(hb, oracle):
+    """C5-shaped case at reduced size: N = 2^22, B = 2^20 (trs = 64, 32768-point rows), one 4-chunk group"""
+    B = 1 << 20
+    oracle.rng_reset()
+    want = oracle.elastic_commit(1 << 22, B, 2)
+    hb.upload_graphs(64, graphs_from(oracle, 64))
+    e = hb.lib.hobbit_elastic_begin
+    import ctypes
+    h = ctypes.c_void_p()
+    hb._chk(hb.lib.hobbit_elastic_begin(hb.ctx, B, 64, 1, 1, ctypes.byref(h)))
+    chunk = hb.to_device(oracle.read_stream_pc(B))
+    for _ in range(4):
+        hb._chk(hb.lib.hobbit_elastic_push(hb.ctx, h, chunk.ptr))
+    lv = hb.alloc(32 * 8 * B)
+    hb._chk(hb.lib.hobbit_elastic_finish(hb.ctx, h, lv.ptr))
+    got = hb.to_host(lv, (8 * B - 1, 32), np.uint8)
+    hb.lib.hobbit_elastic_free(h)
+    T = 4 * B
+    assert np.array_equal(got[:T - 1], want[:T - 1]) and np.array_equal(got[T:], want[T:])
