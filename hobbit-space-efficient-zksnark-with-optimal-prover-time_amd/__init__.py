@@ -39,6 +39,8 @@ ABI_SYMBOLS = [
     "hobbit_commitment_gather", "hobbit_commitment_path", "hobbit_commitment_paths",
     "hobbit_elastic_begin", "hobbit_elastic_push", "hobbit_elastic_finish", "hobbit_elastic_free",
     "hobbit_tensorcode_chunks", "hobbit_inner_digests", "hobbit_chain_digests", "hobbit_blake3_64_host",
+    "hobbit_parity_matrix", "hobbit_phi_g", "hobbit_prepare_matrix_cols", "hobbit_prove_linear_code", "hobbit_prove_fft",
+    "hobbit_prove_fft_matrix",
     "hobbit_aggregate", "hobbit_sumcheck2", "hobbit_sumcheck3", "hobbit_fill_splitmix",
 ]
 
@@ -76,6 +78,9 @@ def load_library(path=LIB_PATH):
         "hobbit_commitment_path": [V, V, S, S, V], "hobbit_commitment_paths": [V, V, V, V, S, V], "hobbit_aggregate": [V, V, S, V, I, V],
         "hobbit_sumcheck2": [V, V, V, S, V, V, V, V, V], "hobbit_sumcheck3": [V, V, V, V, S, V, V, V, V, V],
         "hobbit_fill_splitmix": [V, V, S, U64],
+        "hobbit_parity_matrix": [V, V, S, L, V], "hobbit_phi_g": [V, V, I, V, I, V], "hobbit_prepare_matrix_cols": [V, V, S, S, V, I, V],
+        "hobbit_prove_linear_code": [V, V, S, L, V, V, V, V, V], "hobbit_prove_fft": [V, V, S, V, V, V, V, V],
+        "hobbit_prove_fft_matrix": [V, V, S, S, V, V, V, V, V],
         "hobbit_elastic_begin": [V, S, I, I, I, V], "hobbit_elastic_push": [V, V, V], "hobbit_elastic_finish": [V, V, V],
         "hobbit_elastic_free": [V],
         "hobbit_tensorcode_chunks": [V, V, S, I, I, I, V], "hobbit_inner_digests": [V, V, S, I, I, V],
@@ -419,6 +424,51 @@ class Hobbit:
         d = self.to_device(p); o = self.alloc(16 * (p.shape[0] // K))
         self._chk(self.lib.hobbit_aggregate(self.ctx, c_vp(d.ptr), c_sz(p.shape[0]), _hp(b), c_int(K), c_vp(o.ptr)))
         return self.to_host(o, (p.shape[0] // K, 2), np.uint64)
+
+    # ---- code-membership / FFT-as-sumcheck (reference names)
+    def evaluate_parity_matrix(self, beta, n):
+        b = Fh(beta).reshape(-1, 2)
+        d = self.to_device(b); o = self.alloc(b.nbytes)
+        self._chk(self.lib.hobbit_parity_matrix(self.ctx, d.ptr, b.shape[0], n, o.ptr))
+        return self.to_host(o, b.shape, np.uint64)
+
+    def phiGInit(self, rx, scale=(1, 0), ifft=False):
+        r = Fh(rx).reshape(-1, 2); n = r.shape[0]
+        sc = np.array(scale, np.uint64)
+        o = self.alloc(16 << n)
+        self._chk(self.lib.hobbit_phi_g(self.ctx, _hp(r), n, _hp(sc), int(ifft), o.ptr))
+        return self.to_host(o, (1 << n, 2), np.uint64)
+
+    def prepare_matrix_cols(self, M, r):
+        m = Fh(M); rows, cols = m.shape[0], m.shape[1]; r = Fh(r).reshape(-1, 2)
+        d = self.to_device(m); o = self.alloc(16 * cols)
+        self._chk(self.lib.hobbit_prepare_matrix_cols(self.ctx, d.ptr, rows, cols, _hp(r), r.shape[0], o.ptr))
+        return self.to_host(o, (cols, 2), np.uint64)
+
+    def _proof2(self, rounds):
+        return (np.zeros((rounds, 3, 2), np.uint64), np.zeros((rounds, 2), np.uint64), np.zeros((2, 2), np.uint64), np.zeros(2, np.uint64))
+
+    def prove_linear_code(self, codeword, n, r1):
+        cw = Fh(codeword).reshape(-1, 2); r1 = Fh(r1).reshape(-1, 2)
+        q, r, vr, fin = self._proof2(cw.shape[0].bit_length() - 1)
+        d = self.to_device(cw)
+        self._chk(self.lib.hobbit_prove_linear_code(self.ctx, d.ptr, cw.shape[0], n, _hp(r1), _hp(q), _hp(r), _hp(vr), _hp(fin)))
+        return dict(poly=q, r=r, vr=vr, fin=fin)
+
+    def prove_fft(self, m, rr):
+        m = Fh(m).reshape(-1, 2); rr = Fh(rr).reshape(-1, 2)
+        rounds = (2 * m.shape[0]).bit_length() - 1
+        q, r, vr, fin = self._proof2(rounds)
+        d = self.to_device(m)
+        self._chk(self.lib.hobbit_prove_fft(self.ctx, d.ptr, m.shape[0], _hp(rr), _hp(q), _hp(r), _hp(vr), _hp(fin)))
+        return dict(poly=q, r=r[:rounds - 1], vr=vr, fin=fin)       # the reference pops the last challenge (src/sumcheck.cpp:2985)
+
+    def prove_fft_matrix(self, M, rr):
+        m = Fh(M); rows, cols = m.shape[0], m.shape[1]; rr = Fh(rr).reshape(-1, 2)
+        q, r, vr, fin = self._proof2((2 * cols).bit_length() - 1)
+        d = self.to_device(m)
+        self._chk(self.lib.hobbit_prove_fft_matrix(self.ctx, d.ptr, rows, cols, _hp(rr), _hp(q), _hp(r), _hp(vr), _hp(fin)))
+        return dict(poly=q, r=r, vr=vr, fin=fin)
 
     # ---- Elastic_PC streaming commit (src/Elastic_PC.cpp:174-285) on the synthetic "test" stream
     def read_stream_PC(self, B):

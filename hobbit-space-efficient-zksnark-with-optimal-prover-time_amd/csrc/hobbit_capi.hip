@@ -77,6 +77,9 @@ static void free_code(DeviceCode &c) {
     if (c.d_edges32) hipFree(c.d_edges32);
     if (c.d_eidx) hipFree(c.d_eidx);
     if (c.d_ew) hipFree(c.d_ew);
+    if (c.d_pm_rowptr) hipFree(c.d_pm_rowptr);
+    if (c.d_pm_idx) hipFree(c.d_pm_idx);
+    if (c.d_pm_w) hipFree(c.d_pm_w);
     c = DeviceCode();
 }
 
@@ -499,6 +502,117 @@ int hobbit_chain_digests(hobbit_ctx *ctx, const uint8_t *d_digests, size_t strid
 }
 void hobbit_blake3_64_host(const uint8_t *in, uint8_t *out, size_t n) {
     for (size_t i = 0; i < n; i++) { uint32_t m[16], h[8]; memcpy(m, in + 64 * i, 64); blake3_compress64(m, h); memcpy(out + 32 * i, h, 32); }
+}
+
+// ---- code-membership / FFT-as-sumcheck (src/sumcheck.cpp:2888-2929, 2975-3027, 3223-3235) ---------
+// host recursion of evaluate_parity_matrix, emitting (A index, beta index, weight) triples
+static long long parity_triples(hobbit_ctx *ctx, std::vector<std::vector<std::pair<uint32_t, F>>> &rows, long long Offset, long long n, int dep, long long *lvl) {
+    const long long thr = 13;
+    if (n <= thr) return n;
+    const HostGraph &C = ctx->graphs[{dep, 0}], &D = ctx->graphs[{dep, 1}];
+    long long R = C.R;
+    const F minus1 = fmake(P61 - 1);
+    for (long long i = 0; i < n; i++)
+        for (int d = 0; d < C.degree; d++) rows[i + Offset].push_back({(uint32_t)(C.nbr[i * C.degree + d] + *lvl), C.w[i * C.degree + d]});
+    for (long long i = 0; i < R; i++) rows[i + Offset + n].push_back({(uint32_t)(*lvl + i), minus1});
+    long long l = *lvl + R;
+    long long L = parity_triples(ctx, rows, Offset + n, R, dep + 1, &l);
+    R = D.R;
+    for (long long i = 0; i < L; i++)
+        for (int d = 0; d < D.degree; d++) rows[i + Offset + n].push_back({(uint32_t)(D.nbr[i * D.degree + d] + *lvl), D.w[i * D.degree + d]});
+    for (long long i = 0; i < R; i++) rows[i + Offset + n + L].push_back({(uint32_t)(i + *lvl), minus1});
+    *lvl += R;
+    return n + L + R;
+}
+int hobbit_parity_matrix(hobbit_ctx *ctx, const hobbit_F *d_beta, size_t size_a, long long n, hobbit_F *d_A) {
+    DeviceCode &c = ctx->code;
+    if (c.n != n) return ctx->fail(HOBBIT_ESTATE, "parity_matrix: graphs for this n are not finalized");
+    if (size_a < (size_t)c.len) return ctx->fail(HOBBIT_EINVAL, "parity_matrix: A must hold at least the codeword length");
+    if (!c.d_pm_rowptr || c.pm_rows != size_a) {
+        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (c.d_pm_rowptr) { hipFree(c.d_pm_rowptr); hipFree(c.d_pm_idx); hipFree(c.d_pm_w); c.d_pm_rowptr = nullptr; }
+        std::vector<std::vector<std::pair<uint32_t, F>>> rows(size_a);
+        long long lvl = 0;
+        parity_triples(ctx, rows, 0, n, 0, &lvl);
+        std::vector<uint32_t> rp(size_a + 1, 0), idx; std::vector<F> w;
+        for (size_t a = 0; a < size_a; a++) {
+            rp[a + 1] = rp[a] + (uint32_t)rows[a].size();
+            for (auto &e : rows[a]) { if (e.first >= size_a) return ctx->fail(HOBBIT_EINVAL, "parity_matrix: beta index out of range"); idx.push_back(e.first); w.push_back(e.second); }
+        }
+        if (hipMalloc((void **)&c.d_pm_rowptr, rp.size() * 4) != hipSuccess || hipMalloc((void **)&c.d_pm_idx, idx.size() * 4 + 16) != hipSuccess ||
+            hipMalloc((void **)&c.d_pm_w, w.size() * sizeof(F) + 16) != hipSuccess) return ctx->fail(HOBBIT_ENOMEM, "parity_matrix: alloc failed");
+        HB_CHECK(ctx, hipMemcpy(c.d_pm_rowptr, rp.data(), rp.size() * 4, hipMemcpyHostToDevice));
+        if (!idx.empty()) { HB_CHECK(ctx, hipMemcpy(c.d_pm_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice)); HB_CHECK(ctx, hipMemcpy(c.d_pm_w, w.data(), w.size() * sizeof(F), hipMemcpyHostToDevice)); }
+        c.pm_rows = size_a;
+    }
+    return launch_csr_gather(ctx, c.d_pm_rowptr, c.d_pm_idx, c.d_pm_w, cF(d_beta), mF(d_A), size_a);
+}
+int hobbit_phi_g(hobbit_ctx *ctx, const hobbit_F *h_rx, int n, const hobbit_F *h_scale, int is_ifft, hobbit_F *d_out) {
+    if (n < 1 || n > 30) return ctx->fail(HOBBIT_EINVAL, "phi_g: n must be in [1,30]");
+    const size_t N = (size_t)1 << n;
+    const F *pm; HB_TRY(get_twiddles(ctx, n, is_ifft != 0, &pm));      // phi_mul[k] = rou^k, k < N/2 (all that is indexed)
+    F *g = mF(d_out);
+    HB_CHECK(ctx, hipMemsetAsync(g, 0, N * sizeof(F), ctx->stream));
+    F sc[2] = {*cF(h_scale), *cF(h_scale)};
+    HB_CHECK(ctx, hipMemcpyAsync(g, sc, (is_ifft && N > 1 ? 2 : 1) * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const int last = is_ifft ? n : n - 1;
+    for (int i = 1; i <= last; i++) HB_TRY(launch_phi_step(ctx, g, (size_t)1 << (i - 1), n - i, cF(h_rx)[n - i], pm, 0));
+    if (!is_ifft) HB_TRY(launch_phi_step(ctx, g, (size_t)1 << (n - 1), 0, cF(h_rx)[0], pm, 1));
+    return 0;
+}
+// arr[c] = multilinear evaluation over the ROW index of column c at r (prepare_matrix(transpose(M), r))
+int hobbit_prepare_matrix_cols(hobbit_ctx *ctx, const hobbit_F *d_M, size_t rows, size_t cols, const hobbit_F *h_r, int k, hobbit_F *d_out) {
+    if (ilog2_exact(rows) < 0 || k > ilog2_exact(rows)) return ctx->fail(HOBBIT_EINVAL, "prepare_matrix_cols: rows must be a power of two, k <= log2 rows");
+    if (k == 0) { HB_CHECK(ctx, hipMemcpyAsync(d_out, d_M, cols * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream)); return 0; }
+    F *ws; HB_TRY(ctx->workspace2((rows / 2 + rows / 4 + 1) * cols * sizeof(F), (void **)&ws));
+    F *a = ws, *b = ws + (rows / 2) * cols;
+    const F *src = cF(d_M); F *dst = a; size_t r = rows;
+    for (int t = 0; t < k; t++) {
+        F *o = (t == k - 1 && (r / 2) == 1) ? mF(d_out) : dst;
+        HB_TRY(launch_fold_rows(ctx, src, o, r / 2, cols, cF(h_r)[t]));
+        src = o; dst = dst == a ? b : a; r /= 2;
+    }
+    if (src != cF(d_out)) HB_CHECK(ctx, hipMemcpyAsync(d_out, src, cols * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));   // row 0 (src/utils.cpp:771-773)
+    return 0;
+}
+int hobbit_prove_linear_code(hobbit_ctx *ctx, const hobbit_F *d_codeword, size_t size, long long n, const hobbit_F *h_r1, hobbit_F *h_qpoly,
+                             hobbit_F *h_r, hobbit_F *h_vr, hobbit_F *h_final) {
+    int k = ilog2_exact(size);
+    if (k < 1) return ctx->fail(HOBBIT_EINVAL, "prove_linear_code: size must be a power of two");
+    F *tmp; HB_TRY(ctx->workspace2(2 * size * sizeof(F), (void **)&tmp));
+    F *beta = tmp, *A = tmp + size;
+    HB_TRY(hobbit_eq_table(ctx, h_r1, k, (hobbit_F *)beta));
+    HB_TRY(hobbit_parity_matrix(ctx, (const hobbit_F *)beta, size, n, (hobbit_F *)A));
+    return hobbit_sumcheck2(ctx, (const hobbit_F *)A, d_codeword, size, h_r1 + (k - 1), h_qpoly, h_r, h_vr, h_final);
+}
+int hobbit_prove_fft(hobbit_ctx *ctx, const hobbit_F *d_m, size_t s, const hobbit_F *h_r, hobbit_F *h_qpoly, hobbit_F *h_rr, hobbit_F *h_vr,
+                     hobbit_F *h_final) {
+    const size_t S = 2 * s; int k = ilog2_exact(S);
+    if (k < 1) return ctx->fail(HOBBIT_EINVAL, "prove_fft: size must be a power of two");
+    F *tmp; HB_TRY(ctx->workspace2(2 * S * sizeof(F), (void **)&tmp));
+    F *mm = tmp, *FG = tmp + S;
+    HB_CHECK(ctx, hipMemsetAsync(mm + s, 0, s * sizeof(F), ctx->stream));                       // m.resize(2*m.size(), 0)
+    HB_CHECK(ctx, hipMemcpyAsync(mm, d_m, s * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    hobbit_F one = {1, 0};
+    HB_TRY(hobbit_phi_g(ctx, h_r, k, &one, 0, (hobbit_F *)FG));
+    return hobbit_sumcheck2(ctx, (const hobbit_F *)FG, (const hobbit_F *)mm, S, h_r + (k - 1), h_qpoly, h_rr, h_vr, h_final);
+}
+int hobbit_prove_fft_matrix(hobbit_ctx *ctx, const hobbit_F *d_M, size_t rows, size_t cols, const hobbit_F *h_r, hobbit_F *h_qpoly, hobbit_F *h_rr,
+                            hobbit_F *h_vr, hobbit_F *h_final) {
+    const size_t C2 = 2 * cols; int k2 = ilog2_exact(C2), k1 = ilog2_exact(rows);
+    if (k2 < 1 || k1 < 0) return ctx->fail(HOBBIT_EINVAL, "prove_fft_matrix: rows and cols must be powers of two");
+    // arr = prepare_matrix(transpose(M padded), r1): column evaluations, upper half zero; Fg1 = phiG(r2)
+    F *tmp; HB_TRY(ctx->workspace(2 * C2 * sizeof(F), (void **)&tmp));
+    F *arr = tmp, *Fg = tmp + C2;
+    HB_CHECK(ctx, hipMemsetAsync(arr + cols, 0, cols * sizeof(F), ctx->stream));
+    HB_TRY(hobbit_prepare_matrix_cols(ctx, d_M, rows, cols, h_r + k2, k1, (hobbit_F *)arr));
+    hobbit_F one = {1, 0};
+    HB_TRY(hobbit_phi_g(ctx, h_r, k2, &one, 0, (hobbit_F *)Fg));
+    // sumcheck2 uses ctx->workspace itself: move the two tables to workspace2 first
+    F *t2; HB_TRY(ctx->workspace2(2 * C2 * sizeof(F), (void **)&t2));
+    HB_CHECK(ctx, hipMemcpyAsync(t2, tmp, 2 * C2 * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    return hobbit_sumcheck2(ctx, (const hobbit_F *)(t2 + C2), (const hobbit_F *)t2, C2, h_r + (k1 + k2 - 1), h_qpoly, h_rr, h_vr, h_final);
 }
 
 // ---- open building blocks ---------------------------------------------------------------------

@@ -43,6 +43,8 @@ struct DeviceCode {         // finalized code for one message length n
     uint2 *d_edges32 = nullptr;              // {idx, w32}          (small_weights)
     uint32_t *d_eidx = nullptr; F *d_ew = nullptr;   // general weights
     size_t n_edges_padded = 0, n_edges = 0;
+    // H^T in CSR (evaluate_parity_matrix), built on first use
+    uint32_t *d_pm_rowptr = nullptr, *d_pm_idx = nullptr; F *d_pm_w = nullptr; size_t pm_rows = 0;
 };
 
 struct ProfEntry { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double ms = 0; long long launches = 0; };

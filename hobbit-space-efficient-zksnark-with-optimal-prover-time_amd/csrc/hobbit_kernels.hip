@@ -776,6 +776,54 @@ int launch_eval_fold(hobbit_ctx *ctx, const F *v, F *o, size_t L, F r) {
 }
 
 // ============================================================================================
+// code-membership / FFT-as-sumcheck tables
+// ============================================================================================
+// A = H^T beta (src/sumcheck.cpp:2888-2929) as one CSR gather: A[a] = sum_e w_e * beta[idx_e]
+// (the "-= beta" identity terms are edges of weight -1)
+__global__ void k_csr_gather(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ idx, const F *__restrict__ w,
+                             const F *__restrict__ x, F *__restrict__ y, size_t rows) {
+    for (size_t a = blockIdx.x * (size_t)blockDim.x + threadIdx.x; a < rows; a += (size_t)gridDim.x * blockDim.x) {
+        F acc = fmake(0);
+        for (uint32_t e = rowptr[a]; e < rowptr[a + 1]; e++) acc = fadd(acc, fmul(ldF(x + idx[e]), ldF(w + e)));
+        stF(y + a, acc);
+    }
+}
+int launch_csr_gather(hobbit_ctx *ctx, const uint32_t *rowptr, const uint32_t *idx, const F *w, const F *x, F *y, size_t rows) {
+    if (!rows) return 0;
+    HB_LAUNCH(ctx, "k_csr_gather", k_csr_gather, dim3(grid_for(rows, 256)), dim3(256), 0, rowptr, idx, w, x, y, rows);
+    return 0;
+}
+// one doubling level of phiGInit (src/utils.cpp:694-755): for b < half, l = b, r = b ^ half:
+//   t2 = rx * pm[b << m];  g[r] = g[l] * ((1-rx) - t2);  g[l] = g[l] * ((1-rx) + t2)
+// last_only (the non-inverse table's closing loop) updates g[l] alone.
+__global__ void k_phi_step(F *__restrict__ g, size_t half, int m, F rx, const F *__restrict__ pm, int last_only) {
+    const F t1 = fsub(fmake(1), rx);
+    for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < half; b += (size_t)gridDim.x * blockDim.x) {
+        const F t2 = fmul(rx, ldF(pm + (b << m))), gl = ldF(g + b);
+        if (!last_only) stF(g + (b ^ half), fmul(gl, fsub(t1, t2)));
+        stF(g + b, fmul(gl, fadd(t1, t2)));
+    }
+}
+int launch_phi_step(hobbit_ctx *ctx, F *g, size_t half, int m, F rx, const F *pm, int last_only) {
+    HB_LAUNCH(ctx, "k_phi_step", k_phi_step, dim3(grid_for(half, 256)), dim3(256), 0, g, half, m, rx, pm, last_only);
+    return 0;
+}
+// prepare_matrix(transpose(M), r) step (src/utils.cpp:758-775): fold adjacent ROWS of a row-major matrix
+__global__ void k_fold_rows(const F *__restrict__ in, F *__restrict__ out, size_t out_rows, size_t cols, F r) {
+    const size_t total = out_rows * cols;
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        const size_t j = g / cols, c = g % cols;
+        const F a = ldF(in + (2 * j) * cols + c), b = ldF(in + (2 * j + 1) * cols + c);
+        stF(out + g, fadd(a, fmul(r, fsub(b, a))));
+    }
+}
+int launch_fold_rows(hobbit_ctx *ctx, const F *in, F *out, size_t out_rows, size_t cols, F r) {
+    if (!out_rows || !cols) return 0;
+    HB_LAUNCH(ctx, "k_fold_rows", k_fold_rows, dim3(grid_for(out_rows * cols, 256)), dim3(256), 0, in, out, out_rows, cols, r);
+    return 0;
+}
+
+// ============================================================================================
 // Sumcheck (src/sumcheck.cpp:2391-2460 two-product, 1974-2058 three-product)
 //
 // Per round: one streaming kernel over the tables produces per-workgroup partial sums of the round

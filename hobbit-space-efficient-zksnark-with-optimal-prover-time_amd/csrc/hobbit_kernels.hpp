@@ -28,6 +28,9 @@ int launch_gather(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, uint32_
                   size_t nq, F *d_reply);
 int launch_tensor_row(hobbit_ctx *ctx, const F *chunk, uint32_t rows2, uint32_t cols, uint32_t row, F *d_out);
 int launch_eval_fold(hobbit_ctx *ctx, const F *v, F *o, size_t L, F r);
+int launch_csr_gather(hobbit_ctx *ctx, const uint32_t *rowptr, const uint32_t *idx, const F *w, const F *x, F *y, size_t rows);
+int launch_phi_step(hobbit_ctx *ctx, F *g, size_t half, int m, F rx, const F *pm, int last_only);
+int launch_fold_rows(hobbit_ctx *ctx, const F *in, F *out, size_t out_rows, size_t cols, F r);
 int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev_r, F *h_qpoly, F *h_r, F *h_vr, F *h_final);
 int launch_sumcheck3(hobbit_ctx *ctx, const F *v1, const F *v2, const F *v3, size_t n, F prev_r, F *h_cpoly, F *h_r, F *h_vr, F *h_final);
 }  // namespace hobbit

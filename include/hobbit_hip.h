@@ -176,6 +176,26 @@ int hobbit_sumcheck2(hobbit_ctx *ctx, const hobbit_F *d_v1, const hobbit_F *d_v2
 int hobbit_sumcheck3(hobbit_ctx *ctx, const hobbit_F *d_v1, const hobbit_F *d_v2, const hobbit_F *d_v3, size_t n,
                      const hobbit_F *prev_r, hobbit_F *h_cpoly, hobbit_F *h_r, hobbit_F *h_vr, hobbit_F *h_final);
 
+/* ---- code-membership and FFT-as-sumcheck proofs (pieces of recursive_prover_Spielman) -------- */
+/* evaluate_parity_matrix (src/sumcheck.cpp:2888-2929): d_A[0..size_a) = H^T d_beta over the uploaded
+ * graphs of code length n (size_a >= codeword length; the reference passes codeword.size() = 2n) */
+int hobbit_parity_matrix(hobbit_ctx *ctx, const hobbit_F *d_beta, size_t size_a, long long n, hobbit_F *d_A);
+/* phiGInit (src/utils.cpp:694-755): the 2^n table of the FFT-as-multilinear-extension */
+int hobbit_phi_g(hobbit_ctx *ctx, const hobbit_F *h_rx, int n, const hobbit_F *h_scale, int is_ifft, hobbit_F *d_out);
+/* prepare_matrix(transpose(M), r) (src/utils.cpp:758-775): d_out[c] = evaluation over the row index of
+ * column c of the row-major rows x cols matrix d_M at r[0..k) */
+int hobbit_prepare_matrix_cols(hobbit_ctx *ctx, const hobbit_F *d_M, size_t rows, size_t cols, const hobbit_F *h_r, int k, hobbit_F *d_out);
+/* prove_linear_code (src/sumcheck.cpp:3223-3235) with the challenge vector r1 supplied by the caller
+ * (the reference draws it with generate_randomness; the host mirror does that); outputs as sumcheck2 */
+int hobbit_prove_linear_code(hobbit_ctx *ctx, const hobbit_F *d_codeword, size_t size, long long n, const hobbit_F *h_r1, hobbit_F *h_qpoly,
+                             hobbit_F *h_r, hobbit_F *h_vr, hobbit_F *h_final);
+/* prove_fft (src/sumcheck.cpp:2975-2987): m of s elements is zero-padded to 2s; h_r has log2(2s) entries */
+int hobbit_prove_fft(hobbit_ctx *ctx, const hobbit_F *d_m, size_t s, const hobbit_F *h_r, hobbit_F *h_qpoly, hobbit_F *h_rr, hobbit_F *h_vr,
+                     hobbit_F *h_final);
+/* prove_fft_matrix (src/sumcheck.cpp:2989-3027): M rows x cols row-major; h_r = [log2(2 cols) | log2 rows] */
+int hobbit_prove_fft_matrix(hobbit_ctx *ctx, const hobbit_F *d_M, size_t rows, size_t cols, const hobbit_F *h_r, hobbit_F *h_qpoly, hobbit_F *h_rr,
+                            hobbit_F *h_vr, hobbit_F *h_final);
+
 /* ---- synthetic inputs on the device (bench / tests) ---------------------------------------- */
 /* splitmix64-derived full-range elements: element i = (sm(seed,2i+1) mod p, sm(seed,2i+2) mod p) */
 int hobbit_fill_splitmix(hobbit_ctx *ctx, hobbit_F *d_out, size_t n, uint64_t seed);

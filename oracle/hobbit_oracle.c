@@ -431,6 +431,124 @@ void orc_sumcheck3(const oF *_v1, const oF *_v2, const oF *_v3, size_t n, const 
     free(v1); free(v2); free(v3);
 }
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* code-membership / FFT-as-sumcheck helpers                                                    */
+/* ------------------------------------------------------------------------------------------ */
+/* src/sumcheck.cpp:2888-2929: A = H^T beta over the expander graphs (lvl is passed by reference in
+ * the reference; the recursive call gets a local copy l = lvl + R that is then discarded) */
+static long long parity_rec(oF *A, const oF *beta, long long Offset, long long n, int dep, long long *lvl) {
+    long long R = (long long)(k_alpha * n);
+    if (n <= k_dist_thr) return n;
+    const ograph *C = &gC[dep], *D = &gD[dep];
+    for (long long i = 0; i < n; i++)
+        for (int d = 0; d < C->degree; d++) {
+            long long target = C->nbr[i * C->degree + d] + *lvl;
+            A[i + Offset] = f_add(A[i + Offset], f_mul(beta[target], C->w[i * C->degree + d]));
+        }
+    for (long long i = 0; i < R; i++) A[i + Offset + n] = f_sub(A[i + Offset + n], beta[*lvl + i]);
+    long long l = *lvl + R;
+    long long L = parity_rec(A, beta, Offset + n, R, dep + 1, &l);
+    R = D->R;
+    for (long long i = 0; i < L; i++)
+        for (int d = 0; d < D->degree; d++) {
+            long long target = D->nbr[i * D->degree + d] + *lvl;
+            A[i + Offset + n] = f_add(A[i + Offset + n], f_mul(beta[target], D->w[i * D->degree + d]));
+        }
+    for (long long i = 0; i < R; i++) A[i + Offset + n + L] = f_sub(A[i + Offset + n + L], beta[i + *lvl]);
+    *lvl += R;
+    return n + L + R;
+}
+/* A: size_a elements (zeroed here), beta: size_a elements */
+long long orc_evaluate_parity_matrix(const oF *beta, size_t size_a, long long n, oF *A) {
+    memset(A, 0, sizeof(oF) * size_a);
+    long long lvl = 0;
+    return parity_rec(A, beta, 0, n, 0, &lvl);
+}
+/* src/utils.cpp:676-755 phiPowInit + phiGInit; phi_g has 2^n entries, zero-initialised by the callers */
+void orc_phi_g_init(const oF *rx, int n, const oF *scale, int is_ifft, oF *phi_g) {
+    size_t N = (size_t)1 << n;
+    oF *pm = (oF *)malloc(sizeof(oF) * N);
+    oF phi = root_of_unity(n);
+    if (is_ifft) phi = finv(phi);
+    pm[0] = fint(1);
+    for (size_t i = 1; i < N; i++) pm[i] = f_mul(pm[i - 1], phi);
+    memset(phi_g, 0, sizeof(oF) * N);
+    oF one = fint(1);
+    if (is_ifft) {
+        phi_g[0] = *scale; if (N > 1) phi_g[1] = *scale;
+        for (int i = 1; i <= n; i++)
+            for (size_t b = 0; b < ((size_t)1 << (i - 1)); b++) {
+                size_t l = b, r = b ^ ((size_t)1 << (i - 1));
+                int m = n - i;
+                oF t1 = f_sub(one, rx[m]), t2 = f_mul(rx[m], pm[b << m]);
+                phi_g[r] = f_mul(phi_g[l], f_sub(t1, t2));
+                phi_g[l] = f_mul(phi_g[l], f_add(t1, t2));
+            }
+    } else {
+        phi_g[0] = *scale;
+        for (int i = 1; i < n; i++)
+            for (size_t b = 0; b < ((size_t)1 << (i - 1)); b++) {
+                size_t l = b, r = b ^ ((size_t)1 << (i - 1));
+                int m = n - i;
+                oF t1 = f_sub(one, rx[m]), t2 = f_mul(rx[m], pm[b << m]);
+                phi_g[r] = f_mul(phi_g[l], f_sub(t1, t2));
+                phi_g[l] = f_mul(phi_g[l], f_add(t1, t2));
+            }
+        for (size_t b = 0; b < ((size_t)1 << (n - 1)); b++) {
+            oF t1 = f_sub(one, rx[0]), t2 = f_mul(rx[0], pm[b]);
+            phi_g[b] = f_mul(phi_g[b], f_add(t1, t2));
+        }
+    }
+    free(pm);
+}
+/* src/utils.cpp:758-775 prepare_matrix on a row-major rows x cols matrix: out[i] = fold of row i with r[0..k) */
+void orc_prepare_matrix(const oF *M, size_t rows, size_t cols, const oF *r, int k, oF *out) {
+    oF *row = (oF *)malloc(sizeof(oF) * cols);
+    for (size_t i = 0; i < rows; i++) {
+        memcpy(row, M + i * cols, sizeof(oF) * cols);
+        size_t off = cols / 2;
+        for (int t = 0; t < k; t++) {
+            for (size_t j = 0; j < off; j++) row[j] = f_add(row[2 * j], f_mul(r[t], f_sub(row[2 * j + 1], row[2 * j])));
+            off /= 2;
+        }
+        out[i] = row[0];
+    }
+    free(row);
+}
+/* src/sumcheck.cpp:3223-3235 prove_linear_code, with r1 given (the reference draws it with generate_randomness) */
+void orc_prove_linear_code(const oF *codeword, size_t size, long long n, const oF *r1, oF *qpoly, oF *r, oF *vr, oF *fin) {
+    int k = (int)log2((double)size);
+    oF *beta = (oF *)malloc(sizeof(oF) * size), *A = (oF *)malloc(sizeof(oF) * size);
+    orc_precompute_beta(r1, k, beta);
+    orc_evaluate_parity_matrix(beta, size, n, A);
+    orc_sumcheck2(A, codeword, size, &r1[k - 1], qpoly, r, vr, fin);
+    free(beta); free(A);
+}
+/* src/sumcheck.cpp:2975-2987 prove_fft: m (size s) is zero-padded to 2s; r has log2(2s) entries */
+void orc_prove_fft(const oF *m, size_t s, const oF *rr, oF *qpoly, oF *r, oF *vr, oF *fin) {
+    size_t S = 2 * s; int k = (int)log2((double)S);
+    oF *mm = (oF *)calloc(S, sizeof(oF)), *FG = (oF *)malloc(sizeof(oF) * S);
+    memcpy(mm, m, sizeof(oF) * s);
+    oF one = fint(1);
+    orc_phi_g_init(rr, k, &one, 0, FG);
+    orc_sumcheck2(FG, mm, S, &rr[k - 1], qpoly, r, vr, fin);
+    free(mm); free(FG);
+}
+/* src/sumcheck.cpp:2989-3027 prove_fft_matrix: M rows x cols (row-major); columns zero-padded to 2 cols;
+ * r = [r2 (log2(2cols)) | r1 (log2 rows)] */
+void orc_prove_fft_matrix(const oF *M, size_t rows, size_t cols, const oF *rr, oF *qpoly, oF *r, oF *vr, oF *fin) {
+    size_t C2 = 2 * cols; int k2 = (int)log2((double)C2), k1 = (int)log2((double)rows);
+    /* transpose(M) padded: Mt[c][i] = M[i][c] (c < cols), 0 otherwise: C2 rows of `rows` elements */
+    oF *Mt = (oF *)calloc(C2 * rows, sizeof(oF)), *arr = (oF *)malloc(sizeof(oF) * C2), *Fg = (oF *)malloc(sizeof(oF) * C2);
+    for (size_t i = 0; i < rows; i++) for (size_t c = 0; c < cols; c++) Mt[c * rows + i] = M[i * cols + c];
+    orc_prepare_matrix(Mt, C2, rows, rr + k2, k1, arr);
+    oF one = fint(1);
+    orc_phi_g_init(rr, k2, &one, 0, Fg);
+    orc_sumcheck2(Fg, arr, C2, &rr[k1 + k2 - 1], qpoly, r, vr, fin);
+    free(Mt); free(arr); free(Fg);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* Elastic_PC streaming commit: src/Elastic_PC.cpp:174-285; stream src/witness_stream.cpp:2405-11 */
 /* ------------------------------------------------------------------------------------------ */

@@ -67,6 +67,14 @@ void orc_aggregate(const oF *poly, size_t N, const oF *beta, int K, oF *aggr_out
 void orc_sumcheck2(const oF *v1, const oF *v2, size_t n, const oF *prev_r, oF *qpoly, oF *r, oF *vr, oF *fin);
 void orc_sumcheck3(const oF *v1, const oF *v2, const oF *v3, size_t n, const oF *prev_r, oF *cpoly, oF *r, oF *vr, oF *fin);
 
+/* code-membership / FFT-as-sumcheck helpers */
+long long orc_evaluate_parity_matrix(const oF *beta, size_t size_a, long long n, oF *A);
+void orc_phi_g_init(const oF *rx, int n, const oF *scale, int is_ifft, oF *phi_g);
+void orc_prepare_matrix(const oF *M, size_t rows, size_t cols, const oF *r, int k, oF *out);
+void orc_prove_linear_code(const oF *codeword, size_t size, long long n, const oF *r1, oF *qpoly, oF *r, oF *vr, oF *fin);
+void orc_prove_fft(const oF *m, size_t s, const oF *rr, oF *qpoly, oF *r, oF *vr, oF *fin);
+void orc_prove_fft_matrix(const oF *M, size_t rows, size_t cols, const oF *rr, oF *qpoly, oF *r, oF *vr, oF *fin);
+
 /* Elastic_PC streaming commit on the synthetic "test" stream */
 void orc_read_stream_pc(size_t B, oF *out);
 size_t orc_elastic_commit(size_t N, size_t B, int opt, uint8_t *levels_out);

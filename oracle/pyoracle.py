@@ -191,6 +191,39 @@ class _Base:
         self.fn("sumcheck3")(_p(v1), _p(v2), _p(v3), c_sz(n), _p(pr), _p(q), _p(r), _p(vr), _p(fin))
         return dict(poly=q, r=r, vr=vr, fin=fin)
 
+
+    # ---- code-membership / FFT-as-sumcheck helpers
+    def evaluate_parity_matrix(self, beta, n):
+        b = F(beta).reshape(-1, 2)
+        A = np.zeros_like(b)
+        f = self.fn("evaluate_parity_matrix"); f.restype = ctypes.c_longlong
+        ln = f(_p(b), c_sz(b.shape[0]), ctypes.c_longlong(n), _p(A))
+        return A, ln
+
+    def phi_g_init(self, rx, scale=(1, 0), ifft=False):
+        r = F(rx).reshape(-1, 2); n = r.shape[0]
+        sc = np.array(scale, np.uint64)
+        o = np.zeros((1 << n, 2), np.uint64)
+        self.fn("phi_g_init")(_p(r), ctypes.c_int(n), _p(sc), ctypes.c_int(int(ifft)), _p(o))
+        return o
+
+    def prepare_matrix(self, M, r):
+        m = F(M); rows, cols = m.shape[0], m.shape[1]
+        r = F(r).reshape(-1, 2)
+        o = np.zeros((rows, 2), np.uint64)
+        self.fn("prepare_matrix")(_p(m), c_sz(rows), c_sz(cols), _p(r), ctypes.c_int(r.shape[0]), _p(o))
+        return o
+
+    @staticmethod
+    def _proof2(rounds):
+        return (np.zeros((rounds, 3, 2), np.uint64), np.zeros((rounds, 2), np.uint64), np.zeros((2, 2), np.uint64), np.zeros(2, np.uint64))
+
+    @staticmethod
+    def claim_of(q0):
+        """q(0) + q(1) for a quadratic (a,b,c): 2c + a + b, as python ints mod p"""
+        a, b, c = [tuple(int(x) for x in q0[i]) for i in range(3)]
+        return np.array([(a[0] + b[0] + 2 * c[0]) % P, (a[1] + b[1] + 2 * c[1]) % P], np.uint64)
+
     def elastic_commit(self, N, B, opt):
         o = np.zeros((8 * B, 32), np.uint8)
         f = self.fn("elastic_commit"); f.restype = c_sz
@@ -236,6 +269,28 @@ class Oracle(_Base):
         o = np.zeros((p.shape[0] // K, 2), np.uint64)
         self.lib.orc_aggregate(_p(p), c_sz(p.shape[0]), _p(b), ctypes.c_int(K), _p(o))
         return o
+
+
+    def prove_linear_code(self, codeword, n, r1):
+        cw = F(codeword).reshape(-1, 2); r1 = F(r1).reshape(-1, 2)
+        rounds = cw.shape[0].bit_length() - 1
+        q, r, vr, fin = self._proof2(rounds)
+        self.lib.orc_prove_linear_code(_p(cw), c_sz(cw.shape[0]), ctypes.c_longlong(n), _p(r1), _p(q), _p(r), _p(vr), _p(fin))
+        return dict(poly=q, r=r, vr=vr, fin=fin)
+
+    def prove_fft(self, m, rr):
+        m = F(m).reshape(-1, 2); rr = F(rr).reshape(-1, 2)
+        rounds = (2 * m.shape[0]).bit_length() - 1
+        q, r, vr, fin = self._proof2(rounds)
+        self.lib.orc_prove_fft(_p(m), c_sz(m.shape[0]), _p(rr), _p(q), _p(r), _p(vr), _p(fin))
+        return dict(poly=q, r=r[:rounds - 1], vr=vr, fin=fin)
+
+    def prove_fft_matrix(self, M, rr):
+        m = F(M); rows, cols = m.shape[0], m.shape[1]; rr = F(rr).reshape(-1, 2)
+        rounds = (2 * cols).bit_length() - 1
+        q, r, vr, fin = self._proof2(rounds)
+        self.lib.orc_prove_fft_matrix(_p(m), c_sz(rows), c_sz(cols), _p(rr), _p(q), _p(r), _p(vr), _p(fin))
+        return dict(poly=q, r=r, vr=vr, fin=fin)
 
     def read_stream_pc(self, B):
         o = np.zeros((B, 2), np.uint64)
@@ -290,6 +345,30 @@ class Ref(_Base):
         o = np.zeros((p.shape[0] // K, 2), np.uint64)
         self.lib.ref_aggregate(_p(p), c_sz(p.shape[0]), _p(b), ctypes.c_int(K), ctypes.c_int(trs), ctypes.c_int(lin), _p(o))
         return o
+
+
+    def prove_linear_code(self, codeword, n, seed):
+        """returns (r1 the reference drew from the libc generator seeded with `seed`, proof)"""
+        cw = F(codeword).reshape(-1, 2)
+        rounds = cw.shape[0].bit_length() - 1
+        q, r, vr, fin = self._proof2(rounds)
+        r1 = np.zeros((rounds, 2), np.uint64)
+        self.lib.ref_prove_linear_code(_p(cw), c_sz(cw.shape[0]), ctypes.c_longlong(n), ctypes.c_uint(seed), _p(r1), _p(q), _p(r), _p(vr), _p(fin))
+        return r1, dict(poly=q, r=r, vr=vr, fin=fin)
+
+    def prove_fft(self, m, rr, prev_sum):
+        m = F(m).reshape(-1, 2); rr = F(rr).reshape(-1, 2); ps = F(prev_sum).reshape(2)
+        rounds = (2 * m.shape[0]).bit_length() - 1
+        q, r, vr, fin = self._proof2(rounds)
+        self.lib.ref_prove_fft(_p(m), c_sz(m.shape[0]), _p(rr), _p(ps), _p(q), _p(r), _p(vr), _p(fin))
+        return dict(poly=q, r=r[:rounds - 1], vr=vr, fin=fin)
+
+    def prove_fft_matrix(self, M, rr, prev_sum):
+        m = F(M); rows, cols = m.shape[0], m.shape[1]; rr = F(rr).reshape(-1, 2); ps = F(prev_sum).reshape(2)
+        rounds = (2 * cols).bit_length() - 1
+        q, r, vr, fin = self._proof2(rounds)
+        self.lib.ref_prove_fft_matrix(_p(m), c_sz(rows), c_sz(cols), _p(rr), _p(ps), _p(q), _p(r), _p(vr), _p(fin))
+        return dict(poly=q, r=r, vr=vr, fin=fin)
 
     def read_stream_pc(self, N, B, chunk_idx=0):
         o = np.zeros((B, 2), np.uint64)

@@ -206,6 +206,55 @@ void ref_sumcheck3(const uint64_t *v1, const uint64_t *v2, const uint64_t *v3, s
     stF(vr, P.vr[0]); stF(vr + 2, P.vr[1]); stF(vr + 4, P.vr[2]); stF(fin, P.final_rand);
 }
 
+
+// ---- code-membership / FFT-as-sumcheck helpers (src/sumcheck.cpp:2888-2929, 2975-3027, 3223-3235;
+//      src/utils.cpp:694-775) -------------------------------------------------------------------------
+long long ref_evaluate_parity_matrix(const uint64_t *beta, size_t size_a, long long n, uint64_t *A) {
+    vector<F> a(size_a, F(0)), b = vecF(beta, size_a);
+    int lvl = 0;
+    long long len = evaluate_parity_matrix(a, b, 0, (int)n, 0, lvl);
+    memcpy(A, a.data(), 16 * size_a);
+    return len;
+}
+void ref_phi_g_init(const uint64_t *rx, int n, const uint64_t *scale, int is_ifft, uint64_t *phi_g) {
+    vector<F> r = vecF(rx, n), g((size_t)1 << n, F(0));
+    phiGInit(g, r.begin(), ldF(scale), n, is_ifft != 0);
+    memcpy(phi_g, g.data(), 16 * g.size());
+}
+void ref_prepare_matrix(const uint64_t *M, size_t rows, size_t cols, const uint64_t *r, int k, uint64_t *out) {
+    vector<vector<F>> m(rows);
+    for (size_t i = 0; i < rows; i++) m[i] = vecF(M + 2 * i * cols, cols);
+    vector<F> v = prepare_matrix(m, vecF(r, k));
+    memcpy(out, v.data(), 16 * rows);
+}
+static void dump_proof2(const proof &P, uint64_t *qpoly, uint64_t *r, uint64_t *vr, uint64_t *fin) {
+    for (size_t i = 0; i < P.q_poly.size(); i++) { stF(qpoly + 6 * i, P.q_poly[i].a); stF(qpoly + 6 * i + 2, P.q_poly[i].b); stF(qpoly + 6 * i + 4, P.q_poly[i].c); }
+    for (size_t i = 0; i < P.q_poly.size(); i++) stF(r + 2 * i, i < P.randomness[0].size() ? P.randomness[0][i] : F(0));
+    stF(vr, P.vr[0]); stF(vr + 2, P.vr[1]); stF(fin, P.final_rand);
+}
+// prove_linear_code draws r1 = generate_randomness(log2 size) itself: we seed the libc generator so that
+// the caller can reproduce r1 (returned in r1_out), then hand back the sumcheck transcript.
+void ref_prove_linear_code(const uint64_t *codeword, size_t size, long long n, unsigned seed, uint64_t *r1_out, uint64_t *qpoly, uint64_t *r, uint64_t *vr, uint64_t *fin) {
+    vector<F> cw = vecF(codeword, size); double vt = 0, ps = 0;
+    srandom(seed);
+    proof P = prove_linear_code(cw, (int)n, vt, ps);
+    memcpy(r1_out, P.randomness[1].data(), 16 * P.randomness[1].size());
+    dump_proof2(P, qpoly, r, vr, fin);
+}
+void ref_prove_fft(const uint64_t *m, size_t s, const uint64_t *rr, const uint64_t *prev_sum, uint64_t *qpoly, uint64_t *r, uint64_t *vr, uint64_t *fin) {
+    vector<F> mm = vecF(m, s); int k = (int)log2((double)(2 * s)); double vt = 0, ps = 0;
+    proof P = prove_fft(mm, vecF(rr, k), ldF(prev_sum), vt, ps);
+    P.randomness[0].push_back(F(0));   // prove_fft pops the last challenge; keep the dump shape fixed
+    dump_proof2(P, qpoly, r, vr, fin);
+}
+void ref_prove_fft_matrix(const uint64_t *M, size_t rows, size_t cols, const uint64_t *rr, const uint64_t *prev_sum, uint64_t *qpoly, uint64_t *r, uint64_t *vr, uint64_t *fin) {
+    vector<vector<F>> m(rows);
+    for (size_t i = 0; i < rows; i++) m[i] = vecF(M + 2 * i * cols, cols);
+    int k = (int)log2((double)(2 * cols)) + (int)log2((double)rows); double vt = 0, ps = 0;
+    proof P = prove_fft_matrix(m, vecF(rr, k), ldF(prev_sum), vt, ps);
+    dump_proof2(P, qpoly, r, vr, fin);
+}
+
 // ---- Elastic_PC streaming commit (src/Elastic_PC.cpp:174-285) on the synthetic "test" stream ----
 // opt 1: RSxRS (trs = B/2^11); opt 2: RS x expander (trs = B/2^14, graphs drawn here).
 size_t ref_elastic_commit(size_t N, size_t B, int opt, uint8_t *levels_out) {

@@ -239,5 +239,66 @@ def case_elastic(lib):
     return out
 
 
+def case_codeproofs(lib):
+    """evaluate_parity_matrix / prove_linear_code / phiGInit / prepare_matrix / prove_fft / prove_fft_matrix
+    (src/sumcheck.cpp:2888-2929, 3223-3235, 2975-3027; src/utils.cpp:694-775)"""
+    is_ref = lib.__class__.__name__ == "Ref"
+    out = {}
+    for n in (16, 64, 256, 1024):
+        lib.rng_reset(); ln = lib.expander_init_store(n)
+        if hasattr(lib, "encode_reset_scratch"):
+            lib.encode_reset_scratch()
+        k = (2 * n).bit_length() - 1
+        beta = lib.precompute_beta(splitmix_field(k, 300 + n))
+        A, l2 = lib.evaluate_parity_matrix(beta, n)
+        out["pm_%d" % n] = A if n <= 64 else dg(A)
+        out["pm_%d_len" % n] = np.array([l2, ln], np.int64)
+        # prove_linear_code on a real codeword: the parity check A . codeword must vanish
+        cw, _ = lib.encode_monolithic(splitmix_field(n, 310 + n))
+        if is_ref:
+            r1, res = lib.prove_linear_code(cw, n, 777 + n)
+            out["plc_%d_r1" % n] = r1
+        else:
+            # the reference draws r1 itself (generate_randomness): reproduce the draw from the same seed
+            import ctypes
+            libc = ctypes.CDLL(None); libc.srandom(777 + n)
+            r1 = lib.generate_randomness(k)
+            out["plc_%d_r1" % n] = r1
+            res = lib.prove_linear_code(cw, n, r1)
+        for kk, v in res.items():
+            out["plc_%d_%s" % (n, kk)] = v
+    for nn in (1, 2, 5, 10):
+        rx = splitmix_field(nn, 320 + nn)
+        for ifft in (0, 1):
+            g = lib.phi_g_init(rx, (7, 3) if ifft else (1, 0), bool(ifft))
+            out["phig_%d_%d" % (nn, ifft)] = g if nn <= 5 else dg(g)
+    M = splitmix_field(64 * 256, 330).reshape(64, 256, 2)
+    out["prepmat"] = lib.prepare_matrix(M, splitmix_field(8, 331))
+    # prove_fft on a vector of 512, prove_fft_matrix on 16 x 256
+    m = splitmix_field(512, 340); rr = splitmix_field(10, 341)
+    if is_ref:
+        # previous_sum must equal q0(0)+q0(1) or the reference exits: take it from a first (unchecked-sum) run
+        tmp = lib.prove_fft(m, rr, np.zeros(2, np.uint64))          # prove_fft only prints on mismatch
+        res = lib.prove_fft(m, rr, lib.claim_of(tmp["poly"][0]))
+    else:
+        res = lib.prove_fft(m, rr)
+    for kk, v in res.items():
+        out["pfft_%s" % kk] = v
+    Mx = splitmix_field(16 * 256, 350).reshape(16, 256, 2); rr2 = splitmix_field(9 + 4, 351)
+    out["pfm_inputs_dg"] = dg(Mx)
+    return out
+
+
+def case_codeproofs_matrix(lib, claim=None):
+    """prove_fft_matrix exits the process on a wrong previous_sum, so the reference run needs the claim
+    computed by the (already pinned) restatement: gen_golden passes it in."""
+    Mx = splitmix_field(16 * 256, 350).reshape(16, 256, 2); rr2 = splitmix_field(9 + 4, 351)
+    if lib.__class__.__name__ == "Ref":
+        res = lib.prove_fft_matrix(Mx, rr2, claim)
+    else:
+        res = lib.prove_fft_matrix(Mx, rr2)
+    return {"pfm_%s" % kk: v for kk, v in res.items()}
+
+
 CASES = dict(field=case_field, mimc=case_mimc, blake=case_blake, merkle=case_merkle, graph_encode=case_graph_encode,
-             fft=case_fft, tensorcode=case_tensorcode, commit=case_commit, sumcheck=case_sumcheck, elastic=case_elastic)
+             fft=case_fft, tensorcode=case_tensorcode, commit=case_commit, sumcheck=case_sumcheck, elastic=case_elastic, codeproofs=case_codeproofs)

@@ -414,3 +414,46 @@ def test_elastic_commit_2e22_opt2_vs_oracle(hb, oracle):
     hb.lib.hobbit_elastic_free(h)
     T = 4 * B
     assert np.array_equal(got[:T - 1], want[:T - 1]) and np.array_equal(got[T:], want[T:])
+
+
+# ---- code-membership / FFT-as-sumcheck proofs ----------------------------------------------------
+def test_codeproofs_vs_golden(hb):
+    import ctypes
+    g = gold("codeproofs")
+    for n in (16, 64, 256, 1024):
+        hb.rng_reset(); ln = hb.expander_init_store(n)
+        k = (2 * n).bit_length() - 1
+        beta = hb.precompute_beta(splitmix_field(k, 300 + n))
+        A = hb.evaluate_parity_matrix(beta, n)
+        assert np.array_equal(A if n <= 64 else dg(A), g["pm_%d" % n]), n
+        cw = hb.encode_monolithic(splitmix_field(n, 310 + n))
+        r1 = g["plc_%d_r1" % n]                        # the challenge vector the reference drew (libc, seed 777+n)
+        ctypes.CDLL(None).srandom(777 + n)
+        assert np.array_equal(hb.generate_randomness(k), r1)
+        res = hb.prove_linear_code(cw, n, r1)
+        for kk, v in res.items():
+            assert np.array_equal(v, g["plc_%d_%s" % (n, kk)]), (n, kk)
+        # a codeword satisfies the parity check: claimed sum q0(0)+q0(1) = 0
+        q0 = res["poly"][0].astype(object)
+        assert [(int(q0[0][i]) + int(q0[1][i]) + 2 * int(q0[2][i])) % P for i in range(2)] == [0, 0]
+    for nn in (1, 2, 5, 10):
+        rx = splitmix_field(nn, 320 + nn)
+        for ifft in (0, 1):
+            t = hb.phiGInit(rx, (7, 3) if ifft else (1, 0), bool(ifft))
+            assert np.array_equal(t if nn <= 5 else dg(t), g["phig_%d_%d" % (nn, ifft)]), (nn, ifft)
+    M = splitmix_field(64 * 256, 330).reshape(64, 256, 2)
+    # prepare_matrix(M, r) folds along each ROW of M; the device op folds the row index of columns: feed M^T
+    assert np.array_equal(hb.prepare_matrix_cols(np.ascontiguousarray(M.transpose(1, 0, 2)), splitmix_field(8, 331)), g["prepmat"])
+    res = hb.prove_fft(splitmix_field(512, 340), splitmix_field(10, 341))
+    for kk, v in res.items():
+        assert np.array_equal(v, g["pfft_%s" % kk]), kk
+    gm = gold("codeproofs_matrix")
+    res = hb.prove_fft_matrix(splitmix_field(16 * 256, 350).reshape(16, 256, 2), splitmix_field(9 + 4, 351))
+    for kk, v in res.items():
+        assert np.array_equal(v, gm["pfm_%s" % kk]), kk
+
+
+def test_phi_g_large_vs_oracle(hb, oracle):
+    rx = splitmix_field(16, 77)
+    assert np.array_equal(hb.phiGInit(rx), oracle.phi_g_init(rx))
+    assert np.array_equal(hb.phiGInit(rx, (5, 9), True), oracle.phi_g_init(rx, (5, 9), True))
