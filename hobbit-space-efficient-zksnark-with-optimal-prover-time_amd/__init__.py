@@ -41,6 +41,7 @@ ABI_SYMBOLS = [
     "hobbit_tensorcode_chunks", "hobbit_inner_digests", "hobbit_chain_digests", "hobbit_blake3_64_host",
     "hobbit_parity_matrix", "hobbit_phi_g", "hobbit_prepare_matrix_cols", "hobbit_prove_linear_code", "hobbit_prove_fft",
     "hobbit_prove_fft_matrix",
+    "hobbit_open_core",
     "hobbit_aggregate", "hobbit_sumcheck2", "hobbit_sumcheck3", "hobbit_fill_splitmix",
 ]
 
@@ -81,6 +82,7 @@ def load_library(path=LIB_PATH):
         "hobbit_parity_matrix": [V, V, S, L, V], "hobbit_phi_g": [V, V, I, V, I, V], "hobbit_prepare_matrix_cols": [V, V, S, S, V, I, V],
         "hobbit_prove_linear_code": [V, V, S, L, V, V, V, V, V], "hobbit_prove_fft": [V, V, S, V, V, V, V, V],
         "hobbit_prove_fft_matrix": [V, V, S, S, V, V, V, V, V],
+        "hobbit_open_core": [V, V, S, V, V, I, V],
         "hobbit_elastic_begin": [V, S, I, I, I, V], "hobbit_elastic_push": [V, V, V], "hobbit_elastic_finish": [V, V, V],
         "hobbit_elastic_free": [V],
         "hobbit_tensorcode_chunks": [V, V, S, I, I, I, V], "hobbit_inner_digests": [V, V, S, I, I, V],
@@ -417,6 +419,29 @@ class Hobbit:
         self._chk(self.lib.hobbit_commit_standard(self.ctx, c_vp(ptr), c_sz(N), c_int(K), c_int(trs), c_int(lin), ctypes.byref(h)))
         self.sync()
         return Commitment(self, h, N, K, trs)
+
+    def open_core(self, poly, commitment, x, queries, want_paths=True):
+        """open_standard + recursive_prover_Spielman without the inner shockwave/WHIR PCS (host: libc draws in the
+        reference's order).  poly: host array or (DeviceBuffer, N)."""
+        if isinstance(poly, tuple):
+            ptr, N = poly; ptr = ptr.ptr if isinstance(ptr, DeviceBuffer) else int(ptr); keep = None
+        else:
+            p = Fh(poly).reshape(-1, 2); N = p.shape[0]; keep = self.to_device(p); ptr = keep.ptr
+        c = commitment; x = Fh(x).reshape(-1, 2)
+        R1 = (2 * c.trs).bit_length() - 1; logc = c.cols.bit_length() - 1
+        rounds = R1 + logc + 2 * (R1 + logc) + logc
+        depth = c.M.bit_length() - 1
+
+        class Out(ctypes.Structure):
+            _fields_ = [(n, c_vp) for n in ("cols", "rows", "reply", "paths", "qpoly", "r", "vr", "fin", "scalars", "checks")]
+        res = dict(cols=np.zeros(queries, np.uint32), rows=np.zeros(queries, np.uint32), reply=np.zeros((queries, c.K, 2), np.uint64),
+                   paths=np.zeros((queries, depth, 32), np.uint8) if want_paths else None, poly=np.zeros((rounds, 3, 2), np.uint64),
+                   r=np.zeros((rounds, 2), np.uint64), vr=np.zeros((5, 2, 2), np.uint64), fin=np.zeros((5, 2), np.uint64),
+                   scalars=np.zeros((5, 2), np.uint64), checks=np.zeros(3, np.int32))
+        o = Out(*[(res[k].ctypes.data if res[k] is not None else None) for k in ("cols", "rows", "reply", "paths", "poly", "r", "vr", "fin", "scalars", "checks")])
+        self._chk(self.lib.hobbit_open_core(self.ctx, ptr, N, c.h, _hp(x), queries, ctypes.byref(o)))
+        res["I"] = np.stack([res["cols"], res["rows"]], axis=1)
+        return res
 
     def aggregate(self, poly, beta):
         p = Fh(poly).reshape(-1, 2); b = Fh(beta).reshape(-1, 2)

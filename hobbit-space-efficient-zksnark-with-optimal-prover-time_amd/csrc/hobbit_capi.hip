@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include "hobbit_kernels.hpp"
 #include "hobbit_blake3.hpp"
 
@@ -622,6 +623,105 @@ int hobbit_aggregate(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     HB_CHECK(ctx, hipMemcpyAsync(d_beta, h_beta, (size_t)K * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
     HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return launch_aggregate(ctx, cF(d_poly), N / K, K, d_beta, mF(d_aggr));
+}
+
+// ---- Our_PC open without the inner shockwave/WHIR PCS -------------------------------------------
+// open_standard (src/Our_PC.cpp:604-661) + recursive_prover_Spielman (src/PC_utils.cpp:271-385) minus
+// shockwave_commit / shockwave_prove.  Host: libc draws in the reference's order, the transcript,
+// challenge powers; device: everything that touches a table.
+int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const hobbit_F *h_x, int queries, hobbit_open_out *o) {
+    if (!c || !o || queries <= 0) return ctx->fail(HOBBIT_EINVAL, "open_core: bad arguments");
+    if (!c->lin) return ctx->fail(HOBBIT_EINVAL, "open_core: only the RS x expander (linear_time) code is built");
+    const int K = c->K, trs = c->trs;
+    const size_t M = c->M, cols = c->cols, rows2 = c->rows2, big = rows2 * cols;
+    const int logK = ilog2_exact((size_t)K), logc = ilog2_exact(cols), R1 = ilog2_exact(rows2), R3 = R1 + logc;
+    if (logK < 0 || N != M * (size_t)K || logc != 12) return ctx->fail(HOBBIT_EINVAL, "open_core: needs K a power of two and 4096-point row codes");
+    // beta over the chunk variables (precompute_beta, host: K <= 64 entries) and the r_v[0] draw (:619-623)
+    std::vector<F> beta((size_t)K); beta[0] = fmake(1);
+    for (int i = 0; i < logK; i++) for (size_t j = ((size_t)1 << i); j-- > 0;) { F t = fmul(cF(h_x)[logK - 1 - i], beta[j]); beta[2 * j + 1] = t; beta[2 * j] = fsub(beta[j], t); }
+    { F rv0 = fmake((uint64_t)random()); rv0 = fadd(rv0, fmake((uint64_t)rand())); memcpy(&o->scalars[0], &rv0, sizeof(F)); }   // generate_randomness(1)
+    // device arena
+    F *arena = nullptr;
+    const size_t n_el = M + 4 * big + 2 * cols + 4 * rows2 + 64;
+    if (hipMalloc((void **)&arena, n_el * sizeof(F)) != hipSuccess) return ctx->fail(HOBBIT_ENOMEM, "open_core: arena allocation failed");
+    struct Guard { F *p; hipStream_t s; ~Guard() { hipStreamSynchronize(s); hipFree(p); } } guard{arena, ctx->stream};
+    F *d_aggr = arena, *BIG = d_aggr + M, *Tcm = BIG + big, *d_b = Tcm + big, *d_bb = d_b + big, *d_s = d_bb + big, *d_ev = d_s + cols,
+      *d_ac = d_ev + cols, *d_b1 = d_ac + rows2;
+    F *Mp = BIG, *C = BIG + (size_t)trs * cols;
+    HB_TRY(hobbit_aggregate(ctx, d_poly, N, reinterpret_cast<const hobbit_F *>(beta.data()), K, reinterpret_cast<hobbit_F *>(d_aggr)));   // _aggregate axpy (:258-272)
+    // compute_tensorcode(aggr) (:277): M' = row FFTs (row-major), codeword-major copy, expander encode, parity half back to row-major C
+    HB_TRY(fft_rows(ctx, d_aggr, cols / 2, (uint32_t)(cols / 2), Mp, cols, 1, logc, false, 1, (uint32_t)trs, 0, 0));
+    HB_TRY(launch_transpose(ctx, Mp, 0, (uint32_t)trs, (uint32_t)cols, Tcm, 0, rows2, 1));
+    if (ctx->code.n != trs) { long long l; HB_TRY(hobbit_graph_finalize(ctx, trs, &l)); }
+    HB_TRY(launch_encode(ctx, Tcm, rows2, Tcm, rows2, trs, cols, 0));
+    HB_TRY(launch_transpose_ld(ctx, Tcm + trs, 0, rows2, (uint32_t)cols, (uint32_t)trs, C, 0, cols, 1));
+    // queries (:633-641), replies (:291-305) and Merkle paths (:645-647)
+    std::vector<uint32_t> qc(queries), qr(queries); std::vector<uint64_t> Iv(queries);
+    for (int q = 0; q < queries; q++) { qc[q] = (uint32_t)(rand() % (long)cols); qr[q] = (uint32_t)(rand() % (long)rows2); Iv[q] = qc[q] + cols * (uint64_t)qr[q]; }
+    if (o->cols) memcpy(o->cols, qc.data(), 4 * (size_t)queries);
+    if (o->rows) memcpy(o->rows, qr.data(), 4 * (size_t)queries);
+    if (o->reply) HB_TRY(hobbit_commitment_gather(ctx, c, qr.data(), qc.data(), (size_t)queries, o->reply));
+    if (o->paths) HB_TRY(hobbit_commitment_paths(ctx, c, qc.data(), qr.data(), (size_t)queries, o->paths));
+    // recursive_prover_Spielman: s powers (:293-297), aggr_c = [M' | C] . s (:298-309)
+    std::vector<F> sv(cols);
+    sv[0] = fmake((uint64_t)random()); o->scalars[1] = *reinterpret_cast<hobbit_F *>(&sv[0]);
+    for (size_t i = 1; i < cols; i++) sv[i] = fmul(sv[i - 1], sv[0]);
+    HB_CHECK(ctx, hipMemcpyAsync(d_s, sv.data(), cols * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+    HB_TRY(launch_matvec_rows(ctx, BIG, rows2, cols, d_s, d_ac));
+    // P1 = prove_linear_code(aggr_c, trs) with r1 = generate_randomness(log2 2trs) (:310; src/sumcheck.cpp:3223-3235)
+    std::vector<F> r1(R1);
+    { F cst = fmake(0); for (int i = 0; i < R1; i++) { if (i % 100 == 0) cst = fmake((uint64_t)random()); r1[i] = fadd(cst, fmake((uint64_t)rand())); } }
+    hobbit_F *Q = o->qpoly, *Rr = o->r;
+    HB_TRY(hobbit_prove_linear_code(ctx, reinterpret_cast<hobbit_F *>(d_ac), rows2, trs, reinterpret_cast<hobbit_F *>(r1.data()), Q, Rr, o->vr, o->fin));
+    const hobbit_F *r_p1 = Rr; const hobbit_F *q_p1 = Q; (void)q_p1;
+    Q += 3 * R1; Rr += R1;
+    // evals = beta(P1.r)^T [M' | C] (:311-320); P2 = sumcheck(s, evals, F(021) -- octal) (:322)
+    HB_TRY(hobbit_eq_table(ctx, r_p1, R1, reinterpret_cast<hobbit_F *>(d_b1)));
+    HB_TRY(launch_vecmat(ctx, BIG, rows2, cols, d_b1, d_ev));
+    hobbit_F p17 = {021, 0};
+    HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(d_s), reinterpret_cast<hobbit_F *>(d_ev), cols, &p17, Q, Rr, o->vr + 2, o->fin + 1));
+    const hobbit_F *r_p2 = Rr; const F *q2 = cF(Q);
+    { F c2 = fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])); o->checks[0] = feq(c2, cF(o->vr)[1]); }       // "Error recursion 1" (:323-326)
+    Q += 3 * logc; Rr += logc;
+    // buff2: s2 powers at the queried positions, last write wins (:331-336); P3 (:339)
+    const F s2 = fmake((uint64_t)random()); o->scalars[2] = *reinterpret_cast<const hobbit_F *>(&s2);
+    {
+        std::map<uint64_t, F> last; F pw = s2;
+        for (int q = 0; q < queries; q++) { last[Iv[q]] = pw; pw = fmul(pw, s2); }
+        std::vector<uint64_t> idx; std::vector<F> val;
+        for (auto &kv : last) { idx.push_back(kv.first); val.push_back(kv.second); }
+        HB_CHECK(ctx, hipMemsetAsync(d_b, 0, big * sizeof(F), ctx->stream));
+        F *tmpv = nullptr; uint64_t *tmpi = nullptr;
+        if (hipMalloc((void **)&tmpv, val.size() * sizeof(F) + 16) != hipSuccess || hipMalloc((void **)&tmpi, idx.size() * 8 + 16) != hipSuccess) return ctx->fail(HOBBIT_ENOMEM, "open_core: alloc");
+        HB_CHECK(ctx, hipMemcpyAsync(tmpv, val.data(), val.size() * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+        HB_CHECK(ctx, hipMemcpyAsync(tmpi, idx.data(), idx.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        int rc = launch_scatter(ctx, tmpi, tmpv, idx.size(), d_b);
+        hipStreamSynchronize(ctx->stream); hipFree(tmpv); hipFree(tmpi);
+        if (rc) return rc;
+    }
+    hobbit_F p121 = {121, 0};
+    HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(BIG), reinterpret_cast<hobbit_F *>(d_b), big, &p121, Q, Rr, o->vr + 4, o->fin + 2));
+    const hobbit_F *r_p3 = Rr;
+    Q += 3 * R3; Rr += R3;
+    // a, beta(P2.r | P1.r) + a * beta(P3.r) (:342-349); P4 against [M' | C] (:362); "Error recursion 2" (:364-367)
+    const F a = fmake((uint64_t)random()); o->scalars[3] = *reinterpret_cast<const hobbit_F *>(&a);
+    std::vector<hobbit_F> rcat(R3);
+    memcpy(rcat.data(), r_p2, sizeof(hobbit_F) * logc); memcpy(rcat.data() + logc, r_p1, sizeof(hobbit_F) * R1);
+    HB_TRY(hobbit_eq_table(ctx, rcat.data(), R3, reinterpret_cast<hobbit_F *>(d_b)));
+    HB_TRY(hobbit_eq_table(ctx, r_p3, R3, reinterpret_cast<hobbit_F *>(d_bb)));
+    HB_TRY(launch_axpy(ctx, d_b, d_bb, a, big));
+    hobbit_F p312 = {312, 0};
+    HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(d_b), reinterpret_cast<hobbit_F *>(BIG), big, &p312, Q, Rr, o->vr + 6, o->fin + 3));
+    const hobbit_F *r_p4 = Rr; const F *q4 = cF(Q);
+    { F c4 = fadd(fadd(q4[0], q4[1]), fadd(q4[2], q4[2])); F want = fadd(fmul(a, cF(o->vr)[4]), cF(o->vr)[3]); o->checks[1] = feq(c4, want); }
+    Q += 3 * R3; Rr += R3;
+    // y1 = evaluate_vector(M', P4.r minus its last entry) (:372-373); P5 = prove_fft_matrix(initial tensor, r, y1) (:383)
+    F y1;
+    HB_TRY(hobbit_eval_vector(ctx, reinterpret_cast<hobbit_F *>(Mp), (size_t)trs * cols, r_p4, reinterpret_cast<hobbit_F *>(&y1)));
+    o->scalars[4] = *reinterpret_cast<hobbit_F *>(&y1);
+    HB_TRY(hobbit_prove_fft_matrix(ctx, reinterpret_cast<hobbit_F *>(d_aggr), (size_t)trs, cols / 2, r_p4, Q, Rr, o->vr + 8, o->fin + 4));
+    { const F *q5 = cF(Q); F c5 = fadd(fadd(q5[0], q5[1]), fadd(q5[2], q5[2])); o->checks[2] = feq(c5, y1); }   // src/sumcheck.cpp:3016-3019
+    return 0;
 }
 
 int hobbit_sumcheck2(hobbit_ctx *ctx, const hobbit_F *d_v1, const hobbit_F *d_v2, size_t n, const hobbit_F *prev_r, hobbit_F *h_qpoly,

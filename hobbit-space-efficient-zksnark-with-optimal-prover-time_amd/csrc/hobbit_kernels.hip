@@ -301,7 +301,7 @@ int launch_fft_combine(hobbit_ctx *ctx, int logr, const F *Y, F *dst, size_t dst
 // transposed directly costs a 16-byte scattered store per element: measured 22 ms vs 8 ms for the
 // 2^28 commit's row pass, hence this separate, HBM-bound pass.)
 __global__ void __launch_bounds__(256)
-k_transpose(const F *__restrict__ in, size_t in_gs, uint32_t rows, uint32_t cols, F *__restrict__ out, size_t out_gs, size_t ld_out) {
+k_transpose(const F *__restrict__ in, size_t in_gs, size_t in_ld, uint32_t rows, uint32_t cols, F *__restrict__ out, size_t out_gs, size_t ld_out) {
     __shared__ F tile[32][33];
     const F *src = in + (size_t)blockIdx.z * in_gs;
     F *dst = out + (size_t)blockIdx.z * out_gs;
@@ -310,7 +310,7 @@ k_transpose(const F *__restrict__ in, size_t in_gs, uint32_t rows, uint32_t cols
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const uint32_t r = r0 + ty + 8 * i;
-        if (r < rows && c0 + tx < cols) stF(&tile[ty + 8 * i][tx], ldF(src + (size_t)r * cols + c0 + tx));
+        if (r < rows && c0 + tx < cols) stF(&tile[ty + 8 * i][tx], ldF(src + (size_t)r * in_ld + c0 + tx));
     }
     __syncthreads();
 #pragma unroll
@@ -319,10 +319,15 @@ k_transpose(const F *__restrict__ in, size_t in_gs, uint32_t rows, uint32_t cols
         if (c < cols && r0 + tx < rows) stF(dst + (size_t)c * ld_out + r0 + tx, ldF(&tile[tx][ty + 8 * i]));
     }
 }
-int launch_transpose(hobbit_ctx *ctx, const F *in, size_t in_gs, uint32_t rows, uint32_t cols, F *out, size_t out_gs, size_t ld_out, uint32_t groups) {
+int launch_transpose_ld(hobbit_ctx *ctx, const F *in, size_t in_gs, size_t in_ld, uint32_t rows, uint32_t cols, F *out, size_t out_gs, size_t ld_out,
+                        uint32_t groups) {
     if (!rows || !cols || !groups) return 0;
-    HB_LAUNCH(ctx, "k_transpose", k_transpose, dim3((cols + 31) / 32, (rows + 31) / 32, groups), dim3(256), 0, in, in_gs, rows, cols, out, out_gs, ld_out);
+    HB_LAUNCH(ctx, "k_transpose", k_transpose, dim3((cols + 31) / 32, (rows + 31) / 32, groups), dim3(256), 0, in, in_gs, in_ld, rows, cols, out, out_gs,
+              ld_out);
     return 0;
+}
+int launch_transpose(hobbit_ctx *ctx, const F *in, size_t in_gs, uint32_t rows, uint32_t cols, F *out, size_t out_gs, size_t ld_out, uint32_t groups) {
+    return launch_transpose_ld(ctx, in, in_gs, cols, rows, cols, out, out_gs, ld_out, groups);
 }
 
 // ============================================================================================
@@ -820,6 +825,53 @@ __global__ void k_fold_rows(const F *__restrict__ in, F *__restrict__ out, size_
 int launch_fold_rows(hobbit_ctx *ctx, const F *in, F *out, size_t out_rows, size_t cols, F r) {
     if (!out_rows || !cols) return 0;
     HB_LAUNCH(ctx, "k_fold_rows", k_fold_rows, dim3(grid_for(out_rows * cols, 256)), dim3(256), 0, in, out, out_rows, cols, r);
+    return 0;
+}
+
+// ---- dense helpers of recursive_prover_Spielman (src/PC_utils.cpp:293-345) -------------------
+// out[i] = sum_j v[j] * M[i][j]   (one workgroup per row; aggr_c = [M' | C] . s)
+__global__ void __launch_bounds__(256) k_matvec_rows(const F *__restrict__ Mx, size_t cols, const F *__restrict__ v, F *__restrict__ out) {
+    const F *row = Mx + (size_t)blockIdx.x * cols;
+    F c[1] = {fmake(0)};
+    for (size_t j = threadIdx.x; j < cols; j += blockDim.x) c[0] = fadd(c[0], fmul(ldF(v + j), ldF(row + j)));
+    __shared__ F red[4];
+    F sm = wave_sum(c[0]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sm;
+    __syncthreads();
+    if (threadIdx.x == 0) stF(out + blockIdx.x, fadd(fadd(red[0], red[1]), fadd(red[2], red[3])));
+}
+// out[i] = sum_j v[j] * M[j][i]   (one lane per column, coalesced across i; evals = beta^T [M' | C])
+__global__ void __launch_bounds__(256) k_vecmat(const F *__restrict__ Mx, size_t rows, size_t cols, const F *__restrict__ v, F *__restrict__ out) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cols; i += (size_t)gridDim.x * blockDim.x) {
+        F acc = fmake(0);
+        for (size_t j = 0; j < rows; j++) acc = fadd(acc, fmul(ldF(v + j), ldF(Mx + j * cols + i)));
+        stF(out + i, acc);
+    }
+}
+__global__ void k_scatter(const uint64_t *__restrict__ idx, const F *__restrict__ val, size_t n, F *__restrict__ out) {
+    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (g < n) stF(out + idx[g], ldF(val + g));
+}
+// y += a * x
+__global__ void k_axpy(F *__restrict__ y, const F *__restrict__ x, F a, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) stF(y + i, fadd(ldF(y + i), fmul(a, ldF(x + i))));
+}
+int launch_matvec_rows(hobbit_ctx *ctx, const F *Mx, size_t rows, size_t cols, const F *v, F *out) {
+    if (!rows) return 0;
+    HB_LAUNCH(ctx, "k_matvec_rows", k_matvec_rows, dim3((unsigned)rows), dim3(256), 0, Mx, cols, v, out);
+    return 0;
+}
+int launch_vecmat(hobbit_ctx *ctx, const F *Mx, size_t rows, size_t cols, const F *v, F *out) {
+    HB_LAUNCH(ctx, "k_vecmat", k_vecmat, dim3(grid_for(cols, 256)), dim3(256), 0, Mx, rows, cols, v, out);
+    return 0;
+}
+int launch_scatter(hobbit_ctx *ctx, const uint64_t *idx, const F *val, size_t n, F *out) {
+    if (!n) return 0;
+    HB_LAUNCH(ctx, "k_scatter", k_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx, val, n, out);
+    return 0;
+}
+int launch_axpy(hobbit_ctx *ctx, F *y, const F *x, F a, size_t n) {
+    HB_LAUNCH(ctx, "k_axpy", k_axpy, dim3(grid_for(n, 256)), dim3(256), 0, y, x, a, n);
     return 0;
 }
 

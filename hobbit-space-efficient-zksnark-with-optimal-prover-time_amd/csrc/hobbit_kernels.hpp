@@ -31,6 +31,12 @@ int launch_eval_fold(hobbit_ctx *ctx, const F *v, F *o, size_t L, F r);
 int launch_csr_gather(hobbit_ctx *ctx, const uint32_t *rowptr, const uint32_t *idx, const F *w, const F *x, F *y, size_t rows);
 int launch_phi_step(hobbit_ctx *ctx, F *g, size_t half, int m, F rx, const F *pm, int last_only);
 int launch_fold_rows(hobbit_ctx *ctx, const F *in, F *out, size_t out_rows, size_t cols, F r);
+int launch_transpose_ld(hobbit_ctx *ctx, const F *in, size_t in_gs, size_t in_ld, uint32_t rows, uint32_t cols, F *out, size_t out_gs, size_t ld_out,
+                        uint32_t groups);
+int launch_matvec_rows(hobbit_ctx *ctx, const F *Mx, size_t rows, size_t cols, const F *v, F *out);
+int launch_vecmat(hobbit_ctx *ctx, const F *Mx, size_t rows, size_t cols, const F *v, F *out);
+int launch_scatter(hobbit_ctx *ctx, const uint64_t *idx, const F *val, size_t n, F *out);
+int launch_axpy(hobbit_ctx *ctx, F *y, const F *x, F a, size_t n);
 int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev_r, F *h_qpoly, F *h_r, F *h_vr, F *h_final);
 int launch_sumcheck3(hobbit_ctx *ctx, const F *v1, const F *v2, const F *v3, size_t n, F prev_r, F *h_cpoly, F *h_r, F *h_vr, F *h_final);
 }  // namespace hobbit

@@ -269,6 +269,127 @@ struct proof _generate_3product_sumcheck_proof(vector<F> &v1, vector<F> &v2, vec
     return Pr;
 }
 
+// ---- code-membership / FFT-as-sumcheck ---------------------------------------------------------------
+static struct proof proof_from2(int rounds, const vector<F> &q, const vector<F> &r, const F vr[2], const F &fin) {
+    struct proof Pr;
+    for (int i = 0; i < rounds; i++) Pr.q_poly.push_back(quadratic_poly(q[3 * i], q[3 * i + 1], q[3 * i + 2]));
+    Pr.randomness.push_back(r); Pr.vr = {vr[0], vr[1]}; Pr.final_rand = fin;
+    return Pr;
+}
+int evaluate_parity_matrix(vector<F> &A, vector<F> &beta1, int Offset, int n, int dep, int &lvl) {   // src/sumcheck.cpp:2888-2929
+    if (Offset != 0 || dep != 0 || lvl != 0) { printf("Error: evaluate_parity_matrix recursion is internal to the device path\n"); exit(-1); }
+    DevBuf b(beta1.data(), beta1.size() * sizeof(F)), a(A.size() * sizeof(F));
+    HCHK(hobbit_parity_matrix(hobbit_host_ctx(), (const hobbit_F *)b.p, A.size(), n, (hobbit_F *)a.p));
+    vector<F> t(A.size()); a.to_host(t.data(), t.size() * sizeof(F));
+    for (size_t i = 0; i < A.size(); i++) A[i] += t[i];          // the reference accumulates into A
+    long long len = 0; HCHK(hobbit_graph_finalize(g_ctx, n, &len));
+    return (int)len;
+}
+proof prove_linear_code(vector<F> &codeword, int n, double &vt, double &ps) {       // src/sumcheck.cpp:3223-3235
+    int k = (int)log2((double)codeword.size());
+    vector<F> r1 = generate_randomness(k);
+    DevBuf cw(codeword.data(), codeword.size() * sizeof(F));
+    vector<F> q(3 * (size_t)k), r(k); F vr[2], fin;
+    HCHK(hobbit_prove_linear_code(hobbit_host_ctx(), (const hobbit_F *)cw.p, codeword.size(), n, hF(r1.data()), hF(q.data()), hF(r.data()), hF(vr), hF(&fin)));
+    proof P = proof_from2(k, q, r, vr, fin);
+    ps += k * 3 * sizeof(F) / 1024.0 + 2 * sizeof(F) / 1024.0; (void)vt;
+    if (P.q_poly[0].eval(0) + P.q_poly[0].eval(1) != F(0)) printf("Error in codeword\n");
+    P.randomness.push_back(r1);
+    return P;
+}
+struct proof prove_fft(vector<F> &m, vector<F> r, F previous_sum, double &vt, double &ps) {   // src/sumcheck.cpp:2975-2987
+    size_t s = m.size(); int k = (int)r.size();
+    DevBuf dm(m.data(), s * sizeof(F));
+    m.resize(2 * s, F(0));                                        // the reference pads its argument in place
+    vector<F> q(3 * (size_t)k), rr(k); F vr[2], fin;
+    HCHK(hobbit_prove_fft(hobbit_host_ctx(), (const hobbit_F *)dm.p, s, hF(r.data()), hF(q.data()), hF(rr.data()), hF(vr), hF(&fin)));
+    struct proof Pr = proof_from2(k, q, rr, vr, fin);
+    ps += k * 3 * sizeof(F) / 1024.0 + 2 * sizeof(F) / 1024.0; (void)vt;
+    if (previous_sum != (Pr.q_poly[0].eval(0) + Pr.q_poly[0].eval(1))) printf("Error in fft\n");
+    Pr.randomness[0].pop_back();
+    return Pr;
+}
+struct proof prove_fft_matrix(vector<vector<F>> M, vector<F> r, F previous_sum, double &vt, double &ps) {   // src/sumcheck.cpp:2989-3027
+    size_t rows = M.size(), cols = M[0].size();
+    vector<F> flat(rows * cols);
+    for (size_t i = 0; i < rows; i++) memcpy((void *)(flat.data() + i * cols), M[i].data(), cols * sizeof(F));
+    DevBuf dM(flat.data(), flat.size() * sizeof(F));
+    int k2 = (int)log2((double)(2 * cols)), k1 = (int)log2((double)rows);
+    vector<F> q(3 * (size_t)k2), rr(k2); F vr[2], fin;
+    HCHK(hobbit_prove_fft_matrix(hobbit_host_ctx(), (const hobbit_F *)dM.p, rows, cols, hF(r.data()), hF(q.data()), hF(rr.data()), hF(vr), hF(&fin)));
+    struct proof Pr = proof_from2(k2, q, rr, vr, fin);
+    ps += k2 * 3 * sizeof(F) / 1024.0 + 2 * sizeof(F) / 1024.0; (void)vt;
+    if (previous_sum != (Pr.q_poly[0].eval(0) + Pr.q_poly[0].eval(1))) { printf("Error in fft\n"); exit(-1); }
+    for (int i = 0; i < k1; i++) Pr.randomness[0].push_back(r[i + k2]);
+    return Pr;
+}
+void phiGInit(vector<F> &phi_g, const vector<F>::const_iterator &rx, const F &scale, int n, bool isIFFT) {   // src/utils.cpp:694-755
+    vector<F> r(rx, rx + n);
+    DevBuf g(((size_t)1 << n) * sizeof(F));
+    HCHK(hobbit_phi_g(hobbit_host_ctx(), hF(r.data()), n, hF(&scale), isIFFT ? 1 : 0, (hobbit_F *)g.p));
+    if (phi_g.size() < ((size_t)1 << n)) phi_g.resize((size_t)1 << n);
+    g.to_host(phi_g.data(), ((size_t)1 << n) * sizeof(F));
+}
+vector<vector<F>> transpose(vector<vector<F>> M) {                // src/utils.cpp (host helper)
+    vector<vector<F>> T(M[0].size(), vector<F>(M.size()));
+    for (size_t i = 0; i < M.size(); i++) for (size_t j = 0; j < M[0].size(); j++) T[j][i] = M[i][j];
+    return T;
+}
+vector<F> prepare_matrix(vector<vector<F>> M, vector<F> r) {       // src/utils.cpp:758-775: V[i] = fold of row i
+    size_t n = M.size(), c = M[0].size();
+    vector<F> flat(n * c);                                         // device op folds the ROW index of columns: feed M^T
+    for (size_t i = 0; i < n; i++) for (size_t j = 0; j < c; j++) flat[j * n + i] = M[i][j];
+    DevBuf d(flat.data(), flat.size() * sizeof(F)), o(n * sizeof(F));
+    HCHK(hobbit_prepare_matrix_cols(hobbit_host_ctx(), (const hobbit_F *)d.p, c, n, hF(r.data()), (int)r.size(), (hobbit_F *)o.p));
+    vector<F> V(n); o.to_host(V.data(), n * sizeof(F));
+    return V;
+}
+
+// ---- Elastic_PC streaming commit (src/Elastic_PC.cpp:174-285, 728-771) ------------------------------
+void read_stream_PC(stream_descriptor &fd, F *v, int size) {       // src/witness_stream.cpp:2405-2411 (default branch)
+    if (fd.name == "PC_layer" || fd.name == "witness" || fd.name == "circuit") { printf("Error: stream '%s' belongs to the witness generator (out of scope)\n", fd.name.c_str()); exit(-1); }
+    F n = F(322322);
+    for (int i = 0; i < size; i++) { v[i] = n; n = n * n + F(i); }
+}
+void init_commitment(bool mod) {                                    // src/Elastic_PC.cpp:728-734
+    linear_time = mod;
+    tensor_row_size = (int)(BUFFER_SPACE / (1ULL << 11));
+    if (tensor_row_size == 0) tensor_row_size = 16;
+}
+void commit(stream_descriptor fd, _hash &comm, vector<vector<_hash>> &MT_hashes) {   // src/Elastic_PC.cpp:174-285
+    (void)comm;
+    if (fd.size / BUFFER_SPACE < 4) printf("Decrease buffer size %d\n", (int)(fd.size / BUFFER_SPACE));
+    hobbit_elastic *e = nullptr;
+    HCHK(hobbit_elastic_begin(hobbit_host_ctx(), BUFFER_SPACE, tensor_row_size, linear_time ? 1 : 0, 1, &e));
+    vector<F> buff(BUFFER_SPACE);
+    DevBuf d(BUFFER_SPACE * sizeof(F));
+    for (size_t i = 0; i < fd.size / BUFFER_SPACE; i++) {
+        read_stream_PC(fd, buff.data(), (int)BUFFER_SPACE);
+        HCHK(hobbit_memcpy_h2d(g_ctx, d.p, buff.data(), BUFFER_SPACE * sizeof(F)));
+        HCHK(hobbit_elastic_push(g_ctx, e, (const hobbit_F *)d.p));
+    }
+    size_t T = 4 * BUFFER_SPACE;
+    DevBuf lv(64 * T);
+    HCHK(hobbit_elastic_finish(g_ctx, e, (uint8_t *)lv.p));
+    hobbit_elastic_free(e);
+    size_t levels = (size_t)log2((double)T) + 1, off = 0;
+    MT_hashes.resize(levels);
+    for (size_t l = 0, sz = T; l < levels; l++, sz /= 2) { MT_hashes[l].resize(sz); lv.to_host(MT_hashes[l].data(), 32 * sz, 32 * off); off += sz; }
+}
+void test_Elastic_PC_commit(size_t N, int option) {                 // src/Elastic_PC.cpp:736-771 (commit phase)
+    _hash comm; vector<vector<_hash>> MT_hashes;
+    stream_descriptor commit_data; commit_data.name = "test"; commit_data.size = N;
+    if (option == 1) { linear_time = false; tensor_row_size = (int)(BUFFER_SPACE / (1ULL << 11)); }
+    else { linear_time = true; int K = (int)(N / BUFFER_SPACE); tensor_row_size = (int)(N / (K * 1ULL << 14)); printf("> %d\n", tensor_row_size); expander_init_store(tensor_row_size); }
+    auto start = std::chrono::steady_clock::now();
+    commit(commit_data, comm, MT_hashes);
+    auto end = std::chrono::steady_clock::now();
+    std::cout << "Commit time: " << std::chrono::duration_cast<std::chrono::duration<double>>(end - start).count() << " seconds" << std::endl;
+    printf("root ");
+    for (int i = 0; i < 32; i++) printf("%02x", MT_hashes.back()[0].arr[i]);
+    printf("\n");
+}
+
 // ---- driver (src/Our_PC.cpp:757-826, option 4, commit phase) ---------------------------------------
 void test_PC(size_t N, int option, int K) {
     if (option != 4) { printf("Error: only option 4 (RS x expander Our_PC) is built on the device path\n"); exit(-1); }
@@ -310,6 +431,17 @@ int hobbit_host_sumcheck2(const uint64_t *v1, const uint64_t *v2, size_t n, cons
     memcpy(r, P.randomness[0].data(), 16 * P.randomness[0].size());
     memcpy(vr, P.vr.data(), 32); memcpy(fin, &P.final_rand, 16);
     return (int)P.q_poly.size();
+}
+int hobbit_host_elastic_root(size_t N, size_t B, int option, uint8_t *root_out) {
+    srandom(1);
+    BUFFER_SPACE = B;
+    _hash comm; vector<vector<_hash>> MT;
+    stream_descriptor fd; fd.name = "test"; fd.size = N;
+    if (option == 1) { linear_time = false; tensor_row_size = (int)(B >> 11); }
+    else { linear_time = true; tensor_row_size = (int)(B >> 14); expander_init_store(tensor_row_size); }
+    commit(fd, comm, MT);
+    memcpy(root_out, MT.back()[0].arr, 32);
+    return (int)MT.size();
 }
 void hobbit_host_close(void) { hobbit_host_shutdown(); }
 }

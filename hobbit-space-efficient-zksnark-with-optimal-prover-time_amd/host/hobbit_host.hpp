@@ -120,6 +120,30 @@ void _compute_aggregation_reply(vector<vector<size_t>> &I, vector<vector<F>> &re
 struct proof generate_2product_sumcheck_proof(vector<F> &_v1, vector<F> &_v2, F previous_r, double &vt, double &ps);
 struct proof _generate_3product_sumcheck_proof(vector<F> &v1, vector<F> &v2, vector<F> &v3, F previous_r, double &vt, double &ps);
 
+/* src/sumcheck.h:67,74,78,81 ; src/utils.hpp:24,41 */
+int evaluate_parity_matrix(vector<F> &A, vector<F> &beta1, int Offset, int n, int dep, int &lvl);
+proof prove_linear_code(vector<F> &codeword, int n, double &vt, double &ps);
+struct proof prove_fft(vector<F> &m, vector<F> r, F previous_sum, double &vt, double &ps);
+struct proof prove_fft_matrix(vector<vector<F>> M, vector<F> r, F previous_sum, double &vt, double &ps);
+void phiGInit(vector<F> &phi_g, const vector<F>::const_iterator &rx, const F &scale, int n, bool isIFFT);
+vector<F> prepare_matrix(vector<vector<F>> M, vector<F> r);
+vector<vector<F>> transpose(vector<vector<F>> M);
+
+/* src/witness_stream.h:5-16 (the fields the PCS reads), src/Elastic_PC.hpp:12-16 */
+struct stream_descriptor {
+    int idx = 0, offset = 0, stage = 0;
+    bool finished = false;
+    size_t pos = 0, pos_j = 0;
+    size_t data_size = 0, row_size = 0, col_size = 0, size = 0, layer = 0, tree_pos = 0;
+    std::string name;
+    size_t input_pos = 0, input_pos_j = 0, input_data_size = 0, input_size = 0;
+    std::string input_name;
+};
+void read_stream_PC(stream_descriptor &fd, F *v, int size);      /* synthetic default stream only (src/witness_stream.cpp:2405-2411) */
+void commit(stream_descriptor fd, _hash &comm, vector<vector<_hash>> &MT_hashes);
+void init_commitment(bool mod);
+void test_Elastic_PC_commit(size_t N, int option);              /* commit phase of test_Elastic_PC (src/Elastic_PC.cpp:736-771) */
+
 /* Not in the reference: the 16 GiB `_tensor` of a 2^28 commit stays on the device.
  * commit_standard leaves `_tensor[i]` empty unless HOBBIT_MATERIALIZE_TENSOR=1 (or the tensor is
  * under 256 MiB); the device-resident commitment of the last commit_standard is reachable here

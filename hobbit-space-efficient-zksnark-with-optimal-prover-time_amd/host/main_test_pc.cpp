@@ -3,11 +3,16 @@
 // device-backed host mirror.  Build: see __graft_entry__.build_host().
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include "hobbit_host.hpp"
 int main(int argc, char **argv) {
-    if (argc < 4) { printf("usage: %s <logN> 4 <K>\n", argv[0]); return 1; }
+    if (argc < 4) { printf("usage: %s <logN> 4 <K>   |   %s elastic <logN> <logB> <opt>\n", argv[0], argv[0]); return 1; }
     init_hash();
-    test_PC(1ULL << atoi(argv[1]), atoi(argv[2]), atoi(argv[3]));
+    if (std::string(argv[1]) == "elastic") {          // src/main.cpp:1177-1178: BUFFER_SPACE = 1<<argv[2]; test_Elastic_PC(1<<argv[1], argv[3])
+        BUFFER_SPACE = 1ULL << atoi(argv[3]);
+        test_Elastic_PC_commit(1ULL << atoi(argv[2]), argc > 4 ? atoi(argv[4]) : 1);
+    } else
+        test_PC(1ULL << atoi(argv[1]), atoi(argv[2]), atoi(argv[3]));
     hobbit_host_shutdown();
     return 0;
 }

@@ -165,6 +165,22 @@ void hobbit_blake3_64_host(const uint8_t *h_in, uint8_t *h_out, size_t n);
 /* _aggregate axpy (src/Our_PC.cpp:258-272): d_aggr[j] = sum_i beta[i] * poly[i*M + j], M = N/K */
 int hobbit_aggregate(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_F *h_beta, int K, hobbit_F *d_aggr);
 
+/* Our_PC open WITHOUT the inner shockwave/WHIR PCS: open_standard (src/Our_PC.cpp:604-661) and
+ * recursive_prover_Spielman (src/PC_utils.cpp:271-385) minus shockwave_commit / shockwave_prove.
+ * Draws libc rand()/random() on the host in the reference's order (r_v[0]; 2 x queries; s; r1; s2; a).
+ * All output pointers are host buffers supplied by the caller (cols/rows/reply/paths may be NULL):
+ *   cols, rows : queries x u32;  reply : queries x K F;  paths : queries x log2(M) x 32 B
+ *   qpoly / r  : the five sumcheck transcripts P1..P5 back to back,
+ *                rounds = R1, 12, R1+12, R1+12, 12 with R1 = log2(2 trs)  (3 F per round / 1 F per round)
+ *   vr : 5 x 2 F;  fin : 5 F;  scalars : r_v[0], s, s2, a, y1
+ *   checks[3] : the reference's own consistency checks ("Error recursion 1", "Error recursion 2",
+ *               prove_fft_matrix's claimed sum), 1 = holds */
+typedef struct {
+    uint32_t *cols, *rows; hobbit_F *reply; uint8_t *paths;
+    hobbit_F *qpoly, *r, *vr, *fin, *scalars; int *checks;
+} hobbit_open_out;
+int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const hobbit_F *h_x, int queries, hobbit_open_out *out);
+
 /* ---- sumchecks ----------------------------------------------------------------------------- */
 /* generate_2product_sumcheck_proof (src/sumcheck.cpp:2391-2460).  Inputs preserved.
  * h_qpoly: rounds x 3 F (a,b,c highest degree first); h_r: rounds F; h_vr: 2 F; h_final: 1 F. */

@@ -550,6 +550,104 @@ void orc_prove_fft_matrix(const oF *M, size_t rows, size_t cols, const oF *rr, o
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* Our_PC open, "core" = open_standard (src/Our_PC.cpp:604-661) + recursive_prover_Spielman       */
+/* (src/PC_utils.cpp:271-385) WITHOUT the inner shockwave/WHIR commitments and proofs             */
+/* (shockwave_commit in _aggregate, the two shockwave_prove calls).  The libc draws follow the   */
+/* reference's order up to the first shockwave_prove, so P1..P5 are what the reference computes. */
+/* NOT pinned as a whole against oracle/_ref (the reference's open path ends in SHA3 from the     */
+/* prebuilt libXKCP.a and cannot run); every primitive used here is pinned individually, and the */
+/* reference's own consistency checks ("Error recursion 1/2", prove_fft_matrix's sum check) are   */
+/* evaluated and returned in `checks`.                                                            */
+/* ------------------------------------------------------------------------------------------ */
+static void matvec_rows(const oF *Mx, size_t rows, size_t cols, const oF *v, oF *out) {   /* out[i] = sum_j v[j] M[i][j] */
+    for (size_t i = 0; i < rows; i++) { oF a = fint(0); for (size_t j = 0; j < cols; j++) a = f_add(a, f_mul(v[j], Mx[i * cols + j])); out[i] = a; }
+}
+int orc_open_core(const oF *poly, size_t N, int K, int trs, const oF *x, int queries, uint32_t *I_out, oF *reply_out, const oF *tensor /* K x 2trs x cols, row-major */,
+                  oF *scalars_out /* r_v0, s0, s2, a, y1 */, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks) {
+    size_t M = N / (size_t)K, cols = 2 * M / (size_t)trs, rows2 = 2 * (size_t)trs;
+    int logK = (int)log2((double)K), logc = (int)log2((double)cols), R1 = (int)log2((double)rows2);
+    /* open_standard: beta over the chunk variables, r_v[0] draw, aggregate */
+    oF *beta = (oF *)malloc(sizeof(oF) * (size_t)K);
+    orc_precompute_beta(x, logK, beta);
+    oF rv0; orc_generate_randomness(1, &rv0); scalars_out[0] = rv0;
+    oF *aggr = (oF *)malloc(sizeof(oF) * M);
+    orc_aggregate(poly, N, beta, K, aggr);
+    /* compute_tensorcode(aggr): message half M' (row FFT) and parity half C */
+    oF *T = (oF *)malloc(sizeof(oF) * rows2 * cols);
+    orc_compute_tensorcode(aggr, M, trs, 1, T);
+    const oF *C = T + (size_t)trs * cols;
+    oF *Mp = (oF *)calloc((size_t)trs * cols, sizeof(oF));
+    for (size_t i = 0; i < (size_t)trs; i++) { memcpy(Mp + i * cols, aggr + i * (cols / 2), sizeof(oF) * (cols / 2)); orc_fft(Mp + i * cols, logc, 0); }
+    /* queries (src/Our_PC.cpp:633-641) and replies */
+    size_t *Iv = (size_t *)malloc(sizeof(size_t) * (size_t)queries);
+    for (int q = 0; q < queries; q++) {
+        uint32_t c = (uint32_t)(rand() % (long)cols), rw = (uint32_t)(rand() % (long)rows2);
+        I_out[2 * q] = c; I_out[2 * q + 1] = rw; Iv[q] = c + cols * (size_t)rw;
+        if (tensor && reply_out) for (int i = 0; i < K; i++) reply_out[(size_t)q * K + i] = tensor[((size_t)i * rows2 + rw) * cols + c];
+    }
+    /* recursive_prover_Spielman */
+    oF *sv = (oF *)malloc(sizeof(oF) * cols);
+    sv[0] = fint((uint64_t)random()); scalars_out[1] = sv[0];
+    for (size_t i = 1; i < cols; i++) sv[i] = f_mul(sv[i - 1], sv[0]);
+    oF *aggr_c = (oF *)malloc(sizeof(oF) * rows2);
+    matvec_rows(Mp, trs, cols, sv, aggr_c); matvec_rows(C, trs, cols, sv, aggr_c + trs);
+    oF *r1 = (oF *)malloc(sizeof(oF) * R1);
+    orc_generate_randomness(R1, r1);
+    size_t qo = 0, ro = 0;
+    oF *q1 = qpoly, *rr1 = r_out;
+    orc_prove_linear_code(aggr_c, rows2, trs, r1, q1, rr1, vr, fin);
+    qo += 3 * R1; ro += R1;
+    oF *b1 = (oF *)malloc(sizeof(oF) * rows2);
+    orc_precompute_beta(rr1, R1, b1);
+    oF *evals = (oF *)malloc(sizeof(oF) * cols);
+    for (size_t i = 0; i < cols; i++) {
+        oF a = fint(0);
+        for (size_t j = 0; j < (size_t)trs; j++) a = f_add(a, f_mul(b1[j], Mp[j * cols + i]));
+        for (size_t j = 0; j < (size_t)trs; j++) a = f_add(a, f_mul(b1[j + trs], C[j * cols + i]));
+        evals[i] = a;
+    }
+    oF p17 = fint(021);   /* F(021) in the reference is an OCTAL literal = 17 (src/PC_utils.cpp:322) */
+    oF *q2 = qpoly + qo, *rr2 = r_out + ro;
+    orc_sumcheck2(sv, evals, cols, &p17, q2, rr2, vr + 2, fin + 1);
+    qo += 3 * logc; ro += logc;
+    oF c2 = f_add(f_add(q2[0], q2[1]), f_add(q2[2], q2[2]));            /* q(0)+q(1) = a + b + 2c */
+    checks[0] = (c2.re == vr[1].re && c2.im == vr[1].im);                /* == P1.vr[1] ("Error recursion 1") */
+    size_t big = rows2 * cols;
+    oF *buff1 = (oF *)malloc(sizeof(oF) * big), *buff2 = (oF *)calloc(big, sizeof(oF));
+    memcpy(buff1, Mp, sizeof(oF) * (size_t)trs * cols); memcpy(buff1 + (size_t)trs * cols, C, sizeof(oF) * (size_t)trs * cols);
+    oF s2 = fint((uint64_t)random()); scalars_out[2] = s2;
+    oF pw = s2;
+    for (int q = 0; q < queries; q++) { buff2[Iv[q]] = pw; pw = f_mul(pw, s2); }
+    oF p121 = fint(121);
+    int R3 = R1 + logc;
+    oF *q3 = qpoly + qo, *rr3 = r_out + ro;
+    orc_sumcheck2(buff1, buff2, big, &p121, q3, rr3, vr + 4, fin + 2);
+    qo += 3 * R3; ro += R3;
+    oF a = fint((uint64_t)random()); scalars_out[3] = a;
+    oF *rcat = (oF *)malloc(sizeof(oF) * R3);
+    memcpy(rcat, rr2, sizeof(oF) * logc); memcpy(rcat + logc, rr1, sizeof(oF) * R1);
+    oF *bb = (oF *)malloc(sizeof(oF) * big);
+    orc_precompute_beta(rcat, R3, buff2);            /* buff2 <- beta(r) */
+    orc_precompute_beta(rr3, R3, bb);
+    for (size_t i = 0; i < big; i++) buff2[i] = f_add(buff2[i], f_mul(a, bb[i]));
+    oF p312 = fint(312);
+    oF *q4 = qpoly + qo, *rr4 = r_out + ro;
+    orc_sumcheck2(buff2, buff1, big, &p312, q4, rr4, vr + 6, fin + 3);
+    qo += 3 * R3; ro += R3;
+    oF c4 = f_add(f_add(q4[0], q4[1]), f_add(q4[2], q4[2]));
+    oF want4 = f_add(f_mul(a, vr[4]), vr[3]);                            /* a*P3.vr[0] + P2.vr[1] ("Error recursion 2") */
+    checks[1] = (c4.re == want4.re && c4.im == want4.im);
+    /* y1 = evaluate_vector(M', r), r = P4.randomness minus its last entry; P5 = prove_fft_matrix */
+    oF y1; orc_evaluate_vector(Mp, (size_t)trs * cols, rr4, R3 - 1, &y1); scalars_out[4] = y1;
+    oF *q5 = qpoly + qo, *rr5 = r_out + ro;
+    orc_prove_fft_matrix(aggr, trs, cols / 2, rr4, q5, rr5, vr + 8, fin + 4);
+    oF c5 = f_add(f_add(q5[0], q5[1]), f_add(q5[2], q5[2]));
+    checks[2] = (c5.re == y1.re && c5.im == y1.im);                      /* prove_fft_matrix's own check */
+    free(beta); free(aggr); free(T); free(Mp); free(Iv); free(sv); free(aggr_c); free(r1); free(b1); free(evals); free(buff1); free(buff2); free(rcat); free(bb);
+    return (int)(qo / 3 + logc);
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* Elastic_PC streaming commit: src/Elastic_PC.cpp:174-285; stream src/witness_stream.cpp:2405-11 */
 /* ------------------------------------------------------------------------------------------ */
 void orc_read_stream_pc(size_t B, oF *out) {

@@ -75,6 +75,10 @@ void orc_prove_linear_code(const oF *codeword, size_t size, long long n, const o
 void orc_prove_fft(const oF *m, size_t s, const oF *rr, oF *qpoly, oF *r, oF *vr, oF *fin);
 void orc_prove_fft_matrix(const oF *M, size_t rows, size_t cols, const oF *rr, oF *qpoly, oF *r, oF *vr, oF *fin);
 
+/* Our_PC open without the inner shockwave/WHIR PCS (see hobbit_oracle.c); returns total rounds */
+int orc_open_core(const oF *poly, size_t N, int K, int trs, const oF *x, int queries, uint32_t *I_out, oF *reply_out, const oF *tensor,
+                  oF *scalars_out, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks);
+
 /* Elastic_PC streaming commit on the synthetic "test" stream */
 void orc_read_stream_pc(size_t B, oF *out);
 size_t orc_elastic_commit(size_t N, size_t B, int opt, uint8_t *levels_out);

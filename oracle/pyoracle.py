@@ -292,6 +292,22 @@ class Oracle(_Base):
         self.lib.orc_prove_fft_matrix(_p(m), c_sz(rows), c_sz(cols), _p(rr), _p(q), _p(r), _p(vr), _p(fin))
         return dict(poly=q, r=r, vr=vr, fin=fin)
 
+    def open_core(self, poly, K, trs, x, queries, tensor=None):
+        """open_standard + recursive_prover_Spielman without the inner shockwave/WHIR PCS"""
+        p = F(poly).reshape(-1, 2); x = F(x).reshape(-1, 2)
+        N = p.shape[0]; M = N // K; cols = 2 * M // trs
+        R1 = (2 * trs).bit_length() - 1; logc = cols.bit_length() - 1
+        rounds = R1 + logc + 2 * (R1 + logc) + logc
+        I = np.zeros((queries, 2), np.uint32)
+        reply = np.zeros((queries, K, 2), np.uint64)
+        sc = np.zeros((5, 2), np.uint64); q = np.zeros((rounds, 3, 2), np.uint64); r = np.zeros((rounds, 2), np.uint64)
+        vr = np.zeros((5, 2, 2), np.uint64); fin = np.zeros((5, 2), np.uint64); chk = np.zeros(3, np.int32)
+        t = F(tensor) if tensor is not None else None
+        f = self.lib.orc_open_core; f.restype = ctypes.c_int
+        f(_p(p), c_sz(N), ctypes.c_int(K), ctypes.c_int(trs), _p(x), ctypes.c_int(queries), _p(I), _p(reply) if t is not None else None,
+          _p(t) if t is not None else None, _p(sc), _p(q), _p(r), _p(vr), _p(fin), _p(chk))
+        return dict(I=I, reply=reply, scalars=sc, poly=q, r=r, vr=vr, fin=fin, checks=chk)
+
     def read_stream_pc(self, B):
         o = np.zeros((B, 2), np.uint64)
         self.lib.orc_read_stream_pc(c_sz(B), _p(o))

@@ -457,3 +457,31 @@ def test_phi_g_large_vs_oracle(hb, oracle):
     rx = splitmix_field(16, 77)
     assert np.array_equal(hb.phiGInit(rx), oracle.phi_g_init(rx))
     assert np.array_equal(hb.phiGInit(rx, (5, 9), True), oracle.phi_g_init(rx, (5, 9), True))
+
+
+# ---- Our_PC open without the inner shockwave/WHIR PCS ---------------------------------------------
+@pytest.mark.parametrize("N,K", [(1 << 20, 32), (1 << 22, 32)])
+def test_open_core_vs_oracle(hb, oracle, N, K):
+    """open_standard + recursive_prover_Spielman minus shockwave/WHIR: five sumcheck transcripts, the queries
+    (libc order), replies and Merkle paths, bit-exact against the oracle's restatement; the reference's own
+    consistency checks must hold."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    trs = N // (K << 11)
+    oracle.rng_reset(); poly = oracle.generate_randomness(N); oracle.expander_init_store(trs)
+    x = oracle.generate_randomness(N.bit_length() - 1)
+    lv, T = oracle.commit_standard(poly, K, trs, 1, want_tensor=True)
+    queries = 5900
+    libc.srandom(4242); want = oracle.open_core(poly, K, trs, x, queries, tensor=T)
+    hb.upload_graphs(trs, graphs_from(oracle, trs))
+    c = hb.commit_standard(poly, K, trs, 1)
+    libc.srandom(4242); got = hb.open_core(poly, c, x, queries)
+    assert want["checks"].tolist() == [1, 1, 1] and got["checks"].tolist() == [1, 1, 1]
+    assert np.array_equal(got["I"], want["I"])
+    assert np.array_equal(got["reply"], want["reply"])
+    for k in ("scalars", "poly", "r", "vr", "fin"):
+        assert np.array_equal(got[k], want[k]), k
+    M = N // K
+    for q in (0, 17, queries - 1):
+        assert np.array_equal(got["paths"][q], oracle.open_tree_blake(lv, M, int(got["I"][q, 0]), int(got["I"][q, 1]), 4096))
+    c.free()
