@@ -41,6 +41,20 @@ def commit_op_counts(N, K, edges):
     return mul, add, comp
 
 
+def open_core_op_counts(N, K, edges):
+    """analytic F-mul / F-add of the open core: aggregate N; tensor code of the M-element aggregate; [M'|C].s and
+    beta^T[M'|C] (4M each); eq tables (2 x 4M + small); axpy 4M; 2-product sumchecks 6n mul + 10n add
+    over n = 2trs, 4096, 4M, 4M, 4096; evaluate_vector 2M."""
+    M = N // K
+    trs = N // (K << 11)
+    cols = 2 * M // trs
+    big = 4 * M
+    sc_n = 2 * trs + cols + 2 * big + cols
+    mul = N + trs * fft_butterflies(cols) + cols * edges + 2 * big + 2 * big + big + 6 * sc_n + 2 * M + edges
+    add = N + 2 * trs * fft_butterflies(cols) + cols * edges + 2 * big + 2 * big + big + 10 * sc_n + 2 * M + edges
+    return mul, add
+
+
 def algorithmic_bytes(N, K, world=1, sharded=False):
     """HBM-compulsory bytes per launch of each commit kernel (DESIGN.md 'Kernels'): what the
     algorithm must move given that the tensor is retained, not what the kernel happens to move."""
@@ -70,6 +84,9 @@ def main():
     ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
                     help="N>1: replicas = one independent polynomial per GPU (weak); sharded = ONE commitment, chunks sharded over the GPUs "
                          "with the digest exchange + subtree-root all-gather of parallel.py (strong)")
+    ap.add_argument("--phase", choices=["commit", "commit+open"], default="commit+open",
+                    help="commit+open adds open_standard + recursive_prover_Spielman WITHOUT the inner shockwave/WHIR PCS (DESIGN.md 7)")
+    ap.add_argument("--queries", type=int, default=5900)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-logn", type=int, default=22)
     args = ap.parse_args()
@@ -116,12 +133,20 @@ def main():
         hb.sync()
         last = {}
 
+    do_open = args.phase == "commit+open" and not sharded
+    import numpy as np
+    x_open = np.stack([np.arange(1, args.logn + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15 % ((1 << 61) - 1)) % np.uint64((1 << 61) - 1),
+                       np.arange(7, args.logn + 7, dtype=np.uint64) * np.uint64(1234567891011) % np.uint64((1 << 61) - 1)], axis=1)
+    open_last = {}
+
     def step():
         if sharded:
             last["res"] = mod.parallel.sharded_commit(ops_, dist, plan, rank, (d_local.ptr, len(own)))
             ops_._tensor.free()
             return
         c = hb.commit_standard((d_poly, N), K, trs, 1)
+        if do_open:
+            open_last["res"] = hb.open_core((d_poly, N), c, x_open, args.queries)
         c.free()                          # parks the 16.5 GiB of buffers for the next step
 
     for _ in range(args.warmup):
@@ -153,7 +178,10 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * wall_max / args.steps
-        ops = (mul + add) * (1 if sharded else world)
+        omul, oadd = open_core_op_counts(N, K, edges) if do_open else (0, 0)
+        if do_open:
+            assert open_last["res"]["checks"].tolist() == [1, 1, 1], "open: the reference's consistency checks failed"
+        ops = (mul + add + omul + oadd) * (1 if sharded else world)
         value = ops / (wall_max / args.steps)
         ab = algorithmic_bytes(N, K, world, sharded)
         cand = {k: v for k, v in prof.items() if ab.get(k)}
@@ -161,16 +189,20 @@ def main():
         dom_ms = cand[dom][0] / cand[dom][1]
         achieved = ab[dom] / (dom_ms * 1e-3) / 1e9
         out = {
-            "metric": "Our_PC commit field-ops/s (F_p^2 mul+add), 2^%d-coefficient multilinear" % args.logn,
+            "metric": "Our_PC %s field-ops/s (F_p^2 mul+add), 2^%d-coefficient multilinear" % (args.phase if do_open else "commit", args.logn),
             "value": value, "unit": "field-ops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "u64 (F_{p^2}, p=2^61-1) + u32 (BLAKE3)", "data": "synthetic (device splitmix64 full-range coefficients; libc-drawn expander graphs)",
-            "config": {"workload": "Our_PC commit_standard (test_PC(2^%d,4,%d) commit phase): trs=%d, cols=4096, tensor retained in HBM; open phase not in the timed region" % (args.logn, K, trs),
+            "config": {"workload": ("Our_PC test_PC(2^%d,4,%d): commit_standard + open_standard/recursive_prover_Spielman WITHOUT the inner shockwave/WHIR PCS "
+                                    "(aggregate, tensor code of the aggregate, %d queries + replies + Merkle paths, prove_linear_code, three 2-product sumchecks "
+                                    "(4096, 2^%d, 2^%d), prove_fft_matrix); trs=%d, cols=4096, tensor retained in HBM" % (args.logn, K, args.queries, args.logn - 3, args.logn - 3, trs))
+                       if do_open else
+                       "Our_PC commit_standard (test_PC(2^%d,4,%d) commit phase): trs=%d, cols=4096, tensor retained in HBM; open phase not in the timed region" % (args.logn, K, trs),
                        "N": N, "K": K, "trs": trs, "mode": args.mode, "polynomials_per_gpu": (1.0 / world) if sharded else 1},
             "prover_s": wall_max / args.steps, "hip_event_ms_per_step": ev_ms / args.steps,
             "f_mul_per_s": mul * (1 if sharded else world) / (wall_max / args.steps),
             "blake3_compressions_per_s": comp * (1 if sharded else world) / (wall_max / args.steps),
-            "op_counts": {"f_mul": mul, "f_add": add, "blake3_compress": comp, "expander_edges": edges},
+            "op_counts": {"f_mul": mul, "f_add": add, "blake3_compress": comp, "expander_edges": edges, "open_f_mul": omul, "open_f_add": oadd},
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items())},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": dom_ms,

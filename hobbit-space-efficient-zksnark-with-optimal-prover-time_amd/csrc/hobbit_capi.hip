@@ -75,6 +75,7 @@ static void free_code(DeviceCode &c) {
     if (c.d_steps) hipFree(c.d_steps);
     if (c.d_slice_ptr) hipFree(c.d_slice_ptr);
     if (c.d_slice_width) hipFree(c.d_slice_width);
+    if (c.d_slice_out) hipFree(c.d_slice_out);
     if (c.d_edges32) hipFree(c.d_edges32);
     if (c.d_eidx) hipFree(c.d_eidx);
     if (c.d_ew) hipFree(c.d_ew);
@@ -132,6 +133,7 @@ void hobbit_ctx_destroy(hobbit_ctx *ctx) {
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->ws2) hipFree(ctx->ws2);
     if (ctx->pin) hipHostFree(ctx->pin);
+    if (ctx->ws3) hipFree(ctx->ws3);
     if (ctx->spare_tensor) hipFree(ctx->spare_tensor);
     if (ctx->spare_levels) hipFree(ctx->spare_levels);
     hipEventDestroy(ctx->t0); hipEventDestroy(ctx->t1);
@@ -224,7 +226,7 @@ int hobbit_graph_finalize(hobbit_ctx *ctx, long long n, long long *len_out) {
     for (int d = D - 1; d >= 0; d--) plan.push_back({&ctx->graphs[{d, 1}], off[d + 1], off[d + 1] + cwlen[d + 1]});
     c.small_weights = true;
     for (auto &p : plan) for (auto &w : p.g->w) if (w.im != 0 || w.re >> 32) { c.small_weights = false; break; }
-    std::vector<uint32_t> slice_ptr, slice_width, eidx; std::vector<uint2> e32; std::vector<F> ew;
+    std::vector<uint32_t> slice_ptr, slice_width, slice_out, eidx; std::vector<uint2> e32; std::vector<F> ew;
     size_t pos = 0;
     for (auto &p : plan) {
         const HostGraph &g = *p.g;
@@ -233,17 +235,20 @@ int hobbit_graph_finalize(hobbit_ctx *ctx, long long n, long long *len_out) {
             for (int j = 0; j < g.degree; j++) rows[g.nbr[i * g.degree + j]].push_back({(uint32_t)i, g.w[i * g.degree + j]});
         EncStep s; s.in_off = (uint32_t)p.in_off; s.out_off = (uint32_t)p.out_off; s.out_len = (uint32_t)g.R;
         s.n_slices = (uint32_t)((g.R + ENC_SW - 1) / ENC_SW); s.slice_base = (uint32_t)slice_ptr.size();
+        std::vector<uint32_t> order((size_t)g.R);
+        for (size_t t = 0; t < (size_t)g.R; t++) order[t] = (uint32_t)t;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rows[a].size() > rows[b].size(); });
         for (uint32_t sl = 0; sl < s.n_slices; sl++) {
             size_t width = 0;
-            for (uint32_t l = 0; l < ENC_SW; l++) { size_t t = (size_t)sl * ENC_SW + l; if (t < (size_t)g.R) width = std::max(width, rows[t].size()); }
-            const size_t q = ENC_SPLIT * ENC_UNROLL;
-            width = (width + q - 1) / q * q;
+            for (uint32_t l = 0; l < ENC_SW; l++) { size_t q = (size_t)sl * ENC_SW + l; if (q < (size_t)g.R) width = std::max(width, rows[order[q]].size()); }
+            width = (width + ENC_SPLIT - 1) / ENC_SPLIT * ENC_SPLIT;
             slice_ptr.push_back((uint32_t)pos); slice_width.push_back((uint32_t)width);
+            for (uint32_t l = 0; l < ENC_SW; l++) { size_t q = (size_t)sl * ENC_SW + l; slice_out.push_back(q < (size_t)g.R ? order[q] : 0xFFFFFFFFu); }
             for (size_t k = 0; k < width; k++)
                 for (uint32_t l = 0; l < ENC_SW; l++) {
-                    size_t t = (size_t)sl * ENC_SW + l;
+                    size_t q = (size_t)sl * ENC_SW + l;
                     uint32_t id = 0; F w = fmake(0);
-                    if (t < (size_t)g.R && k < rows[t].size()) { id = rows[t][k].first; w = rows[t][k].second; c.n_edges++; }
+                    if (q < (size_t)g.R && k < rows[order[q]].size()) { id = rows[order[q]][k].first; w = rows[order[q]][k].second; c.n_edges++; }
                     if (c.small_weights) e32.push_back(make_uint2(id, (uint32_t)w.re)); else { eidx.push_back(id); ew.push_back(w); }
                 }
             pos += width * ENC_SW;
@@ -259,6 +264,7 @@ int hobbit_graph_finalize(hobbit_ctx *ctx, long long n, long long *len_out) {
     HB_TRY(up((void **)&c.d_steps, c.steps.data(), c.steps.size() * sizeof(EncStep)));
     HB_TRY(up((void **)&c.d_slice_ptr, slice_ptr.data(), slice_ptr.size() * 4));
     HB_TRY(up((void **)&c.d_slice_width, slice_width.data(), slice_width.size() * 4));
+    HB_TRY(up((void **)&c.d_slice_out, slice_out.data(), slice_out.size() * 4));
     if (c.small_weights) HB_TRY(up((void **)&c.d_edges32, e32.data(), e32.size() * sizeof(uint2)));
     else { HB_TRY(up((void **)&c.d_eidx, eidx.data(), eidx.size() * 4)); HB_TRY(up((void **)&c.d_ew, ew.data(), ew.size() * sizeof(F))); }
     if (len_out) *len_out = c.len;
@@ -643,8 +649,7 @@ int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     // device arena
     F *arena = nullptr;
     const size_t n_el = M + 4 * big + 2 * cols + 4 * rows2 + 64;
-    if (hipMalloc((void **)&arena, n_el * sizeof(F)) != hipSuccess) return ctx->fail(HOBBIT_ENOMEM, "open_core: arena allocation failed");
-    struct Guard { F *p; hipStream_t s; ~Guard() { hipStreamSynchronize(s); hipFree(p); } } guard{arena, ctx->stream};
+    HB_TRY(ctx->workspace3(n_el * sizeof(F), (void **)&arena));
     F *d_aggr = arena, *BIG = d_aggr + M, *Tcm = BIG + big, *d_b = Tcm + big, *d_bb = d_b + big, *d_s = d_bb + big, *d_ev = d_s + cols,
       *d_ac = d_ev + cols, *d_b1 = d_ac + rows2;
     F *Mp = BIG, *C = BIG + (size_t)trs * cols;

@@ -380,8 +380,8 @@ template <bool SMALLW>
 __global__ void __launch_bounds__(1024)
 k_encode(const F *__restrict__ src, size_t ld_src, F *__restrict__ dst, size_t ld_dst, uint32_t len, EncPass ps,
          const EncStep *__restrict__ steps, const uint32_t *__restrict__ slice_ptr,
-         const uint32_t *__restrict__ slice_width, const uint2 *__restrict__ e32, const uint32_t *__restrict__ eidx,
-         const F *__restrict__ ew) {
+         const uint32_t *__restrict__ slice_width, const uint32_t *__restrict__ slice_out, const uint2 *__restrict__ e32,
+         const uint32_t *__restrict__ eidx, const F *__restrict__ ew) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     F *cw = reinterpret_cast<F *>(lds_raw) - ps.base;          // cw[i] addresses codeword index i
     const F *in = src + (size_t)blockIdx.x * ld_src;
@@ -395,28 +395,36 @@ k_encode(const F *__restrict__ src, size_t ld_src, F *__restrict__ dst, size_t l
         const F *cin = cw + sp.in_off;
         for (uint32_t sl = wave; sl < sp.n_slices; sl += nwaves) {
             const uint32_t base = slice_ptr[sp.slice_base + sl] + lane;
-            const uint32_t iters = slice_width[sp.slice_base + sl] / ENC_SPLIT;    // multiple of ENC_UNROLL
+            const uint32_t iters = slice_width[sp.slice_base + sl] / ENC_SPLIT;    // edge records per lane
             F acc;
             if (SMALLW) {
                 Acc96 rl = {0, 0}, rh = {0, 0}, il = {0, 0}, ih = {0, 0};
-                uint2 en[ENC_UNROLL];
+                uint32_t j = 0;
+                if (iters >= ENC_UNROLL) {
+                    uint2 en[ENC_UNROLL];
 #pragma unroll
-                for (int u = 0; u < ENC_UNROLL; u++) en[u] = e32[base + u * 64];
-                for (uint32_t j = 0; j < iters; j += ENC_UNROLL) {
-                    uint2 e[ENC_UNROLL]; uint4 x[ENC_UNROLL];
+                    for (int u = 0; u < ENC_UNROLL; u++) en[u] = e32[base + u * 64];
+                    for (; j + ENC_UNROLL <= iters; j += ENC_UNROLL) {
+                        uint2 e[ENC_UNROLL]; uint4 x[ENC_UNROLL];
 #pragma unroll
-                    for (int u = 0; u < ENC_UNROLL; u++) e[u] = en[u];
-                    if (j + ENC_UNROLL < iters) {          // prefetch the next group of edge records
+                        for (int u = 0; u < ENC_UNROLL; u++) e[u] = en[u];
+                        if (j + 2 * ENC_UNROLL <= iters) {     // prefetch the next full group of edge records
 #pragma unroll
-                        for (int u = 0; u < ENC_UNROLL; u++) en[u] = e32[base + (j + ENC_UNROLL + u) * 64];
+                            for (int u = 0; u < ENC_UNROLL; u++) en[u] = e32[base + (j + ENC_UNROLL + u) * 64];
+                        }
+#pragma unroll
+                        for (int u = 0; u < ENC_UNROLL; u++) x[u] = *reinterpret_cast<const uint4 *>(cin + e[u].x);
+#pragma unroll
+                        for (int u = 0; u < ENC_UNROLL; u++) {
+                            acc96_mad(rl, e[u].y, x[u].x); acc96_mad(rh, e[u].y, x[u].y);
+                            acc96_mad(il, e[u].y, x[u].z); acc96_mad(ih, e[u].y, x[u].w);
+                        }
                     }
-#pragma unroll
-                    for (int u = 0; u < ENC_UNROLL; u++) x[u] = *reinterpret_cast<const uint4 *>(cin + e[u].x);
-#pragma unroll
-                    for (int u = 0; u < ENC_UNROLL; u++) {
-                        acc96_mad(rl, e[u].y, x[u].x); acc96_mad(rh, e[u].y, x[u].y);
-                        acc96_mad(il, e[u].y, x[u].z); acc96_mad(ih, e[u].y, x[u].w);
-                    }
+                }
+                for (; j < iters; j++) {                      // remainder (rows are sorted by in-degree: at most ENC_UNROLL-1 records)
+                    const uint2 e = e32[base + j * 64];
+                    const uint4 x = *reinterpret_cast<const uint4 *>(cin + e.x);
+                    acc96_mad(rl, e.y, x.x); acc96_mad(rh, e.y, x.y); acc96_mad(il, e.y, x.z); acc96_mad(ih, e.y, x.w);
                 }
                 acc = fmake(acc_fold(rl, rh), acc_fold(il, ih));
             } else {
@@ -428,8 +436,8 @@ k_encode(const F *__restrict__ src, size_t ld_src, F *__restrict__ dst, size_t l
             }
 #pragma unroll
             for (int m = ENC_SW; m < 64; m <<= 1) acc = fadd(acc, shfl_xor_F(acc, m));   // combine the lane groups
-            const uint32_t t = sl * ENC_SW + tl;
-            if (lane < ENC_SW && t < sp.out_len) {
+            const uint32_t t = slice_out[(sp.slice_base + sl) * ENC_SW + tl];    // outputs are sliced in order of in-degree
+            if (lane < ENC_SW && t != 0xFFFFFFFFu) {
                 if (ps.direct_out) stF(out + sp.out_off + t, acc); else stF(&cw[sp.out_off + t], acc);
             }
         }
@@ -444,7 +452,7 @@ static int launch_encode_pass(hobbit_ctx *ctx, const char *name, const F *src, s
     DeviceCode &c = ctx->code;
     hipFuncSetAttribute((const void *)k_encode<SMALLW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     HB_LAUNCH(ctx, name, k_encode<SMALLW>, dim3((unsigned)batch), dim3(block), (size_t)lds_elems * 16, src, ld_src, dst, ld_dst, (uint32_t)c.len, ps,
-              c.d_steps, c.d_slice_ptr, c.d_slice_width, c.d_edges32, c.d_eidx, c.d_ew);
+              c.d_steps, c.d_slice_ptr, c.d_slice_width, c.d_slice_out, c.d_edges32, c.d_eidx, c.d_ew);
     return 0;
 }
 static uint32_t block_for(const DeviceCode &c, uint32_t s_lo, uint32_t s_hi, uint32_t max_waves) {
@@ -840,13 +848,22 @@ __global__ void __launch_bounds__(256) k_matvec_rows(const F *__restrict__ Mx, s
     __syncthreads();
     if (threadIdx.x == 0) stF(out + blockIdx.x, fadd(fadd(red[0], red[1]), fadd(red[2], red[3])));
 }
-// out[i] = sum_j v[j] * M[j][i]   (one lane per column, coalesced across i; evals = beta^T [M' | C])
-__global__ void __launch_bounds__(256) k_vecmat(const F *__restrict__ Mx, size_t rows, size_t cols, const F *__restrict__ v, F *__restrict__ out) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cols; i += (size_t)gridDim.x * blockDim.x) {
-        F acc = fmake(0);
-        for (size_t j = 0; j < rows; j++) acc = fadd(acc, fmul(ldF(v + j), ldF(Mx + j * cols + i)));
-        stF(out + i, acc);
-    }
+// out[i] = sum_j v[j] * M[j][i]   (evals = beta^T [M' | C]): lanes run along i (coalesced), the row range is
+// split over blockIdx.y into partial sums that a second launch adds up
+__global__ void __launch_bounds__(256) k_vecmat(const F *__restrict__ Mx, size_t rows, size_t cols, const F *__restrict__ v, F *__restrict__ part) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= cols) return;
+    const size_t per = (rows + gridDim.y - 1) / gridDim.y, j0 = blockIdx.y * per, j1 = j0 + per < rows ? j0 + per : rows;
+    F acc = fmake(0);
+    for (size_t j = j0; j < j1; j++) acc = fadd(acc, fmul(ldF(v + j), ldF(Mx + j * cols + i)));
+    stF(part + (size_t)blockIdx.y * cols + i, acc);
+}
+__global__ void __launch_bounds__(256) k_colsum(const F *__restrict__ part, size_t nparts, size_t cols, F *__restrict__ out) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= cols) return;
+    F acc = fmake(0);
+    for (size_t p = 0; p < nparts; p++) acc = fadd(acc, ldF(part + p * cols + i));
+    stF(out + i, acc);
 }
 __global__ void k_scatter(const uint64_t *__restrict__ idx, const F *__restrict__ val, size_t n, F *__restrict__ out) {
     size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -862,7 +879,12 @@ int launch_matvec_rows(hobbit_ctx *ctx, const F *Mx, size_t rows, size_t cols, c
     return 0;
 }
 int launch_vecmat(hobbit_ctx *ctx, const F *Mx, size_t rows, size_t cols, const F *v, F *out) {
-    HB_LAUNCH(ctx, "k_vecmat", k_vecmat, dim3(grid_for(cols, 256)), dim3(256), 0, Mx, rows, cols, v, out);
+    // enough row slices to fill the chip: (cols/256) x nparts workgroups
+    size_t nparts = 1;
+    while (nparts < 256 && nparts * 2 <= rows && ((cols + 255) / 256) * nparts < 2048) nparts *= 2;
+    F *part; HB_TRY(ctx->workspace(nparts * cols * sizeof(F), (void **)&part));
+    HB_LAUNCH(ctx, "k_vecmat", k_vecmat, dim3((unsigned)((cols + 255) / 256), (unsigned)nparts), dim3(256), 0, Mx, rows, cols, v, part);
+    HB_LAUNCH(ctx, "k_colsum", k_colsum, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, part, nparts, cols, out);
     return 0;
 }
 int launch_scatter(hobbit_ctx *ctx, const uint64_t *idx, const F *val, size_t n, F *out) {
