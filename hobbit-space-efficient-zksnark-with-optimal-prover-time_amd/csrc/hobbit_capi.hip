@@ -3,6 +3,7 @@
 // form), twiddle tables, and the launch sequences of tensor code / commit / open building blocks.
 #include <algorithm>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include "hobbit_kernels.hpp"
@@ -134,6 +135,7 @@ void hobbit_ctx_destroy(hobbit_ctx *ctx) {
     if (ctx->ws2) hipFree(ctx->ws2);
     if (ctx->pin) hipHostFree(ctx->pin);
     if (ctx->ws3) hipFree(ctx->ws3);
+    if (ctx->pinc) hipHostFree(ctx->pinc);
     if (ctx->spare_tensor) hipFree(ctx->spare_tensor);
     if (ctx->spare_levels) hipFree(ctx->spare_levels);
     hipEventDestroy(ctx->t0); hipEventDestroy(ctx->t1);
@@ -625,18 +627,28 @@ int hobbit_prove_fft_matrix(hobbit_ctx *ctx, const hobbit_F *d_M, size_t rows, s
 // ---- open building blocks ---------------------------------------------------------------------
 int hobbit_aggregate(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_F *h_beta, int K, hobbit_F *d_aggr) {
     if (K <= 0 || N % (size_t)K) return ctx->fail(HOBBIT_EINVAL, "aggregate: K must divide N");
-    F *d_beta; HB_TRY(ctx->workspace((size_t)K * sizeof(F), (void **)&d_beta));
-    HB_CHECK(ctx, hipMemcpyAsync(d_beta, h_beta, (size_t)K * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
-    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    return launch_aggregate(ctx, cF(d_poly), N / K, K, d_beta, mF(d_aggr));
+    return launch_aggregate(ctx, cF(d_poly), N / K, K, cF(h_beta), mF(d_aggr));
 }
 
 // ---- Our_PC open without the inner shockwave/WHIR PCS -------------------------------------------
 // open_standard (src/Our_PC.cpp:604-661) + recursive_prover_Spielman (src/PC_utils.cpp:271-385) minus
 // shockwave_commit / shockwave_prove.  Host: libc draws in the reference's order, the transcript,
 // challenge powers; device: everything that touches a table.
+struct OpenTrace {
+    bool on; hobbit_ctx *ctx; std::chrono::steady_clock::time_point t0; const char *last;
+    OpenTrace(hobbit_ctx *c) : on(getenv("HOBBIT_TRACE") != nullptr), ctx(c), t0(std::chrono::steady_clock::now()), last("start") {}
+    void mark(const char *name) {
+        if (!on) return;
+        hipStreamSynchronize(ctx->stream);
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[hobbit open] %-28s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const hobbit_F *h_x, int queries, hobbit_open_out *o) {
     if (!c || !o || queries <= 0) return ctx->fail(HOBBIT_EINVAL, "open_core: bad arguments");
+    OpenTrace tr(ctx);
+    tr.mark("entry (stream drain)");
     if (!c->lin) return ctx->fail(HOBBIT_EINVAL, "open_core: only the RS x expander (linear_time) code is built");
     const int K = c->K, trs = c->trs;
     const size_t M = c->M, cols = c->cols, rows2 = c->rows2, big = rows2 * cols;
@@ -648,18 +660,24 @@ int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     { F rv0 = fmake((uint64_t)random()); rv0 = fadd(rv0, fmake((uint64_t)rand())); memcpy(&o->scalars[0], &rv0, sizeof(F)); }   // generate_randomness(1)
     // device arena
     F *arena = nullptr;
-    const size_t n_el = M + 4 * big + 2 * cols + 4 * rows2 + 64;
+    const size_t n_el = M + 4 * big + 2 * cols + 4 * rows2 + 2 * (size_t)queries + 128;
     HB_TRY(ctx->workspace3(n_el * sizeof(F), (void **)&arena));
     F *d_aggr = arena, *BIG = d_aggr + M, *Tcm = BIG + big, *d_b = Tcm + big, *d_bb = d_b + big, *d_s = d_bb + big, *d_ev = d_s + cols,
       *d_ac = d_ev + cols, *d_b1 = d_ac + rows2;
     F *Mp = BIG, *C = BIG + (size_t)trs * cols;
+    tr.mark("beta + arena");
     HB_TRY(hobbit_aggregate(ctx, d_poly, N, reinterpret_cast<const hobbit_F *>(beta.data()), K, reinterpret_cast<hobbit_F *>(d_aggr)));   // _aggregate axpy (:258-272)
     // compute_tensorcode(aggr) (:277): M' = row FFTs (row-major), codeword-major copy, expander encode, parity half back to row-major C
+    tr.mark("beta, arena, aggregate");
     HB_TRY(fft_rows(ctx, d_aggr, cols / 2, (uint32_t)(cols / 2), Mp, cols, 1, logc, false, 1, (uint32_t)trs, 0, 0));
+    tr.mark("row FFTs");
     HB_TRY(launch_transpose(ctx, Mp, 0, (uint32_t)trs, (uint32_t)cols, Tcm, 0, rows2, 1));
+    tr.mark("transpose");
     if (ctx->code.n != trs) { long long l; HB_TRY(hobbit_graph_finalize(ctx, trs, &l)); }
     HB_TRY(launch_encode(ctx, Tcm, rows2, Tcm, rows2, trs, cols, 0));
+    tr.mark("encode");
     HB_TRY(launch_transpose_ld(ctx, Tcm + trs, 0, rows2, (uint32_t)cols, (uint32_t)trs, C, 0, cols, 1));
+    tr.mark("aggregate+tensorcode");
     // queries (:633-641), replies (:291-305) and Merkle paths (:645-647)
     std::vector<uint32_t> qc(queries), qr(queries); std::vector<uint64_t> Iv(queries);
     for (int q = 0; q < queries; q++) { qc[q] = (uint32_t)(rand() % (long)cols); qr[q] = (uint32_t)(rand() % (long)rows2); Iv[q] = qc[q] + cols * (uint64_t)qr[q]; }
@@ -667,6 +685,7 @@ int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     if (o->rows) memcpy(o->rows, qr.data(), 4 * (size_t)queries);
     if (o->reply) HB_TRY(hobbit_commitment_gather(ctx, c, qr.data(), qc.data(), (size_t)queries, o->reply));
     if (o->paths) HB_TRY(hobbit_commitment_paths(ctx, c, qc.data(), qr.data(), (size_t)queries, o->paths));
+    tr.mark("queries+gather+paths");
     // recursive_prover_Spielman: s powers (:293-297), aggr_c = [M' | C] . s (:298-309)
     std::vector<F> sv(cols);
     sv[0] = fmake((uint64_t)random()); o->scalars[1] = *reinterpret_cast<hobbit_F *>(&sv[0]);
@@ -680,6 +699,7 @@ int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     HB_TRY(hobbit_prove_linear_code(ctx, reinterpret_cast<hobbit_F *>(d_ac), rows2, trs, reinterpret_cast<hobbit_F *>(r1.data()), Q, Rr, o->vr, o->fin));
     const hobbit_F *r_p1 = Rr; const hobbit_F *q_p1 = Q; (void)q_p1;
     Q += 3 * R1; Rr += R1;
+    tr.mark("s, aggr_c, P1");
     // evals = beta(P1.r)^T [M' | C] (:311-320); P2 = sumcheck(s, evals, F(021) -- octal) (:322)
     HB_TRY(hobbit_eq_table(ctx, r_p1, R1, reinterpret_cast<hobbit_F *>(d_b1)));
     HB_TRY(launch_vecmat(ctx, BIG, rows2, cols, d_b1, d_ev));
@@ -688,6 +708,7 @@ int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     const hobbit_F *r_p2 = Rr; const F *q2 = cF(Q);
     { F c2 = fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])); o->checks[0] = feq(c2, cF(o->vr)[1]); }       // "Error recursion 1" (:323-326)
     Q += 3 * logc; Rr += logc;
+    tr.mark("evals, P2");
     // buff2: s2 powers at the queried positions, last write wins (:331-336); P3 (:339)
     const F s2 = fmake((uint64_t)random()); o->scalars[2] = *reinterpret_cast<const hobbit_F *>(&s2);
     {
@@ -696,18 +717,21 @@ int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
         std::vector<uint64_t> idx; std::vector<F> val;
         for (auto &kv : last) { idx.push_back(kv.first); val.push_back(kv.second); }
         HB_CHECK(ctx, hipMemsetAsync(d_b, 0, big * sizeof(F), ctx->stream));
-        F *tmpv = nullptr; uint64_t *tmpi = nullptr;
-        if (hipMalloc((void **)&tmpv, val.size() * sizeof(F) + 16) != hipSuccess || hipMalloc((void **)&tmpi, idx.size() * 8 + 16) != hipSuccess) return ctx->fail(HOBBIT_ENOMEM, "open_core: alloc");
-        HB_CHECK(ctx, hipMemcpyAsync(tmpv, val.data(), val.size() * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
-        HB_CHECK(ctx, hipMemcpyAsync(tmpi, idx.data(), idx.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        // staged through the pinned buffer into the arena tail (no hipMalloc / hipFree on the hot path)
+        F *tmpv = d_b1 + rows2; uint64_t *tmpi = reinterpret_cast<uint64_t *>(tmpv + queries + 1);
+        uint8_t *pin; HB_TRY(ctx->pinned((size_t)queries * (sizeof(F) + 8) + 64, (void **)&pin));   // sized by the query count, not by the distinct positions
+        memcpy(pin, val.data(), val.size() * sizeof(F)); memcpy(pin + val.size() * sizeof(F), idx.data(), idx.size() * 8);
+        HB_CHECK(ctx, hipMemcpyAsync(tmpv, pin, val.size() * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+        HB_CHECK(ctx, hipMemcpyAsync(tmpi, pin + val.size() * sizeof(F), idx.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         int rc = launch_scatter(ctx, tmpi, tmpv, idx.size(), d_b);
-        hipStreamSynchronize(ctx->stream); hipFree(tmpv); hipFree(tmpi);
+        hipStreamSynchronize(ctx->stream);                     // the pinned buffer is reused by the sumcheck that follows
         if (rc) return rc;
     }
     hobbit_F p121 = {121, 0};
     HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(BIG), reinterpret_cast<hobbit_F *>(d_b), big, &p121, Q, Rr, o->vr + 4, o->fin + 2));
     const hobbit_F *r_p3 = Rr;
     Q += 3 * R3; Rr += R3;
+    tr.mark("buff2, P3");
     // a, beta(P2.r | P1.r) + a * beta(P3.r) (:342-349); P4 against [M' | C] (:362); "Error recursion 2" (:364-367)
     const F a = fmake((uint64_t)random()); o->scalars[3] = *reinterpret_cast<const hobbit_F *>(&a);
     std::vector<hobbit_F> rcat(R3);
@@ -720,12 +744,14 @@ int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     const hobbit_F *r_p4 = Rr; const F *q4 = cF(Q);
     { F c4 = fadd(fadd(q4[0], q4[1]), fadd(q4[2], q4[2])); F want = fadd(fmul(a, cF(o->vr)[4]), cF(o->vr)[3]); o->checks[1] = feq(c4, want); }
     Q += 3 * R3; Rr += R3;
+    tr.mark("betas, P4");
     // y1 = evaluate_vector(M', P4.r minus its last entry) (:372-373); P5 = prove_fft_matrix(initial tensor, r, y1) (:383)
     F y1;
     HB_TRY(hobbit_eval_vector(ctx, reinterpret_cast<hobbit_F *>(Mp), (size_t)trs * cols, r_p4, reinterpret_cast<hobbit_F *>(&y1)));
     o->scalars[4] = *reinterpret_cast<hobbit_F *>(&y1);
     HB_TRY(hobbit_prove_fft_matrix(ctx, reinterpret_cast<hobbit_F *>(d_aggr), (size_t)trs, cols / 2, r_p4, Q, Rr, o->vr + 8, o->fin + 4));
-    { const F *q5 = cF(Q); F c5 = fadd(fadd(q5[0], q5[1]), fadd(q5[2], q5[2])); o->checks[2] = feq(c5, y1); }   // src/sumcheck.cpp:3016-3019
+    { const F *q5 = cF(Q); F c5 = fadd(fadd(q5[0], q5[1]), fadd(q5[2], q5[2])); o->checks[2] = feq(c5, y1); }
+    tr.mark("y1, P5");   // src/sumcheck.cpp:3016-3019
     return 0;
 }
 

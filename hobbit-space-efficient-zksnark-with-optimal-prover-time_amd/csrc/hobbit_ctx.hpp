@@ -92,6 +92,18 @@ struct hobbit_ctx {
         }
         *p = pin; return 0;
     }
+    // pinned, device-visible buffer for small per-launch constant tables (read in place by kernels)
+    void *pinc = nullptr; size_t pinc_bytes = 0;
+    int pinned_const(size_t bytes, void **p) {
+        if (bytes > pinc_bytes) {
+            hipStreamSynchronize(stream);
+            if (pinc) hipHostFree(pinc);
+            size_t want = bytes < 65536 ? 65536 : bytes;
+            if (hipHostMalloc(&pinc, want) != hipSuccess) { pinc = nullptr; pinc_bytes = 0; err = "hipHostMalloc failed"; return HOBBIT_ENOMEM; }
+            pinc_bytes = want;
+        }
+        *p = pinc; return 0;
+    }
     // arena of the open phase (tables that live across several sumchecks), kept between calls
     void *ws3 = nullptr; size_t ws3_bytes = 0;
     int workspace3(size_t bytes, void **p) {

@@ -741,15 +741,19 @@ int launch_eq_table(hobbit_ctx *ctx, const F *h_r, int k, F *d_out) {
     return 0;
 }
 // aggr[j] = sum_i beta[i] * poly[i*M + j]   (src/Our_PC.cpp:258-272)
-__global__ void k_aggregate(const F *__restrict__ poly, size_t M, int K, const F *__restrict__ beta, F *__restrict__ aggr) {
+__global__ void k_aggregate_dev(const F *__restrict__ poly, size_t M, int K, const F *__restrict__ beta, F *__restrict__ aggr) {
     for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < M; j += (size_t)gridDim.x * blockDim.x) {
         F acc = fmake(0);
         for (int i = 0; i < K; i++) acc = fadd(acc, fmul(ldF(beta + i), ldF(poly + (size_t)i * M + j)));
         stF(aggr + j, acc);
     }
 }
-int launch_aggregate(hobbit_ctx *ctx, const F *poly, size_t M, int K, const F *d_beta, F *aggr) {
-    HB_LAUNCH(ctx, "k_aggregate", k_aggregate, dim3(grid_for(M, 256)), dim3(256), 0, poly, M, K, d_beta, aggr);
+int launch_aggregate(hobbit_ctx *ctx, const F *poly, size_t M, int K, const F *h_beta, F *aggr) {
+    // the coefficients are read by the kernel straight from a small pinned (device-visible) host buffer:
+    // no H2D copy, no synchronisation in front of the launch
+    F *pc; HB_TRY(ctx->pinned_const((size_t)K * sizeof(F), (void **)&pc));
+    for (int i = 0; i < K; i++) pc[i] = h_beta[i];
+    HB_LAUNCH(ctx, "k_aggregate", k_aggregate_dev, dim3(grid_for(M, 256)), dim3(256), 0, poly, M, K, pc, aggr);
     return 0;
 }
 // reply[q*K + i] = tensor[i][col_q][row_q]   (src/Our_PC.cpp:291-305, codeword-major tensor)

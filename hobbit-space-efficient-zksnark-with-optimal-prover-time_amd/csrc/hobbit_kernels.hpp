@@ -23,7 +23,7 @@ int launch_inner_digests(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, 
 int launch_chain_digests(hobbit_ctx *ctx, const uint8_t *digests, size_t stride_bytes, int K, size_t m, uint8_t *leaves);
 int launch_merkle_paths(hobbit_ctx *ctx, const uint8_t *levels, size_t n, const uint64_t *d_pos, size_t nq, int depth, uint8_t *d_paths);
 int launch_eq_table(hobbit_ctx *ctx, const F *h_r, int k, F *d_out);
-int launch_aggregate(hobbit_ctx *ctx, const F *poly, size_t M, int K, const F *d_beta, F *aggr);
+int launch_aggregate(hobbit_ctx *ctx, const F *poly, size_t M, int K, const F *h_beta, F *aggr);
 int launch_gather(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, uint32_t rows2, int K, const uint32_t *d_rows, const uint32_t *d_cols,
                   size_t nq, F *d_reply);
 int launch_tensor_row(hobbit_ctx *ctx, const F *chunk, uint32_t rows2, uint32_t cols, uint32_t row, F *d_out);
