@@ -41,7 +41,8 @@ ABI_SYMBOLS = [
     "hobbit_tensorcode_chunks", "hobbit_inner_digests", "hobbit_chain_digests", "hobbit_blake3_64_host",
     "hobbit_parity_matrix", "hobbit_phi_g", "hobbit_prepare_matrix_cols", "hobbit_prove_linear_code", "hobbit_prove_fft",
     "hobbit_prove_fft_matrix",
-    "hobbit_open_core",
+    "hobbit_open_core", "hobbit_compute2p_error_terms", "hobbit_compute3p_error_terms", "hobbit_compute4p_error_terms", "hobbit_fold_axpy",
+    "hobbit_fold_axpy_i32", "hobbit_batch_prod",
     "hobbit_aggregate", "hobbit_sumcheck2", "hobbit_sumcheck3", "hobbit_fill_splitmix",
 ]
 
@@ -83,6 +84,9 @@ def load_library(path=LIB_PATH):
         "hobbit_prove_linear_code": [V, V, S, L, V, V, V, V, V], "hobbit_prove_fft": [V, V, S, V, V, V, V, V],
         "hobbit_prove_fft_matrix": [V, V, S, S, V, V, V, V, V],
         "hobbit_open_core": [V, V, S, V, V, I, V],
+        "hobbit_compute2p_error_terms": [V, V, V, V, V, S, V], "hobbit_compute3p_error_terms": [V, V, V, V, V, V, V, S, V],
+        "hobbit_compute4p_error_terms": [V, V, V, V, V, V, V, V, V, S, V], "hobbit_fold_axpy": [V, V, V, V, S],
+        "hobbit_fold_axpy_i32": [V, V, V, V, I, S], "hobbit_batch_prod": [V, V, V, V, V, V, V, I, S, V, V, V, V, V, V],
         "hobbit_elastic_begin": [V, S, I, I, I, V], "hobbit_elastic_push": [V, V, V], "hobbit_elastic_finish": [V, V, V],
         "hobbit_elastic_free": [V],
         "hobbit_tensorcode_chunks": [V, V, S, I, I, I, V], "hobbit_inner_digests": [V, V, S, I, I, V],
@@ -494,6 +498,38 @@ class Hobbit:
         d = self.to_device(m)
         self._chk(self.lib.hobbit_prove_fft_matrix(self.ctx, d.ptr, rows, cols, _hp(rr), _hp(q), _hp(r), _hp(vr), _hp(fin)))
         return dict(poly=q, r=r, vr=vr, fin=fin)
+
+    # ---- streaming-sumcheck error terms / folds (reference names: src/sumcheck.cpp:374-432, 1093-1136)
+    def err2p(self, b1, b2, f1, f2):
+        d = [self.to_device(Fh(x).reshape(-1, 2)) for x in (b1, b2, f1, f2)]
+        K = np.zeros((2, 2), np.uint64)
+        self._chk(self.lib.hobbit_compute2p_error_terms(self.ctx, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, len(Fh(b1).reshape(-1, 2)), _hp(K)))
+        return K
+
+    def err3p(self, b1, gate, f1, f2, f3, beta):
+        g = self.to_device(np.ascontiguousarray(gate, np.int32))
+        d = [self.to_device(Fh(x).reshape(-1, 2)) for x in (b1, f1, f2, f3, beta)]
+        K = np.zeros((3, 2), np.uint64)
+        self._chk(self.lib.hobbit_compute3p_error_terms(self.ctx, d[0].ptr, g.ptr, d[1].ptr, d[2].ptr, d[3].ptr, d[4].ptr, len(gate), _hp(K)))
+        return K
+
+    def err4p(self, b1, b2, b3, gate, f1, f2, f3, f4):
+        g = self.to_device(np.ascontiguousarray(gate, np.int32))
+        d = [self.to_device(Fh(x).reshape(-1, 2)) for x in (b1, b2, b3, f1, f2, f3, f4)]
+        K = np.zeros((4, 2), np.uint64)
+        self._chk(self.lib.hobbit_compute4p_error_terms(self.ctx, d[0].ptr, d[1].ptr, d[2].ptr, g.ptr, d[3].ptr, d[4].ptr, d[5].ptr, d[6].ptr, len(gate), _hp(K)))
+        return K
+
+    def batch_prod(self, f1, f2, f3, b1, b2, b3, r_last, a, rem_beta, Kf, Kp):
+        f = [Fh(x) for x in (f1, f2, f3)]; b = [Fh(x) for x in (b1, b2, b3)]
+        batches, n = f[0].shape[0], f[0].shape[1]
+        df = [self.to_device(x) for x in f]; db = [self.to_device(x) for x in b]
+        rl = Fh(r_last).reshape(2); av = Fh(a).reshape(-1, 2); rb = Fh(rem_beta).reshape(-1, 2)
+        kf = Fh(Kf).reshape(2).copy(); kp = Fh(Kp).reshape(-1, 2).copy(); ro = np.zeros(2, np.uint64)
+        self._chk(self.lib.hobbit_batch_prod(self.ctx, df[0].ptr, df[1].ptr, df[2].ptr, db[0].ptr, db[1].ptr, db[2].ptr, batches, n, _hp(rl), _hp(av), _hp(rb),
+                                             _hp(kf), _hp(kp), _hp(ro)))
+        return dict(rand=ro, Kf=kf, Kp=kp, f1=self.to_host(df[0], f[0].shape, np.uint64), f2=self.to_host(df[1], f[0].shape, np.uint64),
+                    f3=self.to_host(df[2], f[0].shape, np.uint64))
 
     # ---- Elastic_PC streaming commit (src/Elastic_PC.cpp:174-285) on the synthetic "test" stream
     def read_stream_PC(self, B):

@@ -630,6 +630,56 @@ int hobbit_aggregate(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     return launch_aggregate(ctx, cF(d_poly), N / K, K, cF(h_beta), mF(d_aggr));
 }
 
+// ---- streaming-sumcheck error terms and folds (src/sumcheck.cpp:374-432, 862-869, 1093-1136) ------
+static inline void acc_K(hobbit_F *io, const F *k, int nc) { for (int q = 0; q < nc; q++) mF(io)[q] = fadd(cF(io)[q], k[q]); }
+int hobbit_compute2p_error_terms(hobbit_ctx *ctx, const hobbit_F *d_b1, const hobbit_F *d_b2, const hobbit_F *d_f1, const hobbit_F *d_f2, size_t n, hobbit_F *h_K) {
+    const F *t[8] = {cF(d_b1), cF(d_b2), cF(d_f1), cF(d_f2), nullptr, nullptr, nullptr, nullptr}; F k[4];
+    HB_TRY(launch_err_terms(ctx, 2, t, nullptr, n, k)); acc_K(h_K, k, 2); return 0;
+}
+int hobbit_compute3p_error_terms(hobbit_ctx *ctx, const hobbit_F *d_b1, const int32_t *d_gate, const hobbit_F *d_f1, const hobbit_F *d_f2, const hobbit_F *d_f3,
+                                 const hobbit_F *d_beta, size_t n, hobbit_F *h_K) {
+    const F *t[8] = {cF(d_b1), cF(d_f1), cF(d_f2), cF(d_f3), cF(d_beta), nullptr, nullptr, nullptr}; F k[4];
+    HB_TRY(launch_err_terms(ctx, 3, t, d_gate, n, k)); acc_K(h_K, k, 3); return 0;
+}
+int hobbit_compute4p_error_terms(hobbit_ctx *ctx, const hobbit_F *d_b1, const hobbit_F *d_b2, const hobbit_F *d_b3, const int32_t *d_gate, const hobbit_F *d_f1,
+                                 const hobbit_F *d_f2, const hobbit_F *d_f3, const hobbit_F *d_f4, size_t n, hobbit_F *h_K) {
+    const F *t[8] = {cF(d_b1), cF(d_b2), cF(d_b3), cF(d_f1), cF(d_f2), cF(d_f3), cF(d_f4), nullptr}; F k[4];
+    HB_TRY(launch_err_terms(ctx, 4, t, d_gate, n, k)); acc_K(h_K, k, 4); return 0;
+}
+int hobbit_fold_axpy(hobbit_ctx *ctx, hobbit_F *d_fold, const hobbit_F *d_buff, const hobbit_F *h_rand, size_t n) {
+    if (!n) return 0;
+    return launch_axpy(ctx, mF(d_fold), cF(d_buff), *cF(h_rand), n);
+}
+int hobbit_fold_axpy_i32(hobbit_ctx *ctx, hobbit_F *d_fold, const int32_t *d_sel, const hobbit_F *h_rand, int one_minus, size_t n) {
+    return launch_axpy_i32(ctx, mF(d_fold), d_sel, *cF(h_rand), one_minus, n);
+}
+int hobbit_batch_prod(hobbit_ctx *ctx, hobbit_F *d_f1, hobbit_F *d_f2, hobbit_F *d_f3, const hobbit_F *d_b1, const hobbit_F *d_b2, const hobbit_F *d_b3, int batches,
+                      size_t n, const hobbit_F *h_r_last, const hobbit_F *h_a, const hobbit_F *h_rem_beta, hobbit_F *h_Kf, hobbit_F *h_Kp, hobbit_F *h_rand) {
+    if (batches <= 0) return ctx->fail(HOBBIT_EINVAL, "batch_prod: batches must be positive");
+    F K1 = fmake(0), K2 = fmake(0);
+    std::vector<F> K3((size_t)batches);
+    for (int j = 0; j < batches; j++) {
+        const size_t o = (size_t)j * n;
+        const F *t[8] = {cF(d_b1) + o, cF(d_b2) + o, cF(d_b3) + o, cF(d_f1) + o, cF(d_f2) + o, cF(d_f3) + o, nullptr, nullptr}; F k[4];
+        HB_TRY(launch_err_terms(ctx, 13, t, nullptr, n, k));
+        K1 = fadd(K1, fmul(cF(h_a)[j], k[0])); K2 = fadd(K2, fmul(cF(h_a)[j], k[1])); K3[j] = k[2];
+    }
+    F rnd = mimc_hash(K1, *cF(h_r_last));                  // mimc_hash(K, rand): argument order as in the reference (:1112-1116)
+    rnd = mimc_hash(K2, rnd);
+    for (int j = 0; j < batches; j++) rnd = mimc_hash(K3[j], rnd);
+    const F x1 = rnd, x2 = fmul(rnd, x1), x3 = fmul(rnd, x2);
+    F Kf = *cF(h_Kf);
+    for (int j = 0; j < batches; j++) {
+        mF(h_Kp)[j] = fadd(cF(h_Kp)[j], fmul(cF(h_rem_beta)[j], K3[j]));
+        Kf = fadd(Kf, fmul(fmul(x3, cF(h_a)[j]), K3[j]));
+    }
+    Kf = fadd(Kf, fadd(fmul(x2, K2), fmul(x1, K1)));
+    *mF(h_Kf) = Kf; *mF(h_rand) = rnd;
+    const size_t tot = (size_t)batches * n;
+    HB_TRY(launch_axpy(ctx, mF(d_f1), cF(d_b1), rnd, tot)); HB_TRY(launch_axpy(ctx, mF(d_f2), cF(d_b2), rnd, tot));
+    return launch_axpy(ctx, mF(d_f3), cF(d_b3), rnd, tot);
+}
+
 // ---- Our_PC open without the inner shockwave/WHIR PCS -------------------------------------------
 // open_standard (src/Our_PC.cpp:604-661) + recursive_prover_Spielman (src/PC_utils.cpp:271-385) minus
 // shockwave_commit / shockwave_prove.  Host: libc draws in the reference's order, the transcript,

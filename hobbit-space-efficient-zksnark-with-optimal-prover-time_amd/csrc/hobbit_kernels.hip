@@ -987,6 +987,87 @@ static void sc2_host_tail(std::vector<F> &a, std::vector<F> &b, F &rnd, bool pen
     }
 }
 
+// ---- streaming-sumcheck error terms (src/sumcheck.cpp:374-432, 1093-1136): fused multi-output dot products --
+// KIND 2: compute2p (b1,b2,f1,f2) -> K1,K2;  KIND 3: compute3p (b1,gate,f1,f2,f3,beta) -> K1..K3;
+// KIND 4: compute4p (b1,b2,b3,gate,f1..f4) -> K1..K4;  KIND 13: one batch of batch_prod (b1,b2,b3,f1,f2,f3) -> K1,K2,K3
+struct ErrArgs { const F *t[8]; const int32_t *gate; };
+template <int KIND, int NC>
+__global__ void __launch_bounds__(256) k_err_terms(ErrArgs a, size_t n, F *__restrict__ partials) {
+    F K[NC];
+#pragma unroll
+    for (int q = 0; q < NC; q++) K[q] = fmake(0);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (KIND == 2) {
+            const F b1 = ldF(a.t[0] + i), b2 = ldF(a.t[1] + i), f1 = ldF(a.t[2] + i), f2 = ldF(a.t[3] + i);
+            K[0] = fadd(K[0], fadd(fmul(b1, f2), fmul(b2, f1)));
+            K[1] = fadd(K[1], fmul(b1, b2));
+        } else if (KIND == 3) {
+            const F b1 = ldF(a.t[0] + i), f1 = ldF(a.t[1] + i), f2 = ldF(a.t[2] + i), f3 = ldF(a.t[3] + i), be = ldF(a.t[4] + i);
+            const F gate = fmake((uint64_t)(int64_t)a.gate[i]);
+            const F t1 = fadd(fmul(b1, f2), fmul(gate, f1)), t2 = fmul(b1, gate);
+            K[0] = fadd(K[0], fadd(fmul(f3, t1), fmul(fmul(be, f1), f2)));
+            K[1] = fadd(K[1], fadd(fmul(be, t1), fmul(f3, t2)));
+            K[2] = fadd(K[2], fmul(t2, be));
+        } else if (KIND == 4) {
+            const F b1 = ldF(a.t[0] + i), b2 = ldF(a.t[1] + i), b3 = ldF(a.t[2] + i), f1 = ldF(a.t[3] + i), f2 = ldF(a.t[4] + i), f3 = ldF(a.t[5] + i),
+                    f4 = ldF(a.t[6] + i);
+            const F gate = fsub(fmake(1), fmake((uint64_t)(int64_t)a.gate[i]));
+            const F t1 = fadd(fmul(f1, b2), fmul(f2, b1)), t2 = fadd(fmul(f3, gate), fmul(f4, b3));
+            const F t3 = fmul(b1, b2), t4 = fmul(gate, b3), t5 = fmul(f1, f2), t6 = fmul(f3, f4);
+            K[0] = fadd(K[0], fadd(fmul(t1, t6), fmul(t2, t5)));
+            K[1] = fadd(K[1], fadd(fadd(fmul(t1, t2), fmul(t3, t6)), fmul(t4, t5)));
+            K[2] = fadd(K[2], fadd(fmul(t1, t4), fmul(t2, t3)));
+            K[3] = fadd(K[3], fmul(t3, t4));
+        } else {
+            const F b1 = ldF(a.t[0] + i), b2 = ldF(a.t[1] + i), b3 = ldF(a.t[2] + i), f1 = ldF(a.t[3] + i), f2 = ldF(a.t[4] + i), f3 = ldF(a.t[5] + i);
+            const F t1 = fadd(fmul(b1, f2), fmul(b2, f1)), t2 = fmul(b1, b2);
+            K[0] = fadd(K[0], fadd(fmul(f3, t1), fmul(fmul(b3, f1), f2)));
+            K[1] = fadd(K[1], fadd(fmul(b3, t1), fmul(f3, t2)));
+            K[2] = fadd(K[2], fmul(t2, b3));
+        }
+    }
+    block_reduce_store<NC>(K, partials);
+}
+// runs one error-term reduction; h_K receives the NC sums (not accumulated)
+template <int KIND, int NC>
+static int run_err(hobbit_ctx *ctx, const char *name, const ErrArgs &a, size_t n, F *h_K) {
+    const int MAXB = 1024;
+    F *ws; HB_TRY(ctx->workspace(((size_t)MAXB * NC + NC + 4) * sizeof(F), (void **)&ws));
+    F *part = ws, *coef = ws + (size_t)MAXB * NC;
+    F *pin; HB_TRY(ctx->pinned(NC * sizeof(F), (void **)&pin));
+    int nb = grid_for(n, 256, MAXB);
+    HB_LAUNCH(ctx, name, (k_err_terms<KIND, NC>), dim3(nb), dim3(256), 0, a, n, part);
+    HB_LAUNCH(ctx, "k_sc_reduce", k_sc_reduce<NC>, dim3(1), dim3(256), 0, part, nb, coef);
+    HB_CHECK(ctx, hipMemcpyAsync(pin, coef, NC * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int q = 0; q < NC; q++) h_K[q] = pin[q];
+    return 0;
+}
+int launch_err_terms(hobbit_ctx *ctx, int kind, const F *const *tables, const int32_t *gate, size_t n, F *h_K) {
+    ErrArgs a; for (int i = 0; i < 8; i++) a.t[i] = tables[i]; a.gate = gate;
+    if (!n) { int nc = kind == 2 ? 2 : kind == 4 ? 4 : 3; for (int q = 0; q < nc; q++) h_K[q] = fmake(0); return 0; }
+    switch (kind) {
+        case 2: return run_err<2, 2>(ctx, "k_err2p", a, n, h_K);
+        case 3: return run_err<3, 3>(ctx, "k_err3p", a, n, h_K);
+        case 4: return run_err<4, 4>(ctx, "k_err4p", a, n, h_K);
+        case 13: return run_err<13, 3>(ctx, "k_batch_prod_terms", a, n, h_K);
+    }
+    return ctx->fail(HOBBIT_EINVAL, "err_terms: unknown kind");
+}
+// fold[j] += rand * (F)sel[j]  or  rand * (1 - sel[j])   (src/sumcheck.cpp:863,867: gate selector folds)
+__global__ void k_axpy_i32(F *__restrict__ y, const int32_t *__restrict__ sel, F a, int one_minus, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        F v = fmake((uint64_t)(int64_t)sel[i]);
+        if (one_minus) v = fsub(fmake(1), v);
+        stF(y + i, fadd(ldF(y + i), fmul(a, v)));
+    }
+}
+int launch_axpy_i32(hobbit_ctx *ctx, F *y, const int32_t *sel, F a, int one_minus, size_t n) {
+    if (!n) return 0;
+    HB_LAUNCH(ctx, "k_axpy_i32", k_axpy_i32, dim3(grid_for(n, 256)), dim3(256), 0, y, sel, a, one_minus, n);
+    return 0;
+}
+
 int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev_r, F *h_qpoly, F *h_r, F *h_vr, F *h_final) {
     int rounds = 0; while (((size_t)1 << rounds) < n) rounds++;
     if (((size_t)1 << rounds) != n || n < 2) return ctx->fail(HOBBIT_EINVAL, "sumcheck2: n must be a power of two >= 2");

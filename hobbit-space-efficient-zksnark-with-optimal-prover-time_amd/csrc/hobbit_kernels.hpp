@@ -37,6 +37,8 @@ int launch_matvec_rows(hobbit_ctx *ctx, const F *Mx, size_t rows, size_t cols, c
 int launch_vecmat(hobbit_ctx *ctx, const F *Mx, size_t rows, size_t cols, const F *v, F *out);
 int launch_scatter(hobbit_ctx *ctx, const uint64_t *idx, const F *val, size_t n, F *out);
 int launch_axpy(hobbit_ctx *ctx, F *y, const F *x, F a, size_t n);
+int launch_err_terms(hobbit_ctx *ctx, int kind, const F *const *tables, const int32_t *gate, size_t n, F *h_K);
+int launch_axpy_i32(hobbit_ctx *ctx, F *y, const int32_t *sel, F a, int one_minus, size_t n);
 int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev_r, F *h_qpoly, F *h_r, F *h_vr, F *h_final);
 int launch_sumcheck3(hobbit_ctx *ctx, const F *v1, const F *v2, const F *v3, size_t n, F prev_r, F *h_cpoly, F *h_r, F *h_vr, F *h_final);
 }  // namespace hobbit

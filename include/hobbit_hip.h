@@ -212,6 +212,22 @@ int hobbit_prove_fft(hobbit_ctx *ctx, const hobbit_F *d_m, size_t s, const hobbi
 int hobbit_prove_fft_matrix(hobbit_ctx *ctx, const hobbit_F *d_M, size_t rows, size_t cols, const hobbit_F *h_r, hobbit_F *h_qpoly, hobbit_F *h_rr,
                             hobbit_F *h_vr, hobbit_F *h_final);
 
+/* ---- streaming (space-efficient) sumcheck building blocks: per-chunk error terms and folds ---- */
+/* compute{2,3,4}p_error_terms (src/sumcheck.cpp:374-432, has_lookups == false): h_K is ACCUMULATED into, as the
+ * reference's F& parameters are.  d_gate: int32 gate selectors (vector<int> buff_S). */
+int hobbit_compute2p_error_terms(hobbit_ctx *ctx, const hobbit_F *d_b1, const hobbit_F *d_b2, const hobbit_F *d_f1, const hobbit_F *d_f2, size_t n, hobbit_F *h_K);
+int hobbit_compute3p_error_terms(hobbit_ctx *ctx, const hobbit_F *d_b1, const int32_t *d_gate, const hobbit_F *d_f1, const hobbit_F *d_f2, const hobbit_F *d_f3,
+                                 const hobbit_F *d_beta, size_t n, hobbit_F *h_K);
+int hobbit_compute4p_error_terms(hobbit_ctx *ctx, const hobbit_F *d_b1, const hobbit_F *d_b2, const hobbit_F *d_b3, const int32_t *d_gate, const hobbit_F *d_f1,
+                                 const hobbit_F *d_f2, const hobbit_F *d_f3, const hobbit_F *d_f4, size_t n, hobbit_F *h_K);
+/* fold += rand * chunk (src/sumcheck.cpp:862-869, 1130-1135); the i32 form folds a gate selector (or 1 - selector) */
+int hobbit_fold_axpy(hobbit_ctx *ctx, hobbit_F *d_fold, const hobbit_F *d_buff, const hobbit_F *h_rand, size_t n);
+int hobbit_fold_axpy_i32(hobbit_ctx *ctx, hobbit_F *d_fold, const int32_t *d_sel, const hobbit_F *h_rand, int one_minus, size_t n);
+/* batch_prod (src/sumcheck.cpp:1093-1136), one stream step over `batches` table triples of n elements (flat [batches][n]):
+ * error terms on the device, transcript (mimc) on the host, the three fold tables updated in place */
+int hobbit_batch_prod(hobbit_ctx *ctx, hobbit_F *d_f1, hobbit_F *d_f2, hobbit_F *d_f3, const hobbit_F *d_b1, const hobbit_F *d_b2, const hobbit_F *d_b3, int batches,
+                      size_t n, const hobbit_F *h_r_last, const hobbit_F *h_a, const hobbit_F *h_rem_beta, hobbit_F *h_Kf, hobbit_F *h_Kp, hobbit_F *h_rand);
+
 /* ---- synthetic inputs on the device (bench / tests) ---------------------------------------- */
 /* splitmix64-derived full-range elements: element i = (sm(seed,2i+1) mod p, sm(seed,2i+2) mod p) */
 int hobbit_fill_splitmix(hobbit_ctx *ctx, hobbit_F *d_out, size_t n, uint64_t seed);

@@ -550,6 +550,76 @@ void orc_prove_fft_matrix(const oF *M, size_t rows, size_t cols, const oF *rr, o
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* streaming-sumcheck error terms and folds (the per-chunk work of HOBBIT's space-efficient      */
+/* sumchecks): src/sumcheck.cpp:374-432 (compute{2,3,4}p_error_terms, has_lookups == false),      */
+/* 1093-1136 (batch_prod), 862-869 (fold += rand * chunk)                                         */
+/* ------------------------------------------------------------------------------------------ */
+void orc_err2p(const oF *b1, const oF *b2, const oF *f1, const oF *f2, size_t n, oF *K) {
+    for (size_t i = 0; i < n; i++) {
+        K[0] = f_add(K[0], f_add(f_mul(b1[i], f2[i]), f_mul(b2[i], f1[i])));
+        K[1] = f_add(K[1], f_mul(b1[i], b2[i]));
+    }
+}
+void orc_err3p(const oF *b1, const int32_t *b2, const oF *f1, const oF *f2, const oF *f3, const oF *beta, size_t n, oF *K) {
+    for (size_t j = 0; j < n; j++) {
+        oF gate = fint((uint64_t)(int64_t)b2[j]);                 /* F(buff2[j]), selectors are 0/1 */
+        oF t1 = f_add(f_mul(b1[j], f2[j]), f_mul(gate, f1[j]));
+        oF t2 = f_mul(b1[j], gate);
+        K[0] = f_add(K[0], f_add(f_mul(f3[j], t1), f_mul(f_mul(beta[j], f1[j]), f2[j])));
+        K[1] = f_add(K[1], f_add(f_mul(beta[j], t1), f_mul(f3[j], t2)));
+        K[2] = f_add(K[2], f_mul(t2, beta[j]));
+    }
+}
+void orc_err4p(const oF *b1, const oF *b2, const oF *b3, const int32_t *b4, const oF *f1, const oF *f2, const oF *f3, const oF *f4, size_t n, oF *K) {
+    for (size_t i = 0; i < n; i++) {
+        oF gate = f_sub(fint(1), fint((uint64_t)(int64_t)b4[i]));
+        oF t1 = f_add(f_mul(f1[i], b2[i]), f_mul(f2[i], b1[i]));
+        oF t2 = f_add(f_mul(f3[i], gate), f_mul(f4[i], b3[i]));
+        oF t3 = f_mul(b1[i], b2[i]), t4 = f_mul(gate, b3[i]), t5 = f_mul(f1[i], f2[i]), t6 = f_mul(f3[i], f4[i]);
+        K[0] = f_add(K[0], f_add(f_mul(t1, t6), f_mul(t2, t5)));
+        K[1] = f_add(K[1], f_add(f_add(f_mul(t1, t2), f_mul(t3, t6)), f_mul(t4, t5)));
+        K[2] = f_add(K[2], f_add(f_mul(t1, t4), f_mul(t2, t3)));
+        K[3] = f_add(K[3], f_mul(t3, t4));
+    }
+}
+/* one batch of batch_prod's error terms: K[0..2] += (K1_temp, K2_temp, K3[j]) */
+void orc_batch_prod_terms(const oF *b1, const oF *b2, const oF *b3, const oF *f1, const oF *f2, const oF *f3, size_t n, oF *K) {
+    for (size_t k = 0; k < n; k++) {
+        oF t1 = f_add(f_mul(b1[k], f2[k]), f_mul(b2[k], f1[k])), t2 = f_mul(b1[k], b2[k]);
+        K[0] = f_add(K[0], f_add(f_mul(f3[k], t1), f_mul(f_mul(b3[k], f1[k]), f2[k])));
+        K[1] = f_add(K[1], f_add(f_mul(b3[k], t1), f_mul(f3[k], t2)));
+        K[2] = f_add(K[2], f_mul(t2, b3[k]));
+    }
+}
+void orc_fold_axpy(oF *fold, const oF *buff, const oF *rnd, size_t n) { for (size_t i = 0; i < n; i++) fold[i] = f_add(fold[i], f_mul(*rnd, buff[i])); }
+
+/* batch_prod (src/sumcheck.cpp:1093-1136), one step: tables flat [batches][n]; r_last = R.back(); remaining_betas[j][i] given per
+ * batch; Kf / K_partial accumulated; the three fold tables updated in place; returns the new challenge */
+void orc_batch_prod(oF *f1, oF *f2, oF *f3, const oF *b1, const oF *b2, const oF *b3, int batches, size_t n, const oF *r_last, const oF *a,
+                    const oF *rem_beta, oF *Kf, oF *Kp, oF *rand_out) {
+    oF K1 = fint(0), K2 = fint(0);
+    oF *K3 = (oF *)calloc((size_t)batches, sizeof(oF));
+    for (int j = 0; j < batches; j++) {
+        oF K[3] = {fint(0), fint(0), fint(0)};
+        orc_batch_prod_terms(b1 + (size_t)j * n, b2 + (size_t)j * n, b3 + (size_t)j * n, f1 + (size_t)j * n, f2 + (size_t)j * n, f3 + (size_t)j * n, n, K);
+        K1 = f_add(K1, f_mul(a[j], K[0])); K2 = f_add(K2, f_mul(a[j], K[1])); K3[j] = K[2];
+    }
+    oF rnd = mimc_hash(K1, *r_last);                       /* note the argument order: mimc_hash(K, rand) */
+    rnd = mimc_hash(K2, rnd);
+    for (int j = 0; j < batches; j++) rnd = mimc_hash(K3[j], rnd);
+    oF x1 = rnd, x2 = f_mul(rnd, x1), x3 = f_mul(rnd, x2);
+    for (int j = 0; j < batches; j++) {
+        Kp[j] = f_add(Kp[j], f_mul(rem_beta[j], K3[j]));
+        *Kf = f_add(*Kf, f_mul(f_mul(x3, a[j]), K3[j]));
+    }
+    *Kf = f_add(*Kf, f_add(f_mul(x2, K2), f_mul(x1, K1)));
+    *rand_out = rnd;
+    size_t tot = (size_t)batches * n;
+    orc_fold_axpy(f1, b1, &rnd, tot); orc_fold_axpy(f2, b2, &rnd, tot); orc_fold_axpy(f3, b3, &rnd, tot);
+    free(K3);
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* Our_PC open, "core" = open_standard (src/Our_PC.cpp:604-661) + recursive_prover_Spielman       */
 /* (src/PC_utils.cpp:271-385) WITHOUT the inner shockwave/WHIR commitments and proofs             */
 /* (shockwave_commit in _aggregate, the two shockwave_prove calls).  The libc draws follow the   */

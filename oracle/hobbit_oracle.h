@@ -75,6 +75,15 @@ void orc_prove_linear_code(const oF *codeword, size_t size, long long n, const o
 void orc_prove_fft(const oF *m, size_t s, const oF *rr, oF *qpoly, oF *r, oF *vr, oF *fin);
 void orc_prove_fft_matrix(const oF *M, size_t rows, size_t cols, const oF *rr, oF *qpoly, oF *r, oF *vr, oF *fin);
 
+/* streaming-sumcheck error terms / folds (K arrays are accumulated into, as in the reference) */
+void orc_err2p(const oF *b1, const oF *b2, const oF *f1, const oF *f2, size_t n, oF *K);
+void orc_err3p(const oF *b1, const int32_t *b2, const oF *f1, const oF *f2, const oF *f3, const oF *beta, size_t n, oF *K);
+void orc_err4p(const oF *b1, const oF *b2, const oF *b3, const int32_t *b4, const oF *f1, const oF *f2, const oF *f3, const oF *f4, size_t n, oF *K);
+void orc_batch_prod_terms(const oF *b1, const oF *b2, const oF *b3, const oF *f1, const oF *f2, const oF *f3, size_t n, oF *K);
+void orc_fold_axpy(oF *fold, const oF *buff, const oF *rnd, size_t n);
+void orc_batch_prod(oF *f1, oF *f2, oF *f3, const oF *b1, const oF *b2, const oF *b3, int batches, size_t n, const oF *r_last, const oF *a,
+                    const oF *rem_beta, oF *Kf, oF *Kp, oF *rand_out);
+
 /* Our_PC open without the inner shockwave/WHIR PCS (see hobbit_oracle.c); returns total rounds */
 int orc_open_core(const oF *poly, size_t N, int K, int trs, const oF *x, int queries, uint32_t *I_out, oF *reply_out, const oF *tensor,
                   oF *scalars_out, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks);

@@ -224,6 +224,37 @@ class _Base:
         a, b, c = [tuple(int(x) for x in q0[i]) for i in range(3)]
         return np.array([(a[0] + b[0] + 2 * c[0]) % P, (a[1] + b[1] + 2 * c[1]) % P], np.uint64)
 
+    # ---- streaming-sumcheck error terms / folds
+    def err2p(self, b1, b2, f1, f2):
+        a = [F(x).reshape(-1, 2) for x in (b1, b2, f1, f2)]
+        K = np.zeros((2, 2), np.uint64)
+        self.fn("err2p")(*[_p(x) for x in a], c_sz(a[0].shape[0]), _p(K))
+        return K
+
+    def err3p(self, b1, gate, f1, f2, f3, beta):
+        g = np.ascontiguousarray(gate, np.int32)
+        a = [F(x).reshape(-1, 2) for x in (b1, f1, f2, f3, beta)]
+        K = np.zeros((3, 2), np.uint64)
+        self.fn("err3p")(_p(a[0]), _p(g), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), c_sz(a[0].shape[0]), _p(K))
+        return K
+
+    def err4p(self, b1, b2, b3, gate, f1, f2, f3, f4):
+        g = np.ascontiguousarray(gate, np.int32)
+        a = [F(x).reshape(-1, 2) for x in (b1, b2, b3, f1, f2, f3, f4)]
+        K = np.zeros((4, 2), np.uint64)
+        self.fn("err4p")(_p(a[0]), _p(a[1]), _p(a[2]), _p(g), _p(a[3]), _p(a[4]), _p(a[5]), _p(a[6]), c_sz(a[0].shape[0]), _p(K))
+        return K
+
+    def batch_prod(self, f1, f2, f3, b1, b2, b3, r_last, a, rem_beta, Kf, Kp):
+        """one batch_prod step; tables (batches, n, 2); returns dict(rand, Kf, Kp, f1, f2, f3)"""
+        f = [F(x).copy() for x in (f1, f2, f3)]; b = [F(x) for x in (b1, b2, b3)]
+        batches, n = f[0].shape[0], f[0].shape[1]
+        rl = F(r_last).reshape(2); av = F(a).reshape(-1, 2); rb = F(rem_beta).reshape(-1, 2)
+        kf = F(Kf).reshape(2).copy(); kp = F(Kp).reshape(-1, 2).copy(); ro = np.zeros(2, np.uint64)
+        self.fn("batch_prod")(_p(f[0]), _p(f[1]), _p(f[2]), _p(b[0]), _p(b[1]), _p(b[2]), ctypes.c_int(batches), c_sz(n), _p(rl), _p(av), _p(rb),
+                              _p(kf), _p(kp), _p(ro))
+        return dict(rand=ro, Kf=kf, Kp=kp, f1=f[0], f2=f[1], f3=f[2])
+
     def elastic_commit(self, N, B, opt):
         o = np.zeros((8 * B, 32), np.uint8)
         f = self.fn("elastic_commit"); f.restype = c_sz

@@ -33,6 +33,16 @@ void _aggregate(vector<F> &poly, vector<F> beta1, vector<F> random_points, vecto
 void _compute_aggregation_reply(vector<vector<size_t>> &I, vector<vector<F>> &reply,
                                 vector<vector<vector<F>>> &_tensor, int K);        // src/Our_PC.cpp:291
 
+void compute2p_error_terms(vector<F> &buff1, vector<F> &buff2, vector<F> &fold_buff1, vector<F> &fold_buff2, F &K1, F &K2);                 // src/sumcheck.cpp:374
+void compute4p_error_terms(vector<F> &buff1, vector<F> &buff2, vector<F> &buff3, vector<int> &buff4, vector<F> &fold_buff1, vector<F> &fold_buff2,
+                           vector<F> &fold_buff3, vector<F> &fold_buff4, F &K1, F &K2, F &K3, F &K4);                                       // :381
+void compute3p_error_terms(vector<F> &buff1, vector<int> &buff2, vector<F> &fold_buff1, vector<F> &fold_buff2, vector<F> &fold_buff3,
+                           vector<F> &beta, F &K1, F &K2, F &K3);                                                                            // :408
+void batch_prod(vector<vector<F>> &fold_buff1, vector<vector<F>> &fold_buff2, vector<vector<F>> &fold_buff3, vector<vector<F>> &buff1,
+                vector<vector<F>> &buff2, vector<vector<F>> &buff3, int batches, vector<F> &R, F &Kf, vector<F> &K_partial,
+                vector<vector<F>> &remaining_betas, vector<F> a, int i, double &vt, double &ps);                                            // :1093
+struct proof batch_3product_sumcheck(vector<vector<F>> &arr1, vector<vector<F>> &arr2, vector<vector<F>> &arr3, vector<F> a, double &vt, double &ps);   // :275
+
 static_assert(sizeof(F) == 16, "fieldElement must be 16 bytes");
 static_assert(sizeof(_hash) == 32, "_hash must be 32 bytes");
 
@@ -253,6 +263,43 @@ void ref_prove_fft_matrix(const uint64_t *M, size_t rows, size_t cols, const uin
     int k = (int)log2((double)(2 * cols)) + (int)log2((double)rows); double vt = 0, ps = 0;
     proof P = prove_fft_matrix(m, vecF(rr, k), ldF(prev_sum), vt, ps);
     dump_proof2(P, qpoly, r, vr, fin);
+}
+
+// ---- streaming-sumcheck error terms (src/sumcheck.cpp:374-432, has_lookups == false) and batch_prod (:1093-1136)
+void ref_err2p(const uint64_t *b1, const uint64_t *b2, const uint64_t *f1, const uint64_t *f2, size_t n, uint64_t *K) {
+    vector<F> B1 = vecF(b1, n), B2 = vecF(b2, n), F1 = vecF(f1, n), F2 = vecF(f2, n);
+    F K1 = ldF(K), K2 = ldF(K + 2);
+    compute2p_error_terms(B1, B2, F1, F2, K1, K2);
+    stF(K, K1); stF(K + 2, K2);
+}
+void ref_err3p(const uint64_t *b1, const int32_t *b2, const uint64_t *f1, const uint64_t *f2, const uint64_t *f3, const uint64_t *beta, size_t n, uint64_t *K) {
+    vector<F> B1 = vecF(b1, n), F1 = vecF(f1, n), F2 = vecF(f2, n), F3 = vecF(f3, n), Bt = vecF(beta, n);
+    vector<int> B2(b2, b2 + n);
+    F K1 = ldF(K), K2 = ldF(K + 2), K3 = ldF(K + 4);
+    compute3p_error_terms(B1, B2, F1, F2, F3, Bt, K1, K2, K3);
+    stF(K, K1); stF(K + 2, K2); stF(K + 4, K3);
+}
+void ref_err4p(const uint64_t *b1, const uint64_t *b2, const uint64_t *b3, const int32_t *b4, const uint64_t *f1, const uint64_t *f2, const uint64_t *f3,
+               const uint64_t *f4, size_t n, uint64_t *K) {
+    vector<F> B1 = vecF(b1, n), B2 = vecF(b2, n), B3 = vecF(b3, n), F1 = vecF(f1, n), F2 = vecF(f2, n), F3 = vecF(f3, n), F4 = vecF(f4, n);
+    vector<int> B4(b4, b4 + n);
+    F K1 = ldF(K), K2 = ldF(K + 2), K3 = ldF(K + 4), K4 = ldF(K + 6);
+    compute4p_error_terms(B1, B2, B3, B4, F1, F2, F3, F4, K1, K2, K3, K4);
+    stF(K, K1); stF(K + 2, K2); stF(K + 4, K3); stF(K + 6, K4);
+}
+// one batch_prod step with `batches` table triples of n elements each (flat [batches][n]); R has one entry on input.
+// outputs: new challenge, Kf, K_partial[batches], folded tables in place.
+void ref_batch_prod(uint64_t *f1, uint64_t *f2, uint64_t *f3, const uint64_t *b1, const uint64_t *b2, const uint64_t *b3, int batches, size_t n,
+                    const uint64_t *r_last, const uint64_t *a, const uint64_t *rem_beta, uint64_t *Kf_io, uint64_t *Kp_io, uint64_t *rand_out) {
+    auto split = [&](const uint64_t *p) { vector<vector<F>> v(batches); for (int j = 0; j < batches; j++) v[j] = vecF(p + 2 * (size_t)j * n, n); return v; };
+    vector<vector<F>> F1 = split(f1), F2 = split(f2), F3 = split(f3), B1 = split(b1), B2 = split(b2), B3 = split(b3);
+    vector<F> R = {ldF(r_last)}, Kp = vecF(Kp_io, batches), A = vecF(a, batches);
+    vector<vector<F>> rb(batches); for (int j = 0; j < batches; j++) rb[j] = {ldF(rem_beta + 2 * j)};
+    F Kf = ldF(Kf_io); double vt = 0, ps = 0;
+    batch_prod(F1, F2, F3, B1, B2, B3, batches, R, Kf, Kp, rb, A, 0, vt, ps);
+    stF(Kf_io, Kf); stF(rand_out, R.back());
+    memcpy(Kp_io, Kp.data(), 16 * (size_t)batches);
+    for (int j = 0; j < batches; j++) { memcpy(f1 + 2 * (size_t)j * n, F1[j].data(), 16 * n); memcpy(f2 + 2 * (size_t)j * n, F2[j].data(), 16 * n); memcpy(f3 + 2 * (size_t)j * n, F3[j].data(), 16 * n); }
 }
 
 // ---- Elastic_PC streaming commit (src/Elastic_PC.cpp:174-285) on the synthetic "test" stream ----

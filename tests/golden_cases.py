@@ -300,5 +300,20 @@ def case_codeproofs_matrix(lib, claim=None):
     return {"pfm_%s" % kk: v for kk, v in res.items()}
 
 
+def case_streamfold(lib):
+    """compute{2,3,4}p_error_terms (src/sumcheck.cpp:374-432) and one batch_prod step (:1093-1136)"""
+    n = 4096
+    t = [splitmix_field(n, 400 + i) for i in range(8)]
+    gate = (np.arange(n) * 7 % 5 < 2).astype(np.int32)               # 0/1 gate selectors
+    out = dict(e2=lib.err2p(t[0], t[1], t[2], t[3]), e3=lib.err3p(t[0], gate, t[1], t[2], t[3], t[4]),
+               e4=lib.err4p(t[0], t[1], t[2], gate, t[3], t[4], t[5], t[6]))
+    batches, m = 3, 1024
+    tb = [splitmix_field(batches * m, 420 + i).reshape(batches, m, 2) for i in range(6)]
+    res = lib.batch_prod(tb[0], tb[1], tb[2], tb[3], tb[4], tb[5], np.array([1, 0], np.uint64), splitmix_field(batches, 430), splitmix_field(batches, 431),
+                         splitmix_field(1, 432)[0], splitmix_field(batches, 433))
+    out.update(bp_rand=res["rand"], bp_Kf=res["Kf"], bp_Kp=res["Kp"], bp_f1=dg(res["f1"]), bp_f2=dg(res["f2"]), bp_f3=dg(res["f3"]))
+    return out
+
+
 CASES = dict(field=case_field, mimc=case_mimc, blake=case_blake, merkle=case_merkle, graph_encode=case_graph_encode,
-             fft=case_fft, tensorcode=case_tensorcode, commit=case_commit, sumcheck=case_sumcheck, elastic=case_elastic, codeproofs=case_codeproofs)
+             fft=case_fft, tensorcode=case_tensorcode, commit=case_commit, sumcheck=case_sumcheck, elastic=case_elastic, codeproofs=case_codeproofs, streamfold=case_streamfold)

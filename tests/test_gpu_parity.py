@@ -485,3 +485,21 @@ def test_open_core_vs_oracle(hb, oracle, N, K):
     for q in (0, 17, queries - 1):
         assert np.array_equal(got["paths"][q], oracle.open_tree_blake(lv, M, int(got["I"][q, 0]), int(got["I"][q, 1]), 4096))
     c.free()
+
+
+# ---- streaming-sumcheck error terms and folds ----------------------------------------------------
+def test_streamfold_vs_golden(hb):
+    g = gold("streamfold")
+    got = golden_cases.case_streamfold(hb)
+    assert set(got) == set(g.files)
+    for k in g.files:
+        assert np.array_equal(got[k], g[k]), k
+
+
+def test_streamfold_large_vs_oracle(hb, oracle):
+    n = 1 << 18                                     # B = 2^18, the MLP config's chunk size
+    t = [splitmix_field(n, 600 + i) for i in range(8)]
+    gate = (np.arange(n) % 3 == 0).astype(np.int32)
+    assert np.array_equal(hb.err2p(t[0], t[1], t[2], t[3]), oracle.err2p(t[0], t[1], t[2], t[3]))
+    assert np.array_equal(hb.err3p(t[0], gate, t[1], t[2], t[3], t[4]), oracle.err3p(t[0], gate, t[1], t[2], t[3], t[4]))
+    assert np.array_equal(hb.err4p(t[0], t[1], t[2], gate, t[3], t[4], t[5], t[6]), oracle.err4p(t[0], t[1], t[2], gate, t[3], t[4], t[5], t[6]))
