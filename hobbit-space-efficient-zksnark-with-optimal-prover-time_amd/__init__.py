@@ -41,6 +41,7 @@ ABI_SYMBOLS = [
     "hobbit_tensorcode_chunks", "hobbit_inner_digests", "hobbit_chain_digests", "hobbit_blake3_64_host",
     "hobbit_parity_matrix", "hobbit_phi_g", "hobbit_prepare_matrix_cols", "hobbit_prove_linear_code", "hobbit_prove_fft",
     "hobbit_prove_fft_matrix",
+    "hobbit_batch_3product_sumcheck", "hobbit_mul_tree",
     "hobbit_open_core", "hobbit_compute2p_error_terms", "hobbit_compute3p_error_terms", "hobbit_compute4p_error_terms", "hobbit_fold_axpy",
     "hobbit_fold_axpy_i32", "hobbit_batch_prod",
     "hobbit_aggregate", "hobbit_sumcheck2", "hobbit_sumcheck3", "hobbit_fill_splitmix",
@@ -84,6 +85,7 @@ def load_library(path=LIB_PATH):
         "hobbit_prove_linear_code": [V, V, S, L, V, V, V, V, V], "hobbit_prove_fft": [V, V, S, V, V, V, V, V],
         "hobbit_prove_fft_matrix": [V, V, S, S, V, V, V, V, V],
         "hobbit_open_core": [V, V, S, V, V, I, V],
+        "hobbit_batch_3product_sumcheck": [V, V, V, V, V, I, V, V, V, V], "hobbit_mul_tree": [V, V, S, S, V, V, V, V, V, V, V, V, V, V],
         "hobbit_compute2p_error_terms": [V, V, V, V, V, S, V], "hobbit_compute3p_error_terms": [V, V, V, V, V, V, V, S, V],
         "hobbit_compute4p_error_terms": [V, V, V, V, V, V, V, V, V, S, V], "hobbit_fold_axpy": [V, V, V, V, S],
         "hobbit_fold_axpy_i32": [V, V, V, V, I, S], "hobbit_batch_prod": [V, V, V, V, V, V, V, I, S, V, V, V, V, V, V],
@@ -498,6 +500,30 @@ class Hobbit:
         d = self.to_device(m)
         self._chk(self.lib.hobbit_prove_fft_matrix(self.ctx, d.ptr, rows, cols, _hp(rr), _hp(q), _hp(r), _hp(vr), _hp(fin)))
         return dict(poly=q, r=r, vr=vr, fin=fin)
+
+    # ---- batched cubic sumcheck / multiplication tree (src/sumcheck.cpp:275-372, 35-257)
+    def batch_3product_sumcheck(self, t1, t2, t3, lens, a):
+        T = [Fh(x).reshape(-1, 2) for x in (t1, t2, t3)]
+        d = [self.to_device(x) for x in T]
+        lens = np.ascontiguousarray(lens, np.uint64); av = Fh(a).reshape(-1, 2)
+        rounds = int(max(lens)).bit_length() - 1; nb = len(lens)
+        q = np.zeros((rounds, 4, 2), np.uint64); r = np.zeros((rounds, 2), np.uint64); vr = np.zeros((nb, 3, 2), np.uint64)
+        self._chk(self.lib.hobbit_batch_3product_sumcheck(self.ctx, d[0].ptr, d[1].ptr, d[2].ptr, _hp(lens), nb, _hp(av), _hp(q), _hp(r), _hp(vr)))
+        return dict(poly=q, r=r, vr=vr)
+
+    def mul_tree(self, inp, previous_r, prev_x=None):
+        x = Fh(inp); vectors, size = x.shape[0], x.shape[1]
+        lt = (vectors * size).bit_length() - 1; depth = size.bit_length() - 1
+        nr = sum(range(lt))
+        q = np.zeros((nr + 1, 4, 2), np.uint64); r = np.zeros((nr + 1, 2), np.uint64)
+        vr = np.zeros((depth, 3, 2), np.uint64); fin = np.zeros((depth, 2), np.uint64)
+        final_r = np.zeros((lt, 2), np.uint64); oe = np.zeros(2, np.uint64); fe = np.zeros(2, np.uint64)
+        pr = Fh(previous_r).reshape(2); px = Fh(prev_x).reshape(-1, 2) if prev_x is not None else None
+        d = self.to_device(x); layers = ctypes.c_int()
+        self._chk(self.lib.hobbit_mul_tree(self.ctx, d.ptr, vectors, size, _hp(pr), _hp(px) if px is not None else None, _hp(q), _hp(r), _hp(vr), _hp(fin),
+                                           _hp(final_r), _hp(oe), _hp(fe), ctypes.byref(layers)))
+        L = layers.value
+        return dict(layers=np.array([L]), poly=q, r=r, vr=vr[:L], fin=fin[:L], final_r=final_r, out_eval=oe, final_eval=fe)
 
     # ---- streaming-sumcheck error terms / folds (reference names: src/sumcheck.cpp:374-432, 1093-1136)
     def err2p(self, b1, b2, f1, f2):

@@ -680,6 +680,118 @@ int hobbit_batch_prod(hobbit_ctx *ctx, hobbit_F *d_f1, hobbit_F *d_f2, hobbit_F 
     return launch_axpy(ctx, mF(d_f3), cF(d_b3), rnd, tot);
 }
 
+// ---- batch_3product_sumcheck (src/sumcheck.cpp:275-372) -------------------------------------------------
+static inline void cubic_of(const F &x0, const F &x1, const F &y0, const F &y1, const F &z0, const F &z1, F *p) {
+    F dx = fsub(x1, x0), dy = fsub(y1, y0), dz = fsub(z1, z0);
+    F qa = fmul(dx, dy), qb = fadd(fmul(dx, y0), fmul(x0, dy)), qc = fmul(x0, y0);
+    p[0] = fadd(p[0], fmul(qa, dz)); p[1] = fadd(p[1], fadd(fmul(qa, z0), fmul(qb, dz)));
+    p[2] = fadd(p[2], fadd(fmul(qb, z0), fmul(qc, dz))); p[3] = fadd(p[3], fmul(qc, z0));
+}
+int hobbit_batch_3product_sumcheck(hobbit_ctx *ctx, const hobbit_F *d_t1, const hobbit_F *d_t2, const hobbit_F *d_t3, const size_t *h_lens, int batches,
+                                   const hobbit_F *h_a, hobbit_F *h_cpoly, hobbit_F *h_r, hobbit_F *h_vr) {
+    if (batches <= 0) return ctx->fail(HOBBIT_EINVAL, "batch_3product_sumcheck: batches must be positive");
+    size_t tot = 0, Lmax = 0;
+    for (int j = 0; j < batches; j++) { if (ilog2_exact(h_lens[j]) < 0) return ctx->fail(HOBBIT_EINVAL, "batch_3product_sumcheck: lengths must be powers of two"); tot += h_lens[j]; Lmax = std::max(Lmax, h_lens[j]); }
+    const int rounds = ilog2_exact(Lmax);
+    // ping-pong copies of the three concatenated tables (inputs are preserved), partials, per-table coefficients
+    F *ws; HB_TRY(ctx->workspace2((6 * tot + 4 * 1024 + 4 * (size_t)batches + 16) * sizeof(F), (void **)&ws));
+    F *A = ws, *B = ws + 3 * tot, *part = B + 3 * tot, *coef = part + 4 * 1024;
+    HB_CHECK(ctx, hipMemcpyAsync(A, d_t1, tot * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    HB_CHECK(ctx, hipMemcpyAsync(A + tot, d_t2, tot * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    HB_CHECK(ctx, hipMemcpyAsync(A + 2 * tot, d_t3, tot * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    std::vector<size_t> off(batches), len(batches); std::vector<char> set(batches, 0);
+    std::vector<F> sc(3 * (size_t)batches);                          // host copies of tables that are down to one element
+    { size_t o = 0; for (int j = 0; j < batches; j++) { off[j] = o; len[j] = h_lens[j]; o += h_lens[j]; } }
+    F *pin; HB_TRY(ctx->pinned((4 * (size_t)batches + 3 * (size_t)batches) * sizeof(F), (void **)&pin));
+    F *cur = A, *nxt = B;
+    auto fetch_scalars = [&]() -> int {                             // read element 0 of every table that just reached length 1
+        for (int j = 0; j < batches; j++) if (len[j] == 1 && set[j] == 0) {
+            for (int t = 0; t < 3; t++) HB_CHECK(ctx, hipMemcpyAsync(pin + 4 * batches + 3 * j + t, cur + t * tot + off[j], sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int j = 0; j < batches; j++) if (len[j] == 1 && set[j] == 0) { for (int t = 0; t < 3; t++) sc[3 * j + t] = pin[4 * batches + 3 * j + t]; set[j] = 2; }
+        return 0;
+    };
+    HB_TRY(fetch_scalars());
+    F rnd = fmake(312);
+    for (int i = 0; i < rounds; i++) {
+        for (int j = 0; j < batches; j++) if (len[j] >= 2) HB_TRY(launch_sc3_poly(ctx, cur + off[j], cur + tot + off[j], cur + 2 * tot + off[j], len[j] / 2, part, coef + 4 * j));
+        HB_CHECK(ctx, hipMemcpyAsync(pin, coef, 4 * (size_t)batches * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        F poly[4] = {fmake(0), fmake(0), fmake(0), fmake(0)};
+        for (int j = 0; j < batches; j++) {
+            F p[4] = {fmake(0), fmake(0), fmake(0), fmake(0)};
+            if (len[j] >= 2) { for (int q = 0; q < 4; q++) p[q] = pin[4 * j + q]; }
+            else {
+                if (set[j] != 1) { for (int t = 0; t < 3; t++) mF(h_vr)[3 * j + t] = sc[3 * j + t]; set[j] = 1; }     // P.vr recorded the first time (:316-320)
+                cubic_of(sc[3 * j], fmake(0), sc[3 * j + 1], fmake(0), sc[3 * j + 2], fmake(0), p);                      // linear_poly(-v, v)
+            }
+            for (int q = 0; q < 4; q++) poly[q] = fadd(poly[q], fmul(cF(h_a)[j], p[q]));
+        }
+        for (int q = 0; q < 4; q++) { rnd = mimc_hash(rnd, poly[q]); mF(h_cpoly)[4 * i + q] = poly[q]; }
+        mF(h_r)[i] = rnd;
+        for (int j = 0; j < batches; j++) {
+            if (len[j] >= 2) { HB_TRY(launch_fold3(ctx, cur + off[j], cur + tot + off[j], cur + 2 * tot + off[j], nxt + off[j], nxt + tot + off[j], nxt + 2 * tot + off[j], len[j] / 2, rnd)); len[j] /= 2; }
+            else { F om = fsub(fmake(1), rnd); for (int t = 0; t < 3; t++) sc[3 * j + t] = fmul(om, sc[3 * j + t]); }
+        }
+        std::swap(cur, nxt);
+        // tables of length 1 were not copied by the fold: their scalars live on the host from now on
+        HB_TRY(fetch_scalars());
+    }
+    for (int j = 0; j < batches; j++) if (set[j] != 1) for (int t = 0; t < 3; t++) mF(h_vr)[3 * j + t] = sc[3 * j + t];
+    return 0;
+}
+
+// ---- prove_multiplication_tree_new (src/sumcheck.cpp:35-257), power-of-two vectors x size ---------------------
+int hobbit_mul_tree(hobbit_ctx *ctx, const hobbit_F *d_input, size_t vectors, size_t size, const hobbit_F *h_previous_r, const hobbit_F *h_prev_x,
+                    hobbit_F *h_cpoly, hobbit_F *h_r, hobbit_F *h_vr, hobbit_F *h_fin, hobbit_F *h_final_r, hobbit_F *h_out_eval, hobbit_F *h_final_eval, int *layers_out) {
+    const int depth = ilog2_exact(size), lv = ilog2_exact(vectors);
+    if (depth < 1 || lv < 0) return ctx->fail(HOBBIT_EINVAL, "mul_tree: vectors and size must be powers of two (the host mirror pads as the reference does)");
+    const size_t total = vectors * size;
+    F *arena; HB_TRY(ctx->workspace3((3 * total + total + 16) * sizeof(F), (void **)&arena));    // in1 | in2 | transcript layers (sum = total each), beta
+    F *in1 = arena, *in2 = arena + total, *tr = arena + 2 * total, *beta = arena + 3 * total;
+    std::vector<size_t> lo(depth);
+    { size_t o = 0, len = total; const F *src = cF(d_input);
+      for (int i = 0; i < depth; i++) { len /= 2; lo[i] = o; HB_TRY(launch_mul_layer(ctx, src, len, in1 + o, in2 + o, tr + o)); src = tr + o; o += len; } }
+    F previous_r = *cF(h_previous_r), sum;
+    std::vector<F> r; int layers = 0; size_t qo = 0, ro = 0;
+    if (vectors == 1) {
+        F top; HB_TRY(hobbit_memcpy_d2h(ctx, &top, tr + lo[depth - 1], sizeof(F)));
+        previous_r = mimc_hash(previous_r, top); sum = top;
+    } else {
+        r.resize(lv);
+        if (h_prev_x) memcpy((void *)r.data(), h_prev_x, sizeof(F) * lv);
+        else { F cst = fmake(0); for (int i = 0; i < lv; i++) { if (i % 100 == 0) cst = fmake((uint64_t)random()); r[i] = fadd(cst, fmake((uint64_t)rand())); } }   // generate_randomness
+        HB_TRY(hobbit_eval_vector(ctx, reinterpret_cast<hobbit_F *>(tr + lo[depth - 1]), vectors, reinterpret_cast<hobbit_F *>(r.data()), reinterpret_cast<hobbit_F *>(&sum)));
+        if (!h_prev_x) previous_r = mimc_hash(r[lv - 1], sum);
+    }
+    *mF(h_out_eval) = sum;
+    for (int i = depth - 1; i >= 0; i--) {
+        if (r.empty()) {
+            F a, b; HB_TRY(hobbit_memcpy_d2h(ctx, &a, in1 + lo[i], sizeof(F))); HB_TRY(hobbit_memcpy_d2h(ctx, &b, in2 + lo[i], sizeof(F)));
+            F num = mimc_hash(previous_r, a); previous_r = mimc_hash(num, b);
+            sum = fadd(fmul(fsub(fmake(1), previous_r), a), fmul(previous_r, b));
+            r.push_back(previous_r);
+        } else {
+            const int rl = (int)r.size(); const size_t n = (size_t)1 << rl;
+            HB_TRY(hobbit_eq_table(ctx, reinterpret_cast<hobbit_F *>(r.data()), rl, reinterpret_cast<hobbit_F *>(beta)));
+            HB_TRY(hobbit_sumcheck3(ctx, reinterpret_cast<hobbit_F *>(in1 + lo[i]), reinterpret_cast<hobbit_F *>(in2 + lo[i]), reinterpret_cast<hobbit_F *>(beta), n,
+                                    reinterpret_cast<hobbit_F *>(&previous_r), h_cpoly + qo, h_r + ro, h_vr + 3 * layers, h_fin + layers));
+            const F *q0 = cF(h_cpoly + qo);
+            F claim = fadd(fadd(fadd(q0[0], q0[1]), fadd(q0[2], q0[3])), q0[3]);        // P.c_poly[0].eval(1) + eval(0)
+            if (!feq(claim, sum)) printf("error %d\n", i);                              // the reference's own (non-fatal) check, :151,:203
+            for (int t = 0; t < rl; t++) r[t] = cF(h_r + ro)[t];
+            previous_r = cF(h_fin)[layers];
+            sum = fadd(fmul(cF(h_vr)[3 * layers], fsub(fmake(1), previous_r)), fmul(cF(h_vr)[3 * layers + 1], previous_r));
+            r.insert(r.begin(), previous_r);
+            qo += 4 * (size_t)rl; ro += (size_t)rl; layers++;
+        }
+    }
+    memcpy(h_final_r, r.data(), sizeof(F) * r.size()); *mF(h_final_eval) = sum;
+    if (layers_out) *layers_out = layers;
+    return 0;
+}
+
 // ---- Our_PC open without the inner shockwave/WHIR PCS -------------------------------------------
 // open_standard (src/Our_PC.cpp:604-661) + recursive_prover_Spielman (src/PC_utils.cpp:271-385) minus
 // shockwave_commit / shockwave_prove.  Host: libc draws in the reference's order, the transcript,

@@ -1134,6 +1134,50 @@ __global__ void __launch_bounds__(256) k_sc3_poly_fold(const F *__restrict__ s1,
     }
     block_reduce_store<4>(c, partials);
 }
+// cubic round polynomial only / fold only (batch_3product_sumcheck hashes first, then folds: src/sumcheck.cpp:327-352)
+__global__ void __launch_bounds__(256) k_sc3_poly(const F *__restrict__ s1, const F *__restrict__ s2, const F *__restrict__ s3, size_t L, F *__restrict__ partials) {
+    F c[4] = {fmake(0), fmake(0), fmake(0), fmake(0)};
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < L; j += (size_t)gridDim.x * blockDim.x) {
+        F x0 = ldF(s1 + 2 * j), x1 = ldF(s1 + 2 * j + 1), y0 = ldF(s2 + 2 * j), y1 = ldF(s2 + 2 * j + 1), z0 = ldF(s3 + 2 * j), z1 = ldF(s3 + 2 * j + 1);
+        F dx = fsub(x1, x0), dy = fsub(y1, y0), dz = fsub(z1, z0);
+        F qa = fmul(dx, dy), qb = fadd(fmul(dx, y0), fmul(x0, dy)), qc = fmul(x0, y0);
+        c[0] = fadd(c[0], fmul(qa, dz));
+        c[1] = fadd(c[1], fadd(fmul(qa, z0), fmul(qb, dz)));
+        c[2] = fadd(c[2], fadd(fmul(qb, z0), fmul(qc, dz)));
+        c[3] = fadd(c[3], fmul(qc, z0));
+    }
+    block_reduce_store<4>(c, partials);
+}
+__global__ void __launch_bounds__(256) k_fold3(const F *__restrict__ s1, const F *__restrict__ s2, const F *__restrict__ s3, F *__restrict__ d1, F *__restrict__ d2,
+                                               F *__restrict__ d3, size_t L, F r) {
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < L; j += (size_t)gridDim.x * blockDim.x) {
+        F x0 = ldF(s1 + 2 * j), x1 = ldF(s1 + 2 * j + 1), y0 = ldF(s2 + 2 * j), y1 = ldF(s2 + 2 * j + 1), z0 = ldF(s3 + 2 * j), z1 = ldF(s3 + 2 * j + 1);
+        stF(d1 + j, fadd(x0, fmul(r, fsub(x1, x0)))); stF(d2 + j, fadd(y0, fmul(r, fsub(y1, y0)))); stF(d3 + j, fadd(z0, fmul(r, fsub(z1, z0))));
+    }
+}
+int launch_sc3_poly(hobbit_ctx *ctx, const F *s1, const F *s2, const F *s3, size_t L, F *part, F *coef) {
+    int nb = grid_for(L, 256, 1024);
+    HB_LAUNCH(ctx, "k_sc3_poly", k_sc3_poly, dim3(nb), dim3(256), 0, s1, s2, s3, L, part);
+    HB_LAUNCH(ctx, "k_sc_reduce4", k_sc_reduce<4>, dim3(1), dim3(256), 0, part, nb, coef);
+    return 0;
+}
+int launch_fold3(hobbit_ctx *ctx, const F *s1, const F *s2, const F *s3, F *d1, F *d2, F *d3, size_t L, F r) {
+    HB_LAUNCH(ctx, "k_fold3", k_fold3, dim3(grid_for(L, 256)), dim3(256), 0, s1, s2, s3, d1, d2, d3, L, r);
+    return 0;
+}
+// one layer of the multiplication tree (src/sumcheck.cpp:88-110): in1[j] = x[2j], in2[j] = x[2j+1], tr[j] = x[2j]*x[2j+1]
+__global__ void __launch_bounds__(256) k_mul_layer(const F *__restrict__ x, size_t n_out, F *__restrict__ in1, F *__restrict__ in2, F *__restrict__ tr) {
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < n_out; j += (size_t)gridDim.x * blockDim.x) {
+        const F a = ldF(x + 2 * j), b = ldF(x + 2 * j + 1);
+        stF(in1 + j, a); stF(in2 + j, b); stF(tr + j, fmul(a, b));
+    }
+}
+int launch_mul_layer(hobbit_ctx *ctx, const F *x, size_t n_out, F *in1, F *in2, F *tr) {
+    if (!n_out) return 0;
+    HB_LAUNCH(ctx, "k_mul_layer", k_mul_layer, dim3(grid_for(n_out, 256)), dim3(256), 0, x, n_out, in1, in2, tr);
+    return 0;
+}
+
 // host rounds of the 3-product sumcheck on tables of size sz (src/sumcheck.cpp:1981-2037)
 static void sc3_host_tail(std::vector<F> &a, std::vector<F> &b, std::vector<F> &c3, F &rnd, int round, int rounds, F *h_cpoly, F *h_r) {
     size_t sz = a.size();

@@ -39,6 +39,9 @@ int launch_scatter(hobbit_ctx *ctx, const uint64_t *idx, const F *val, size_t n,
 int launch_axpy(hobbit_ctx *ctx, F *y, const F *x, F a, size_t n);
 int launch_err_terms(hobbit_ctx *ctx, int kind, const F *const *tables, const int32_t *gate, size_t n, F *h_K);
 int launch_axpy_i32(hobbit_ctx *ctx, F *y, const int32_t *sel, F a, int one_minus, size_t n);
+int launch_sc3_poly(hobbit_ctx *ctx, const F *s1, const F *s2, const F *s3, size_t L, F *part, F *coef);
+int launch_fold3(hobbit_ctx *ctx, const F *s1, const F *s2, const F *s3, F *d1, F *d2, F *d3, size_t L, F r);
+int launch_mul_layer(hobbit_ctx *ctx, const F *x, size_t n_out, F *in1, F *in2, F *tr);
 int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev_r, F *h_qpoly, F *h_r, F *h_vr, F *h_final);
 int launch_sumcheck3(hobbit_ctx *ctx, const F *v1, const F *v2, const F *v3, size_t n, F prev_r, F *h_cpoly, F *h_r, F *h_vr, F *h_final);
 }  // namespace hobbit

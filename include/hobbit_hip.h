@@ -212,6 +212,18 @@ int hobbit_prove_fft(hobbit_ctx *ctx, const hobbit_F *d_m, size_t s, const hobbi
 int hobbit_prove_fft_matrix(hobbit_ctx *ctx, const hobbit_F *d_M, size_t rows, size_t cols, const hobbit_F *h_r, hobbit_F *h_qpoly, hobbit_F *h_rr,
                             hobbit_F *h_vr, hobbit_F *h_final);
 
+/* batch_3product_sumcheck (src/sumcheck.cpp:275-372): `batches` table triples of power-of-two lengths h_lens[j],
+ * concatenated in d_t1/d_t2/d_t3 (inputs preserved; the reference folds in place).  h_cpoly: rounds x 4 F
+ * (rounds = log2 max length), h_r: rounds F, h_vr: batches x 3 F. */
+int hobbit_batch_3product_sumcheck(hobbit_ctx *ctx, const hobbit_F *d_t1, const hobbit_F *d_t2, const hobbit_F *d_t3, const size_t *h_lens, int batches,
+                                   const hobbit_F *h_a, hobbit_F *h_cpoly, hobbit_F *h_r, hobbit_F *h_vr);
+/* prove_multiplication_tree_new (src/sumcheck.cpp:35-257) for power-of-two vectors x size (d_input row-major).
+ * h_prev_x NULL: the challenge over the vector index is drawn with generate_randomness on the host (vectors > 1).
+ * Layer transcripts (top layer first) back to back in h_cpoly (4 F per round) / h_r; h_vr 3 F and h_fin 1 F per
+ * layer; h_final_r: log2(vectors*size) F.  *layers_out = number of sumcheck layers. */
+int hobbit_mul_tree(hobbit_ctx *ctx, const hobbit_F *d_input, size_t vectors, size_t size, const hobbit_F *h_previous_r, const hobbit_F *h_prev_x,
+                    hobbit_F *h_cpoly, hobbit_F *h_r, hobbit_F *h_vr, hobbit_F *h_fin, hobbit_F *h_final_r, hobbit_F *h_out_eval, hobbit_F *h_final_eval, int *layers_out);
+
 /* ---- streaming (space-efficient) sumcheck building blocks: per-chunk error terms and folds ---- */
 /* compute{2,3,4}p_error_terms (src/sumcheck.cpp:374-432, has_lookups == false): h_K is ACCUMULATED into, as the
  * reference's F& parameters are.  d_gate: int32 gate selectors (vector<int> buff_S). */

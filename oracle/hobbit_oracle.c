@@ -550,6 +550,120 @@ void orc_prove_fft_matrix(const oF *M, size_t rows, size_t cols, const oF *rr, o
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* batch_3product_sumcheck (src/sumcheck.cpp:275-372): cubic sumcheck over `batches` table       */
+/* triples of different power-of-two lengths with coefficients a[j]; hash first, then fold;      */
+/* a triple already folded to one element contributes (-x t + x)^3-style terms and folds by      */
+/* (1 - rand).  Tables are passed concatenated (lens[j] elements each) and folded in place.      */
+/* vr: 3*batches F (the values when a triple first reaches length 1, else the final elements).   */
+/* ------------------------------------------------------------------------------------------ */
+static void cubic_of(oF x0, oF x1, oF y0, oF y1, oF z0, oF z1, oF *p) {   /* p[0..3] += (l1*l2)*l3 coefficients */
+    oF dx = f_sub(x1, x0), dy = f_sub(y1, y0), dz = f_sub(z1, z0);
+    oF qa = f_mul(dx, dy), qb = f_add(f_mul(dx, y0), f_mul(x0, dy)), qc = f_mul(x0, y0);
+    p[0] = f_add(p[0], f_mul(qa, dz));
+    p[1] = f_add(p[1], f_add(f_mul(qa, z0), f_mul(qb, dz)));
+    p[2] = f_add(p[2], f_add(f_mul(qb, z0), f_mul(qc, dz)));
+    p[3] = f_add(p[3], f_mul(qc, z0));
+}
+int orc_batch_3product_sumcheck(oF *t1, oF *t2, oF *t3, const size_t *lens, int batches, const oF *a, oF *cpoly, oF *r_out, oF *vr) {
+    size_t Lmax = 0;
+    for (int j = 0; j < batches; j++) if (lens[j] > Lmax) Lmax = lens[j];
+    int rounds = (int)log2((double)Lmax);
+    oF rnd = fint(312);
+    size_t *off = (size_t *)malloc(sizeof(size_t) * (size_t)batches);
+    char *set = (char *)calloc((size_t)batches, 1);
+    size_t o = 0; for (int j = 0; j < batches; j++) { off[j] = o; o += lens[j]; }
+    for (int i = 0; i < rounds; i++) {
+        oF poly[4] = {fint(0), fint(0), fint(0), fint(0)};
+        for (int j = 0; j < batches; j++) {
+            oF *x = t1 + off[j], *y = t2 + off[j], *z = t3 + off[j];
+            int lg = (int)log2((double)lens[j]);
+            size_t L = (lg - 1 - i >= 0) ? ((size_t)1 << (lg - 1 - i)) : 0;
+            oF p[4] = {fint(0), fint(0), fint(0), fint(0)};
+            if (L >= 1) { for (size_t k = 0; k < L; k++) cubic_of(x[2 * k], x[2 * k + 1], y[2 * k], y[2 * k + 1], z[2 * k], z[2 * k + 1], p); }
+            else {
+                if (!set[j]) { vr[3 * j] = x[0]; vr[3 * j + 1] = y[0]; vr[3 * j + 2] = z[0]; set[j] = 1; }
+                cubic_of(x[0], fint(0), y[0], fint(0), z[0], fint(0), p);       /* linear_poly(-v, v): value v at 0, 0 at 1 */
+            }
+            for (int q = 0; q < 4; q++) poly[q] = f_add(poly[q], f_mul(a[j], p[q]));
+        }
+        for (int q = 0; q < 4; q++) { rnd = mimc_hash(rnd, poly[q]); cpoly[4 * i + q] = poly[q]; }
+        r_out[i] = rnd;
+        for (int j = 0; j < batches; j++) {
+            oF *x = t1 + off[j], *y = t2 + off[j], *z = t3 + off[j];
+            int lg = (int)log2((double)lens[j]);
+            size_t L = (lg - 1 - i >= 0) ? ((size_t)1 << (lg - 1 - i)) : 0;
+            if (L >= 1) for (size_t k = 0; k < L; k++) {
+                x[k] = f_add(x[2 * k], f_mul(rnd, f_sub(x[2 * k + 1], x[2 * k])));
+                y[k] = f_add(y[2 * k], f_mul(rnd, f_sub(y[2 * k + 1], y[2 * k])));
+                z[k] = f_add(z[2 * k], f_mul(rnd, f_sub(z[2 * k + 1], z[2 * k])));
+            } else {
+                oF om = f_sub(fint(1), rnd);
+                x[0] = f_mul(om, x[0]); y[0] = f_mul(om, y[0]); z[0] = f_mul(om, z[0]);
+            }
+        }
+    }
+    for (int j = 0; j < batches; j++) if (!set[j]) { vr[3 * j] = t1[off[j]]; vr[3 * j + 1] = t2[off[j]]; vr[3 * j + 2] = t3[off[j]]; }
+    free(off); free(set);
+    return rounds;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* prove_multiplication_tree_new (src/sumcheck.cpp:35-257) for power-of-two `vectors` x `size`     */
+/* inputs (the reference pads otherwise).  prev_x: NULL -> the reference draws                   */
+/* generate_randomness(log2 vectors) (vectors > 1).  Layer proofs are written back to back from   */
+/* the top layer (depth-1) down to layer 0: cpoly (4 per round), r, and per layer vr[3], fin.     */
+/* final_r has log2(vectors*size) entries.  Returns the number of sumcheck layers written.       */
+/* ------------------------------------------------------------------------------------------ */
+int orc_mul_tree(const oF *input, size_t vectors, size_t size, const oF *previous_r_in, const oF *prev_x, oF *cpoly, oF *r_out, oF *vr, oF *fin,
+                 oF *final_r, oF *out_eval, oF *final_eval) {
+    size_t total = vectors * size;
+    int depth = (int)log2((double)size), lt = (int)log2((double)total);
+    oF **tr = (oF **)malloc(sizeof(oF *) * (size_t)depth), **in1 = (oF **)malloc(sizeof(oF *) * (size_t)depth), **in2 = (oF **)malloc(sizeof(oF *) * (size_t)depth);
+    const oF *src = input; size_t len = total;
+    for (int i = 0; i < depth; i++) {
+        len /= 2;
+        tr[i] = (oF *)malloc(sizeof(oF) * len); in1[i] = (oF *)malloc(sizeof(oF) * len); in2[i] = (oF *)malloc(sizeof(oF) * len);
+        for (size_t j = 0; j < len; j++) { in1[i][j] = src[2 * j]; in2[i][j] = src[2 * j + 1]; tr[i][j] = f_mul(src[2 * j], src[2 * j + 1]); }
+        src = tr[i];
+    }
+    oF previous_r = *previous_r_in, sum;
+    oF *r = (oF *)malloc(sizeof(oF) * (size_t)(lt + 1)); int rl = 0, layers = 0;
+    size_t qo = 0, ro = 0;
+    if (vectors == 1) {
+        previous_r = mimc_hash(previous_r, tr[depth - 1][0]);
+        sum = tr[depth - 1][0]; *out_eval = sum;
+    } else {
+        rl = (int)log2((double)vectors);
+        if (prev_x) memcpy(r, prev_x, sizeof(oF) * (size_t)rl); else orc_generate_randomness(rl, r);
+        orc_evaluate_vector(tr[depth - 1], vectors, r, rl, &sum); *out_eval = sum;
+        if (!prev_x) previous_r = mimc_hash(r[rl - 1], sum);
+    }
+    for (int i = depth - 1; i >= 0; i--) {
+        if (rl == 0) {
+            oF num = mimc_hash(previous_r, in1[i][0]);
+            previous_r = mimc_hash(num, in2[i][0]);
+            sum = f_add(f_mul(f_sub(fint(1), previous_r), in1[i][0]), f_mul(previous_r, in2[i][0]));
+            r[rl++] = previous_r;
+        } else {
+            size_t n = (size_t)1 << rl;
+            oF *beta = (oF *)malloc(sizeof(oF) * n);
+            orc_precompute_beta(r, rl, beta);
+            orc_sumcheck3(in1[i], in2[i], beta, n, &previous_r, cpoly + qo, r_out + ro, vr + 3 * layers, fin + layers);
+            free(beta);
+            memcpy(r + 1, r_out + ro, sizeof(oF) * (size_t)rl);          /* r = P.randomness[0]; r.insert(begin, previous_r) */
+            previous_r = fin[layers];
+            sum = f_add(f_mul(vr[3 * layers], f_sub(fint(1), previous_r)), f_mul(vr[3 * layers + 1], previous_r));
+            r[0] = previous_r;
+            qo += 4 * (size_t)rl; ro += (size_t)rl; rl++; layers++;
+        }
+    }
+    memcpy(final_r, r, sizeof(oF) * (size_t)rl); *final_eval = sum;
+    for (int i = 0; i < depth; i++) { free(tr[i]); free(in1[i]); free(in2[i]); }
+    free(tr); free(in1); free(in2); free(r);
+    return layers;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* streaming-sumcheck error terms and folds (the per-chunk work of HOBBIT's space-efficient      */
 /* sumchecks): src/sumcheck.cpp:374-432 (compute{2,3,4}p_error_terms, has_lookups == false),      */
 /* 1093-1136 (batch_prod), 862-869 (fold += rand * chunk)                                         */

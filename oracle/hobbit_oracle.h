@@ -75,6 +75,11 @@ void orc_prove_linear_code(const oF *codeword, size_t size, long long n, const o
 void orc_prove_fft(const oF *m, size_t s, const oF *rr, oF *qpoly, oF *r, oF *vr, oF *fin);
 void orc_prove_fft_matrix(const oF *M, size_t rows, size_t cols, const oF *rr, oF *qpoly, oF *r, oF *vr, oF *fin);
 
+/* batched cubic sumcheck and the multiplication-tree prover */
+int orc_batch_3product_sumcheck(oF *t1, oF *t2, oF *t3, const size_t *lens, int batches, const oF *a, oF *cpoly, oF *r_out, oF *vr);
+int orc_mul_tree(const oF *input, size_t vectors, size_t size, const oF *previous_r_in, const oF *prev_x, oF *cpoly, oF *r_out, oF *vr, oF *fin,
+                 oF *final_r, oF *out_eval, oF *final_eval);
+
 /* streaming-sumcheck error terms / folds (K arrays are accumulated into, as in the reference) */
 void orc_err2p(const oF *b1, const oF *b2, const oF *f1, const oF *f2, size_t n, oF *K);
 void orc_err3p(const oF *b1, const int32_t *b2, const oF *f1, const oF *f2, const oF *f3, const oF *beta, size_t n, oF *K);

@@ -224,6 +224,31 @@ class _Base:
         a, b, c = [tuple(int(x) for x in q0[i]) for i in range(3)]
         return np.array([(a[0] + b[0] + 2 * c[0]) % P, (a[1] + b[1] + 2 * c[1]) % P], np.uint64)
 
+    # ---- batched cubic sumcheck / multiplication tree
+    def batch_3product_sumcheck(self, t1, t2, t3, lens, a):
+        """tables concatenated (sum(lens), 2); returns dict(poly, r, vr)"""
+        T = [F(x).reshape(-1, 2).copy() for x in (t1, t2, t3)]
+        lens = np.ascontiguousarray(lens, np.uint64); av = F(a).reshape(-1, 2)
+        rounds = int(max(lens)).bit_length() - 1; nb = len(lens)
+        q = np.zeros((rounds, 4, 2), np.uint64); r = np.zeros((rounds, 2), np.uint64); vr = np.zeros((nb, 3, 2), np.uint64)
+        f = self.fn("batch_3product_sumcheck"); f.restype = ctypes.c_int
+        f(_p(T[0]), _p(T[1]), _p(T[2]), _p(lens), ctypes.c_int(nb), _p(av), _p(q), _p(r), _p(vr))
+        return dict(poly=q, r=r, vr=vr)
+
+    def mul_tree(self, inp, previous_r, prev_x=None):
+        """inp (vectors, size, 2), both powers of two"""
+        x = F(inp); vectors, size = x.shape[0], x.shape[1]
+        lt = (vectors * size).bit_length() - 1; depth = size.bit_length() - 1
+        nr = sum(range(lt))                                   # generous bound on total rounds
+        q = np.zeros((nr + 1, 4, 2), np.uint64); r = np.zeros((nr + 1, 2), np.uint64)
+        vr = np.zeros((depth, 3, 2), np.uint64); fin = np.zeros((depth, 2), np.uint64)
+        final_r = np.zeros((lt, 2), np.uint64); oe = np.zeros(2, np.uint64); fe = np.zeros(2, np.uint64)
+        pr = F(previous_r).reshape(2); px = F(prev_x).reshape(-1, 2) if prev_x is not None else None
+        f = self.fn("mul_tree"); f.restype = ctypes.c_int
+        layers = f(_p(x), c_sz(vectors), c_sz(size), _p(pr), _p(px) if px is not None else None, _p(q), _p(r), _p(vr), _p(fin), _p(final_r), _p(oe), _p(fe))
+        # rounds per layer: top layer has log2(vectors) rounds (or 1 after the first scalar step), growing by one per layer
+        return dict(layers=np.array([layers]), poly=q, r=r, vr=vr[:layers], fin=fin[:layers], final_r=final_r, out_eval=oe, final_eval=fe)
+
     # ---- streaming-sumcheck error terms / folds
     def err2p(self, b1, b2, f1, f2):
         a = [F(x).reshape(-1, 2) for x in (b1, b2, f1, f2)]

@@ -265,6 +265,37 @@ void ref_prove_fft_matrix(const uint64_t *M, size_t rows, size_t cols, const uin
     dump_proof2(P, qpoly, r, vr, fin);
 }
 
+// ---- batch_3product_sumcheck (src/sumcheck.cpp:275-372) and prove_multiplication_tree_new (:35-257) ----
+int ref_batch_3product_sumcheck(uint64_t *t1, uint64_t *t2, uint64_t *t3, const size_t *lens, int batches, const uint64_t *a, uint64_t *cpoly, uint64_t *r_out, uint64_t *vr) {
+    vector<vector<F>> A1(batches), A2(batches), A3(batches); size_t o = 0;
+    for (int j = 0; j < batches; j++) { A1[j] = vecF(t1 + 2 * o, lens[j]); A2[j] = vecF(t2 + 2 * o, lens[j]); A3[j] = vecF(t3 + 2 * o, lens[j]); o += lens[j]; }
+    double vt = 0, ps = 0;
+    proof P = batch_3product_sumcheck(A1, A2, A3, vecF(a, batches), vt, ps);
+    for (size_t i = 0; i < P.c_poly.size(); i++) { stF(cpoly + 8 * i, P.c_poly[i].a); stF(cpoly + 8 * i + 2, P.c_poly[i].b); stF(cpoly + 8 * i + 4, P.c_poly[i].c); stF(cpoly + 8 * i + 6, P.c_poly[i].d); }
+    for (size_t i = 0; i < P.randomness[0].size(); i++) stF(r_out + 2 * i, P.randomness[0][i]);
+    memcpy(vr, P.vr.data(), 16 * P.vr.size());
+    return (int)P.c_poly.size();
+}
+int ref_mul_tree(const uint64_t *input, size_t vectors, size_t size, const uint64_t *previous_r, const uint64_t *prev_x, uint64_t *cpoly, uint64_t *r_out, uint64_t *vr,
+                 uint64_t *fin, uint64_t *final_r, uint64_t *out_eval, uint64_t *final_eval) {
+    vector<vector<F>> in(vectors);
+    for (size_t j = 0; j < vectors; j++) in[j] = vecF(input + 2 * j * size, size);
+    vector<F> px; if (prev_x) px = vecF(prev_x, (size_t)log2((double)vectors));
+    double vt = 0, ps = 0;
+    mul_tree_proof MP = prove_multiplication_tree_new(in, ldF(previous_r), px, vt, ps);
+    size_t qo = 0, ro = 0;
+    for (size_t l = 0; l < MP.proofs.size(); l++) {
+        proof &P = MP.proofs[l];
+        for (size_t i = 0; i < P.c_poly.size(); i++) { stF(cpoly + 2 * (qo + 4 * i), P.c_poly[i].a); stF(cpoly + 2 * (qo + 4 * i + 1), P.c_poly[i].b); stF(cpoly + 2 * (qo + 4 * i + 2), P.c_poly[i].c); stF(cpoly + 2 * (qo + 4 * i + 3), P.c_poly[i].d); }
+        for (size_t i = 0; i < P.randomness[0].size(); i++) stF(r_out + 2 * (ro + i), P.randomness[0][i]);
+        stF(vr + 6 * l, P.vr[0]); stF(vr + 6 * l + 2, P.vr[1]); stF(vr + 6 * l + 4, P.vr[2]); stF(fin + 2 * l, P.final_rand);
+        qo += 4 * P.c_poly.size(); ro += P.randomness[0].size();
+    }
+    memcpy(final_r, MP.final_r.data(), 16 * MP.final_r.size());
+    stF(out_eval, MP.out_eval); stF(final_eval, MP.final_eval);
+    return (int)MP.proofs.size();
+}
+
 // ---- streaming-sumcheck error terms (src/sumcheck.cpp:374-432, has_lookups == false) and batch_prod (:1093-1136)
 void ref_err2p(const uint64_t *b1, const uint64_t *b2, const uint64_t *f1, const uint64_t *f2, size_t n, uint64_t *K) {
     vector<F> B1 = vecF(b1, n), B2 = vecF(b2, n), F1 = vecF(f1, n), F2 = vecF(f2, n);

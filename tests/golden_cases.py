@@ -315,5 +315,26 @@ def case_streamfold(lib):
     return out
 
 
+def case_multree(lib):
+    """batch_3product_sumcheck (src/sumcheck.cpp:275-372) and prove_multiplication_tree_new (:35-257)"""
+    out = {}
+    lens = [256, 64, 256, 4, 1024]
+    tot = sum(lens)
+    t = [splitmix_field(tot, 500 + i) for i in range(3)]
+    res = lib.batch_3product_sumcheck(t[0], t[1], t[2], lens, splitmix_field(len(lens), 503))
+    for k, v in res.items():
+        out["b3_" + k] = v
+    pr = np.array([17, 5], np.uint64)
+    for (vectors, size, tag) in ((8, 256, "v8"), (1, 512, "v1"), (4, 64, "v4x")):
+        x = splitmix_field(vectors * size, 510 + vectors).reshape(vectors, size, 2)
+        px = splitmix_field(max(1, vectors.bit_length() - 1), 520) if tag == "v4x" else None
+        if px is None and vectors > 1:
+            lib.rng_reset()                                   # the reference draws r with generate_randomness
+        res = lib.mul_tree(x, pr, px)
+        for k, v in res.items():
+            out["mt_%s_%s" % (tag, k)] = v
+    return out
+
+
 CASES = dict(field=case_field, mimc=case_mimc, blake=case_blake, merkle=case_merkle, graph_encode=case_graph_encode,
-             fft=case_fft, tensorcode=case_tensorcode, commit=case_commit, sumcheck=case_sumcheck, elastic=case_elastic, codeproofs=case_codeproofs, streamfold=case_streamfold)
+             fft=case_fft, tensorcode=case_tensorcode, commit=case_commit, sumcheck=case_sumcheck, elastic=case_elastic, codeproofs=case_codeproofs, streamfold=case_streamfold, multree=case_multree)

@@ -503,3 +503,20 @@ def test_streamfold_large_vs_oracle(hb, oracle):
     assert np.array_equal(hb.err2p(t[0], t[1], t[2], t[3]), oracle.err2p(t[0], t[1], t[2], t[3]))
     assert np.array_equal(hb.err3p(t[0], gate, t[1], t[2], t[3], t[4]), oracle.err3p(t[0], gate, t[1], t[2], t[3], t[4]))
     assert np.array_equal(hb.err4p(t[0], t[1], t[2], gate, t[3], t[4], t[5], t[6]), oracle.err4p(t[0], t[1], t[2], gate, t[3], t[4], t[5], t[6]))
+
+
+# ---- batched cubic sumcheck and the multiplication-tree prover -------------------------------------
+def test_multree_vs_golden(hb):
+    g = gold("multree")
+    got = golden_cases.case_multree(hb)
+    assert set(got) == set(g.files)
+    for k in g.files:
+        assert np.array_equal(got[k], g[k]), k
+
+
+def test_mul_tree_2e20_vs_oracle(hb, oracle):
+    x = splitmix_field(8 << 17, 700).reshape(8, 1 << 17, 2)          # C4's shape scaled: 8 vectors
+    pr = np.array([17, 5], np.uint64); px = splitmix_field(3, 701)
+    a = hb.mul_tree(x, pr, px); b = oracle.mul_tree(x, pr, px)
+    for k in b:
+        assert np.array_equal(a[k], b[k]), k
