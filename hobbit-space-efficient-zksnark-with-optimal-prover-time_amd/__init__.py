@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "hobbit_tensorcode_chunks", "hobbit_inner_digests", "hobbit_chain_digests", "hobbit_blake3_64_host",
     "hobbit_parity_matrix", "hobbit_phi_g", "hobbit_prepare_matrix_cols", "hobbit_prove_linear_code", "hobbit_prove_fft",
     "hobbit_prove_fft_matrix",
-    "hobbit_batch_3product_sumcheck", "hobbit_mul_tree",
+    "hobbit_batch_3product_sumcheck", "hobbit_mul_tree", "hobbit_shockwave_commit", "hobbit_change_form", "hobbit_whir_commit",
     "hobbit_open_core", "hobbit_compute2p_error_terms", "hobbit_compute3p_error_terms", "hobbit_compute4p_error_terms", "hobbit_fold_axpy",
     "hobbit_fold_axpy_i32", "hobbit_batch_prod",
     "hobbit_aggregate", "hobbit_sumcheck2", "hobbit_sumcheck3", "hobbit_fill_splitmix",
@@ -85,6 +85,7 @@ def load_library(path=LIB_PATH):
         "hobbit_prove_linear_code": [V, V, S, L, V, V, V, V, V], "hobbit_prove_fft": [V, V, S, V, V, V, V, V],
         "hobbit_prove_fft_matrix": [V, V, S, S, V, V, V, V, V],
         "hobbit_open_core": [V, V, S, V, V, I, V],
+        "hobbit_shockwave_commit": [V, V, S, I, V, V], "hobbit_change_form": [V, V, I], "hobbit_whir_commit": [V, V, S, V, V],
         "hobbit_batch_3product_sumcheck": [V, V, V, V, V, I, V, V, V, V], "hobbit_mul_tree": [V, V, S, S, V, V, V, V, V, V, V, V, V, V],
         "hobbit_compute2p_error_terms": [V, V, V, V, V, S, V], "hobbit_compute3p_error_terms": [V, V, V, V, V, V, V, S, V],
         "hobbit_compute4p_error_terms": [V, V, V, V, V, V, V, V, V, S, V], "hobbit_fold_axpy": [V, V, V, V, S],
@@ -500,6 +501,25 @@ class Hobbit:
         d = self.to_device(m)
         self._chk(self.lib.hobbit_prove_fft_matrix(self.ctx, d.ptr, rows, cols, _hp(rr), _hp(q), _hp(r), _hp(vr), _hp(fin)))
         return dict(poly=q, r=r, vr=vr, fin=fin)
+
+    # ---- inner PCS commitments of the opening (src/Virgo.cpp:104-178)
+    def shockwave_commit(self, poly, k):
+        p = Fh(poly).reshape(-1, 2); N = p.shape[0]; W = 2 * N // k
+        d = self.to_device(p); enc = self.alloc(16 * k * W); lv = self.alloc(64 * W)
+        self._chk(self.lib.hobbit_shockwave_commit(self.ctx, d.ptr, N, k, enc.ptr, lv.ptr))
+        return self.to_host(enc, (k, W, 2), np.uint64), self.to_host(lv, (2 * W - 1, 32), np.uint8)
+
+    def change_form(self, poly):
+        p = Fh(poly).reshape(-1, 2)
+        d = self.to_device(p)
+        self._chk(self.lib.hobbit_change_form(self.ctx, d.ptr, p.shape[0].bit_length() - 1))
+        return self.to_host(d, p.shape, np.uint64)
+
+    def whir_commit(self, poly):
+        p = Fh(poly).reshape(-1, 2); N = p.shape[0]
+        d = self.to_device(p); com = self.alloc(32 * N); lv = self.alloc(32 * N)
+        self._chk(self.lib.hobbit_whir_commit(self.ctx, d.ptr, N, com.ptr, lv.ptr))
+        return self.to_host(com, (2 * N, 2), np.uint64), self.to_host(lv, (N - 1, 32), np.uint8)
 
     # ---- batched cubic sumcheck / multiplication tree (src/sumcheck.cpp:275-372, 35-257)
     def batch_3product_sumcheck(self, t1, t2, t3, lens, a):

@@ -101,6 +101,29 @@ static int fft_rows(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_l
     return launch_fft_rows(ctx, src, src_ld, src_len, dst, dst_ld, dst_es, logn, tw, scale, inverse ? 1 : 0, groups, rows_per_group, src_gs, dst_gs);
 }
 
+// Long forward/inverse transform of `batch` rows: row b of src (src_len nonzero elements, the rest of the 2^logn
+// transform length zero) -> row b of dst (2^logn elements, contiguous).  13 <= logn <= 24.  src may equal dst.
+static int fft_long(hobbit_ctx *ctx, const F *src, size_t src_ld, size_t src_len, F *dst, int logn, bool inverse, uint32_t batch) {
+    const size_t len = (size_t)1 << logn; const int lr = logn - 12; const uint32_t R = 1u << lr;
+    if (lr < 1 || lr > 12) return ctx->fail(HOBBIT_EINVAL, "fft_long: logn must be in [13,24]");
+    if (inverse) return ctx->fail(HOBBIT_EINVAL, "fft_long: only forward transforms are built");
+    if (src_len != len && src_len != len / 2) return ctx->fail(HOBBIT_EINVAL, "fft_long: source must be the full length or its zero-padded half");
+    F *t1, *t2;
+    HB_TRY(ctx->workspace((size_t)batch * len * sizeof(F), (void **)&t1));
+    HB_TRY(ctx->workspace2((size_t)batch * len * sizeof(F), (void **)&t2));
+    const F *twl; HB_TRY(get_twiddles(ctx, logn, inverse, &twl));
+    HB_TRY(get_tw8(ctx, inverse));
+    const int d = inverse ? 1 : 0; const F *t8 = ctx->tw8[d];
+    // (n2, n1) -> (n1, n2); only the nonzero n2 rows are moved (x[R n2 + n1] != 0 needs n2 < src_len / R)
+    HB_TRY(launch_transpose_ld(ctx, src, src_ld, R, (uint32_t)(src_len / R), R, t1, len, 4096, batch));
+    HB_TRY(launch_fft4096(ctx, t1, 4096, 1, src_len == len ? 4096u : 2048u, t1, 4096, 1, t8, t8 + 7 * 8, t8 + 7 * 8 + 7 * 64, ctx->tw8_w8[d], ctx->tw8_w83[d],
+                          ctx->tw8_w4_plus_i[d], fmake(1), 0, batch, R, len, len));
+    HB_TRY(launch_transpose_tw(ctx, t1, len, R, t2, twl, (uint32_t)(len / 2), batch));
+    HB_TRY(fft_rows(ctx, t2, R, R, t2, R, 1, lr, inverse, 1, (uint32_t)((size_t)batch * 4096), 0, 0));       // scale applied below, not here
+    HB_TRY(launch_transpose_ld(ctx, t2, len, R, 4096, R, dst, len, 4096, batch));
+    return 0;
+}
+
 extern "C" {
 
 const char *hobbit_version(void) { return "hobbit-hip 0.1 (gfx950)"; }
@@ -279,9 +302,14 @@ int hobbit_encode_batch(hobbit_ctx *ctx, const hobbit_F *d_src, hobbit_F *d_dst,
 
 // ---- FFT --------------------------------------------------------------------------------------
 int hobbit_fft_batch(hobbit_ctx *ctx, hobbit_F *d_data, int logn, size_t batch, size_t ld, int inverse) {
-    if (logn < 0 || logn > 12) return ctx->fail(HOBBIT_EINVAL, "fft_batch: logn must be in [0,12]");
+    if (logn < 0 || logn > 24) return ctx->fail(HOBBIT_EINVAL, "fft_batch: logn must be in [0,24]");
     if (logn == 0 || batch == 0) return 0;
     if (ld < ((size_t)1 << logn)) return ctx->fail(HOBBIT_EINVAL, "fft_batch: ld < 2^logn");
+    if (logn > 12) {
+        if (inverse) return ctx->fail(HOBBIT_EINVAL, "fft_batch: inverse transforms longer than 4096 are not built (the hot path only needs forward)");
+        if (ld != ((size_t)1 << logn)) return ctx->fail(HOBBIT_EINVAL, "fft_batch: long rows must be contiguous");
+        return fft_long(ctx, cF(d_data), ld, (size_t)1 << logn, mF(d_data), logn, false, (uint32_t)batch);
+    }
     return fft_rows(ctx, cF(d_data), ld, 1u << logn, mF(d_data), ld, 1, logn, inverse != 0, 1, (uint32_t)batch, 0, 0);
 }
 
@@ -493,6 +521,44 @@ void hobbit_elastic_free(hobbit_elastic *e) {
     for (int i = 0; i < 4; i++) if (e->t[i]) hipFree(e->t[i]);
     if (e->state) hipFree(e->state);
     delete e;
+}
+
+// ---- inner PCS commitments of the opening (src/Virgo.cpp:104-178) --------------------------------------
+// rows zero-padded to twice their length and transformed: d_enc row i = FFT(row i of d_poly | zeros)
+static int rs_rows(hobbit_ctx *ctx, const F *d_poly, size_t w, int k, F *d_enc) {
+    const size_t W = 2 * w; const int lg = ilog2_exact(W);
+    if (lg < 1) return ctx->fail(HOBBIT_EINVAL, "row length must be a power of two");
+    if (lg <= 12) return fft_rows(ctx, d_poly, w, (uint32_t)w, d_enc, W, 1, lg, false, 1, (uint32_t)k, 0, 0);
+    return fft_long(ctx, d_poly, w, w, d_enc, lg, false, (uint32_t)k);
+}
+int hobbit_shockwave_commit(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, int k, hobbit_F *d_enc, uint8_t *d_levels) {
+    if (k < 4 || k > 64 || ilog2_exact((size_t)k) < 0 || N % (size_t)k) return ctx->fail(HOBBIT_EINVAL, "shockwave_commit: k must be a power of two in [4,64] dividing N");
+    const size_t w = N / k, W = 2 * w;
+    HB_TRY(rs_rows(ctx, cF(d_poly), w, k, mF(d_enc)));          // an all-zero row transforms to zeros: the reference's skip is value-neutral (:133-141)
+    HB_TRY(launch_col_digest(ctx, cF(d_enc), W, k, 1, d_levels));
+    return launch_merkle_levels(ctx, d_levels, W, 1);
+}
+int hobbit_change_form(hobbit_ctx *ctx, hobbit_F *d_poly, int logn) {
+    if (logn < 1 || logn > 30) return ctx->fail(HOBBIT_EINVAL, "change_form: bad logn");
+    const size_t n = (size_t)1 << logn;
+    F *tmp; HB_TRY(ctx->workspace2(n * sizeof(F), (void **)&tmp));
+    F *cur = mF(d_poly), *nxt = tmp;
+    for (int l = 0; l < logn; l++) { HB_TRY(launch_change_form_level(ctx, cur, nxt, n, n >> l)); std::swap(cur, nxt); }
+    if (cur != mF(d_poly)) HB_CHECK(ctx, hipMemcpyAsync(d_poly, cur, n * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+int hobbit_whir_commit(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, hobbit_F *d_com, uint8_t *d_levels) {
+    const int logn = ilog2_exact(N);
+    if (logn < 4 || logn > 23) return ctx->fail(HOBBIT_EINVAL, "whir_commit: N must be a power of two in [16, 2^23]");
+    const size_t L = 2 * N;
+    F *pc; HB_TRY(ctx->workspace3(2 * L * sizeof(F), (void **)&pc));
+    F *enc = pc + L;
+    HB_CHECK(ctx, hipMemcpyAsync(pc, d_poly, N * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    HB_TRY(hobbit_change_form(ctx, reinterpret_cast<hobbit_F *>(pc), logn));
+    HB_TRY(rs_rows(ctx, pc, N, 1, enc));                                        // resize(2N, 0) + _fft (:165-166)
+    // buff[j*16 + kk] = poly_com[j + kk * L/16] (:168-173): a (16 x L/16) -> (L/16 x 16) transpose
+    HB_TRY(launch_transpose_ld(ctx, enc, 0, L / 16, 16, (uint32_t)(L / 16), mF(d_com), 0, 16, 1));
+    return hobbit_mt_commit_blake(ctx, d_com, L, d_levels);
 }
 
 // ---- multi-GPU commit building blocks -------------------------------------------

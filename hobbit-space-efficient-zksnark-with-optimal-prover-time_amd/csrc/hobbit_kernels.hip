@@ -330,6 +330,38 @@ int launch_transpose(hobbit_ctx *ctx, const F *in, size_t in_gs, uint32_t rows, 
     return launch_transpose_ld(ctx, in, in_gs, cols, rows, cols, out, out_gs, ld_out, groups);
 }
 
+// Long transforms (len = 4096 * R, R up to 4096) by one Cooley-Tukey split, every pass coalesced:
+//   transpose (n2,n1)->(n1,n2) | R x FFT-4096 | twiddle W_len^(n1 k2) fused into the transpose (n1,k2)->(k2,n1)
+//   | 4096 x FFT-R | transpose (k2,k1)->(k1,k2).  This kernel is the middle one.  tw[m] = W_len^m, m < len/2.
+__global__ void __launch_bounds__(256)
+k_transpose_tw(const F *__restrict__ in, size_t gs, uint32_t R, F *__restrict__ out, const F *__restrict__ tw, uint32_t half) {
+    __shared__ F tile[32][33];
+    const F *src = in + (size_t)blockIdx.z * gs;
+    F *dst = out + (size_t)blockIdx.z * gs;
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const uint32_t k20 = blockIdx.x * 32, n10 = blockIdx.y * 32;          // input: R rows (n1) x 4096 cols (k2)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t n1 = n10 + ty + 8 * i, k2 = k20 + tx;
+        if (n1 < R) {
+            F v = ldF(src + (size_t)n1 * 4096 + k2);
+            const uint32_t m = n1 * k2;                                   // < len = 2*half
+            if (m) { v = fmul(v, ldF(tw + (m & (half - 1)))); if (m >= half) v = fneg(v); }
+            stF(&tile[ty + 8 * i][tx], v);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t k2 = k20 + ty + 8 * i, n1 = n10 + tx;
+        if (n1 < R) stF(dst + (size_t)k2 * R + n1, ldF(&tile[tx][ty + 8 * i]));
+    }
+}
+int launch_transpose_tw(hobbit_ctx *ctx, const F *in, size_t gs, uint32_t R, F *out, const F *tw, uint32_t half, uint32_t groups) {
+    HB_LAUNCH(ctx, "k_transpose_tw", k_transpose_tw, dim3(4096 / 32, (R + 31) / 32, groups), dim3(256), 0, in, gs, R, out, tw, half);
+    return 0;
+}
+
 // ============================================================================================
 // Expander encode (src/linear_code_encode.h:62-119), one workgroup per message, the whole
 // codeword in LDS.  The recursion unrolls into a straight sequence of SpMV steps over one buffer
@@ -665,6 +697,48 @@ int launch_elastic_leaf(hobbit_ctx *ctx, const F *t0, const F *t1, const F *t2, 
 }
 int launch_elastic_finish(hobbit_ctx *ctx, const uint8_t *state, uint32_t rows2, uint32_t cols, uint8_t *leaves) {
     HB_LAUNCH(ctx, "k_elastic_finish", k_elastic_finish, dim3(grid_for((size_t)rows2 * cols, 256, 1 << 16)), dim3(256), 0, state, rows2, cols, leaves);
+    return 0;
+}
+// shockwave_commit column digests (src/Virgo.cpp:143-151): digest of column c = root of MT_commit_Blake over the
+// k entries enc[0..k)[c] (k/4 leaves of 4 elements, then the tree with the configured parent rule), k <= 64
+__global__ void __launch_bounds__(256)
+k_col_digest(const F *__restrict__ enc, size_t W, int k, int quirk, uint8_t *__restrict__ out) {
+    for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < W; c += (size_t)gridDim.x * blockDim.x) {
+        uint32_t node[16][8];
+        const int leaves = k / 4;
+        for (int l = 0; l < leaves; l++) {
+            uint32_t m[16];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const F v = ldF(enc + (size_t)(4 * l + e) * W + c);
+                m[4 * e] = (uint32_t)v.re; m[4 * e + 1] = (uint32_t)(v.re >> 32); m[4 * e + 2] = (uint32_t)v.im; m[4 * e + 3] = (uint32_t)(v.im >> 32);
+            }
+            blake3_compress64(m, node[l]);
+        }
+        for (int n = leaves / 2; n >= 1; n /= 2)
+            for (int i = 0; i < n; i++) {
+                uint32_t m[16];
+#pragma unroll
+                for (int q = 0; q < 8; q++) { m[q] = node[2 * i][q]; m[8 + q] = quirk ? node[2 * i][q] : node[2 * i + 1][q]; }
+                blake3_compress64(m, node[i]);
+            }
+        store8w(out + 32 * c, node[0]);
+    }
+}
+int launch_col_digest(hobbit_ctx *ctx, const F *enc, size_t W, int k, int quirk, uint8_t *out) {
+    HB_LAUNCH(ctx, "k_col_digest", k_col_digest, dim3(grid_for(W, 256)), dim3(256), 0, enc, W, k, quirk, out);
+    return 0;
+}
+// one level of change_form (src/Virgo.cpp:104-118): every block of S elements becomes [even entries | odd - even]
+__global__ void k_change_form_level(const F *__restrict__ in, F *__restrict__ out, size_t n, size_t S) {
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < n / 2; g += (size_t)gridDim.x * blockDim.x) {
+        const size_t blk = g / (S / 2), i = g % (S / 2), pos = blk * S;
+        const F a = ldF(in + pos + 2 * i), b = ldF(in + pos + 2 * i + 1);
+        stF(out + pos + i, a); stF(out + pos + S / 2 + i, fsub(b, a));
+    }
+}
+int launch_change_form_level(hobbit_ctx *ctx, const F *in, F *out, size_t n, size_t S) {
+    HB_LAUNCH(ctx, "k_change_form_level", k_change_form_level, dim3(grid_for(n / 2, 256)), dim3(256), 0, in, out, n, S);
     return 0;
 }
 // paths[q][l] = levels[off_l + (pos_q >> l) ^ 1]   (src/merkle_tree.cpp:308-324)

@@ -85,7 +85,8 @@ int hobbit_encode_batch(hobbit_ctx *ctx, const hobbit_F *d_src, hobbit_F *d_dst,
                         size_t batch, size_t ld_src, size_t ld_dst);
 
 /* ---- FFT (src/utils.cpp:605-673 _fft; natural order in and out) ---------------------------- */
-/* in place on `batch` rows of 2^logn F, row b at d_data + b*ld.  inverse!=0 scales by 1/len.
+/* in place on `batch` rows of 2^logn F, row b at d_data + b*ld (logn <= 12; forward transforms up to 2^24 on
+ * contiguous rows).  inverse!=0 scales by 1/len.
  * Twiddles are always those of the requested direction (the reference's length-keyed cache quirk,
  * SURVEY.md 1, is NOT reproduced here; the host mirror documents where it matters). */
 int hobbit_fft_batch(hobbit_ctx *ctx, hobbit_F *d_data, int logn, size_t batch, size_t ld, int inverse);
@@ -147,6 +148,15 @@ int hobbit_elastic_begin(hobbit_ctx *ctx, size_t B, int trs, int linear_time, in
 int hobbit_elastic_push(hobbit_ctx *ctx, hobbit_elastic *e, const hobbit_F *d_chunk);
 int hobbit_elastic_finish(hobbit_ctx *ctx, hobbit_elastic *e, uint8_t *d_levels);
 void hobbit_elastic_free(hobbit_elastic *e);
+
+/* ---- inner PCS commitments of the opening (src/Virgo.cpp:104-178) ------------------------------ */
+/* shockwave_commit: poly as k rows of N/k, rows RS-encoded to 2N/k (d_enc: k x 2N/k row-major), column digests
+ * (MT_commit_Blake over the k entries of a column) and the tree over them (d_levels: (2*(2N/k)-1) hashes) */
+int hobbit_shockwave_commit(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, int k, hobbit_F *d_enc, uint8_t *d_levels);
+/* change_form (src/Virgo.cpp:104-118), in place on 2^logn elements */
+int hobbit_change_form(hobbit_ctx *ctx, hobbit_F *d_poly, int logn);
+/* whir_commit: change_form, zero-pad x2, FFT, 16-way regroup (d_com: 2N F), MT_commit_Blake (d_levels: N - 1 hashes... (2N/4)*2-1) */
+int hobbit_whir_commit(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, hobbit_F *d_com, uint8_t *d_levels);
 
 /* ---- multi-GPU commit building blocks (chunk-sharded commit) ------------------ */
 /* tensor codes of `nchunks` consecutive messages of M F each (chunk i at d_msg + i*M), outputs

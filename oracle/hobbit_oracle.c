@@ -550,6 +550,53 @@ void orc_prove_fft_matrix(const oF *M, size_t rows, size_t cols, const oF *rr, o
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* inner PCS commitments of the opening: shockwave_commit (src/Virgo.cpp:120-157) and            */
+/* whir_commit (:160-178) with change_form (:104-118)                                             */
+/* ------------------------------------------------------------------------------------------ */
+/* enc_out: k x (2N/k) row-major; levels_out: (2*(2N/k) - 1) hashes (column digests, then the tree) */
+size_t orc_shockwave_commit(const oF *poly, size_t N, int k, oF *enc_out, uint8_t *levels_out) {
+    size_t w = N / (size_t)k, W = 2 * w;
+    int lg = (int)log2((double)W);
+    for (int i = 0; i < k; i++) {
+        oF *row = enc_out + (size_t)i * W; int nz = 0;
+        memset(row, 0, sizeof(oF) * W);
+        for (size_t j = 0; j < w; j++) { row[j] = poly[(size_t)i * w + j]; if (!fis0(row[j])) nz = 1; }
+        if (nz) orc_fft(row, lg, 0);
+    }
+    oF *buff = (oF *)malloc(sizeof(oF) * (size_t)k);
+    uint8_t *H = (uint8_t *)malloc(64 * (size_t)k);
+    for (size_t c = 0; c < W; c++) {
+        for (int j = 0; j < k; j++) buff[j] = enc_out[(size_t)j * W + c];
+        size_t cnt = orc_mt_commit_blake(buff, (size_t)k, H);            /* column digest = root of the (quirky) tree over k/4 leaves */
+        memcpy(levels_out + 32 * c, H + 32 * (cnt - 1), 32);
+    }
+    free(buff); free(H);
+    return create_tree(levels_out, W);
+}
+static void change_form(oF *poly, int logn, int l, size_t pos, oF *buff) {
+    size_t S = (size_t)1 << (logn - l);
+    for (size_t i = 0; i < S / 2; i++) { buff[i] = poly[pos + 2 * i]; buff[i + S / 2] = f_sub(poly[pos + 2 * i + 1], poly[pos + 2 * i]); }
+    memcpy(poly + pos, buff, sizeof(oF) * S);
+    if (l + 1 == logn) return;
+    change_form(poly, logn, l + 1, pos, buff);
+    change_form(poly, logn, l + 1, pos + S / 2, buff);
+}
+void orc_change_form(oF *poly, int logn) { oF *b = (oF *)malloc(sizeof(oF) * ((size_t)1 << logn)); change_form(poly, logn, 0, 0, b); free(b); }
+/* com_out: 2N F (poly_com after the permutation); levels_out: (2N/4)*2-1 hashes */
+size_t orc_whir_commit(const oF *poly, size_t N, oF *com_out, uint8_t *levels_out) {
+    int logn = (int)log2((double)N);
+    size_t L = 2 * N;
+    oF *pc = (oF *)calloc(L, sizeof(oF));
+    memcpy(pc, poly, sizeof(oF) * N);
+    orc_change_form(pc, logn);
+    orc_fft(pc, logn + 1, 0);
+    size_t q = L / 16, cnt = 0;
+    for (size_t j = 0; j < q; j++) for (size_t kk = 0; kk < 16; kk++) com_out[cnt++] = pc[j + kk * q];
+    free(pc);
+    return orc_mt_commit_blake(com_out, L, levels_out);
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* batch_3product_sumcheck (src/sumcheck.cpp:275-372): cubic sumcheck over `batches` table       */
 /* triples of different power-of-two lengths with coefficients a[j]; hash first, then fold;      */
 /* a triple already folded to one element contributes (-x t + x)^3-style terms and folds by      */

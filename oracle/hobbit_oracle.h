@@ -75,6 +75,11 @@ void orc_prove_linear_code(const oF *codeword, size_t size, long long n, const o
 void orc_prove_fft(const oF *m, size_t s, const oF *rr, oF *qpoly, oF *r, oF *vr, oF *fin);
 void orc_prove_fft_matrix(const oF *M, size_t rows, size_t cols, const oF *rr, oF *qpoly, oF *r, oF *vr, oF *fin);
 
+/* inner PCS commitments of the opening */
+size_t orc_shockwave_commit(const oF *poly, size_t N, int k, oF *enc_out, uint8_t *levels_out);
+void orc_change_form(oF *poly, int logn);
+size_t orc_whir_commit(const oF *poly, size_t N, oF *com_out, uint8_t *levels_out);
+
 /* batched cubic sumcheck and the multiplication-tree prover */
 int orc_batch_3product_sumcheck(oF *t1, oF *t2, oF *t3, const size_t *lens, int batches, const oF *a, oF *cpoly, oF *r_out, oF *vr);
 int orc_mul_tree(const oF *input, size_t vectors, size_t size, const oF *previous_r_in, const oF *prev_x, oF *cpoly, oF *r_out, oF *vr, oF *fin,

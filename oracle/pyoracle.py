@@ -224,6 +224,26 @@ class _Base:
         a, b, c = [tuple(int(x) for x in q0[i]) for i in range(3)]
         return np.array([(a[0] + b[0] + 2 * c[0]) % P, (a[1] + b[1] + 2 * c[1]) % P], np.uint64)
 
+    # ---- inner PCS commitments of the opening
+    def shockwave_commit(self, poly, k):
+        p = F(poly).reshape(-1, 2); N = p.shape[0]; W = 2 * N // k
+        enc = np.zeros((k, W, 2), np.uint64); lv = np.zeros((2 * W, 32), np.uint8)
+        f = self.fn("shockwave_commit"); f.restype = c_sz
+        cnt = f(_p(p), c_sz(N), ctypes.c_int(k), _p(enc), _p(lv))
+        return enc, lv[:cnt]
+
+    def change_form(self, poly):
+        p = F(poly).reshape(-1, 2).copy()
+        self.fn("change_form")(_p(p), ctypes.c_int(p.shape[0].bit_length() - 1))
+        return p
+
+    def whir_commit(self, poly):
+        p = F(poly).reshape(-1, 2); N = p.shape[0]
+        com = np.zeros((2 * N, 2), np.uint64); lv = np.zeros((N, 32), np.uint8)
+        f = self.fn("whir_commit"); f.restype = c_sz
+        cnt = f(_p(p), c_sz(N), _p(com), _p(lv))
+        return com, lv[:cnt]
+
     # ---- batched cubic sumcheck / multiplication tree
     def batch_3product_sumcheck(self, t1, t2, t3, lens, a):
         """tables concatenated (sum(lens), 2); returns dict(poly, r, vr)"""

@@ -265,6 +265,24 @@ void ref_prove_fft_matrix(const uint64_t *M, size_t rows, size_t cols, const uin
     dump_proof2(P, qpoly, r, vr, fin);
 }
 
+// ---- inner PCS commitments (src/Virgo.cpp:104-178) ------------------------------------------------------------
+size_t ref_shockwave_commit(const uint64_t *poly, size_t N, int k, uint64_t *enc_out, uint8_t *levels_out) {
+    vector<F> p = vecF(poly, N);
+    shockwave_data *d = shockwave_commit(p, k);
+    size_t W = 2 * N / k;
+    for (int i = 0; i < k; i++) memcpy(enc_out + 2 * (size_t)i * W, d->encoded_matrix[i], 16 * W);
+    size_t cnt = flatten_levels(d->MT, levels_out);
+    delete d;
+    return cnt;
+}
+void ref_change_form(uint64_t *poly, int logn) { vector<F> p = vecF(poly, (size_t)1 << logn); change_form(p, logn, 0, 0); memcpy(poly, p.data(), 16 * p.size()); }
+size_t ref_whir_commit(const uint64_t *poly, size_t N, uint64_t *com_out, uint8_t *levels_out) {
+    vector<F> p = vecF(poly, N); Whir_data W;
+    whir_commit(p, W);
+    memcpy(com_out, W.poly_com.data(), 16 * W.poly_com.size());
+    return flatten_levels(W.MT, levels_out);
+}
+
 // ---- batch_3product_sumcheck (src/sumcheck.cpp:275-372) and prove_multiplication_tree_new (:35-257) ----
 int ref_batch_3product_sumcheck(uint64_t *t1, uint64_t *t2, uint64_t *t3, const size_t *lens, int batches, const uint64_t *a, uint64_t *cpoly, uint64_t *r_out, uint64_t *vr) {
     vector<vector<F>> A1(batches), A2(batches), A3(batches); size_t o = 0;

@@ -336,5 +336,22 @@ def case_multree(lib):
     return out
 
 
+def case_innerpcs(lib):
+    """shockwave_commit, change_form, whir_commit (src/Virgo.cpp:104-178): FFTs up to 2^17 here"""
+    out = {}
+    for (N, k) in ((1 << 10, 32), (1 << 16, 32), (1 << 13, 8)):
+        p = splitmix_field(N, 800 + k)
+        if N == 1 << 13:
+            p[N // k:2 * N // k] = 0                    # an all-zero row takes the reference's no-FFT shortcut
+        enc, lv = lib.shockwave_commit(p, k)
+        out["sw_%d_%d_enc" % (N, k)] = dg(enc); out["sw_%d_%d_root" % (N, k)] = lv[-1].copy(); out["sw_%d_%d_lv" % (N, k)] = dg(lv)
+    for logn in (1, 2, 5, 12):
+        out["cf_%d" % logn] = dg(lib.change_form(splitmix_field(1 << logn, 810 + logn)))
+    for N in (1 << 9, 1 << 14):
+        com, lv = lib.whir_commit(splitmix_field(N, 820))
+        out["wh_%d_com" % N] = dg(com); out["wh_%d_root" % N] = lv[-1].copy(); out["wh_%d_lv" % N] = dg(lv)
+    return out
+
+
 CASES = dict(field=case_field, mimc=case_mimc, blake=case_blake, merkle=case_merkle, graph_encode=case_graph_encode,
-             fft=case_fft, tensorcode=case_tensorcode, commit=case_commit, sumcheck=case_sumcheck, elastic=case_elastic, codeproofs=case_codeproofs, streamfold=case_streamfold, multree=case_multree)
+             fft=case_fft, tensorcode=case_tensorcode, commit=case_commit, sumcheck=case_sumcheck, elastic=case_elastic, codeproofs=case_codeproofs, streamfold=case_streamfold, multree=case_multree, innerpcs=case_innerpcs)

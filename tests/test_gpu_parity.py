@@ -520,3 +520,25 @@ def test_mul_tree_2e20_vs_oracle(hb, oracle):
     a = hb.mul_tree(x, pr, px); b = oracle.mul_tree(x, pr, px)
     for k in b:
         assert np.array_equal(a[k], b[k]), k
+
+
+# ---- long FFTs and the inner PCS commitments of the opening ----------------------------------------
+@pytest.mark.parametrize("logn", [13, 14, 16, 19])
+def test_fft_long_vs_oracle(hb, oracle, logn):
+    x = splitmix_field(1 << logn, 900 + logn)
+    assert np.array_equal(hb.fft(x), oracle.fft(x))
+
+
+def test_innerpcs_vs_golden(hb):
+    g = gold("innerpcs")
+    got = golden_cases.case_innerpcs(hb)
+    assert set(got) == set(g.files)
+    for k in g.files:
+        assert np.array_equal(got[k], g[k]), k
+
+
+def test_shockwave_commit_2e21_vs_oracle(hb, oracle):
+    """shape of C_f at N = 2^26: aggregate of 2^21 elements in 32 rows -> 32 FFTs of 2^17"""
+    p = splitmix_field(1 << 21, 950)
+    e1, l1 = hb.shockwave_commit(p, 32); e2, l2 = oracle.shockwave_commit(p, 32)
+    assert np.array_equal(e1, e2) and np.array_equal(l1, l2)
