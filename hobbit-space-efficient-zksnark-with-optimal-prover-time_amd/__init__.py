@@ -440,12 +440,12 @@ class Hobbit:
         depth = c.M.bit_length() - 1
 
         class Out(ctypes.Structure):
-            _fields_ = [(n, c_vp) for n in ("cols", "rows", "reply", "paths", "qpoly", "r", "vr", "fin", "scalars", "checks")]
+            _fields_ = [(n, c_vp) for n in ("cols", "rows", "reply", "paths", "qpoly", "r", "vr", "fin", "scalars", "checks", "roots")]
         res = dict(cols=np.zeros(queries, np.uint32), rows=np.zeros(queries, np.uint32), reply=np.zeros((queries, c.K, 2), np.uint64),
                    paths=np.zeros((queries, depth, 32), np.uint8) if want_paths else None, poly=np.zeros((rounds, 3, 2), np.uint64),
                    r=np.zeros((rounds, 2), np.uint64), vr=np.zeros((5, 2, 2), np.uint64), fin=np.zeros((5, 2), np.uint64),
-                   scalars=np.zeros((5, 2), np.uint64), checks=np.zeros(3, np.int32))
-        o = Out(*[(res[k].ctypes.data if res[k] is not None else None) for k in ("cols", "rows", "reply", "paths", "poly", "r", "vr", "fin", "scalars", "checks")])
+                   scalars=np.zeros((5, 2), np.uint64), checks=np.zeros(3, np.int32), roots=np.zeros((2, 32), np.uint8))
+        o = Out(*[(res[k].ctypes.data if res[k] is not None else None) for k in ("cols", "rows", "reply", "paths", "poly", "r", "vr", "fin", "scalars", "checks", "roots")])
         self._chk(self.lib.hobbit_open_core(self.ctx, ptr, N, c.h, _hp(x), queries, ctypes.byref(o)))
         res["I"] = np.stack([res["cols"], res["rows"]], axis=1)
         return res

@@ -888,8 +888,17 @@ int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     { F rv0 = fmake((uint64_t)random()); rv0 = fadd(rv0, fmake((uint64_t)rand())); memcpy(&o->scalars[0], &rv0, sizeof(F)); }   // generate_randomness(1)
     // device arena
     F *arena = nullptr;
-    const size_t n_el = M + 4 * big + 2 * cols + 4 * rows2 + 2 * (size_t)queries + 128;
+    // + the two inner shockwave commitments kept for the later shockwave_prove: encoded matrices (2M and 2*trs*cols F) and their trees
+    const size_t nc_el = (size_t)trs * cols, sw_el = 2 * M + 2 * nc_el + 2 * (2 * M / 32 + 2 * nc_el / 32) * 2 + 64;
+    const size_t n_el = M + 4 * big + 2 * cols + 4 * rows2 + 2 * (size_t)queries + 128 + sw_el;
     HB_TRY(ctx->workspace3(n_el * sizeof(F), (void **)&arena));
+    {   // size the shared scratch buffers once for the largest user below (the 4M-element sumchecks, the 32-row long FFTs of
+        // the inner commitments): growing them step by step frees and re-maps device memory several times per call
+        void *dummy;
+        const size_t sc_need = (3 * big / 2 + 3 * 1024 + 64) * sizeof(F), fft_need = (size_t)2 * nc_el * sizeof(F);
+        HB_TRY(ctx->workspace(std::max(sc_need, fft_need), &dummy));
+        HB_TRY(ctx->workspace2(std::max(fft_need, (size_t)4 * rows2 * sizeof(F)), &dummy));
+    }
     F *d_aggr = arena, *BIG = d_aggr + M, *Tcm = BIG + big, *d_b = Tcm + big, *d_bb = d_b + big, *d_s = d_bb + big, *d_ev = d_s + cols,
       *d_ac = d_ev + cols, *d_b1 = d_ac + rows2;
     F *Mp = BIG, *C = BIG + (size_t)trs * cols;
@@ -906,6 +915,18 @@ int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     tr.mark("encode");
     HB_TRY(launch_transpose_ld(ctx, Tcm + trs, 0, rows2, (uint32_t)cols, (uint32_t)trs, C, 0, cols, 1));
     tr.mark("aggregate+tensorcode");
+    // _aggregate's inner commitments (src/Our_PC.cpp:274-287): C_f = shockwave_commit(aggr, 32), C_c = shockwave_commit(parity half, 32)
+    {
+        F *sw = d_b1 + rows2 + 2 * (size_t)queries + 64;
+        F *encf = sw, *encc = encf + 2 * M; uint8_t *lvf = reinterpret_cast<uint8_t *>(encc + 2 * nc_el), *lvc = lvf + 64 * (2 * M / 32) ;
+        HB_TRY(hobbit_shockwave_commit(ctx, reinterpret_cast<hobbit_F *>(d_aggr), M, 32, reinterpret_cast<hobbit_F *>(encf), lvf));
+        HB_TRY(hobbit_shockwave_commit(ctx, reinterpret_cast<hobbit_F *>(C), nc_el, 32, reinterpret_cast<hobbit_F *>(encc), lvc));
+        if (o->roots) {
+            HB_TRY(hobbit_memcpy_d2h(ctx, o->roots, lvf + 32 * (2 * (2 * M / 32) - 2), 32));
+            HB_TRY(hobbit_memcpy_d2h(ctx, o->roots + 32, lvc + 32 * (2 * (2 * nc_el / 32) - 2), 32));
+        }
+    }
+    tr.mark("shockwave_commit C_f, C_c");
     // queries (:633-641), replies (:291-305) and Merkle paths (:645-647)
     std::vector<uint32_t> qc(queries), qr(queries); std::vector<uint64_t> Iv(queries);
     for (int q = 0; q < queries; q++) { qc[q] = (uint32_t)(rand() % (long)cols); qr[q] = (uint32_t)(rand() % (long)rows2); Iv[q] = qc[q] + cols * (uint64_t)qr[q]; }

@@ -176,7 +176,8 @@ void hobbit_blake3_64_host(const uint8_t *h_in, uint8_t *h_out, size_t n);
 int hobbit_aggregate(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_F *h_beta, int K, hobbit_F *d_aggr);
 
 /* Our_PC open WITHOUT the inner shockwave/WHIR PCS: open_standard (src/Our_PC.cpp:604-661) and
- * recursive_prover_Spielman (src/PC_utils.cpp:271-385) minus shockwave_commit / shockwave_prove.
+ * recursive_prover_Spielman (src/PC_utils.cpp:271-385) minus the two shockwave_prove calls (shockwave_commit of
+ * the aggregate and of its parity half IS included).
  * Draws libc rand()/random() on the host in the reference's order (r_v[0]; 2 x queries; s; r1; s2; a).
  * All output pointers are host buffers supplied by the caller (cols/rows/reply/paths may be NULL):
  *   cols, rows : queries x u32;  reply : queries x K F;  paths : queries x log2(M) x 32 B
@@ -188,6 +189,8 @@ int hobbit_aggregate(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
 typedef struct {
     uint32_t *cols, *rows; hobbit_F *reply; uint8_t *paths;
     hobbit_F *qpoly, *r, *vr, *fin, *scalars; int *checks;
+    uint8_t *roots;      /* 64 B or NULL: roots of _aggregate's inner commitments C_f = shockwave_commit(aggr, 32) and
+                            C_c = shockwave_commit(parity half, 32) (src/Our_PC.cpp:274-287); both are always computed */
 } hobbit_open_out;
 int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const hobbit_F *h_x, int queries, hobbit_open_out *out);
 

@@ -794,7 +794,7 @@ static void matvec_rows(const oF *Mx, size_t rows, size_t cols, const oF *v, oF 
     for (size_t i = 0; i < rows; i++) { oF a = fint(0); for (size_t j = 0; j < cols; j++) a = f_add(a, f_mul(v[j], Mx[i * cols + j])); out[i] = a; }
 }
 int orc_open_core(const oF *poly, size_t N, int K, int trs, const oF *x, int queries, uint32_t *I_out, oF *reply_out, const oF *tensor /* K x 2trs x cols, row-major */,
-                  oF *scalars_out /* r_v0, s0, s2, a, y1 */, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks) {
+                  oF *scalars_out /* r_v0, s0, s2, a, y1 */, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks, uint8_t *roots /* C_f, C_c (64 B) or NULL */) {
     size_t M = N / (size_t)K, cols = 2 * M / (size_t)trs, rows2 = 2 * (size_t)trs;
     int logK = (int)log2((double)K), logc = (int)log2((double)cols), R1 = (int)log2((double)rows2);
     /* open_standard: beta over the chunk variables, r_v[0] draw, aggregate */
@@ -807,6 +807,14 @@ int orc_open_core(const oF *poly, size_t N, int K, int trs, const oF *x, int que
     oF *T = (oF *)malloc(sizeof(oF) * rows2 * cols);
     orc_compute_tensorcode(aggr, M, trs, 1, T);
     const oF *C = T + (size_t)trs * cols;
+    if (roots) {   /* _aggregate's inner commitments (src/Our_PC.cpp:274-287): C_f over aggr, C_c over the parity half, 32 rows each */
+        size_t nf = M, nc = (size_t)trs * cols;
+        oF *enc = (oF *)malloc(sizeof(oF) * 2 * (nf > nc ? nf : nc));
+        uint8_t *lv = (uint8_t *)malloc(64 * (2 * (nf > nc ? nf : nc) / 32) * 2);
+        size_t cnt = orc_shockwave_commit(aggr, nf, 32, enc, lv); memcpy(roots, lv + 32 * (cnt - 1), 32);
+        cnt = orc_shockwave_commit(C, nc, 32, enc, lv); memcpy(roots + 32, lv + 32 * (cnt - 1), 32);
+        free(enc); free(lv);
+    }
     oF *Mp = (oF *)calloc((size_t)trs * cols, sizeof(oF));
     for (size_t i = 0; i < (size_t)trs; i++) { memcpy(Mp + i * cols, aggr + i * (cols / 2), sizeof(oF) * (cols / 2)); orc_fft(Mp + i * cols, logc, 0); }
     /* queries (src/Our_PC.cpp:633-641) and replies */

@@ -96,7 +96,7 @@ void orc_batch_prod(oF *f1, oF *f2, oF *f3, const oF *b1, const oF *b2, const oF
 
 /* Our_PC open without the inner shockwave/WHIR PCS (see hobbit_oracle.c); returns total rounds */
 int orc_open_core(const oF *poly, size_t N, int K, int trs, const oF *x, int queries, uint32_t *I_out, oF *reply_out, const oF *tensor,
-                  oF *scalars_out, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks);
+                  oF *scalars_out, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks, uint8_t *roots);
 
 /* Elastic_PC streaming commit on the synthetic "test" stream */
 void orc_read_stream_pc(size_t B, oF *out);

@@ -378,11 +378,12 @@ class Oracle(_Base):
         reply = np.zeros((queries, K, 2), np.uint64)
         sc = np.zeros((5, 2), np.uint64); q = np.zeros((rounds, 3, 2), np.uint64); r = np.zeros((rounds, 2), np.uint64)
         vr = np.zeros((5, 2, 2), np.uint64); fin = np.zeros((5, 2), np.uint64); chk = np.zeros(3, np.int32)
+        roots = np.zeros((2, 32), np.uint8)
         t = F(tensor) if tensor is not None else None
         f = self.lib.orc_open_core; f.restype = ctypes.c_int
         f(_p(p), c_sz(N), ctypes.c_int(K), ctypes.c_int(trs), _p(x), ctypes.c_int(queries), _p(I), _p(reply) if t is not None else None,
-          _p(t) if t is not None else None, _p(sc), _p(q), _p(r), _p(vr), _p(fin), _p(chk))
-        return dict(I=I, reply=reply, scalars=sc, poly=q, r=r, vr=vr, fin=fin, checks=chk)
+          _p(t) if t is not None else None, _p(sc), _p(q), _p(r), _p(vr), _p(fin), _p(chk), _p(roots))
+        return dict(I=I, reply=reply, scalars=sc, poly=q, r=r, vr=vr, fin=fin, checks=chk, roots=roots)
 
     def read_stream_pc(self, B):
         o = np.zeros((B, 2), np.uint64)

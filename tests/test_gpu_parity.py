@@ -479,7 +479,7 @@ def test_open_core_vs_oracle(hb, oracle, N, K):
     assert want["checks"].tolist() == [1, 1, 1] and got["checks"].tolist() == [1, 1, 1]
     assert np.array_equal(got["I"], want["I"])
     assert np.array_equal(got["reply"], want["reply"])
-    for k in ("scalars", "poly", "r", "vr", "fin"):
+    for k in ("scalars", "poly", "r", "vr", "fin", "roots"):
         assert np.array_equal(got[k], want[k]), k
     M = N // K
     for q in (0, 17, queries - 1):
