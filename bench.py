@@ -41,6 +41,29 @@ def commit_op_counts(N, K, edges):
     return mul, add, comp
 
 
+ROOFLINE_NOTES = {
+    "k_leaf_chain": "VALU-issue bound, not HBM bound: BLAKE3 compress = 2023 SIMD-cycles per wave-compression with v_alignbit/v_add3 at half rate "
+                    "(profiles/r01_microbench.txt); 2^29+2^23 compressions = 9.4 ms at the 1.78 GHz the chip holds = the measured time",
+    "k_fft4096": "bound by v_mad_u64_u32 issue (12 per F_{p^2} product, half rate)",
+    "k_encode_A": "bound by gather latency (L2 edge records + LDS) and per-slice reduction overhead",
+    "k_encode_B": "bound by seven small dependent SpMV steps (barriers) and gather latency",
+    "k_transpose": "HBM bound",
+}
+
+
+def measured_traffic(kernel, logn, K):
+    """HBM bytes per launch from the rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this same command (profiles/, gfx950-corrected);
+    only valid for the default 2^28 / K=32 workload."""
+    if logn != 28 or K != 32:
+        return None
+    path = os.path.join(ROOT, "profiles", "r01_c_hbm_traffic_commit_2e28.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def open_core_op_counts(N, K, edges):
     """analytic F-mul / F-add of the open core: aggregate N; tensor code of the M-element aggregate; [M'|C].s and
     beta^T[M'|C] (4M each); eq tables (2 x 4M + small); axpy 4M; 2-product sumchecks 6n mul + 10n add
@@ -170,6 +193,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     prof = hb.profile_report()
+    prof.pop("k_fill_splitmix", None)          # the untimed filler in front of the barrier
     hb.profile(False)
 
     t = torch.tensor([wall], dtype=torch.float64, device="cuda")
@@ -214,8 +238,8 @@ def main():
             "op_counts": {"f_mul": mul, "f_add": add, "blake3_compress": comp, "expander_edges": edges, "open_f_mul": omul, "open_f_add": oadd},
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items())},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": dom_ms,
-                         "note": "integer-ALU-bound kernel (v_mad_u64_u32); HBM fraction reported as the contract asks"},
+                         "traffic": measured_traffic(dom, args.logn, K), "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": dom_ms,
+                         "note": ROOFLINE_NOTES.get(dom, "")},
             "root": root,
         }
         if not args.no_cpu_baseline and world == 1:
