@@ -41,6 +41,7 @@ ABI_SYMBOLS = [
     "hobbit_tensorcode_chunks", "hobbit_inner_digests", "hobbit_chain_digests", "hobbit_blake3_64_host",
     "hobbit_parity_matrix", "hobbit_phi_g", "hobbit_prepare_matrix_cols", "hobbit_prove_linear_code", "hobbit_prove_fft",
     "hobbit_prove_fft_matrix",
+    "hobbit_whir_prove", "hobbit_shockwave_prove",
     "hobbit_batch_3product_sumcheck", "hobbit_mul_tree", "hobbit_shockwave_commit", "hobbit_change_form", "hobbit_whir_commit",
     "hobbit_open_core", "hobbit_compute2p_error_terms", "hobbit_compute3p_error_terms", "hobbit_compute4p_error_terms", "hobbit_fold_axpy",
     "hobbit_fold_axpy_i32", "hobbit_batch_prod",
@@ -85,6 +86,7 @@ def load_library(path=LIB_PATH):
         "hobbit_prove_linear_code": [V, V, S, L, V, V, V, V, V], "hobbit_prove_fft": [V, V, S, V, V, V, V, V],
         "hobbit_prove_fft_matrix": [V, V, S, S, V, V, V, V, V],
         "hobbit_open_core": [V, V, S, V, V, I, V],
+        "hobbit_whir_prove": [V, V, S, V, V, V, V, V, V, V], "hobbit_shockwave_prove": [V, V, V, S, I, V, I, V],
         "hobbit_shockwave_commit": [V, V, S, I, V, V], "hobbit_change_form": [V, V, I], "hobbit_whir_commit": [V, V, S, V, V],
         "hobbit_batch_3product_sumcheck": [V, V, V, V, V, I, V, V, V, V], "hobbit_mul_tree": [V, V, S, S, V, V, V, V, V, V, V, V, V, V],
         "hobbit_compute2p_error_terms": [V, V, V, V, V, S, V], "hobbit_compute3p_error_terms": [V, V, V, V, V, V, V, S, V],
@@ -520,6 +522,34 @@ class Hobbit:
         d = self.to_device(p); com = self.alloc(32 * N); lv = self.alloc(32 * N)
         self._chk(self.lib.hobbit_whir_commit(self.ctx, d.ptr, N, com.ptr, lv.ptr))
         return self.to_host(com, (2 * N, 2), np.uint64), self.to_host(lv, (N - 1, 32), np.uint8)
+
+    def whir_prove(self, poly, x):
+        p = Fh(poly).reshape(-1, 2); x = Fh(x).reshape(-1, 2); N = p.shape[0]; logN = N.bit_length() - 1
+        q = np.zeros((logN + 8, 3, 2), np.uint64); a = np.zeros((logN + 8, 2), np.uint64); roots = np.zeros((logN, 32), np.uint8)
+        sc = np.zeros((2, 2), np.uint64); chk = np.zeros(2, np.int32); it = ctypes.c_int()
+        d = self.to_device(p)
+        self._chk(self.lib.hobbit_whir_prove(self.ctx, d.ptr, N, _hp(x), _hp(q), _hp(a), _hp(roots), _hp(sc), _hp(chk), ctypes.byref(it)))
+        it = it.value
+        return dict(iters=np.array([it]), poly=q[:4 * it], a=a[:4 * it], roots=roots[:it], scal=sc, checks=chk)
+
+    def shockwave_prove(self, matrix, enc, k, x):
+        m = Fh(matrix).reshape(-1, 2); e = Fh(enc).reshape(-1, 2); x = Fh(x).reshape(-1, 2)
+        N = m.shape[0]; w = N // k; W = 2 * w; lgW = W.bit_length() - 1; lw = w.bit_length() - 1
+        out = dict(I=np.zeros(240, np.uint32), q1=np.zeros((lgW, 3, 2), np.uint64), r1=np.zeros((lgW, 2), np.uint64), vr1=np.zeros((2, 2), np.uint64),
+                   fin1=np.zeros(2, np.uint64), q2=np.zeros((lgW, 3, 2), np.uint64), r2=np.zeros((lgW, 2), np.uint64), vr2=np.zeros((2, 2), np.uint64),
+                   fin2=np.zeros(2, np.uint64), wq=np.zeros((lw + 8, 3, 2), np.uint64), wa=np.zeros((lw + 8, 2), np.uint64), wroots=np.zeros((lw + 1, 32), np.uint8),
+                   wscal=np.zeros((2, 2), np.uint64), wchecks=np.zeros(2, np.int32), whir_root=np.zeros(32, np.uint8), iters=np.zeros(1, np.int32))
+        names = ("I", "q1", "r1", "vr1", "fin1", "q2", "r2", "vr2", "fin2", "wq", "wa", "wroots", "wscal", "wchecks", "whir_root", "iters")
+
+        class Out(ctypes.Structure):
+            _fields_ = [(n, c_vp) for n in names]
+        o = Out(*[out[n].ctypes.data for n in names])
+        dm, de = self.to_device(m), self.to_device(e)
+        self._chk(self.lib.hobbit_shockwave_prove(self.ctx, dm.ptr, de.ptr, N, k, _hp(x), x.shape[0], ctypes.byref(o)))
+        it = int(out["iters"][0])
+        out["r2"] = out["r2"][:lgW - 1]; out["wq"] = out["wq"][:4 * it]; out["wa"] = out["wa"][:4 * it]; out["wroots"] = out["wroots"][:it]
+        out["iters"] = np.array([it])
+        return out
 
     # ---- batched cubic sumcheck / multiplication tree (src/sumcheck.cpp:275-372, 35-257)
     def batch_3product_sumcheck(self, t1, t2, t3, lens, a):

@@ -158,6 +158,7 @@ void hobbit_ctx_destroy(hobbit_ctx *ctx) {
     if (ctx->ws2) hipFree(ctx->ws2);
     if (ctx->pin) hipHostFree(ctx->pin);
     if (ctx->ws3) hipFree(ctx->ws3);
+    if (ctx->ws4) hipFree(ctx->ws4);
     if (ctx->pinc) hipHostFree(ctx->pinc);
     if (ctx->spare_tensor) hipFree(ctx->spare_tensor);
     if (ctx->spare_levels) hipFree(ctx->spare_levels);
@@ -551,7 +552,7 @@ int hobbit_whir_commit(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, hobbit
     const int logn = ilog2_exact(N);
     if (logn < 4 || logn > 23) return ctx->fail(HOBBIT_EINVAL, "whir_commit: N must be a power of two in [16, 2^23]");
     const size_t L = 2 * N;
-    F *pc; HB_TRY(ctx->workspace3(2 * L * sizeof(F), (void **)&pc));
+    F *pc; HB_TRY(ctx->workspace4(2 * L * sizeof(F), (void **)&pc));      // (the open arena, workspace3, may hold d_poly)
     F *enc = pc + L;
     HB_CHECK(ctx, hipMemcpyAsync(pc, d_poly, N * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
     HB_TRY(hobbit_change_form(ctx, reinterpret_cast<hobbit_F *>(pc), logn));
@@ -559,6 +560,138 @@ int hobbit_whir_commit(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, hobbit
     // buff[j*16 + kk] = poly_com[j + kk * L/16] (:168-173): a (16 x L/16) -> (L/16 x 16) transpose
     HB_TRY(launch_transpose_ld(ctx, enc, 0, L / 16, 16, (uint32_t)(L / 16), mF(d_com), 0, 16, 1));
     return hobbit_mt_commit_blake(ctx, d_com, L, d_levels);
+}
+
+// zero-pad `cur` elements to fsz, change_form, FFT, 16-way regroup, MT_commit_Blake -> root (one FRI layer of _whir_prove,
+// src/Virgo.cpp:581-598).  scratch: 2*fsz F + fsz/2 hashes.
+static int whir_fri_layer(hobbit_ctx *ctx, const F *d_poly, size_t cur, size_t fsz, F *scratch, uint8_t *h_root) {
+    F *fp = scratch, *buf = scratch + fsz; uint8_t *lv = reinterpret_cast<uint8_t *>(buf + fsz);
+    HB_CHECK(ctx, hipMemsetAsync(fp, 0, fsz * sizeof(F), ctx->stream));
+    HB_CHECK(ctx, hipMemcpyAsync(fp, d_poly, cur * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    HB_TRY(hobbit_change_form(ctx, reinterpret_cast<hobbit_F *>(fp), ilog2_exact(cur)));
+    const int lg = ilog2_exact(fsz);
+    if (lg <= 12) HB_TRY(fft_rows(ctx, fp, fsz, (uint32_t)fsz, fp, fsz, 1, lg, false, 1, 1, 0, 0));
+    else HB_TRY(fft_long(ctx, fp, fsz, fsz, fp, lg, false, 1));
+    HB_TRY(launch_transpose_ld(ctx, fp, 0, fsz / 16, 16, (uint32_t)(fsz / 16), buf, 0, 16, 1));
+    HB_TRY(hobbit_mt_commit_blake(ctx, reinterpret_cast<hobbit_F *>(buf), fsz, lv));
+    return hobbit_memcpy_d2h(ctx, h_root, lv + 32 * (2 * (fsz / 4) - 2), 32);
+}
+// compute_zetas (src/Virgo.cpp:220-236), host side, libc draws in the reference's order
+static void compute_zetas_host(std::vector<F> &z, int reps, int v, size_t Nq) {
+    z.assign((size_t)reps * v, fmake(0));
+    z[0] = fmake((uint64_t)random());
+    const F omega = root_of_unity(ilog2_exact(Nq));
+    for (int i = 1; i < reps; i++) z[(size_t)i * v] = fpow(omega, (u128)(rand() % (long)Nq));
+    for (int i = 0; i < reps; i++) for (int j = 1; j < v; j++) z[(size_t)i * v + j] = fmul(z[(size_t)i * v + j - 1], z[(size_t)i * v + j - 1]);
+}
+int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_F *h_x, hobbit_F *h_qpoly, hobbit_F *h_a, uint8_t *h_fri_roots,
+                      hobbit_F *h_scal, int *h_checks, int *iters_out) {
+    const int k = 4, logN = ilog2_exact(N);
+    if (logN < 9 || logN > 24) return ctx->fail(HOBBIT_EINVAL, "whir_prove: N must be a power of two in [2^9, 2^24]");
+    const size_t curmax = N >> k;
+    // scratch (workspace4), carved in order; the first 4N elements are left to a whir_commit an enclosing shockwave_prove ran
+    const size_t sz_front = 4 * N, sz_E = 100 * curmax, sz_fri = 3 * N + 64 /* fp | regrouped copy | Merkle levels */, sz_small = 3 * 1024 + 64 + 100 * 32 + 256 + 256;
+    const size_t n_el = sz_front + 2 * N + 2 * sz_E + sz_fri + sz_small;
+    F *base; HB_TRY(ctx->workspace4(n_el * sizeof(F), (void **)&base));
+    F *poly = base + sz_front, *beta = poly + N, *E0 = beta + N, *E1 = E0 + sz_E, *fri = E1 + sz_E, *part = fri + sz_fri, *coef = part + 3 * 1024, *dz = coef + 64,
+      *dy = dz + 100 * 32, *dpw = dy + 256;
+    HB_CHECK(ctx, hipMemcpyAsync(poly, d_poly, N * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    HB_TRY(hobbit_eq_table(ctx, h_x, logN, reinterpret_cast<hobbit_F *>(beta)));
+    F eval;
+    HB_TRY(launch_matvec_rows(ctx, beta, 1, N, poly, coef));                    // eval = <beta, poly> (:535-538)
+    HB_TRY(hobbit_memcpy_d2h(ctx, &eval, coef, sizeof(F)));
+    F *pin; HB_TRY(ctx->pinned(256 * sizeof(F), (void **)&pin));
+    int iter = 0, repeats = 100, nq = 0; size_t remaining = 0;
+    h_checks[0] = 1; h_checks[1] = 0;
+    for (;;) {
+        for (int i = 0; i < k; i++) {
+            const size_t L = N >> (iter * k + i + 1);
+            const F a = fmake((uint64_t)random());                              // a.push_back(random()) (:561)
+            HB_TRY(launch_whir_round(ctx, poly, beta, L, a, part, coef));
+            HB_CHECK(ctx, hipMemcpyAsync(pin, coef, 3 * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+            HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            const F pa = pin[0], pb = pin[1], pc = pin[2];
+            if (!feq(fadd(fadd(pa, pb), fadd(pc, pc)), eval)) h_checks[0] = 0;  // "Error in %d" (:562-565)
+            eval = fadd(fmul(fadd(fmul(pa, a), pb), a), pc);
+            mF(h_qpoly)[3 * nq] = pa; mF(h_qpoly)[3 * nq + 1] = pb; mF(h_qpoly)[3 * nq + 2] = pc; mF(h_a)[nq] = a; nq++;
+        }
+        iter++;
+        const size_t cur = N >> (k * iter), fsz = (2 * N) >> iter;
+        HB_TRY(whir_fri_layer(ctx, poly, cur, fsz, fri, h_fri_roots + 32 * (iter - 1)));
+        const int queries = (int)(100.0 / log2((double)fsz / (double)cur));
+        if (logN - iter * k <= k) { repeats = queries; remaining = (size_t)1 << (logN - iter * k); break; }
+        const int v = logN - iter * k;
+        std::vector<F> z; compute_zetas_host(z, repeats, v, (2 * N) >> (iter + k));
+        HB_CHECK(ctx, hipMemcpyAsync(dz, z.data(), z.size() * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+        // the `repeats` eq tables side by side, then y = E poly, beta += pows^T E, eval += sum pow_i y_i (:613-633)
+        F *cE = E0, *nE = E1;
+        HB_TRY(launch_fill_F(ctx, cE, cur, (size_t)repeats, fmake(1)));
+        for (int l = 0; l < v; l++) { HB_TRY(launch_eq_step_batched(ctx, cE, nE, (size_t)1 << l, cur, dz, v, l, repeats)); std::swap(cE, nE); }
+        HB_TRY(launch_matvec_rows(ctx, cE, (size_t)repeats, cur, poly, dy));
+        std::vector<F> y(repeats), pw(repeats);
+        HB_TRY(hobbit_memcpy_d2h(ctx, y.data(), dy, (size_t)repeats * sizeof(F)));
+        const F sch = fmake((uint64_t)random()); F p = sch;
+        for (int i = 0; i < repeats; i++) { pw[i] = p; eval = fadd(eval, fmul(p, y[i])); p = fmul(p, sch); }
+        HB_CHECK(ctx, hipMemcpyAsync(dpw, pw.data(), (size_t)repeats * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+        HB_TRY(launch_vecmat(ctx, cE, (size_t)repeats, cur, dpw, nE));          // nE[0..cur) = sum_i pow_i E[i]   (uses ctx->workspace for partials)
+        HB_TRY(launch_axpy(ctx, beta, nE, fmake(1), cur));
+        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));                       // z / pw are stack-owned host vectors
+        repeats = queries;
+    }
+    // final verification step (:641-651)
+    F sum;
+    HB_TRY(launch_matvec_rows(ctx, beta, 1, remaining, poly, coef));
+    HB_TRY(hobbit_memcpy_d2h(ctx, &sum, coef, sizeof(F)));
+    h_checks[1] = feq(sum, eval);
+    mF(h_scal)[0] = eval; mF(h_scal)[1] = sum;
+    {   // closing draws (:652-655), so that the libc stream is left where the reference leaves it
+        const int lr = ilog2_exact(remaining);
+        F cst = fmake(0); for (int i = 0; i < lr; i++) { if (i % 100 == 0) cst = fmake((uint64_t)random()); (void)rand(); }
+        (void)cst;
+        std::vector<F> z; if (repeats > 0 && lr > 0) compute_zetas_host(z, repeats, lr, (2 * N) >> (iter * k));
+    }
+    if (iters_out) *iters_out = iter;
+    return 0;
+}
+// shockwave_prove (src/Virgo.cpp:435-517), prover side
+int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobbit_F *d_enc, size_t N, int k, const hobbit_F *h_x, int xlen, hobbit_shockwave_out *o) {
+    const int lk = ilog2_exact((size_t)k);
+    if (lk < 0 || k > 64 || N % (size_t)k || xlen < lk) return ctx->fail(HOBBIT_EINVAL, "shockwave_prove: bad k / N / x");
+    const size_t w = N / k, W = 2 * w;
+    std::vector<F> beta1((size_t)k); beta1[0] = fmake(1);
+    for (int i = 0; i < lk; i++) for (size_t j = ((size_t)1 << i); j-- > 0;) { F t = fmul(cF(h_x)[xlen - lk + (lk - 1 - i)], beta1[j]); beta1[2 * j + 1] = t; beta1[2 * j] = fsub(beta1[j], t); }
+    // workspace4 layout: [0, nested) belongs to the nested whir_commit / whir_prove calls (they carve from the start and never ask
+    // for more than `nested`, so the buffer is not reallocated under us); our own vectors follow.
+    const size_t nested = 4 * w + 2 * w + 2 * 100 * (w >> 4) + 3 * w + 64 + 3 * 1024 + 64 + 100 * 32 + 512 + 1024;
+    const size_t own = w + W + W + 64 + 256 + 256 /* idx */ + 2 * w + 2 * w /* whir_commit outputs: com, levels */ + 64;
+    F *base; HB_TRY(ctx->workspace4((nested + own) * sizeof(F), (void **)&base));
+    F *mine = base + nested; F *aggr = mine, *at = aggr + w, *b1v = at + W, *dbeta = b1v + W, *ones = dbeta + 64; uint64_t *didx = reinterpret_cast<uint64_t *>(ones + 256);
+    F *wcom = ones + 256 + 256; uint8_t *wlv = reinterpret_cast<uint8_t *>(wcom + 2 * w);
+    HB_CHECK(ctx, hipMemcpyAsync(dbeta, beta1.data(), (size_t)k * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    HB_TRY(launch_vecmat(ctx, cF(d_matrix), (size_t)k, w, dbeta, aggr));        // aggr = beta1^T matrix (:444-456)
+    HB_TRY(launch_vecmat(ctx, cF(d_enc), (size_t)k, W, dbeta, at));
+    if (w > 256 && o->whir_root) {                                           // whir_commit(aggr, C) (:458-461)
+        HB_TRY(hobbit_whir_commit(ctx, reinterpret_cast<hobbit_F *>(aggr), w, reinterpret_cast<hobbit_F *>(wcom), wlv));
+        HB_TRY(hobbit_memcpy_d2h(ctx, o->whir_root, wlv + 32 * (w - 2), 32));
+    }
+    std::vector<uint64_t> I(240); std::vector<F> one(240, fmake(1));
+    for (int i = 0; i < 240; i++) { I[i] = (uint64_t)(rand() % (long)W); if (o->I) o->I[i] = (uint32_t)I[i]; }      // (:463-467)
+    HB_CHECK(ctx, hipMemsetAsync(b1v, 0, W * sizeof(F), ctx->stream));
+    HB_CHECK(ctx, hipMemcpyAsync(ones, one.data(), 240 * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+    HB_CHECK(ctx, hipMemcpyAsync(didx, I.data(), 240 * 8, hipMemcpyHostToDevice, ctx->stream));
+    HB_TRY(launch_scatter(ctx, didx, ones, 240, b1v));
+    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    hobbit_F p33 = {33, 0};
+    HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(at), reinterpret_cast<hobbit_F *>(b1v), W, &p33, o->q1, o->r1, o->vr1, o->fin1));         // (:477)
+    HB_TRY(hobbit_prove_fft(ctx, reinterpret_cast<hobbit_F *>(aggr), w, o->r1, o->q2, o->r2, o->vr2, o->fin2));                                            // (:478)
+    int iters = 0;
+    if (w / 2 > 256) {
+        // _whir_prove works on a copy of aggr inside its own scratch (from the start of workspace4): aggr lives beyond it
+        HB_TRY(hobbit_whir_prove(ctx, reinterpret_cast<hobbit_F *>(aggr), w, o->r2, o->wq, o->wa, o->wroots, o->wscal, o->wchecks, &iters));                 // (:480-481)
+    }
+    if (o->iters) *o->iters = iters;
+    return 0;
 }
 
 // ---- multi-GPU commit building blocks -------------------------------------------

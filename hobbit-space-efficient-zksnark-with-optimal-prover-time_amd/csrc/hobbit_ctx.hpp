@@ -114,6 +114,16 @@ struct hobbit_ctx {
         }
         *p = ws3; return 0;
     }
+    // scratch of the inner-PCS provers (whir / shockwave), separate from the open arena that holds their inputs
+    void *ws4 = nullptr; size_t ws4_bytes = 0;
+    int workspace4(size_t bytes, void **p) {
+        if (bytes > ws4_bytes) {
+            if (ws4) { hipStreamSynchronize(stream); hipFree(ws4); ws4 = nullptr; ws4_bytes = 0; }
+            if (hipMalloc(&ws4, bytes) != hipSuccess) { err = "workspace4 hipMalloc failed"; return HOBBIT_ENOMEM; }
+            ws4_bytes = bytes;
+        }
+        *p = ws4; return 0;
+    }
     // one retired commitment's buffers, kept for the next commit of the same shape (a 2^28 commit
     // owns 16.5 GiB; re-allocating it per call would dominate a repeated-commit loop)
     void *spare_tensor = nullptr; size_t spare_tensor_bytes = 0;

@@ -1142,6 +1142,50 @@ int launch_axpy_i32(hobbit_ctx *ctx, F *y, const int32_t *sel, F a, int one_minu
     return 0;
 }
 
+// ---- _whir_prove (src/Virgo.cpp:519-686) device pieces -----------------------------------------------
+// one fold round over the half split (j, j+L): quadratic coefficients of sum (dp t + p)(db t + b) and, in the same pass,
+// poly[j] += a (poly[j+L] - poly[j]), beta[j] += a (beta[j+L] - beta[j])  (the challenge a = random() does not depend on
+// the polynomial, so it is drawn before the pass)
+__global__ void __launch_bounds__(256) k_whir_round(F *__restrict__ poly, F *__restrict__ beta, size_t L, F a, F *__restrict__ partials) {
+    F c[3] = {fmake(0), fmake(0), fmake(0)};
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < L; j += (size_t)gridDim.x * blockDim.x) {
+        const F p0 = ldF(poly + j), p1 = ldF(poly + j + L), b0 = ldF(beta + j), b1 = ldF(beta + j + L);
+        const F d1 = fsub(p1, p0), d2 = fsub(b1, b0);
+        c[0] = fadd(c[0], fmul(d1, d2)); c[1] = fadd(c[1], fadd(fmul(d1, b0), fmul(p0, d2))); c[2] = fadd(c[2], fmul(p0, b0));
+        stF(poly + j, fadd(p0, fmul(a, d1))); stF(beta + j, fadd(b0, fmul(a, d2)));
+    }
+    block_reduce_store<3>(c, partials);
+}
+int launch_whir_round(hobbit_ctx *ctx, F *poly, F *beta, size_t L, F a, F *part, F *coef) {
+    int nb = grid_for(L, 256, 1024);
+    HB_LAUNCH(ctx, "k_whir_round", k_whir_round, dim3(nb), dim3(256), 0, poly, beta, L, a, part);
+    HB_LAUNCH(ctx, "k_sc_reduce", k_sc_reduce<3>, dim3(1), dim3(256), 0, part, nb, coef);
+    return 0;
+}
+// batched precompute_beta: reps tables of 2^v entries side by side (row stride ld); one doubling level per launch;
+// z[p*v + (v-1-level)] is the challenge of table p at this level
+__global__ void k_eq_step_batched(const F *__restrict__ old, F *__restrict__ nw, size_t m, size_t ld, const F *__restrict__ z, int v, int level) {
+    const F *o = old + (size_t)blockIdx.y * ld; F *n = nw + (size_t)blockIdx.y * ld;
+    const F r = ldF(z + (size_t)blockIdx.y * v + (v - 1 - level));
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < m; j += (size_t)gridDim.x * blockDim.x) {
+        const F x = ldF(o + j), t = fmul(r, x);
+        stF(n + 2 * j, fsub(x, t)); stF(n + 2 * j + 1, t);
+    }
+}
+int launch_eq_step_batched(hobbit_ctx *ctx, const F *old, F *nw, size_t m, size_t ld, const F *z, int v, int level, int reps) {
+    HB_LAUNCH(ctx, "k_eq_step_batched", k_eq_step_batched, dim3(grid_for(m, 256, 256), reps), dim3(256), 0, old, nw, m, ld, z, v, level);
+    return 0;
+}
+__global__ void k_fill_F(F *__restrict__ p, size_t stride, size_t n, F v) {
+    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (g < n) stF(p + g * stride, v);
+}
+int launch_fill_F(hobbit_ctx *ctx, F *p, size_t stride, size_t n, F v) {
+    if (!n) return 0;
+    HB_LAUNCH(ctx, "k_fill_F", k_fill_F, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p, stride, n, v);
+    return 0;
+}
+
 int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev_r, F *h_qpoly, F *h_r, F *h_vr, F *h_final) {
     int rounds = 0; while (((size_t)1 << rounds) < n) rounds++;
     if (((size_t)1 << rounds) != n || n < 2) return ctx->fail(HOBBIT_EINVAL, "sumcheck2: n must be a power of two >= 2");

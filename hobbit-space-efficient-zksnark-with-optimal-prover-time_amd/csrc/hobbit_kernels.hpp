@@ -45,6 +45,9 @@ int launch_mul_layer(hobbit_ctx *ctx, const F *x, size_t n_out, F *in1, F *in2, 
 int launch_transpose_tw(hobbit_ctx *ctx, const F *in, size_t gs, uint32_t R, F *out, const F *tw, uint32_t half, uint32_t groups);
 int launch_col_digest(hobbit_ctx *ctx, const F *enc, size_t W, int k, int quirk, uint8_t *out);
 int launch_change_form_level(hobbit_ctx *ctx, const F *in, F *out, size_t n, size_t S);
+int launch_whir_round(hobbit_ctx *ctx, F *poly, F *beta, size_t L, F a, F *part, F *coef);
+int launch_eq_step_batched(hobbit_ctx *ctx, const F *old, F *nw, size_t m, size_t ld, const F *z, int v, int level, int reps);
+int launch_fill_F(hobbit_ctx *ctx, F *p, size_t stride, size_t n, F v);
 int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev_r, F *h_qpoly, F *h_r, F *h_vr, F *h_final);
 int launch_sumcheck3(hobbit_ctx *ctx, const F *v1, const F *v2, const F *v3, size_t n, F prev_r, F *h_cpoly, F *h_r, F *h_vr, F *h_final);
 }  // namespace hobbit

@@ -158,6 +158,20 @@ int hobbit_change_form(hobbit_ctx *ctx, hobbit_F *d_poly, int logn);
 /* whir_commit: change_form, zero-pad x2, FFT, 16-way regroup (d_com: 2N F), MT_commit_Blake (d_levels: N - 1 hashes... (2N/4)*2-1) */
 int hobbit_whir_commit(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, hobbit_F *d_com, uint8_t *d_levels);
 
+/* _whir_prove (src/Virgo.cpp:519-686), prover side (the verifier emulation inside it draws nothing and changes no
+ * prover state; it is not run).  libc draws on the host in the reference's order.  d_poly: N F (preserved); h_x: log2 N.
+ * h_qpoly: 3 F per fold round, h_a: the fold challenges, h_fri_roots: 32 B per iteration, h_scal: {eval, final sum},
+ * h_checks[2]: the reference's exit(-1) checks (round sums; final verification), 1 = holds. */
+int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_F *h_x, hobbit_F *h_qpoly, hobbit_F *h_a, uint8_t *h_fri_roots,
+                      hobbit_F *h_scal, int *h_checks, int *iters_out);
+/* shockwave_prove (src/Virgo.cpp:435-517), prover side: row aggregation, whir_commit of the aggregate, 240 libc queries,
+ * P1 = 2-product sumcheck against the query indicator, P2 = prove_fft, then _whir_prove.  d_matrix: k x N/k, d_enc: k x 2N/k
+ * (as produced by hobbit_shockwave_commit).  All outputs are host buffers (sizes as hobbit_sumcheck2 / hobbit_whir_prove). */
+typedef struct {
+    uint32_t *I; hobbit_F *q1, *r1, *vr1, *fin1, *q2, *r2, *vr2, *fin2, *wq, *wa; uint8_t *wroots; hobbit_F *wscal; int *wchecks; uint8_t *whir_root; int *iters;
+} hobbit_shockwave_out;
+int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobbit_F *d_enc, size_t N, int k, const hobbit_F *h_x, int xlen, hobbit_shockwave_out *out);
+
 /* ---- multi-GPU commit building blocks (chunk-sharded commit) ------------------ */
 /* tensor codes of `nchunks` consecutive messages of M F each (chunk i at d_msg + i*M), outputs
  * codeword-major per chunk at d_out + i*4M */

@@ -597,6 +597,126 @@ size_t orc_whir_commit(const oF *poly, size_t N, oF *com_out, uint8_t *levels_ou
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* _whir_prove (src/Virgo.cpp:519-686) and shockwave_prove (:435-517), PROVER side only: the     */
+/* verifier emulation inside them (_verify_iteration, MT_commit of replies, verify_claim_opt_     */
+/* blake = SHA3) changes no prover state and draws nothing from libc, and is left out.  libc draws */
+/* are made in the reference's order.  NOT pinned as a whole (the reference functions end in      */
+/* SHA3 and cannot run in oracle/_ref); built from pinned pieces; the reference's own exit(-1)     */
+/* checks ("Error in %d", "Error in final verification step") are evaluated into `checks`.        */
+/* ------------------------------------------------------------------------------------------ */
+static void compute_zetas(oF *z /* [reps][v] */, int reps, int v, size_t Nq) {   /* src/Virgo.cpp:220-236 */
+    z[0] = fint((uint64_t)random());
+    oF omega = root_of_unity((int)log2((double)Nq));
+    for (int i = 1; i < reps; i++) {
+        u128 e = (u128)(rand() % (long)Nq);
+        oF ret = fint(1), tmp = omega;
+        while (e) { if (e & 1) ret = f_mul(ret, tmp); tmp = f_mul(tmp, tmp); e >>= 1; }
+        z[(size_t)i * v] = ret;
+    }
+    for (int i = 0; i < reps; i++) for (int j = 1; j < v; j++) z[(size_t)i * v + j] = f_mul(z[(size_t)i * v + j - 1], z[(size_t)i * v + j - 1]);
+}
+/* outputs: qpoly (3 per fold round, all iterations back to back), a_out (the libc fold challenges), fri_roots (32 B per
+ * iteration), scal = {final eval, final sum}; checks[0] = all round sums matched, checks[1] = final sum == eval.
+ * Returns the number of iterations. */
+int orc_whir_prove(const oF *poly_in, size_t N, const oF *x, oF *qpoly, oF *a_out, uint8_t *fri_roots, oF *scal, int *checks) {
+    const int k = 4, logN = (int)log2((double)N);
+    oF *poly = (oF *)malloc(sizeof(oF) * N), *beta = (oF *)malloc(sizeof(oF) * N);
+    memcpy(poly, poly_in, sizeof(oF) * N);
+    orc_precompute_beta(x, logN, beta);
+    oF eval = fint(0);
+    for (size_t i = 0; i < N; i++) eval = f_add(eval, f_mul(beta[i], poly[i]));
+    int iter = 0, repeats = 100, nq = 0; size_t remaining = 0;
+    checks[0] = 1; checks[1] = 0;
+    for (;;) {
+        for (int i = 0; i < k; i++) {
+            size_t L = N >> (iter * k + i + 1);
+            oF pa = fint(0), pb = fint(0), pc = fint(0);
+            for (size_t j = 0; j < L; j++) {
+                oF d1 = f_sub(poly[j + L], poly[j]), d2 = f_sub(beta[j + L], beta[j]);
+                pa = f_add(pa, f_mul(d1, d2)); pb = f_add(pb, f_add(f_mul(d1, beta[j]), f_mul(poly[j], d2))); pc = f_add(pc, f_mul(poly[j], beta[j]));
+            }
+            oF a = fint((uint64_t)random());
+            oF s01 = f_add(f_add(pa, pb), f_add(pc, pc));
+            if (!(s01.re == eval.re && s01.im == eval.im)) checks[0] = 0;
+            eval = f_add(f_mul(f_add(f_mul(pa, a), pb), a), pc);
+            qpoly[3 * nq] = pa; qpoly[3 * nq + 1] = pb; qpoly[3 * nq + 2] = pc; a_out[nq] = a; nq++;
+            for (size_t j = 0; j < L; j++) { poly[j] = f_add(poly[j], f_mul(a, f_sub(poly[j + L], poly[j]))); beta[j] = f_add(beta[j], f_mul(a, f_sub(beta[j + L], beta[j]))); }
+        }
+        iter++;
+        size_t cur = N >> (k * iter), fsz = (2 * N) >> iter;
+        oF *fp = (oF *)calloc(fsz, sizeof(oF)), *buff = (oF *)malloc(sizeof(oF) * fsz);
+        memcpy(fp, poly, sizeof(oF) * cur);
+        orc_change_form(fp, (int)log2((double)cur));
+        orc_fft(fp, (int)log2((double)fsz), 0);
+        int queries = (int)(100.0 / log2((double)fsz / (double)cur));
+        size_t q16 = fsz / 16, cnt = 0;
+        for (size_t i = 0; i < q16; i++) for (size_t j = 0; j < 16; j++) buff[cnt++] = fp[i + j * q16];
+        uint8_t *lv = (uint8_t *)malloc(32 * (fsz / 2));
+        size_t nl = orc_mt_commit_blake(buff, fsz, lv);
+        memcpy(fri_roots + 32 * (iter - 1), lv + 32 * (nl - 1), 32);
+        free(lv); free(fp); free(buff);
+        if (logN - iter * k <= k) { repeats = queries; remaining = (size_t)1 << (logN - iter * k); break; }
+        int v = logN - iter * k;
+        oF *z = (oF *)malloc(sizeof(oF) * (size_t)repeats * v), *y = (oF *)malloc(sizeof(oF) * (size_t)repeats), *_b = (oF *)malloc(sizeof(oF) * cur);
+        compute_zetas(z, repeats, v, (2 * N) >> (iter + k));
+        for (int i = 0; i < repeats; i++) {
+            orc_precompute_beta(z + (size_t)i * v, v, _b);
+            oF acc = fint(0);
+            for (size_t j = 0; j < cur; j++) acc = f_add(acc, f_mul(_b[j], poly[j]));
+            y[i] = acc;
+        }
+        oF sch = fint((uint64_t)random()), pw = sch;
+        for (int i = 0; i < repeats; i++) {
+            orc_precompute_beta(z + (size_t)i * v, v, _b);
+            for (size_t j = 0; j < cur; j++) beta[j] = f_add(beta[j], f_mul(pw, _b[j]));
+            eval = f_add(eval, f_mul(pw, y[i]));
+            pw = f_mul(pw, sch);
+        }
+        free(z); free(y); free(_b);
+        repeats = queries;
+    }
+    oF sum = fint(0);
+    for (size_t i = 0; i < remaining; i++) sum = f_add(sum, f_mul(poly[i], beta[i]));
+    checks[1] = (sum.re == eval.re && sum.im == eval.im);
+    scal[0] = eval; scal[1] = sum;
+    /* closing draws (src/Virgo.cpp:652-655): generate_randomness(log2 remaining) and one more compute_zetas, kept so that
+     * the libc stream after this call is where the reference leaves it */
+    {
+        int lr = (int)log2((double)remaining);
+        oF *a2 = (oF *)malloc(sizeof(oF) * (size_t)(lr + 1)); orc_generate_randomness(lr, a2); free(a2);
+        oF *z = (oF *)malloc(sizeof(oF) * (size_t)repeats * (size_t)(lr > 0 ? lr : 1));
+        if (repeats > 0 && lr > 0) compute_zetas(z, repeats, lr, (2 * N) >> (iter * k));
+        free(z);
+    }
+    free(poly); free(beta);
+    return iter;
+}
+/* matrix: k x w (the committed polynomial, row-major), enc: k x 2w; x: challenge vector (its last log2 k entries pick the rows).
+ * P1/P2 transcripts as sumcheck2 (P1: log2(2w) rounds, P2: log2(2w) rounds), whir outputs as orc_whir_prove, I_out: 240 indices. */
+int orc_shockwave_prove(const oF *matrix, const oF *enc, size_t N, int k, const oF *x, int xlen, uint32_t *I_out, oF *q1, oF *r1o, oF *vr1, oF *fin1,
+                        oF *q2, oF *r2o, oF *vr2, oF *fin2, oF *wq, oF *wa, uint8_t *wroots, oF *wscal, int *wchecks, uint8_t *whir_root) {
+    size_t w = N / (size_t)k, W = 2 * w; int lk = (int)log2((double)k), lgW = (int)log2((double)W);
+    oF *beta1 = (oF *)malloc(sizeof(oF) * (size_t)k), *aggr = (oF *)calloc(w, sizeof(oF)), *at = (oF *)calloc(W, sizeof(oF));
+    orc_precompute_beta(x + xlen - lk, lk, beta1);
+    for (size_t i = 0; i < W; i++) {
+        if (i < w) for (int j = 0; j < k; j++) aggr[i] = f_add(aggr[i], f_mul(beta1[j], matrix[(size_t)j * w + i]));
+        for (int j = 0; j < k; j++) at[i] = f_add(at[i], f_mul(beta1[j], enc[(size_t)j * W + i]));
+    }
+    if (w > 256) { oF *com = (oF *)malloc(sizeof(oF) * 2 * w); uint8_t *lv = (uint8_t *)malloc(32 * w); size_t c = orc_whir_commit(aggr, w, com, lv); memcpy(whir_root, lv + 32 * (c - 1), 32); free(com); free(lv); }
+    oF *buff1 = (oF *)calloc(W, sizeof(oF));
+    for (int i = 0; i < 240; i++) { I_out[i] = (uint32_t)(rand() % (long)W); }
+    for (int i = 0; i < 240; i++) buff1[I_out[i]] = fint(1);
+    oF p33 = fint(33);
+    orc_sumcheck2(at, buff1, W, &p33, q1, r1o, vr1, fin1);
+    orc_prove_fft(aggr, w, r1o, q2, r2o, vr2, fin2);                 /* prove_fft(aggr, P1.randomness[0], P1.vr[0]) */
+    int iters = 0;
+    if (w / 2 > 256) iters = orc_whir_prove(aggr, w, r2o, wq, wa, wroots, wscal, wchecks);   /* x = P2.randomness[0] minus its last entry: log2 w entries */
+    free(beta1); free(aggr); free(at); free(buff1);
+    (void)lgW;
+    return iters;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* batch_3product_sumcheck (src/sumcheck.cpp:275-372): cubic sumcheck over `batches` table       */
 /* triples of different power-of-two lengths with coefficients a[j]; hash first, then fold;      */
 /* a triple already folded to one element contributes (-x t + x)^3-style terms and folds by      */

@@ -80,6 +80,10 @@ size_t orc_shockwave_commit(const oF *poly, size_t N, int k, oF *enc_out, uint8_
 void orc_change_form(oF *poly, int logn);
 size_t orc_whir_commit(const oF *poly, size_t N, oF *com_out, uint8_t *levels_out);
 
+int orc_whir_prove(const oF *poly_in, size_t N, const oF *x, oF *qpoly, oF *a_out, uint8_t *fri_roots, oF *scal, int *checks);
+int orc_shockwave_prove(const oF *matrix, const oF *enc, size_t N, int k, const oF *x, int xlen, uint32_t *I_out, oF *q1, oF *r1o, oF *vr1, oF *fin1,
+                        oF *q2, oF *r2o, oF *vr2, oF *fin2, oF *wq, oF *wa, uint8_t *wroots, oF *wscal, int *wchecks, uint8_t *whir_root);
+
 /* batched cubic sumcheck and the multiplication-tree prover */
 int orc_batch_3product_sumcheck(oF *t1, oF *t2, oF *t3, const size_t *lens, int batches, const oF *a, oF *cpoly, oF *r_out, oF *vr);
 int orc_mul_tree(const oF *input, size_t vectors, size_t size, const oF *previous_r_in, const oF *prev_x, oF *cpoly, oF *r_out, oF *vr, oF *fin,

@@ -385,6 +385,29 @@ class Oracle(_Base):
           _p(t) if t is not None else None, _p(sc), _p(q), _p(r), _p(vr), _p(fin), _p(chk), _p(roots))
         return dict(I=I, reply=reply, scalars=sc, poly=q, r=r, vr=vr, fin=fin, checks=chk, roots=roots)
 
+    def whir_prove(self, poly, x):
+        p = F(poly).reshape(-1, 2); x = F(x).reshape(-1, 2); N = p.shape[0]
+        logN = N.bit_length() - 1
+        q = np.zeros((logN + 8, 3, 2), np.uint64); a = np.zeros((logN + 8, 2), np.uint64); roots = np.zeros((logN, 32), np.uint8)
+        sc = np.zeros((2, 2), np.uint64); chk = np.zeros(2, np.int32)
+        f = self.lib.orc_whir_prove; f.restype = ctypes.c_int
+        it = f(_p(p), c_sz(N), _p(x), _p(q), _p(a), _p(roots), _p(sc), _p(chk))
+        return dict(iters=np.array([it]), poly=q[:4 * it], a=a[:4 * it], roots=roots[:it], scal=sc, checks=chk)
+
+    def shockwave_prove(self, matrix, enc, k, x):
+        m = F(matrix).reshape(-1, 2); e = F(enc).reshape(-1, 2); x = F(x).reshape(-1, 2)
+        N = m.shape[0]; w = N // k; W = 2 * w; lgW = W.bit_length() - 1; lw = w.bit_length() - 1
+        I = np.zeros(240, np.uint32)
+        q1 = np.zeros((lgW, 3, 2), np.uint64); r1 = np.zeros((lgW, 2), np.uint64); vr1 = np.zeros((2, 2), np.uint64); f1 = np.zeros(2, np.uint64)
+        q2 = np.zeros((lgW, 3, 2), np.uint64); r2 = np.zeros((lgW, 2), np.uint64); vr2 = np.zeros((2, 2), np.uint64); f2 = np.zeros(2, np.uint64)
+        wq = np.zeros((lw + 8, 3, 2), np.uint64); wa = np.zeros((lw + 8, 2), np.uint64); wr = np.zeros((lw + 1, 32), np.uint8)
+        ws = np.zeros((2, 2), np.uint64); wc = np.zeros(2, np.int32); wroot = np.zeros(32, np.uint8)
+        f = self.lib.orc_shockwave_prove; f.restype = ctypes.c_int
+        it = f(_p(m), _p(e), c_sz(N), ctypes.c_int(k), _p(x), ctypes.c_int(x.shape[0]), _p(I), _p(q1), _p(r1), _p(vr1), _p(f1), _p(q2), _p(r2), _p(vr2), _p(f2),
+               _p(wq), _p(wa), _p(wr), _p(ws), _p(wc), _p(wroot))
+        return dict(I=I, q1=q1, r1=r1, vr1=vr1, fin1=f1, q2=q2, r2=r2[:lgW - 1], vr2=vr2, fin2=f2, iters=np.array([it]), wq=wq[:4 * it], wa=wa[:4 * it],
+                    wroots=wr[:it], wscal=ws, wchecks=wc, whir_root=wroot)
+
     def read_stream_pc(self, B):
         o = np.zeros((B, 2), np.uint64)
         self.lib.orc_read_stream_pc(c_sz(B), _p(o))

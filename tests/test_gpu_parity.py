@@ -542,3 +542,30 @@ def test_shockwave_commit_2e21_vs_oracle(hb, oracle):
     p = splitmix_field(1 << 21, 950)
     e1, l1 = hb.shockwave_commit(p, 32); e2, l2 = oracle.shockwave_commit(p, 32)
     assert np.array_equal(e1, e2) and np.array_equal(l1, l2)
+
+
+# ---- inner PCS provers of the opening (prover side) --------------------------------------------------
+@pytest.mark.parametrize("logN", [10, 13, 16, 18])
+def test_whir_prove_vs_oracle(hb, oracle, logN):
+    import ctypes
+    libc = ctypes.CDLL(None)
+    p = splitmix_field(1 << logN, 1); x = splitmix_field(logN, 2)
+    libc.srandom(7); want = oracle.whir_prove(p, x)
+    libc.srandom(7); got = hb.whir_prove(p, x)
+    assert want["checks"].tolist() == [1, 1] and got["checks"].tolist() == [1, 1]      # the reference's exit(-1) checks hold
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+    assert libc.rand() == (libc.srandom(7), oracle.whir_prove(p, x), libc.rand())[2]    # both leave the libc stream at the same point
+
+
+@pytest.mark.parametrize("N,k", [(1 << 16, 32), (1 << 19, 32), (1 << 12, 8)])
+def test_shockwave_prove_vs_oracle(hb, oracle, N, k):
+    import ctypes
+    libc = ctypes.CDLL(None)
+    p = splitmix_field(N, 3)
+    enc, lv = oracle.shockwave_commit(p, k)
+    x = splitmix_field(N.bit_length() - 1, 4)
+    libc.srandom(9); want = oracle.shockwave_prove(p, enc, k, x)
+    libc.srandom(9); got = hb.shockwave_prove(p, enc, k, x)
+    for kk in want:
+        assert np.array_equal(got[kk], want[kk]), kk
