@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "hobbit_prove_fft_matrix",
     "hobbit_whir_prove", "hobbit_shockwave_prove",
     "hobbit_batch_3product_sumcheck", "hobbit_mul_tree", "hobbit_shockwave_commit", "hobbit_change_form", "hobbit_whir_commit",
-    "hobbit_open_core", "hobbit_compute2p_error_terms", "hobbit_compute3p_error_terms", "hobbit_compute4p_error_terms", "hobbit_fold_axpy",
+    "hobbit_open_core", "hobbit_open_standard", "hobbit_compute2p_error_terms", "hobbit_compute3p_error_terms", "hobbit_compute4p_error_terms", "hobbit_fold_axpy",
     "hobbit_fold_axpy_i32", "hobbit_batch_prod",
     "hobbit_aggregate", "hobbit_sumcheck2", "hobbit_sumcheck3", "hobbit_fill_splitmix",
 ]
@@ -85,7 +85,7 @@ def load_library(path=LIB_PATH):
         "hobbit_parity_matrix": [V, V, S, L, V], "hobbit_phi_g": [V, V, I, V, I, V], "hobbit_prepare_matrix_cols": [V, V, S, S, V, I, V],
         "hobbit_prove_linear_code": [V, V, S, L, V, V, V, V, V], "hobbit_prove_fft": [V, V, S, V, V, V, V, V],
         "hobbit_prove_fft_matrix": [V, V, S, S, V, V, V, V, V],
-        "hobbit_open_core": [V, V, S, V, V, I, V],
+        "hobbit_open_core": [V, V, S, V, V, I, V], "hobbit_open_standard": [V, V, S, V, V, I, V],
         "hobbit_whir_prove": [V, V, S, V, V, V, V, V, V, V], "hobbit_shockwave_prove": [V, V, V, S, I, V, I, V],
         "hobbit_shockwave_commit": [V, V, S, I, V, V], "hobbit_change_form": [V, V, I], "hobbit_whir_commit": [V, V, S, V, V],
         "hobbit_batch_3product_sumcheck": [V, V, V, V, V, I, V, V, V, V], "hobbit_mul_tree": [V, V, S, S, V, V, V, V, V, V, V, V, V, V],
@@ -429,9 +429,9 @@ class Hobbit:
         self.sync()
         return Commitment(self, h, N, K, trs)
 
-    def open_core(self, poly, commitment, x, queries, want_paths=True):
-        """open_standard + recursive_prover_Spielman without the inner shockwave/WHIR PCS (host: libc draws in the
-        reference's order).  poly: host array or (DeviceBuffer, N)."""
+    def open_core(self, poly, commitment, x, queries, want_paths=True, full=False):
+        """open_standard + recursive_prover_Spielman (host: libc draws in the reference's order); full=False stops before the
+        two shockwave_prove calls.  poly: host array or (DeviceBuffer, N)."""
         if isinstance(poly, tuple):
             ptr, N = poly; ptr = ptr.ptr if isinstance(ptr, DeviceBuffer) else int(ptr); keep = None
         else:
@@ -440,17 +440,52 @@ class Hobbit:
         R1 = (2 * c.trs).bit_length() - 1; logc = c.cols.bit_length() - 1
         rounds = R1 + logc + 2 * (R1 + logc) + logc
         depth = c.M.bit_length() - 1
+        names = ("cols", "rows", "reply", "paths", "qpoly", "r", "vr", "fin", "scalars", "checks", "roots", "sp_c", "sp_f")
 
         class Out(ctypes.Structure):
-            _fields_ = [(n, c_vp) for n in ("cols", "rows", "reply", "paths", "qpoly", "r", "vr", "fin", "scalars", "checks", "roots")]
+            _fields_ = [(n, c_vp) for n in names]
         res = dict(cols=np.zeros(queries, np.uint32), rows=np.zeros(queries, np.uint32), reply=np.zeros((queries, c.K, 2), np.uint64),
                    paths=np.zeros((queries, depth, 32), np.uint8) if want_paths else None, poly=np.zeros((rounds, 3, 2), np.uint64),
                    r=np.zeros((rounds, 2), np.uint64), vr=np.zeros((5, 2, 2), np.uint64), fin=np.zeros((5, 2), np.uint64),
                    scalars=np.zeros((5, 2), np.uint64), checks=np.zeros(3, np.int32), roots=np.zeros((2, 32), np.uint8))
-        o = Out(*[(res[k].ctypes.data if res[k] is not None else None) for k in ("cols", "rows", "reply", "paths", "poly", "r", "vr", "fin", "scalars", "checks", "roots")])
-        self._chk(self.lib.hobbit_open_core(self.ctx, ptr, N, c.h, _hp(x), queries, ctypes.byref(o)))
+        vals = [(res[k].ctypes.data if res[k] is not None else None) for k in ("cols", "rows", "reply", "paths", "poly", "r", "vr", "fin", "scalars", "checks", "roots")]
+        sp = []
+        if full:
+            sp = [self._sp_buffers(c.trs * c.cols, 32), self._sp_buffers(c.M, 32)]
+            vals += [ctypes.addressof(sp[0][1]), ctypes.addressof(sp[1][1])]
+        else:
+            vals += [None, None]
+        o = Out(*vals)
+        fn = self.lib.hobbit_open_standard if full else self.lib.hobbit_open_core
+        self._chk(fn(self.ctx, ptr, N, c.h, _hp(x), queries, ctypes.byref(o)))
         res["I"] = np.stack([res["cols"], res["rows"]], axis=1)
+        if full:
+            res["sp_c"] = self._sp_trim(sp[0][0], c.trs * c.cols, 32); res["sp_f"] = self._sp_trim(sp[1][0], c.M, 32)
         return res
+
+    def open_standard(self, poly, commitment, x, queries=5900, want_paths=True):
+        """open_standard (src/Our_PC.cpp:604-661), prover side, including both shockwave_prove calls"""
+        return self.open_core(poly, commitment, x, queries, want_paths, full=True)
+
+    _SP_NAMES = ("I", "q1", "r1", "vr1", "fin1", "q2", "r2", "vr2", "fin2", "wq", "wa", "wroots", "wscal", "wchecks", "whir_root", "iters")
+
+    def _sp_buffers(self, N, k):
+        w = N // k; W = 2 * w; lgW = W.bit_length() - 1; lw = w.bit_length() - 1
+        out = dict(I=np.zeros(240, np.uint32), q1=np.zeros((lgW, 3, 2), np.uint64), r1=np.zeros((lgW, 2), np.uint64), vr1=np.zeros((2, 2), np.uint64),
+                   fin1=np.zeros(2, np.uint64), q2=np.zeros((lgW, 3, 2), np.uint64), r2=np.zeros((lgW, 2), np.uint64), vr2=np.zeros((2, 2), np.uint64),
+                   fin2=np.zeros(2, np.uint64), wq=np.zeros((lw + 8, 3, 2), np.uint64), wa=np.zeros((lw + 8, 2), np.uint64), wroots=np.zeros((lw + 1, 32), np.uint8),
+                   wscal=np.zeros((2, 2), np.uint64), wchecks=np.zeros(2, np.int32), whir_root=np.zeros(32, np.uint8), iters=np.zeros(1, np.int32))
+
+        class Out(ctypes.Structure):
+            _fields_ = [(n, c_vp) for n in self._SP_NAMES]
+        return out, Out(*[out[n].ctypes.data for n in self._SP_NAMES])
+
+    @staticmethod
+    def _sp_trim(out, N, k):
+        lgW = (2 * N // k).bit_length() - 1; it = int(out["iters"][0])
+        out["r2"] = out["r2"][:lgW - 1]; out["wq"] = out["wq"][:4 * it]; out["wa"] = out["wa"][:4 * it]; out["wroots"] = out["wroots"][:it]
+        out["iters"] = np.array([it])
+        return out
 
     def aggregate(self, poly, beta):
         p = Fh(poly).reshape(-1, 2); b = Fh(beta).reshape(-1, 2)
@@ -534,22 +569,11 @@ class Hobbit:
 
     def shockwave_prove(self, matrix, enc, k, x):
         m = Fh(matrix).reshape(-1, 2); e = Fh(enc).reshape(-1, 2); x = Fh(x).reshape(-1, 2)
-        N = m.shape[0]; w = N // k; W = 2 * w; lgW = W.bit_length() - 1; lw = w.bit_length() - 1
-        out = dict(I=np.zeros(240, np.uint32), q1=np.zeros((lgW, 3, 2), np.uint64), r1=np.zeros((lgW, 2), np.uint64), vr1=np.zeros((2, 2), np.uint64),
-                   fin1=np.zeros(2, np.uint64), q2=np.zeros((lgW, 3, 2), np.uint64), r2=np.zeros((lgW, 2), np.uint64), vr2=np.zeros((2, 2), np.uint64),
-                   fin2=np.zeros(2, np.uint64), wq=np.zeros((lw + 8, 3, 2), np.uint64), wa=np.zeros((lw + 8, 2), np.uint64), wroots=np.zeros((lw + 1, 32), np.uint8),
-                   wscal=np.zeros((2, 2), np.uint64), wchecks=np.zeros(2, np.int32), whir_root=np.zeros(32, np.uint8), iters=np.zeros(1, np.int32))
-        names = ("I", "q1", "r1", "vr1", "fin1", "q2", "r2", "vr2", "fin2", "wq", "wa", "wroots", "wscal", "wchecks", "whir_root", "iters")
-
-        class Out(ctypes.Structure):
-            _fields_ = [(n, c_vp) for n in names]
-        o = Out(*[out[n].ctypes.data for n in names])
+        N = m.shape[0]
+        out, o = self._sp_buffers(N, k)
         dm, de = self.to_device(m), self.to_device(e)
         self._chk(self.lib.hobbit_shockwave_prove(self.ctx, dm.ptr, de.ptr, N, k, _hp(x), x.shape[0], ctypes.byref(o)))
-        it = int(out["iters"][0])
-        out["r2"] = out["r2"][:lgW - 1]; out["wq"] = out["wq"][:4 * it]; out["wa"] = out["wa"][:4 * it]; out["wroots"] = out["wroots"][:it]
-        out["iters"] = np.array([it])
-        return out
+        return self._sp_trim(out, N, k)
 
     # ---- batched cubic sumcheck / multiplication tree (src/sumcheck.cpp:275-372, 35-257)
     def batch_3product_sumcheck(self, t1, t2, t3, lens, a):

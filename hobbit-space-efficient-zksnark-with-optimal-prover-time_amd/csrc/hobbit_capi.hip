@@ -1006,8 +1006,8 @@ struct OpenTrace {
         t0 = t1;
     }
 };
-int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const hobbit_F *h_x, int queries, hobbit_open_out *o) {
-    if (!c || !o || queries <= 0) return ctx->fail(HOBBIT_EINVAL, "open_core: bad arguments");
+static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const hobbit_F *h_x, int queries, hobbit_open_out *o, bool full) {
+    if (!c || !o || queries <= 0 || (full && (!o->sp_c || !o->sp_f))) return ctx->fail(HOBBIT_EINVAL, "open: bad arguments");
     OpenTrace tr(ctx);
     tr.mark("entry (stream drain)");
     if (!c->lin) return ctx->fail(HOBBIT_EINVAL, "open_core: only the RS x expander (linear_time) code is built");
@@ -1049,9 +1049,10 @@ int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     HB_TRY(launch_transpose_ld(ctx, Tcm + trs, 0, rows2, (uint32_t)cols, (uint32_t)trs, C, 0, cols, 1));
     tr.mark("aggregate+tensorcode");
     // _aggregate's inner commitments (src/Our_PC.cpp:274-287): C_f = shockwave_commit(aggr, 32), C_c = shockwave_commit(parity half, 32)
+    F *sw = d_b1 + rows2 + 2 * (size_t)queries + 64;
+    F *encf = sw, *encc = encf + 2 * M;
     {
-        F *sw = d_b1 + rows2 + 2 * (size_t)queries + 64;
-        F *encf = sw, *encc = encf + 2 * M; uint8_t *lvf = reinterpret_cast<uint8_t *>(encc + 2 * nc_el), *lvc = lvf + 64 * (2 * M / 32) ;
+        uint8_t *lvf = reinterpret_cast<uint8_t *>(encc + 2 * nc_el), *lvc = lvf + 64 * (2 * M / 32) ;
         HB_TRY(hobbit_shockwave_commit(ctx, reinterpret_cast<hobbit_F *>(d_aggr), M, 32, reinterpret_cast<hobbit_F *>(encf), lvf));
         HB_TRY(hobbit_shockwave_commit(ctx, reinterpret_cast<hobbit_F *>(C), nc_el, 32, reinterpret_cast<hobbit_F *>(encc), lvc));
         if (o->roots) {
@@ -1134,7 +1135,23 @@ int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     HB_TRY(hobbit_prove_fft_matrix(ctx, reinterpret_cast<hobbit_F *>(d_aggr), (size_t)trs, cols / 2, r_p4, Q, Rr, o->vr + 8, o->fin + 4));
     { const F *q5 = cF(Q); F c5 = fadd(fadd(q5[0], q5[1]), fadd(q5[2], q5[2])); o->checks[2] = feq(c5, y1); }
     tr.mark("y1, P5");   // src/sumcheck.cpp:3016-3019
+    if (!full) return 0;
+    // shockwave_prove(C_c, P4.r minus its last entry) (src/PC_utils.cpp:368) -- in the reference it runs before P5; P5 draws nothing
+    // from libc, so running it here leaves every draw where the reference has it
+    HB_TRY(hobbit_shockwave_prove(ctx, reinterpret_cast<hobbit_F *>(C), reinterpret_cast<hobbit_F *>(encc), nc_el, 32, r_p4, R3 - 1, o->sp_c));
+    tr.mark("shockwave_prove C_c");
+    // shockwave_prove(C_f, P5.randomness minus its last entry) (:384-385); P5.randomness = [sumcheck r | r1 = P4.r[logc .. logc+log2 trs)] (src/sumcheck.cpp:3021-3023)
+    std::vector<hobbit_F> x5((size_t)logc + (size_t)(R1 - 1));
+    memcpy(x5.data(), Rr, sizeof(hobbit_F) * (size_t)logc); memcpy(x5.data() + logc, r_p4 + logc, sizeof(hobbit_F) * (size_t)(R1 - 1));
+    HB_TRY(hobbit_shockwave_prove(ctx, reinterpret_cast<hobbit_F *>(d_aggr), reinterpret_cast<hobbit_F *>(encf), M, 32, x5.data(), (int)x5.size() - 1, o->sp_f));
+    tr.mark("shockwave_prove C_f");
     return 0;
+}
+int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const hobbit_F *h_x, int queries, hobbit_open_out *o) {
+    return open_impl(ctx, d_poly, N, c, h_x, queries, o, false);
+}
+int hobbit_open_standard(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const hobbit_F *h_x, int queries, hobbit_open_out *o) {
+    return open_impl(ctx, d_poly, N, c, h_x, queries, o, true);
 }
 
 int hobbit_sumcheck2(hobbit_ctx *ctx, const hobbit_F *d_v1, const hobbit_F *d_v2, size_t n, const hobbit_F *prev_r, hobbit_F *h_qpoly,

@@ -205,8 +205,15 @@ typedef struct {
     hobbit_F *qpoly, *r, *vr, *fin, *scalars; int *checks;
     uint8_t *roots;      /* 64 B or NULL: roots of _aggregate's inner commitments C_f = shockwave_commit(aggr, 32) and
                             C_c = shockwave_commit(parity half, 32) (src/Our_PC.cpp:274-287); both are always computed */
+    hobbit_shockwave_out *sp_c, *sp_f;   /* hobbit_open_standard only: transcripts of shockwave_prove(C_c, .) and shockwave_prove(C_f, .) */
 } hobbit_open_out;
 int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const hobbit_F *h_x, int queries, hobbit_open_out *out);
+/* The whole prover side of open_standard (src/Our_PC.cpp:604-661): hobbit_open_core followed by
+ * shockwave_prove(C_c, P4.randomness minus its last entry) (src/PC_utils.cpp:368) and
+ * shockwave_prove(C_f, P5.randomness minus its last entry) (:385), C_c over 32 x (trs*cols/32), C_f over 32 x (M/32).
+ * out->sp_c / out->sp_f must be set (buffer sizes as hobbit_shockwave_prove).  What the reference runs after that
+ * (src/Our_PC.cpp:663-690) is verifier-side accounting whose results are discarded; it is not built. */
+int hobbit_open_standard(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const hobbit_F *h_x, int queries, hobbit_open_out *out);
 
 /* ---- sumchecks ----------------------------------------------------------------------------- */
 /* generate_2product_sumcheck_proof (src/sumcheck.cpp:2391-2460).  Inputs preserved.

@@ -385,6 +385,24 @@ class Oracle(_Base):
           _p(t) if t is not None else None, _p(sc), _p(q), _p(r), _p(vr), _p(fin), _p(chk), _p(roots))
         return dict(I=I, reply=reply, scalars=sc, poly=q, r=r, vr=vr, fin=fin, checks=chk, roots=roots)
 
+    def open_standard(self, poly, K, trs, x, queries, tensor=None):
+        """Prover side of open_standard (src/Our_PC.cpp:604-661): open_core, then shockwave_prove(C_c, P4.r[:-1])
+        (src/PC_utils.cpp:368) and shockwave_prove(C_f, P5.randomness[:-1]) (:385).  The libc generator runs on across the
+        three calls as in the reference (shockwave_commit / aggregate / tensorcode draw nothing)."""
+        p = F(poly).reshape(-1, 2); x = F(x).reshape(-1, 2)
+        N = p.shape[0]; M = N // K; cols = 2 * M // trs
+        R1 = (2 * trs).bit_length() - 1; logc = cols.bit_length() - 1; R3 = R1 + logc; logK = K.bit_length() - 1
+        res = self.open_core(p, K, trs, x, queries, tensor)
+        aggr = self.aggregate(p, self.precompute_beta(x[:logK]))
+        C = self.compute_tensorcode(aggr, trs, 1).reshape(2 * trs, cols, 2)[trs:].reshape(-1, 2)
+        o4 = R1 + logc + R3; r4 = res["r"][o4:o4 + R3]; r5 = res["r"][o4 + R3:o4 + R3 + logc]
+        enc_c, _ = self.shockwave_commit(C, 32)
+        res["sp_c"] = self.shockwave_prove(C, enc_c, 32, r4[:-1])
+        enc_f, _ = self.shockwave_commit(aggr, 32)
+        x5 = np.concatenate([r5, r4[logc:logc + R1 - 1]])[:-1]
+        res["sp_f"] = self.shockwave_prove(aggr, enc_f, 32, x5)
+        return res
+
     def whir_prove(self, poly, x):
         p = F(poly).reshape(-1, 2); x = F(x).reshape(-1, 2); N = p.shape[0]
         logN = N.bit_length() - 1

@@ -487,6 +487,34 @@ def test_open_core_vs_oracle(hb, oracle, N, K):
     c.free()
 
 
+SP_KEYS = ("I", "q1", "r1", "vr1", "fin1", "q2", "r2", "vr2", "fin2", "iters", "wq", "wa", "wroots", "wscal", "wchecks", "whir_root")
+
+
+@pytest.mark.parametrize("N,K", [(1 << 20, 32), (1 << 22, 32)])
+def test_open_standard_vs_oracle(hb, oracle, N, K):
+    """The whole prover side of open_standard (src/Our_PC.cpp:604-661): the core above followed by
+    shockwave_prove(C_c, .) and shockwave_prove(C_f, .) (src/PC_utils.cpp:368,385) with their WHIR proofs; every transcript
+    bit-exact against the oracle, libc draws in the reference's order across all three stages."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    trs = N // (K << 11)
+    oracle.rng_reset(); poly = oracle.generate_randomness(N); oracle.expander_init_store(trs)
+    x = oracle.generate_randomness(N.bit_length() - 1)
+    queries = 5900
+    libc.srandom(777); want = oracle.open_standard(poly, K, trs, x, queries)
+    hb.upload_graphs(trs, graphs_from(oracle, trs))
+    c = hb.commit_standard(poly, K, trs, 1)
+    libc.srandom(777); got = hb.open_standard(poly, c, x, queries, want_paths=False)
+    assert want["checks"].tolist() == [1, 1, 1] and got["checks"].tolist() == [1, 1, 1]
+    for k in ("I", "scalars", "poly", "r", "vr", "fin", "roots"):
+        assert np.array_equal(got[k], want[k]), k
+    for sp in ("sp_c", "sp_f"):
+        assert want[sp]["wchecks"].tolist() == [1, 1], sp
+        for k in SP_KEYS:
+            assert np.array_equal(got[sp][k], want[sp][k]), (sp, k)
+    c.free()
+
+
 # ---- streaming-sumcheck error terms and folds ----------------------------------------------------
 def test_streamfold_vs_golden(hb):
     g = gold("streamfold")
