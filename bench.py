@@ -78,6 +78,47 @@ def open_core_op_counts(N, K, edges):
     return mul, add
 
 
+def whir_prove_op_counts(N):
+    """F-mul / F-add of _whir_prove's prover side (src/Virgo.cpp:519-686) on an N-coefficient polynomial, counted from the
+    restatement in oracle/hobbit_oracle.c: eq table + evaluation (2N), 4 fold rounds per iteration (6L mul + 10L add each),
+    one FRI layer FFT per iteration, and 100 (then 100/log2(rate)) out-of-domain eq tables of N/16^iter entries used three times."""
+    logn = N.bit_length() - 1
+    mul = add = 2 * N
+    it, reps = 0, 100
+    while True:
+        for i in range(4):
+            L = N >> (4 * it + i + 1)
+            mul += 6 * L; add += 10 * L
+        it += 1
+        cur, fsz = N >> (4 * it), (2 * N) >> it
+        mul += fft_butterflies(fsz); add += 2 * fft_butterflies(fsz) + fft_butterflies(cur)       # FFT + change_form
+        if logn - 4 * it <= 4:
+            return mul + cur, add + cur
+        mul += reps * 4 * cur; add += reps * 4 * cur
+        reps = int(100.0 / ((fsz // cur).bit_length() - 1))
+
+
+def shockwave_prove_op_counts(N, k=32):
+    """shockwave_prove (src/Virgo.cpp:435-517) on a k x (N/k) matrix: row aggregation of the matrix and of its encoding (3N),
+    whir_commit of the aggregate (change_form + 2w-point FFT), P1 (2-product sumcheck over 2w), prove_fft (phiGInit + sumcheck
+    over 2w) and _whir_prove on w coefficients."""
+    w = N // k; W = 2 * w
+    mul = 3 * N + fft_butterflies(W) + 6 * W + W + 6 * W
+    add = 3 * N + 2 * fft_butterflies(W) + fft_butterflies(w) + 10 * W + W + 10 * W
+    wm, wa = whir_prove_op_counts(w)
+    return mul + wm, add + wa
+
+
+def open_op_counts(N, K, edges, full=True):
+    mul, add = open_core_op_counts(N, K, edges)
+    if full:
+        M = N // K
+        for n in (2 * M, M):                         # C_c over the parity half (trs*cols = 2M), C_f over the aggregate (M)
+            m_, a_ = shockwave_prove_op_counts(n)
+            mul += m_; add += a_
+    return mul, add
+
+
 def algorithmic_bytes(N, K, world=1, sharded=False):
     """HBM-compulsory bytes per launch of each commit kernel (DESIGN.md 'Kernels'): what the
     algorithm must move given that the tensor is retained, not what the kernel happens to move."""
@@ -107,8 +148,9 @@ def main():
     ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
                     help="N>1: replicas = one independent polynomial per GPU (weak); sharded = ONE commitment, chunks sharded over the GPUs "
                          "with the digest exchange + subtree-root all-gather of parallel.py (strong)")
-    ap.add_argument("--phase", choices=["commit", "commit+open"], default="commit+open",
-                    help="commit+open adds open_standard + recursive_prover_Spielman WITHOUT the inner shockwave/WHIR PCS (DESIGN.md 7)")
+    ap.add_argument("--phase", choices=["commit", "commit+open", "commit+opencore"], default="commit+open",
+                    help="commit+open adds the whole prover side of open_standard (recursive_prover_Spielman with both shockwave_prove/WHIR proofs); "
+                         "commit+opencore stops before the two shockwave_prove calls")
     ap.add_argument("--queries", type=int, default=5900)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-logn", type=int, default=22)
@@ -156,7 +198,8 @@ def main():
         hb.sync()
         last = {}
 
-    do_open = args.phase == "commit+open" and not sharded
+    do_open = args.phase != "commit" and not sharded
+    full_open = args.phase == "commit+open"
     import numpy as np
     x_open = np.stack([np.arange(1, args.logn + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15 % ((1 << 61) - 1)) % np.uint64((1 << 61) - 1),
                        np.arange(7, args.logn + 7, dtype=np.uint64) * np.uint64(1234567891011) % np.uint64((1 << 61) - 1)], axis=1)
@@ -169,7 +212,7 @@ def main():
             return
         c = hb.commit_standard((d_poly, N), K, trs, 1)
         if do_open:
-            open_last["res"] = hb.open_core((d_poly, N), c, x_open, args.queries)
+            open_last["res"] = hb.open_core((d_poly, N), c, x_open, args.queries, full=full_open)
         c.free()                          # parks the 16.5 GiB of buffers for the next step
 
     for _ in range(args.warmup):
@@ -211,9 +254,12 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * wall_max / args.steps
-        omul, oadd = open_core_op_counts(N, K, edges) if do_open else (0, 0)
+        omul, oadd = open_op_counts(N, K, edges, full_open) if do_open else (0, 0)
         if do_open:
             assert open_last["res"]["checks"].tolist() == [1, 1, 1], "open: the reference's consistency checks failed"
+            if full_open:
+                for sp in ("sp_c", "sp_f"):
+                    assert open_last["res"][sp]["wchecks"].tolist() == [1, 1], "open: WHIR round / final checks failed in " + sp
         ops = (mul + add + omul + oadd) * (1 if sharded else world)
         value = ops / (wall_max / args.steps)
         ab = algorithmic_bytes(N, K, world, sharded)
@@ -226,9 +272,11 @@ def main():
             "value": value, "unit": "field-ops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "u64 (F_{p^2}, p=2^61-1) + u32 (BLAKE3)", "data": "synthetic (device splitmix64 full-range coefficients; libc-drawn expander graphs)",
-            "config": {"workload": ("Our_PC test_PC(2^%d,4,%d): commit_standard + open_standard/recursive_prover_Spielman WITHOUT the inner shockwave/WHIR PCS "
-                                    "(aggregate, tensor code of the aggregate, %d queries + replies + Merkle paths, prove_linear_code, three 2-product sumchecks "
-                                    "(4096, 2^%d, 2^%d), prove_fft_matrix); trs=%d, cols=4096, tensor retained in HBM" % (args.logn, K, args.queries, args.logn - 3, args.logn - 3, trs))
+            "config": {"workload": ("Our_PC test_PC(2^%d,4,%d): commit_standard + open_standard/recursive_prover_Spielman %s "
+                                    "(aggregate, tensor code of the aggregate, shockwave_commit C_f/C_c, %d queries + replies + Merkle paths, prove_linear_code, "
+                                    "three 2-product sumchecks (4096, 2^%d, 2^%d), prove_fft_matrix%s); trs=%d, cols=4096, tensor retained in HBM"
+                                    % (args.logn, K, "prover side in full" if full_open else "WITHOUT the two shockwave_prove/WHIR proofs", args.queries,
+                                       args.logn - 3, args.logn - 3, ", shockwave_prove(C_c) and shockwave_prove(C_f) with their WHIR proofs" if full_open else "", trs))
                        if do_open else
                        "Our_PC commit_standard (test_PC(2^%d,4,%d) commit phase): trs=%d, cols=4096, tensor retained in HBM; open phase not in the timed region" % (args.logn, K, trs),
                        "N": N, "K": K, "trs": trs, "mode": args.mode, "polynomials_per_gpu": (1.0 / world) if sharded else 1},
@@ -245,7 +293,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_logn, K)
             if do_open:
-                out["cpu_baseline_open_port"] = cpu_open_port(args.cpu_logn, K, args.queries)
+                out["cpu_baseline_open_port"] = cpu_open_port(args.cpu_logn, K, args.queries, full_open)
         print(json.dumps(out))
     hb.close()
     if dist is not None:
@@ -276,8 +324,8 @@ def cpu_baseline(logn, K):
                       "test_PC(2^%d,4,%d) inputs (trs=%d): the bench workload at 1/%d of its size, single thread" % (logn, K, trs, 1 << (28 - logn))}
 
 
-def cpu_open_port(logn, K, queries):
-    """The open core on the CPU: the oracle's restatement (kind "port", 1 thread); the reference's own open_standard cannot
+def cpu_open_port(logn, K, queries, full=True):
+    """The open on the CPU: the oracle's restatement (kind "port", 1 thread); the reference's own open_standard cannot
     run here because it ends in SHA3 from the prebuilt lib/libXKCP.a, which is not linked."""
     from oracle import pyoracle
     orc = pyoracle.Oracle()
@@ -286,15 +334,16 @@ def cpu_open_port(logn, K, queries):
     orc.rng_reset(); poly = orc.generate_randomness(n); orc.expander_init_store(trs)
     x = orc.generate_randomness(logn)
     t0 = time.perf_counter()
-    res = orc.open_core(poly, K, trs, x, queries)
+    res = orc.open_standard(poly, K, trs, x, queries) if full else orc.open_core(poly, K, trs, x, queries)
     secs = time.perf_counter() - t0
     edges, dep, m = 0, 0, trs
     while m > 13:
         edges += orc.graph(dep, 0)["L"] * 9 + orc.graph(dep, 1)["L"] * 12
         m = int(0.211 * m); dep += 1
-    mul, add = open_core_op_counts(n, K, edges)
+    mul, add = open_op_counts(n, K, edges, full)
     return {"value": (mul + add) / secs, "unit": "field-ops/s", "cores": 1, "kind": "port", "seconds": secs, "checks": res["checks"].tolist(),
-            "sample": "open core (no shockwave_prove/WHIR) on test_PC(2^%d,4,%d) inputs, single thread, includes the two shockwave_commit" % (logn, K)}
+            "sample": "open_standard prover side (%s) on test_PC(2^%d,4,%d) inputs, single thread"
+                      % ("with both shockwave_prove/WHIR proofs" if full else "no shockwave_prove/WHIR", logn, K)}
 
 
 if __name__ == "__main__":
