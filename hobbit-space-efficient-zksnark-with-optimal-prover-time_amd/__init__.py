@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "hobbit_prove_fft_matrix",
     "hobbit_whir_prove", "hobbit_shockwave_prove",
     "hobbit_batch_3product_sumcheck", "hobbit_mul_tree", "hobbit_shockwave_commit", "hobbit_change_form", "hobbit_whir_commit",
-    "hobbit_open_core", "hobbit_open_standard", "hobbit_compute2p_error_terms", "hobbit_compute3p_error_terms", "hobbit_compute4p_error_terms", "hobbit_fold_axpy",
+    "hobbit_open_core", "hobbit_open_standard", "hobbit_gate_sumcheck", "hobbit_compute2p_error_terms", "hobbit_compute3p_error_terms", "hobbit_compute4p_error_terms", "hobbit_fold_axpy",
     "hobbit_fold_axpy_i32", "hobbit_batch_prod",
     "hobbit_aggregate", "hobbit_sumcheck2", "hobbit_sumcheck3", "hobbit_fill_splitmix",
 ]
@@ -85,6 +85,7 @@ def load_library(path=LIB_PATH):
         "hobbit_parity_matrix": [V, V, S, L, V], "hobbit_phi_g": [V, V, I, V, I, V], "hobbit_prepare_matrix_cols": [V, V, S, S, V, I, V],
         "hobbit_prove_linear_code": [V, V, S, L, V, V, V, V, V], "hobbit_prove_fft": [V, V, S, V, V, V, V, V],
         "hobbit_prove_fft_matrix": [V, V, S, S, V, V, V, V, V],
+        "hobbit_gate_sumcheck": [V, V, V, V, V, V, V, S, V, V, V, V, V, V, V],
         "hobbit_open_core": [V, V, S, V, V, I, V], "hobbit_open_standard": [V, V, S, V, V, I, V],
         "hobbit_whir_prove": [V, V, S, V, V, V, V, V, V, V], "hobbit_shockwave_prove": [V, V, V, S, I, V, I, V],
         "hobbit_shockwave_commit": [V, V, S, I, V, V], "hobbit_change_form": [V, V, I], "hobbit_whir_commit": [V, V, S, V, V],
@@ -690,6 +691,15 @@ class Hobbit:
         q = np.zeros((rounds, 4, 2), np.uint64); r = np.zeros((rounds, 2), np.uint64); vr = np.zeros((3, 2), np.uint64); fin = np.zeros(2, np.uint64)
         self._chk(self.lib.hobbit_sumcheck3(self.ctx, c_vp(p1), c_vp(p2), c_vp(p3), c_sz(n), _hp(pr), _hp(q), _hp(r), _hp(vr), _hp(fin)))
         return dict(poly=q, r=r, vr=vr, fin=fin)
+
+    def gate_sumcheck(self, tables, a, rand, claimed_sum):
+        """degree-4 gate-consistency sumcheck (src/sumcheck.cpp:875-929); tables = (add, beta, L, R, O, mul)"""
+        devs = [self._dev_table(t) for t in tables]
+        n = devs[0][1]; rounds = n.bit_length() - 1
+        a = Fh(a).reshape(4, 2); rnd = Fh(rand).reshape(2).copy(); sm = Fh(claimed_sum).reshape(2).copy()
+        q = np.zeros((rounds, 5, 2), np.uint64); r = np.zeros((rounds, 2), np.uint64); fin = np.zeros((6, 2), np.uint64); chk = ctypes.c_int(0)
+        self._chk(self.lib.hobbit_gate_sumcheck(self.ctx, *[c_vp(d[0]) for d in devs], c_sz(n), _hp(a), _hp(rnd), _hp(sm), _hp(q), _hp(r), _hp(fin), ctypes.byref(chk)))
+        return dict(poly=q, r=r, fin=fin, rand=rnd, sum=sm, check=np.array([chk.value], np.int32))
 
 
 # ---- submodule: chunk-sharded multi-GPU commit orchestration --------------------------------

@@ -1158,6 +1158,11 @@ int hobbit_sumcheck2(hobbit_ctx *ctx, const hobbit_F *d_v1, const hobbit_F *d_v2
                      hobbit_F *h_r, hobbit_F *h_vr, hobbit_F *h_final) {
     return launch_sumcheck2(ctx, cF(d_v1), cF(d_v2), n, *cF(prev_r), mF(h_qpoly), mF(h_r), mF(h_vr), mF(h_final));
 }
+int hobbit_gate_sumcheck(hobbit_ctx *ctx, const hobbit_F *d_add, const hobbit_F *d_beta, const hobbit_F *d_L, const hobbit_F *d_R, const hobbit_F *d_O, const hobbit_F *d_mul,
+                         size_t n, const hobbit_F *h_a, hobbit_F *h_rand, hobbit_F *h_sum, hobbit_F *h_poly, hobbit_F *h_r, hobbit_F *h_final, int *h_check) {
+    const F *tabs[6] = {cF(d_add), cF(d_beta), cF(d_L), cF(d_R), cF(d_O), cF(d_mul)};
+    return launch_gate_sumcheck(ctx, tabs, n, cF(h_a), mF(h_rand), mF(h_sum), mF(h_poly), mF(h_r), mF(h_final), h_check);
+}
 int hobbit_sumcheck3(hobbit_ctx *ctx, const hobbit_F *d_v1, const hobbit_F *d_v2, const hobbit_F *d_v3, size_t n, const hobbit_F *prev_r,
                      hobbit_F *h_cpoly, hobbit_F *h_r, hobbit_F *h_vr, hobbit_F *h_final) {
     return launch_sumcheck3(ctx, cF(d_v1), cF(d_v2), cF(d_v3), n, *cF(prev_r), mF(h_cpoly), mF(h_r), mF(h_vr), mF(h_final));

@@ -1234,6 +1234,134 @@ int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev
     return 0;
 }
 
+// ---- degree-4 gate-consistency sumcheck (src/sumcheck.cpp:875-929) --------------------------------------
+// Tables t[0..5] = fold_add, fold_beta, fold_L, fold_R, fold_O, fold_mul.  Per pair, twelve coefficient sums:
+// c[0..3]  cubic   add * beta * (a0 L + a1 R)      (l1*l2*l3, src/polynomial.cpp:91-93,133-135)
+// c[4..8]  quartic mul * beta * L * R              (cubic * linear, :99-101)
+// c[9..11] quadratic beta * O
+// The host combines them with a2, a3 (:899-903), hashes (mimc_hash(coefficient, rand): coefficient is the input) and folds.
+struct GateTabs { const F *s[6]; F *d[6]; };
+HB_HD void gate_acc(F (&c)[12], const F (&b)[6], const F (&e)[6], const F &a0, const F &a1) {
+    F d[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) d[q] = fsub(e[q], b[q]);
+    F l3a = fadd(fmul(a0, d[2]), fmul(a1, d[3])), l3b = fadd(fmul(a0, b[2]), fmul(a1, b[3]));
+    F qa = fmul(d[0], d[1]), qb = fadd(fmul(d[0], b[1]), fmul(b[0], d[1])), qc = fmul(b[0], b[1]);
+    c[0] = fadd(c[0], fmul(qa, l3a));
+    c[1] = fadd(c[1], fadd(fmul(qa, l3b), fmul(qb, l3a)));
+    c[2] = fadd(c[2], fadd(fmul(qb, l3b), fmul(qc, l3a)));
+    c[3] = fadd(c[3], fmul(qc, l3b));
+    F ma = fmul(d[5], d[1]), mb = fadd(fmul(d[5], b[1]), fmul(b[5], d[1])), mc = fmul(b[5], b[1]);
+    F ka = fmul(ma, d[2]), kb = fadd(fmul(ma, b[2]), fmul(mb, d[2])), kc = fadd(fmul(mb, b[2]), fmul(mc, d[2])), kd = fmul(mc, b[2]);
+    c[4] = fadd(c[4], fmul(ka, d[3]));
+    c[5] = fadd(c[5], fadd(fmul(ka, b[3]), fmul(kb, d[3])));
+    c[6] = fadd(c[6], fadd(fmul(kb, b[3]), fmul(kc, d[3])));
+    c[7] = fadd(c[7], fadd(fmul(kc, b[3]), fmul(kd, d[3])));
+    c[8] = fadd(c[8], fmul(kd, b[3]));
+    c[9] = fadd(c[9], fmul(d[1], d[4]));
+    c[10] = fadd(c[10], fadd(fmul(d[1], b[4]), fmul(b[1], d[4])));
+    c[11] = fadd(c[11], fmul(b[1], b[4]));
+}
+// round 0: polynomial only
+__global__ void __launch_bounds__(256) k_gate_poly(GateTabs t, size_t L, F a0, F a1, F *__restrict__ partials) {
+    F c[12];
+#pragma unroll
+    for (int q = 0; q < 12; q++) c[q] = fmake(0);
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < L; j += (size_t)gridDim.x * blockDim.x) {
+        F b[6], e[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) { b[q] = ldF(t.s[q] + 2 * j); e[q] = ldF(t.s[q] + 2 * j + 1); }
+        gate_acc(c, b, e, a0, a1);
+    }
+    block_reduce_store<12>(c, partials);
+}
+// rounds >= 1: fold the previous tables (4 -> 2 elements per thread and table) and accumulate this round's sums
+__global__ void __launch_bounds__(256) k_gate_fold_poly(GateTabs t, size_t L, F r, F a0, F a1, F *__restrict__ partials) {
+    F c[12];
+#pragma unroll
+    for (int q = 0; q < 12; q++) c[q] = fmake(0);
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < L; j += (size_t)gridDim.x * blockDim.x) {
+        F b[6], e[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            F x0 = ldF(t.s[q] + 4 * j), x1 = ldF(t.s[q] + 4 * j + 1), x2 = ldF(t.s[q] + 4 * j + 2), x3 = ldF(t.s[q] + 4 * j + 3);
+            b[q] = fadd(x0, fmul(r, fsub(x1, x0))); e[q] = fadd(x2, fmul(r, fsub(x3, x2)));
+            stF(t.d[q] + 2 * j, b[q]); stF(t.d[q] + 2 * j + 1, e[q]);
+        }
+        gate_acc(c, b, e, a0, a1);
+    }
+    block_reduce_store<12>(c, partials);
+}
+// one transcript step: combine the twelve sums into the quartic (a..e), hash, check against the running sum, evaluate
+static bool gate_round_host(const F *c, const F *a, F &rnd, F &sum, F *poly_out, F *r_out) {
+    F p[5];
+    p[0] = fmul(a[2], c[4]);
+    p[1] = fadd(fmul(a[2], c[5]), c[0]);
+    p[2] = fadd(fadd(fmul(a[2], c[6]), c[1]), fmul(a[3], c[9]));
+    p[3] = fadd(fadd(fmul(a[2], c[7]), c[2]), fmul(a[3], c[10]));
+    p[4] = fadd(fadd(fmul(a[2], c[8]), c[3]), fmul(a[3], c[11]));
+    for (int q = 0; q < 5; q++) { rnd = mimc_hash(p[q], rnd); poly_out[q] = p[q]; }
+    F s01 = fadd(fadd(fadd(p[0], p[1]), fadd(p[2], p[3])), fadd(p[4], p[4]));
+    bool ok = feq(s01, sum);                                              // "Error in gate consistency 2" (:909-912)
+    sum = fadd(fmul(fadd(fmul(fadd(fmul(fadd(fmul(p[0], rnd), p[1]), rnd), p[2]), rnd), p[3]), rnd), p[4]);
+    *r_out = rnd;
+    return ok;
+}
+// inputs are preserved (the reference folds in place and afterwards only reads element 0 of each table: h_final)
+int launch_gate_sumcheck(hobbit_ctx *ctx, const F *const tabs[6], size_t n, const F *h_a, F *h_rand, F *h_sum, F *h_poly, F *h_r, F *h_final, int *h_check) {
+    int rounds = 0; while (((size_t)1 << rounds) < n) rounds++;
+    if (((size_t)1 << rounds) != n || n < 2) return ctx->fail(HOBBIT_EINVAL, "gate_sumcheck: n must be a power of two >= 2");
+    const int MAXB = 512;
+    F rnd = *h_rand, sum = *h_sum; bool ok = true;
+    std::vector<F> host[6];
+    size_t cur = n; int i = 0; bool pending = false;
+    if (n > SC_TAIL) {
+        size_t szA = n / 2, szB = n / 4;
+        F *ws; HB_TRY(ctx->workspace((6 * (szA + szB) + (size_t)MAXB * 12 + 16) * sizeof(F), (void **)&ws));
+        F *A = ws, *B = A + 6 * szA, *part = B + 6 * szB, *coef = part + (size_t)MAXB * 12;
+        F *pin; HB_TRY(ctx->pinned(12 * sizeof(F), (void **)&pin));
+        GateTabs t;
+        for (int q = 0; q < 6; q++) { t.s[q] = tabs[q]; t.d[q] = A + (size_t)q * szA; }
+        bool toA = true;
+        for (;; i++) {
+            size_t L = n >> (i + 1);
+            int nb = grid_for(L, 256, MAXB);
+            if (i == 0) HB_LAUNCH(ctx, "k_gate_poly", k_gate_poly, dim3(nb), dim3(256), 0, t, L, h_a[0], h_a[1], part);
+            else {
+                HB_LAUNCH(ctx, "k_gate_fold_poly", k_gate_fold_poly, dim3(nb), dim3(256), 0, t, L, rnd, h_a[0], h_a[1], part);
+                cur = 2 * L; toA = !toA;
+                for (int q = 0; q < 6; q++) { t.s[q] = t.d[q]; t.d[q] = toA ? A + (size_t)q * szA : B + (size_t)q * szB; }
+            }
+            HB_LAUNCH(ctx, "k_sc_reduce12", k_sc_reduce<12>, dim3(1), dim3(256), 0, part, nb, coef);
+            HB_CHECK(ctx, hipMemcpyAsync(pin, coef, 12 * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+            HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            ok &= gate_round_host(pin, h_a, rnd, sum, h_poly + 5 * i, h_r + i);
+            if (cur <= 2 * SC_TAIL || i == rounds - 1) break;
+        }
+        for (int q = 0; q < 6; q++) { host[q].resize(cur); HB_CHECK(ctx, hipMemcpyAsync(host[q].data(), t.s[q], cur * sizeof(F), hipMemcpyDeviceToHost, ctx->stream)); }
+        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        pending = true; i++;
+    } else {
+        for (int q = 0; q < 6; q++) { host[q].resize(n); HB_CHECK(ctx, hipMemcpyAsync(host[q].data(), tabs[q], n * sizeof(F), hipMemcpyDeviceToHost, ctx->stream)); }
+        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    auto fold = [&]() { for (int q = 0; q < 6; q++) for (size_t j = 0; j < cur / 2; j++) host[q][j] = fadd(host[q][2 * j], fmul(rnd, fsub(host[q][2 * j + 1], host[q][2 * j]))); cur /= 2; };
+    if (pending) fold();
+    for (; i < rounds; i++) {
+        F c[12]; for (int q = 0; q < 12; q++) c[q] = fmake(0);
+        for (size_t j = 0; j < cur / 2; j++) {
+            F b[6], e[6];
+            for (int q = 0; q < 6; q++) { b[q] = host[q][2 * j]; e[q] = host[q][2 * j + 1]; }
+            gate_acc(c, b, e, h_a[0], h_a[1]);
+        }
+        ok &= gate_round_host(c, h_a, rnd, sum, h_poly + 5 * i, h_r + i);
+        fold();
+    }
+    for (int q = 0; q < 6; q++) h_final[q] = host[q][0];
+    *h_rand = rnd; *h_sum = sum; *h_check = ok ? 1 : 0;
+    return 0;
+}
+
 // 3-product: polynomial of the current tables and fold with the PRE-round challenge in one pass
 __global__ void __launch_bounds__(256) k_sc3_poly_fold(const F *__restrict__ s1, const F *__restrict__ s2, const F *__restrict__ s3,
                                                        F *__restrict__ d1, F *__restrict__ d2, F *__restrict__ d3, size_t L,

@@ -220,6 +220,16 @@ int hobbit_open_standard(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, cons
  * h_qpoly: rounds x 3 F (a,b,c highest degree first); h_r: rounds F; h_vr: 2 F; h_final: 1 F. */
 int hobbit_sumcheck2(hobbit_ctx *ctx, const hobbit_F *d_v1, const hobbit_F *d_v2, size_t n, const hobbit_F *prev_r,
                      hobbit_F *h_qpoly, hobbit_F *h_r, hobbit_F *h_vr, hobbit_F *h_final);
+/* Degree-4 gate-consistency sumcheck: the in-memory phase of prove_gate_consistency (src/sumcheck.cpp:875-929) over the six
+ * folded tables fold_add, fold_beta, fold_L, fold_R, fold_O, fold_mul (n F each, device):
+ *   sum_j  add*beta*(a0 L + a1 R) + a2*mul*beta*L*R + a3*beta*O,   h_a = a[0..3] (generate_randomness(4), :873).
+ * Transcript as the reference: rand = mimc_hash(coefficient, rand) for poly.a..e, challenge = rand, adjacent-pair fold.
+ * The reference folds the tables in place and then only reads element 0 of each; here the inputs are preserved and those six
+ * values are returned in h_final (order as the arguments).  h_rand / h_sum: transcript state and claimed sum, in/out;
+ * h_poly: rounds x 5 F (a..e); h_r: rounds F; *h_check = 1 iff every "Error in gate consistency 2" comparison held. */
+int hobbit_gate_sumcheck(hobbit_ctx *ctx, const hobbit_F *d_add, const hobbit_F *d_beta, const hobbit_F *d_L, const hobbit_F *d_R, const hobbit_F *d_O,
+                         const hobbit_F *d_mul, size_t n, const hobbit_F *h_a, hobbit_F *h_rand, hobbit_F *h_sum, hobbit_F *h_poly, hobbit_F *h_r,
+                         hobbit_F *h_final, int *h_check);
 /* _generate_3product_sumcheck_proof (src/sumcheck.cpp:1974-2058): pre-round-challenge fold order
  * kept.  The reference destroys its inputs in place; here d_v1..3 are preserved (the folded
  * values are returned in h_vr).  h_cpoly: rounds x 4 F; h_vr: 3 F. */

@@ -393,6 +393,72 @@ void orc_sumcheck2(const oF *_v1, const oF *_v2, size_t n, const oF *prev_r, oF 
     vr[0] = v1[0]; vr[1] = v2[0]; *fin = rnd;
     free(v1); free(v2);
 }
+/* Degree-4 gate-consistency sumcheck, src/sumcheck.cpp:875-929 (the in-memory phase of prove_gate_consistency after the
+ * streaming folds): sum over the six folded tables of  add*beta*(a0 L + a1 R) + a2*mul*beta*L*R + a3*beta*O.
+ * Tables (n each, folded IN PLACE, adjacent pairs 2j,2j+1): t[0]=fold_add, t[1]=fold_beta, t[2]=fold_L, t[3]=fold_R, t[4]=fold_O,
+ * t[5]=fold_mul.  Note the transcript order mimc_hash(coefficient, rand) (coefficient is the INPUT, rand the key).
+ * poly: rounds x 5 (a..e, highest degree first); r: rounds; fin: the six t[i][0]; *check = every "Error in gate consistency 2"
+ * comparison held; *sum_io: claimed sum in, last poly.eval(rand) out; *rand_io: transcript state in/out.
+ * NOT pinned against oracle/_ref as a whole: the loop is inline in prove_gate_consistency, which only runs on the witness
+ * stream machinery (out of scope); the linear_poly products follow src/polynomial.cpp:91-147, which sumcheck2/3 pin. */
+void orc_gate_claim(oF *const t[6], size_t n, const oF *a, oF *out) {
+    oF s = fint(0);
+    for (size_t j = 0; j < n; j++) {
+        oF lr = f_add(f_mul(a[0], t[2][j]), f_mul(a[1], t[3][j]));
+        oF x = f_mul(f_mul(t[0][j], t[1][j]), lr);
+        oF y = f_mul(a[2], f_mul(f_mul(t[5][j], t[1][j]), f_mul(t[2][j], t[3][j])));
+        oF z = f_mul(a[3], f_mul(t[1][j], t[4][j]));
+        s = f_add(s, f_add(x, f_add(y, z)));
+    }
+    *out = s;
+}
+void orc_gate_sumcheck(oF *t0, oF *t1, oF *t2, oF *t3, oF *t4, oF *t5, size_t n, const oF *a, oF *rand_io, oF *sum_io, oF *poly, oF *r, oF *fin, int *check) {
+    oF *t[6] = {t0, t1, t2, t3, t4, t5};
+    int rounds = (int)log2((double)n);
+    oF rnd = *rand_io, sum = *sum_io;
+    *check = 1;
+    for (int rd = 0, i = rounds - 1; i >= 0; i--, rd++) {
+        size_t L = (size_t)1 << i;
+        oF c1[4] = {fint(0), fint(0), fint(0), fint(0)}, c4[5] = {fint(0), fint(0), fint(0), fint(0), fint(0)}, c2[3] = {fint(0), fint(0), fint(0)};
+        for (size_t j = 0; j < L; j++) {
+            oF d[6], b[6];
+            for (int q = 0; q < 6; q++) { b[q] = t[q][2 * j]; d[q] = f_sub(t[q][2 * j + 1], b[q]); }
+            /* l1 = add, l2 = beta, l3 = a0 L + a1 R  -> cubic */
+            oF l3a = f_add(f_mul(a[0], d[2]), f_mul(a[1], d[3])), l3b = f_add(f_mul(a[0], b[2]), f_mul(a[1], b[3]));
+            oF qa = f_mul(d[0], d[1]), qb = f_add(f_mul(d[0], b[1]), f_mul(b[0], d[1])), qc = f_mul(b[0], b[1]);
+            c1[0] = f_add(c1[0], f_mul(qa, l3a));
+            c1[1] = f_add(c1[1], f_add(f_mul(qa, l3b), f_mul(qb, l3a)));
+            c1[2] = f_add(c1[2], f_add(f_mul(qb, l3b), f_mul(qc, l3a)));
+            c1[3] = f_add(c1[3], f_mul(qc, l3b));
+            /* l1 = mul, l2 = beta, l3 = L, l4 = R -> quartic */
+            oF ma = f_mul(d[5], d[1]), mb = f_add(f_mul(d[5], b[1]), f_mul(b[5], d[1])), mc = f_mul(b[5], b[1]);
+            oF ka = f_mul(ma, d[2]), kb = f_add(f_mul(ma, b[2]), f_mul(mb, d[2])), kc = f_add(f_mul(mb, b[2]), f_mul(mc, d[2])), kd = f_mul(mc, b[2]);
+            c4[0] = f_add(c4[0], f_mul(ka, d[3]));
+            c4[1] = f_add(c4[1], f_add(f_mul(ka, b[3]), f_mul(kb, d[3])));
+            c4[2] = f_add(c4[2], f_add(f_mul(kb, b[3]), f_mul(kc, d[3])));
+            c4[3] = f_add(c4[3], f_add(f_mul(kc, b[3]), f_mul(kd, d[3])));
+            c4[4] = f_add(c4[4], f_mul(kd, b[3]));
+            /* beta * O -> quadratic */
+            c2[0] = f_add(c2[0], f_mul(d[1], d[4]));
+            c2[1] = f_add(c2[1], f_add(f_mul(d[1], b[4]), f_mul(b[1], d[4])));
+            c2[2] = f_add(c2[2], f_mul(b[1], b[4]));
+        }
+        oF p[5];
+        p[0] = f_mul(a[2], c4[0]);
+        p[1] = f_add(f_mul(a[2], c4[1]), c1[0]);
+        p[2] = f_add(f_add(f_mul(a[2], c4[2]), c1[1]), f_mul(a[3], c2[0]));
+        p[3] = f_add(f_add(f_mul(a[2], c4[3]), c1[2]), f_mul(a[3], c2[1]));
+        p[4] = f_add(f_add(f_mul(a[2], c4[4]), c1[3]), f_mul(a[3], c2[2]));
+        for (int q = 0; q < 5; q++) { rnd = mimc_hash(p[q], rnd); poly[5 * rd + q] = p[q]; }
+        oF s01 = f_add(f_add(f_add(p[0], p[1]), f_add(p[2], p[3])), f_add(p[4], p[4]));      /* eval(0) + eval(1) */
+        if (!(s01.re == sum.re && s01.im == sum.im)) *check = 0;
+        sum = f_add(f_mul(f_add(f_mul(f_add(f_mul(f_add(f_mul(p[0], rnd), p[1]), rnd), p[2]), rnd), p[3]), rnd), p[4]);
+        r[rd] = rnd;
+        for (size_t j = 0; j < L; j++) for (int q = 0; q < 6; q++) t[q][j] = f_add(t[q][2 * j], f_mul(rnd, f_sub(t[q][2 * j + 1], t[q][2 * j])));
+    }
+    for (int q = 0; q < 6; q++) fin[q] = t[q][0];
+    *rand_io = rnd; *sum_io = sum;
+}
 /* src/sumcheck.cpp:1974-2058: round i's tables are folded with the challenge that was current
  * BEFORE round i's polynomial is hashed (the fold sits in the same loop as the polynomial);
  * randomness[i] records that pre-round challenge.  v2-zero pairs contribute nothing; all-zero

@@ -67,6 +67,10 @@ void orc_aggregate(const oF *poly, size_t N, const oF *beta, int K, oF *aggr_out
 void orc_sumcheck2(const oF *v1, const oF *v2, size_t n, const oF *prev_r, oF *qpoly, oF *r, oF *vr, oF *fin);
 void orc_sumcheck3(const oF *v1, const oF *v2, const oF *v3, size_t n, const oF *prev_r, oF *cpoly, oF *r, oF *vr, oF *fin);
 
+/* degree-4 gate-consistency sumcheck (src/sumcheck.cpp:875-929); tables add, beta, L, R, O, mul folded in place */
+void orc_gate_claim(oF *const t[6], size_t n, const oF *a, oF *out);
+void orc_gate_sumcheck(oF *t0, oF *t1, oF *t2, oF *t3, oF *t4, oF *t5, size_t n, const oF *a, oF *rand_io, oF *sum_io, oF *poly, oF *r, oF *fin, int *check);
+
 /* code-membership / FFT-as-sumcheck helpers */
 long long orc_evaluate_parity_matrix(const oF *beta, size_t size_a, long long n, oF *A);
 void orc_phi_g_init(const oF *rx, int n, const oF *scale, int is_ifft, oF *phi_g);

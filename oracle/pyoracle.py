@@ -192,6 +192,21 @@ class _Base:
         return dict(poly=q, r=r, vr=vr, fin=fin)
 
 
+    def gate_claim(self, tables, a):
+        ts = [F(t).reshape(-1, 2) for t in tables]; a = F(a).reshape(4, 2); o = np.zeros(2, np.uint64)
+        arr = (ctypes.c_void_p * 6)(*[t.ctypes.data for t in ts])
+        self.lib.orc_gate_claim(arr, c_sz(ts[0].shape[0]), _p(a), _p(o))
+        return o
+
+    def gate_sumcheck(self, tables, a, rand, claimed_sum):
+        """degree-4 gate-consistency sumcheck (src/sumcheck.cpp:875-929); tables = (add, beta, L, R, O, mul), copied"""
+        ts = [F(t).reshape(-1, 2).copy() for t in tables]; a = F(a).reshape(4, 2)
+        n = ts[0].shape[0]; rounds = n.bit_length() - 1
+        rnd = F(rand).reshape(2).copy(); sm = F(claimed_sum).reshape(2).copy()
+        q = np.zeros((rounds, 5, 2), np.uint64); r = np.zeros((rounds, 2), np.uint64); fin = np.zeros((6, 2), np.uint64); chk = np.zeros(1, np.int32)
+        self.lib.orc_gate_sumcheck(*[_p(t) for t in ts], c_sz(n), _p(a), _p(rnd), _p(sm), _p(q), _p(r), _p(fin), _p(chk))
+        return dict(poly=q, r=r, fin=fin, rand=rnd, sum=sm, check=chk)
+
     # ---- code-membership / FFT-as-sumcheck helpers
     def evaluate_parity_matrix(self, beta, n):
         b = F(beta).reshape(-1, 2)

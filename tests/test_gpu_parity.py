@@ -515,6 +515,26 @@ def test_open_standard_vs_oracle(hb, oracle, N, K):
     c.free()
 
 
+# ---- degree-4 gate-consistency sumcheck (a22) -------------------------------------------------------
+@pytest.mark.parametrize("logn", [4, 10, 11, 14, 18])
+def test_gate_sumcheck_vs_oracle(hb, oracle, logn):
+    """src/sumcheck.cpp:875-929 over six folded tables; B = 2^18 is the MLP config's chunk size.  The oracle's loop is the
+    restatement (not runnable in oracle/_ref: inline in prove_gate_consistency); the reference's own round check must hold."""
+    n = 1 << logn
+    sel = (np.arange(n) % 3 == 0)
+    add = splitmix_field(n, 801); mul = splitmix_field(n, 802)          # folded selectors are full-range after the streaming phase
+    tabs = [add, splitmix_field(n, 803), splitmix_field(n, 804), splitmix_field(n, 805), splitmix_field(n, 806), mul]
+    a = splitmix_field(4, 807); rand0 = splitmix_field(1, 808)[0]
+    claim = oracle.gate_claim(tabs, a)
+    want = oracle.gate_sumcheck(tabs, a, rand0, claim)
+    got = hb.gate_sumcheck(tabs, a, rand0, claim)
+    assert want["check"].tolist() == [1] and got["check"].tolist() == [1]
+    for k in ("poly", "r", "fin", "rand", "sum"):
+        assert np.array_equal(got[k], want[k]), k
+    bad = claim.copy(); bad[0] ^= np.uint64(1)
+    assert hb.gate_sumcheck(tabs, a, rand0, bad)["check"].tolist() == [0]
+
+
 # ---- streaming-sumcheck error terms and folds ----------------------------------------------------
 def test_streamfold_vs_golden(hb):
     g = gold("streamfold")
