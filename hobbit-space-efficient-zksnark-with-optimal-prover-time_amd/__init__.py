@@ -87,7 +87,7 @@ def load_library(path=LIB_PATH):
         "hobbit_prove_fft_matrix": [V, V, S, S, V, V, V, V, V],
         "hobbit_gate_sumcheck": [V, V, V, V, V, V, V, S, V, V, V, V, V, V, V],
         "hobbit_open_core": [V, V, S, V, V, I, V], "hobbit_open_standard": [V, V, S, V, V, I, V],
-        "hobbit_whir_prove": [V, V, S, V, V, V, V, V, V, V], "hobbit_shockwave_prove": [V, V, V, S, I, V, I, V],
+        "hobbit_whir_prove": [V, V, S, V, V, V, V], "hobbit_shockwave_prove": [V, V, V, V, S, I, V, I, V],
         "hobbit_shockwave_commit": [V, V, S, I, V, V], "hobbit_change_form": [V, V, I], "hobbit_whir_commit": [V, V, S, V, V],
         "hobbit_batch_3product_sumcheck": [V, V, V, V, V, I, V, V, V, V], "hobbit_mul_tree": [V, V, S, S, V, V, V, V, V, V, V, V, V, V],
         "hobbit_compute2p_error_terms": [V, V, V, V, V, S, V], "hobbit_compute3p_error_terms": [V, V, V, V, V, V, V, S, V],
@@ -468,14 +468,17 @@ class Hobbit:
         """open_standard (src/Our_PC.cpp:604-661), prover side, including both shockwave_prove calls"""
         return self.open_core(poly, commitment, x, queries, want_paths, full=True)
 
-    _SP_NAMES = ("I", "q1", "r1", "vr1", "fin1", "q2", "r2", "vr2", "fin2", "wq", "wa", "wroots", "wscal", "wchecks", "whir_root", "iters")
+    _SP_NAMES = ("I", "q1", "r1", "vr1", "fin1", "q2", "r2", "vr2", "fin2", "wq", "wa", "wroots", "wscal", "wchecks", "whir_root", "iters",
+                 "reply", "paths", "qidx", "qreply", "qpaths", "final_pb", "qn")
 
     def _sp_buffers(self, N, k):
         w = N // k; W = 2 * w; lgW = W.bit_length() - 1; lw = w.bit_length() - 1
         out = dict(I=np.zeros(240, np.uint32), q1=np.zeros((lgW, 3, 2), np.uint64), r1=np.zeros((lgW, 2), np.uint64), vr1=np.zeros((2, 2), np.uint64),
                    fin1=np.zeros(2, np.uint64), q2=np.zeros((lgW, 3, 2), np.uint64), r2=np.zeros((lgW, 2), np.uint64), vr2=np.zeros((2, 2), np.uint64),
                    fin2=np.zeros(2, np.uint64), wq=np.zeros((lw + 8, 3, 2), np.uint64), wa=np.zeros((lw + 8, 2), np.uint64), wroots=np.zeros((lw + 1, 32), np.uint8),
-                   wscal=np.zeros((2, 2), np.uint64), wchecks=np.zeros(2, np.int32), whir_root=np.zeros(32, np.uint8), iters=np.zeros(1, np.int32))
+                   wscal=np.zeros((2, 2), np.uint64), wchecks=np.zeros(2, np.int32), whir_root=np.zeros(32, np.uint8), iters=np.zeros(1, np.int32),
+                   reply=np.zeros((240, k, 2), np.uint64), paths=np.zeros((240, lgW, 32), np.uint8))
+        out.update(self._wq_buffers())
 
         class Out(ctypes.Structure):
             _fields_ = [(n, c_vp) for n in self._SP_NAMES]
@@ -486,6 +489,10 @@ class Hobbit:
         lgW = (2 * N // k).bit_length() - 1; it = int(out["iters"][0])
         out["r2"] = out["r2"][:lgW - 1]; out["wq"] = out["wq"][:4 * it]; out["wa"] = out["wa"][:4 * it]; out["wroots"] = out["wroots"][:it]
         out["iters"] = np.array([it])
+        if it:
+            out.update(Hobbit._wq_trim(out, N // k, it))
+        else:
+            out.update(qn=np.zeros(0, np.int32), qidx=np.zeros(0, np.int32), qreply=np.zeros((0, 16, 2), np.uint64), qpaths=np.zeros(0, np.uint8), final_pb=np.zeros((0, 2), np.uint64))
         return out
 
     def aggregate(self, poly, beta):
@@ -559,21 +566,47 @@ class Hobbit:
         self._chk(self.lib.hobbit_whir_commit(self.ctx, d.ptr, N, com.ptr, lv.ptr))
         return self.to_host(com, (2 * N, 2), np.uint64), self.to_host(lv, (N - 1, 32), np.uint8)
 
-    def whir_prove(self, poly, x):
-        p = Fh(poly).reshape(-1, 2); x = Fh(x).reshape(-1, 2); N = p.shape[0]; logN = N.bit_length() - 1
-        q = np.zeros((logN + 8, 3, 2), np.uint64); a = np.zeros((logN + 8, 2), np.uint64); roots = np.zeros((logN, 32), np.uint8)
-        sc = np.zeros((2, 2), np.uint64); chk = np.zeros(2, np.int32); it = ctypes.c_int()
-        d = self.to_device(p)
-        self._chk(self.lib.hobbit_whir_prove(self.ctx, d.ptr, N, _hp(x), _hp(q), _hp(a), _hp(roots), _hp(sc), _hp(chk), ctypes.byref(it)))
-        it = it.value
-        return dict(iters=np.array([it]), poly=q[:4 * it], a=a[:4 * it], roots=roots[:it], scal=sc, checks=chk)
+    _WQ_NAMES = ("qidx", "qreply", "qpaths", "final_pb", "qn")
 
-    def shockwave_prove(self, matrix, enc, k, x):
+    @staticmethod
+    def _wq_buffers():
+        return dict(qidx=np.zeros(256, np.int32), qreply=np.zeros((256, 16, 2), np.uint64), qpaths=np.zeros(256 * 24 * 32, np.uint8),
+                    final_pb=np.zeros((32, 2), np.uint64), qn=np.zeros(8, np.int32))
+
+    @staticmethod
+    def _wq_trim(b, N, iters):
+        nq = b["qn"][:iters].copy(); tot = int(nq.sum())
+        pbytes = sum(int(nq[t]) * 32 * (((2 * N) >> t).bit_length() - 1 - 2) for t in range(iters))
+        rem = N >> (4 * iters)
+        return dict(qn=nq, qidx=b["qidx"][:tot].copy(), qreply=b["qreply"][:tot].copy(), qpaths=b["qpaths"][:pbytes].copy(), final_pb=b["final_pb"][:2 * rem].copy())
+
+    def whir_prove(self, poly, x, com=None, com_levels=None):
+        """_whir_prove (src/Virgo.cpp:519-686), prover side; com / com_levels: device buffers from whir_commit (computed here if None)"""
+        p = Fh(poly).reshape(-1, 2); x = Fh(x).reshape(-1, 2); N = p.shape[0]; logN = N.bit_length() - 1
+        out = dict(qpoly=np.zeros((logN + 8, 3, 2), np.uint64), a=np.zeros((logN + 8, 2), np.uint64), fri_roots=np.zeros((logN, 32), np.uint8),
+                   scal=np.zeros((2, 2), np.uint64), checks=np.zeros(2, np.int32), iters=np.zeros(1, np.int32))
+        out.update(self._wq_buffers())
+        names = ("qpoly", "a", "fri_roots", "scal", "checks", "iters") + self._WQ_NAMES
+
+        class Out(ctypes.Structure):
+            _fields_ = [(n, c_vp) for n in names]
+        o = Out(*[out[n].ctypes.data for n in names])
+        d = self.to_device(p)
+        dc, dl = self.alloc(16 * 2 * N), self.alloc(32 * N)
+        self._chk(self.lib.hobbit_whir_commit(self.ctx, d.ptr, N, dc.ptr, dl.ptr))
+        self._chk(self.lib.hobbit_whir_prove(self.ctx, d.ptr, N, dc.ptr, dl.ptr, _hp(x), ctypes.byref(o)))
+        it = int(out["iters"][0])
+        res = dict(iters=np.array([it]), poly=out["qpoly"][:4 * it], a=out["a"][:4 * it], roots=out["fri_roots"][:it], scal=out["scal"], checks=out["checks"])
+        res.update(self._wq_trim(out, N, it))
+        return res
+
+    def shockwave_prove(self, matrix, enc, k, x, levels=None):
         m = Fh(matrix).reshape(-1, 2); e = Fh(enc).reshape(-1, 2); x = Fh(x).reshape(-1, 2)
         N = m.shape[0]
         out, o = self._sp_buffers(N, k)
         dm, de = self.to_device(m), self.to_device(e)
-        self._chk(self.lib.hobbit_shockwave_prove(self.ctx, dm.ptr, de.ptr, N, k, _hp(x), x.shape[0], ctypes.byref(o)))
+        dl = self.to_device(np.ascontiguousarray(levels, np.uint8)) if levels is not None else None
+        self._chk(self.lib.hobbit_shockwave_prove(self.ctx, dm.ptr, de.ptr, dl.ptr if dl is not None else None, N, k, _hp(x), x.shape[0], ctypes.byref(o)))
         return self._sp_trim(out, N, k)
 
     # ---- batched cubic sumcheck / multiplication tree (src/sumcheck.cpp:275-372, 35-257)

@@ -563,9 +563,10 @@ int hobbit_whir_commit(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, hobbit
 }
 
 // zero-pad `cur` elements to fsz, change_form, FFT, 16-way regroup, MT_commit_Blake -> root (one FRI layer of _whir_prove,
-// src/Virgo.cpp:581-598).  scratch: 2*fsz F + fsz/2 hashes.
-static int whir_fri_layer(hobbit_ctx *ctx, const F *d_poly, size_t cur, size_t fsz, F *scratch, uint8_t *h_root) {
-    F *fp = scratch, *buf = scratch + fsz; uint8_t *lv = reinterpret_cast<uint8_t *>(buf + fsz);
+// src/Virgo.cpp:581-598).  fp: fsz F transient; keep: the regrouped codeword (fsz F) followed by its Merkle levels (fsz/2 hashes),
+// which the next query round reads.
+static int whir_fri_layer(hobbit_ctx *ctx, const F *d_poly, size_t cur, size_t fsz, F *fp, F *keep, uint8_t *h_root) {
+    F *buf = keep; uint8_t *lv = reinterpret_cast<uint8_t *>(buf + fsz);
     HB_CHECK(ctx, hipMemsetAsync(fp, 0, fsz * sizeof(F), ctx->stream));
     HB_CHECK(ctx, hipMemcpyAsync(fp, d_poly, cur * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
     HB_TRY(hobbit_change_form(ctx, reinterpret_cast<hobbit_F *>(fp), ilog2_exact(cur)));
@@ -577,24 +578,46 @@ static int whir_fri_layer(hobbit_ctx *ctx, const F *d_poly, size_t cur, size_t f
     return hobbit_memcpy_d2h(ctx, h_root, lv + 32 * (2 * (fsz / 4) - 2), 32);
 }
 // compute_zetas (src/Virgo.cpp:220-236), host side, libc draws in the reference's order
-static void compute_zetas_host(std::vector<F> &z, int reps, int v, size_t Nq) {
-    z.assign((size_t)reps * v, fmake(0));
+static void compute_zetas_host(std::vector<F> &z, std::vector<uint64_t> &ridx, int reps, int v, size_t Nq) {
+    z.assign((size_t)reps * v, fmake(0)); ridx.clear();
     z[0] = fmake((uint64_t)random());
     const F omega = root_of_unity(ilog2_exact(Nq));
-    for (int i = 1; i < reps; i++) z[(size_t)i * v] = fpow(omega, (u128)(rand() % (long)Nq));
+    for (int i = 1; i < reps; i++) { ridx.push_back((uint64_t)(rand() % (long)Nq)); z[(size_t)i * v] = fpow(omega, (u128)ridx.back()); }
     for (int i = 0; i < reps; i++) for (int j = 1; j < v; j++) z[(size_t)i * v + j] = fmul(z[(size_t)i * v + j - 1], z[(size_t)i * v + j - 1]);
 }
-int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_F *h_x, hobbit_F *h_qpoly, hobbit_F *h_a, uint8_t *h_fri_roots,
-                      hobbit_F *h_scal, int *h_checks, int *iters_out) {
+// scratch elements hobbit_whir_prove carves from workspace4 AFTER the first 4N (left to a whir_commit of the same polynomial)
+static size_t whir_scratch_elems(size_t N) {
+    return 2 * N /* poly, beta */ + 2 * 100 * (N >> 4) /* batched eq tables */ + N /* fp */ + 2 * N + N /* two kept layers */ + 64
+           + 3 * 1024 + 64 + 100 * 32 + 256 + 256 + 256 + 100 * 16 + 64 /* partials, coef, z, y, pows, query idx, replies */;
+}
+// _verify_iteration's prover part (src/Virgo.cpp:245-275): replies (16 regrouped elements per index) and open_tree_blake(tree, {r,0}, 0)
+struct WhirQueryCursor { size_t q = 0, path_off = 0; int round = 0; };
+static int whir_answer(hobbit_ctx *ctx, hobbit_whir_out *o, WhirQueryCursor &cur, const F *layer, const uint8_t *levels, size_t size, const std::vector<uint64_t> &ridx,
+                       uint64_t *d_idx, F *d_rep) {
+    const size_t n = ridx.size(); const int depth = ilog2_exact(size / 4);
+    if (o->qn) o->qn[cur.round] = (int32_t)n;
+    cur.round++;
+    if (n && layer) {
+        if (o->qidx) for (size_t i = 0; i < n; i++) o->qidx[cur.q + i] = (int32_t)ridx[i];
+        if (o->qreply) {
+            HB_CHECK(ctx, hipMemcpyAsync(d_idx, ridx.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+            HB_TRY(launch_gather_strided(ctx, layer, d_idx, n, 16, 16, 1, d_rep));
+            HB_TRY(hobbit_memcpy_d2h(ctx, o->qreply + 16 * cur.q, d_rep, n * 16 * sizeof(F)));
+        }
+        if (o->qpaths) HB_TRY(hobbit_merkle_paths(ctx, levels, size / 4, ridx.data(), n, o->qpaths + cur.path_off));
+    }
+    cur.q += n; cur.path_off += n * 32 * (size_t)depth;
+    return 0;
+}
+int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_F *d_com, const uint8_t *d_com_levels, const hobbit_F *h_x, hobbit_whir_out *o) {
     const int k = 4, logN = ilog2_exact(N);
-    if (logN < 9 || logN > 24) return ctx->fail(HOBBIT_EINVAL, "whir_prove: N must be a power of two in [2^9, 2^24]");
-    const size_t curmax = N >> k;
-    // scratch (workspace4), carved in order; the first 4N elements are left to a whir_commit an enclosing shockwave_prove ran
-    const size_t sz_front = 4 * N, sz_E = 100 * curmax, sz_fri = 3 * N + 64 /* fp | regrouped copy | Merkle levels */, sz_small = 3 * 1024 + 64 + 100 * 32 + 256 + 256;
-    const size_t n_el = sz_front + 2 * N + 2 * sz_E + sz_fri + sz_small;
-    F *base; HB_TRY(ctx->workspace4(n_el * sizeof(F), (void **)&base));
-    F *poly = base + sz_front, *beta = poly + N, *E0 = beta + N, *E1 = E0 + sz_E, *fri = E1 + sz_E, *part = fri + sz_fri, *coef = part + 3 * 1024, *dz = coef + 64,
-      *dy = dz + 100 * 32, *dpw = dy + 256;
+    if (logN < 9 || logN > 24 || !o) return ctx->fail(HOBBIT_EINVAL, "whir_prove: N must be a power of two in [2^9, 2^24]");
+    hobbit_F *h_qpoly = o->qpoly, *h_a = o->a, *h_scal = o->scal; uint8_t *h_fri_roots = o->fri_roots; int *h_checks = o->checks;
+    const size_t curmax = N >> k, sz_front = 4 * N, sz_E = 100 * curmax;
+    F *base; HB_TRY(ctx->workspace4((sz_front + whir_scratch_elems(N)) * sizeof(F), (void **)&base));
+    F *poly = base + sz_front, *beta = poly + N, *E0 = beta + N, *E1 = E0 + sz_E, *fp = E1 + sz_E, *keepA = fp + N, *keepB = keepA + 2 * N, *part = keepB + N + 64,
+      *coef = part + 3 * 1024, *dz = coef + 64, *dy = dz + 100 * 32, *dpw = dy + 256, *d_rep = dpw + 256 + 256;
+    uint64_t *d_idx = reinterpret_cast<uint64_t *>(dpw + 256);
     HB_CHECK(ctx, hipMemcpyAsync(poly, d_poly, N * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
     HB_TRY(hobbit_eq_table(ctx, h_x, logN, reinterpret_cast<hobbit_F *>(beta)));
     F eval;
@@ -603,6 +626,8 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
     F *pin; HB_TRY(ctx->pinned(256 * sizeof(F), (void **)&pin));
     int iter = 0, repeats = 100, nq = 0; size_t remaining = 0;
     h_checks[0] = 1; h_checks[1] = 0;
+    const F *prev = cF(d_com); const uint8_t *prev_lv = d_com_levels; size_t prev_sz = 2 * N;   // the layer the next query round reads
+    WhirQueryCursor qc; std::vector<uint64_t> ridx;
     for (;;) {
         for (int i = 0; i < k; i++) {
             const size_t L = N >> (iter * k + i + 1);
@@ -617,11 +642,12 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
         }
         iter++;
         const size_t cur = N >> (k * iter), fsz = (2 * N) >> iter;
-        HB_TRY(whir_fri_layer(ctx, poly, cur, fsz, fri, h_fri_roots + 32 * (iter - 1)));
+        F *keep = (iter & 1) ? keepA : keepB;                                   // layer sizes halve: odd layers need <= 2N, even <= N elements
+        HB_TRY(whir_fri_layer(ctx, poly, cur, fsz, fp, keep, h_fri_roots + 32 * (iter - 1)));
         const int queries = (int)(100.0 / log2((double)fsz / (double)cur));
         if (logN - iter * k <= k) { repeats = queries; remaining = (size_t)1 << (logN - iter * k); break; }
         const int v = logN - iter * k;
-        std::vector<F> z; compute_zetas_host(z, repeats, v, (2 * N) >> (iter + k));
+        std::vector<F> z; compute_zetas_host(z, ridx, repeats, v, (2 * N) >> (iter + k));
         HB_CHECK(ctx, hipMemcpyAsync(dz, z.data(), z.size() * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
         // the `repeats` eq tables side by side, then y = E poly, beta += pows^T E, eval += sum pow_i y_i (:613-633)
         F *cE = E0, *nE = E1;
@@ -636,6 +662,8 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
         HB_TRY(launch_vecmat(ctx, cE, (size_t)repeats, cur, dpw, nE));          // nE[0..cur) = sum_i pow_i E[i]   (uses ctx->workspace for partials)
         HB_TRY(launch_axpy(ctx, beta, nE, fmake(1), cur));
         HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));                       // z / pw are stack-owned host vectors
+        HB_TRY(whir_answer(ctx, o, qc, prev, prev_lv, prev_sz, ridx, d_idx, d_rep));   // _verify_iteration(data, a, r, repeats, iter) (:634)
+        prev = keep; prev_lv = reinterpret_cast<const uint8_t *>(keep + fsz); prev_sz = fsz;
         repeats = queries;
     }
     // final verification step (:641-651)
@@ -644,36 +672,46 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
     HB_TRY(hobbit_memcpy_d2h(ctx, &sum, coef, sizeof(F)));
     h_checks[1] = feq(sum, eval);
     mF(h_scal)[0] = eval; mF(h_scal)[1] = sum;
-    {   // closing draws (:652-655), so that the libc stream is left where the reference leaves it
+    if (o->final_pb) {
+        HB_TRY(hobbit_memcpy_d2h(ctx, o->final_pb, poly, remaining * sizeof(F)));
+        HB_TRY(hobbit_memcpy_d2h(ctx, o->final_pb + remaining, beta, remaining * sizeof(F)));
+    }
+    {   // closing draws (:652-655) and the last query round (:656), leaving the libc stream where the reference leaves it
         const int lr = ilog2_exact(remaining);
         F cst = fmake(0); for (int i = 0; i < lr; i++) { if (i % 100 == 0) cst = fmake((uint64_t)random()); (void)rand(); }
         (void)cst;
-        std::vector<F> z; if (repeats > 0 && lr > 0) compute_zetas_host(z, repeats, lr, (2 * N) >> (iter * k));
+        std::vector<F> z;
+        if (repeats > 0 && lr > 0) {
+            compute_zetas_host(z, ridx, repeats, lr, (2 * N) >> (iter * k));
+            HB_TRY(whir_answer(ctx, o, qc, prev, prev_lv, prev_sz, ridx, d_idx, d_rep));
+        }
     }
-    if (iters_out) *iters_out = iter;
+    if (o->iters) *o->iters = iter;
     return 0;
 }
 // shockwave_prove (src/Virgo.cpp:435-517), prover side
-int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobbit_F *d_enc, size_t N, int k, const hobbit_F *h_x, int xlen, hobbit_shockwave_out *o) {
+int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobbit_F *d_enc, const uint8_t *d_levels, size_t N, int k, const hobbit_F *h_x, int xlen,
+                           hobbit_shockwave_out *o) {
     const int lk = ilog2_exact((size_t)k);
-    if (lk < 0 || k > 64 || N % (size_t)k || xlen < lk) return ctx->fail(HOBBIT_EINVAL, "shockwave_prove: bad k / N / x");
+    if (lk < 0 || k > 64 || N % (size_t)k || xlen < lk || !o) return ctx->fail(HOBBIT_EINVAL, "shockwave_prove: bad k / N / x");
     const size_t w = N / k, W = 2 * w;
     std::vector<F> beta1((size_t)k); beta1[0] = fmake(1);
     for (int i = 0; i < lk; i++) for (size_t j = ((size_t)1 << i); j-- > 0;) { F t = fmul(cF(h_x)[xlen - lk + (lk - 1 - i)], beta1[j]); beta1[2 * j + 1] = t; beta1[2 * j] = fsub(beta1[j], t); }
     // workspace4 layout: [0, nested) belongs to the nested whir_commit / whir_prove calls (they carve from the start and never ask
     // for more than `nested`, so the buffer is not reallocated under us); our own vectors follow.
-    const size_t nested = 4 * w + 2 * w + 2 * 100 * (w >> 4) + 3 * w + 64 + 3 * 1024 + 64 + 100 * 32 + 512 + 1024;
-    const size_t own = w + W + W + 64 + 256 + 256 /* idx */ + 2 * w + 2 * w /* whir_commit outputs: com, levels */ + 64;
+    const size_t nested = 4 * w + whir_scratch_elems(w) + 64;
+    const size_t own = w + W + W + 64 + 256 + 256 /* idx */ + 2 * w + 2 * w /* whir_commit outputs: com, levels */ + 240 * (size_t)k /* replies */ + 64;
     F *base; HB_TRY(ctx->workspace4((nested + own) * sizeof(F), (void **)&base));
     F *mine = base + nested; F *aggr = mine, *at = aggr + w, *b1v = at + W, *dbeta = b1v + W, *ones = dbeta + 64; uint64_t *didx = reinterpret_cast<uint64_t *>(ones + 256);
-    F *wcom = ones + 256 + 256; uint8_t *wlv = reinterpret_cast<uint8_t *>(wcom + 2 * w);
+    F *wcom = ones + 256 + 256; uint8_t *wlv = reinterpret_cast<uint8_t *>(wcom + 2 * w); F *d_rep = wcom + 4 * w;
     HB_CHECK(ctx, hipMemcpyAsync(dbeta, beta1.data(), (size_t)k * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
     HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     HB_TRY(launch_vecmat(ctx, cF(d_matrix), (size_t)k, w, dbeta, aggr));        // aggr = beta1^T matrix (:444-456)
     HB_TRY(launch_vecmat(ctx, cF(d_enc), (size_t)k, W, dbeta, at));
-    if (w > 256 && o->whir_root) {                                           // whir_commit(aggr, C) (:458-461)
+    const bool committed = w > 256;
+    if (committed) {                                                         // whir_commit(aggr, C) (:458-461)
         HB_TRY(hobbit_whir_commit(ctx, reinterpret_cast<hobbit_F *>(aggr), w, reinterpret_cast<hobbit_F *>(wcom), wlv));
-        HB_TRY(hobbit_memcpy_d2h(ctx, o->whir_root, wlv + 32 * (w - 2), 32));
+        if (o->whir_root) HB_TRY(hobbit_memcpy_d2h(ctx, o->whir_root, wlv + 32 * (w - 2), 32));
     }
     std::vector<uint64_t> I(240); std::vector<F> one(240, fmake(1));
     for (int i = 0; i < 240; i++) { I[i] = (uint64_t)(rand() % (long)W); if (o->I) o->I[i] = (uint32_t)I[i]; }      // (:463-467)
@@ -681,14 +719,20 @@ int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobb
     HB_CHECK(ctx, hipMemcpyAsync(ones, one.data(), 240 * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
     HB_CHECK(ctx, hipMemcpyAsync(didx, I.data(), 240 * 8, hipMemcpyHostToDevice, ctx->stream));
     HB_TRY(launch_scatter(ctx, didx, ones, 240, b1v));
+    if (o->reply) {                                                          // reply[i][j] = encoded_matrix[j][I[i]] (:468-472)
+        HB_TRY(launch_gather_strided(ctx, cF(d_enc), didx, 240, (uint32_t)k, 1, W, d_rep));
+        HB_TRY(hobbit_memcpy_d2h(ctx, o->reply, d_rep, 240 * (size_t)k * sizeof(F)));
+    }
     HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (o->paths && d_levels) HB_TRY(hobbit_merkle_paths(ctx, d_levels, W, I.data(), 240, o->paths));     // open_tree_blake(data->MT, {I[i],0}, 0) (:503)
     hobbit_F p33 = {33, 0};
     HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(at), reinterpret_cast<hobbit_F *>(b1v), W, &p33, o->q1, o->r1, o->vr1, o->fin1));         // (:477)
     HB_TRY(hobbit_prove_fft(ctx, reinterpret_cast<hobbit_F *>(aggr), w, o->r1, o->q2, o->r2, o->vr2, o->fin2));                                            // (:478)
     int iters = 0;
     if (w / 2 > 256) {
-        // _whir_prove works on a copy of aggr inside its own scratch (from the start of workspace4): aggr lives beyond it
-        HB_TRY(hobbit_whir_prove(ctx, reinterpret_cast<hobbit_F *>(aggr), w, o->r2, o->wq, o->wa, o->wroots, o->wscal, o->wchecks, &iters));                 // (:480-481)
+        // _whir_prove works on a copy of aggr inside its own scratch (from the start of workspace4): aggr and the commitment live beyond it
+        hobbit_whir_out wo = {o->wq, o->wa, o->wroots, o->wscal, o->wchecks, &iters, o->wqidx, o->wqreply, o->wqpaths, o->wfinal, o->wqn};
+        HB_TRY(hobbit_whir_prove(ctx, reinterpret_cast<hobbit_F *>(aggr), w, reinterpret_cast<hobbit_F *>(wcom), wlv, o->r2, &wo));                          // (:480-481)
     }
     if (o->iters) *o->iters = iters;
     return 0;
@@ -1051,8 +1095,9 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     // _aggregate's inner commitments (src/Our_PC.cpp:274-287): C_f = shockwave_commit(aggr, 32), C_c = shockwave_commit(parity half, 32)
     F *sw = d_b1 + rows2 + 2 * (size_t)queries + 64;
     F *encf = sw, *encc = encf + 2 * M;
+    uint8_t *lvf = nullptr, *lvc = nullptr;
     {
-        uint8_t *lvf = reinterpret_cast<uint8_t *>(encc + 2 * nc_el), *lvc = lvf + 64 * (2 * M / 32) ;
+        lvf = reinterpret_cast<uint8_t *>(encc + 2 * nc_el); lvc = lvf + 64 * (2 * M / 32);
         HB_TRY(hobbit_shockwave_commit(ctx, reinterpret_cast<hobbit_F *>(d_aggr), M, 32, reinterpret_cast<hobbit_F *>(encf), lvf));
         HB_TRY(hobbit_shockwave_commit(ctx, reinterpret_cast<hobbit_F *>(C), nc_el, 32, reinterpret_cast<hobbit_F *>(encc), lvc));
         if (o->roots) {
@@ -1138,12 +1183,12 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     if (!full) return 0;
     // shockwave_prove(C_c, P4.r minus its last entry) (src/PC_utils.cpp:368) -- in the reference it runs before P5; P5 draws nothing
     // from libc, so running it here leaves every draw where the reference has it
-    HB_TRY(hobbit_shockwave_prove(ctx, reinterpret_cast<hobbit_F *>(C), reinterpret_cast<hobbit_F *>(encc), nc_el, 32, r_p4, R3 - 1, o->sp_c));
+    HB_TRY(hobbit_shockwave_prove(ctx, reinterpret_cast<hobbit_F *>(C), reinterpret_cast<hobbit_F *>(encc), lvc, nc_el, 32, r_p4, R3 - 1, o->sp_c));
     tr.mark("shockwave_prove C_c");
     // shockwave_prove(C_f, P5.randomness minus its last entry) (:384-385); P5.randomness = [sumcheck r | r1 = P4.r[logc .. logc+log2 trs)] (src/sumcheck.cpp:3021-3023)
     std::vector<hobbit_F> x5((size_t)logc + (size_t)(R1 - 1));
     memcpy(x5.data(), Rr, sizeof(hobbit_F) * (size_t)logc); memcpy(x5.data() + logc, r_p4 + logc, sizeof(hobbit_F) * (size_t)(R1 - 1));
-    HB_TRY(hobbit_shockwave_prove(ctx, reinterpret_cast<hobbit_F *>(d_aggr), reinterpret_cast<hobbit_F *>(encf), M, 32, x5.data(), (int)x5.size() - 1, o->sp_f));
+    HB_TRY(hobbit_shockwave_prove(ctx, reinterpret_cast<hobbit_F *>(d_aggr), reinterpret_cast<hobbit_F *>(encf), lvf, M, 32, x5.data(), (int)x5.size() - 1, o->sp_f));
     tr.mark("shockwave_prove C_f");
     return 0;
 }

@@ -965,6 +965,18 @@ int launch_vecmat(hobbit_ctx *ctx, const F *Mx, size_t rows, size_t cols, const 
     HB_LAUNCH(ctx, "k_colsum", k_colsum, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, part, nparts, cols, out);
     return 0;
 }
+// out[q*m + j] = src[idx[q]*bmul + j*stride]: query replies (WHIR: 16 consecutive regrouped elements; shockwave: one column of k rows)
+__global__ void k_gather_strided(const F *__restrict__ src, const uint64_t *__restrict__ idx, size_t nq, uint32_t m, size_t bmul, size_t stride, F *__restrict__ out) {
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= nq * m) return;
+    size_t q = t / m, j = t % m;
+    stF(out + t, ldF(src + idx[q] * bmul + j * stride));
+}
+int launch_gather_strided(hobbit_ctx *ctx, const F *src, const uint64_t *d_idx, size_t nq, uint32_t m, size_t bmul, size_t stride, F *out) {
+    if (!nq) return 0;
+    HB_LAUNCH(ctx, "k_gather_strided", k_gather_strided, dim3((unsigned)((nq * m + 255) / 256)), dim3(256), 0, src, d_idx, nq, m, bmul, stride, out);
+    return 0;
+}
 int launch_scatter(hobbit_ctx *ctx, const uint64_t *idx, const F *val, size_t n, F *out) {
     if (!n) return 0;
     HB_LAUNCH(ctx, "k_scatter", k_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx, val, n, out);

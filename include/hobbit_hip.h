@@ -158,19 +158,35 @@ int hobbit_change_form(hobbit_ctx *ctx, hobbit_F *d_poly, int logn);
 /* whir_commit: change_form, zero-pad x2, FFT, 16-way regroup (d_com: 2N F), MT_commit_Blake (d_levels: N - 1 hashes... (2N/4)*2-1) */
 int hobbit_whir_commit(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, hobbit_F *d_com, uint8_t *d_levels);
 
-/* _whir_prove (src/Virgo.cpp:519-686), prover side (the verifier emulation inside it draws nothing and changes no
- * prover state; it is not run).  libc draws on the host in the reference's order.  d_poly: N F (preserved); h_x: log2 N.
- * h_qpoly: 3 F per fold round, h_a: the fold challenges, h_fri_roots: 32 B per iteration, h_scal: {eval, final sum},
- * h_checks[2]: the reference's exit(-1) checks (round sums; final verification), 1 = holds. */
-int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_F *h_x, hobbit_F *h_qpoly, hobbit_F *h_a, uint8_t *h_fri_roots,
-                      hobbit_F *h_scal, int *h_checks, int *iters_out);
-/* shockwave_prove (src/Virgo.cpp:435-517), prover side: row aggregation, whir_commit of the aggregate, 240 libc queries,
- * P1 = 2-product sumcheck against the query indicator, P2 = prove_fft, then _whir_prove.  d_matrix: k x N/k, d_enc: k x 2N/k
- * (as produced by hobbit_shockwave_commit).  All outputs are host buffers (sizes as hobbit_sumcheck2 / hobbit_whir_prove). */
+/* _whir_prove (src/Virgo.cpp:519-686), prover side.  The verifier emulation inside it (fold of the replies,
+ * verify_claim_opt_blake = SHA3 accounting) draws nothing and changes no prover state; it is not run -- but the query
+ * material _verify_iteration assembles for it (:245-275) IS produced.  libc draws on the host in the reference's order.
+ * d_poly: N F (preserved); h_x: log2 N; d_com / d_com_levels: the outputs of hobbit_whir_commit(d_poly) (NULL: round-1
+ * queries are drawn but not answered).  All pointers of hobbit_whir_out are host buffers:
+ *   qpoly: 3 F per fold round (4 per iteration); a: the fold challenges; fri_roots: 32 B per iteration;
+ *   scal: {eval, final sum}; checks[2]: the reference's exit(-1) checks (round sums; final verification), 1 = holds;
+ *   iters: number of iterations T.
+ *   Query rounds t = 1..T (nullable outputs): qn[t-1] indices each (99, then 100/(3t-2) - 1 ...; the last round uses
+ *   100/(1+3T) - 1), answered against the previous layer (t = 1: the commitment, size 2N; t >= 2: FRI layer t-1, size 2N >> (t-1)):
+ *   qidx: the indices r; qreply: 16 F per index (layer[r + j*size/16], j < 16); qpaths: open_tree_blake(tree, {r,0}, 0),
+ *   log2(size/4) x 32 B per index, back to back; final_pb: final_poly | final_beta (N >> 4T F each, :641-646). */
+typedef struct {
+    hobbit_F *qpoly, *a; uint8_t *fri_roots; hobbit_F *scal; int *checks; int *iters;
+    int32_t *qidx; hobbit_F *qreply; uint8_t *qpaths; hobbit_F *final_pb; int32_t *qn;
+} hobbit_whir_out;
+int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_F *d_com, const uint8_t *d_com_levels, const hobbit_F *h_x, hobbit_whir_out *out);
+/* shockwave_prove (src/Virgo.cpp:435-517), prover side: row aggregation, whir_commit of the aggregate, 240 libc queries with
+ * their replies (column I[i] of the encoded matrix, k F) and paths (open_tree_blake(MT, {I[i],0}, 0), log2(2N/k) x 32 B),
+ * P1 = 2-product sumcheck against the query indicator, P2 = prove_fft, then _whir_prove.  d_matrix: k x N/k, d_enc: k x 2N/k,
+ * d_levels: the column tree (all as produced by hobbit_shockwave_commit; d_levels NULL: no paths).  All outputs are host
+ * buffers (sizes as hobbit_sumcheck2 / hobbit_whir_out; reply, paths and the wq* query fields may be NULL). */
 typedef struct {
     uint32_t *I; hobbit_F *q1, *r1, *vr1, *fin1, *q2, *r2, *vr2, *fin2, *wq, *wa; uint8_t *wroots; hobbit_F *wscal; int *wchecks; uint8_t *whir_root; int *iters;
+    hobbit_F *reply; uint8_t *paths;
+    int32_t *wqidx; hobbit_F *wqreply; uint8_t *wqpaths; hobbit_F *wfinal; int32_t *wqn;
 } hobbit_shockwave_out;
-int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobbit_F *d_enc, size_t N, int k, const hobbit_F *h_x, int xlen, hobbit_shockwave_out *out);
+int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobbit_F *d_enc, const uint8_t *d_levels, size_t N, int k, const hobbit_F *h_x, int xlen,
+                           hobbit_shockwave_out *out);
 
 /* ---- multi-GPU commit building blocks (chunk-sharded commit) ------------------ */
 /* tensor codes of `nchunks` consecutive messages of M F each (chunk i at d_msg + i*M), outputs

@@ -670,22 +670,47 @@ size_t orc_whir_commit(const oF *poly, size_t N, oF *com_out, uint8_t *levels_ou
 /* SHA3 and cannot run in oracle/_ref); built from pinned pieces; the reference's own exit(-1)     */
 /* checks ("Error in %d", "Error in final verification step") are evaluated into `checks`.        */
 /* ------------------------------------------------------------------------------------------ */
-static void compute_zetas(oF *z /* [reps][v] */, int reps, int v, size_t Nq) {   /* src/Virgo.cpp:220-236 */
+static void compute_zetas(oF *z /* [reps][v] */, int reps, int v, size_t Nq, int32_t *ridx /* reps-1 or NULL */) {   /* src/Virgo.cpp:220-236 */
     z[0] = fint((uint64_t)random());
     oF omega = root_of_unity((int)log2((double)Nq));
     for (int i = 1; i < reps; i++) {
-        u128 e = (u128)(rand() % (long)Nq);
+        long rr = rand() % (long)Nq;
+        if (ridx) ridx[i - 1] = (int32_t)rr;
+        u128 e = (u128)rr;
         oF ret = fint(1), tmp = omega;
         while (e) { if (e & 1) ret = f_mul(ret, tmp); tmp = f_mul(tmp, tmp); e >>= 1; }
         z[(size_t)i * v] = ret;
     }
     for (int i = 0; i < reps; i++) for (int j = 1; j < v; j++) z[(size_t)i * v + j] = f_mul(z[(size_t)i * v + j - 1], z[(size_t)i * v + j - 1]);
 }
+static void whir_answer(orc_whir_queries *Q, const oF *layer /* regrouped */, const uint8_t *levels, size_t size, const int32_t *ridx, int n,
+                        size_t *q_tot, size_t *path_off, int round_t) {
+    int depth = (int)log2((double)(size / 4));
+    for (int i = 0; i < n; i++) {
+        size_t q = *q_tot + (size_t)i;
+        if (Q->qidx) Q->qidx[q] = ridx[i];
+        if (Q->qreply) memcpy(Q->qreply + 16 * q, layer + 16 * (size_t)ridx[i], 16 * sizeof(oF));
+        if (Q->qpaths) { orc_open_tree_blake(levels, size / 4, (size_t)ridx[i], 0, 0, Q->qpaths + *path_off); }
+        *path_off += 32 * (size_t)depth;
+    }
+    *q_tot += (size_t)n;
+    if (Q->nq) Q->nq[round_t] = n;
+}
 /* outputs: qpoly (3 per fold round, all iterations back to back), a_out (the libc fold challenges), fri_roots (32 B per
  * iteration), scal = {final eval, final sum}; checks[0] = all round sums matched, checks[1] = final sum == eval.
  * Returns the number of iterations. */
-int orc_whir_prove(const oF *poly_in, size_t N, const oF *x, oF *qpoly, oF *a_out, uint8_t *fri_roots, oF *scal, int *checks) {
+/* Query material of _verify_iteration (src/Virgo.cpp:245-275), which the prover assembles: round t = 1..iters answers
+ * R_t - 1 indices r (compute_zetas' rand() % Nq draws) against the PREVIOUS layer (t = 1: the whir_commit codeword `com`
+ * (regrouped, as orc_whir_commit returns it) and its tree; t >= 2: FRI layer t-1): reply = the 16 elements
+ * layer[r + j*size/16] = regrouped[16 r + j], path = open_tree_blake(tree, {r, 0}, 0) (leaf r: the reference opens leaf r,
+ * not the four leaves that hold the 16 reply elements -- kept).  Q->qidx / qreply (16 per query) / qpaths (depth_t x 32 B per
+ * query, back to back; depth_t = log2(size_t / 4)) / final_pb (final_poly | final_beta, `remaining` each) / nq[t-1] per round. */
+int orc_whir_prove_ex(const oF *poly_in, size_t N, const oF *x, const oF *com, const uint8_t *com_levels, oF *qpoly, oF *a_out, uint8_t *fri_roots,
+                      oF *scal, int *checks, orc_whir_queries *Q) {
     const int k = 4, logN = (int)log2((double)N);
+    const oF *prev = com; const uint8_t *prev_lv = com_levels; size_t prev_sz = 2 * N;     /* layer the next query round reads */
+    oF *keep_buf = NULL; uint8_t *keep_lv = NULL;
+    size_t q_tot = 0, path_off = 0; int round_t = 0;
     oF *poly = (oF *)malloc(sizeof(oF) * N), *beta = (oF *)malloc(sizeof(oF) * N);
     memcpy(poly, poly_in, sizeof(oF) * N);
     orc_precompute_beta(x, logN, beta);
@@ -720,11 +745,12 @@ int orc_whir_prove(const oF *poly_in, size_t N, const oF *x, oF *qpoly, oF *a_ou
         uint8_t *lv = (uint8_t *)malloc(32 * (fsz / 2));
         size_t nl = orc_mt_commit_blake(buff, fsz, lv);
         memcpy(fri_roots + 32 * (iter - 1), lv + 32 * (nl - 1), 32);
-        free(lv); free(fp); free(buff);
-        if (logN - iter * k <= k) { repeats = queries; remaining = (size_t)1 << (logN - iter * k); break; }
+        free(fp);
+        if (logN - iter * k <= k) { repeats = queries; remaining = (size_t)1 << (logN - iter * k); free(lv); free(buff); break; }
         int v = logN - iter * k;
         oF *z = (oF *)malloc(sizeof(oF) * (size_t)repeats * v), *y = (oF *)malloc(sizeof(oF) * (size_t)repeats), *_b = (oF *)malloc(sizeof(oF) * cur);
-        compute_zetas(z, repeats, v, (2 * N) >> (iter + k));
+        int32_t *ridx = (int32_t *)malloc(sizeof(int32_t) * (size_t)repeats);
+        compute_zetas(z, repeats, v, (2 * N) >> (iter + k), ridx);
         for (int i = 0; i < repeats; i++) {
             orc_precompute_beta(z + (size_t)i * v, v, _b);
             oF acc = fint(0);
@@ -739,6 +765,11 @@ int orc_whir_prove(const oF *poly_in, size_t N, const oF *x, oF *qpoly, oF *a_ou
             pw = f_mul(pw, sch);
         }
         free(z); free(y); free(_b);
+        /* _verify_iteration(data, a, r, repeats, iter): replies and paths against the previous layer */
+        if (Q && prev) whir_answer(Q, prev, prev_lv, prev_sz, ridx, repeats - 1, &q_tot, &path_off, round_t);
+        round_t++;
+        free(ridx);
+        free(keep_buf); free(keep_lv); keep_buf = buff; keep_lv = lv; prev = buff; prev_lv = lv; prev_sz = fsz;
         repeats = queries;
     }
     oF sum = fint(0);
@@ -751,16 +782,29 @@ int orc_whir_prove(const oF *poly_in, size_t N, const oF *x, oF *qpoly, oF *a_ou
         int lr = (int)log2((double)remaining);
         oF *a2 = (oF *)malloc(sizeof(oF) * (size_t)(lr + 1)); orc_generate_randomness(lr, a2); free(a2);
         oF *z = (oF *)malloc(sizeof(oF) * (size_t)repeats * (size_t)(lr > 0 ? lr : 1));
-        if (repeats > 0 && lr > 0) compute_zetas(z, repeats, lr, (2 * N) >> (iter * k));
-        free(z);
+        int32_t *ridx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(repeats + 1));
+        if (repeats > 0 && lr > 0) {
+            compute_zetas(z, repeats, lr, (2 * N) >> (iter * k), ridx);
+            if (Q && prev) whir_answer(Q, prev, prev_lv, prev_sz, ridx, repeats - 1, &q_tot, &path_off, round_t);
+        }
+        free(z); free(ridx);
     }
+    if (Q && Q->final_pb) { memcpy(Q->final_pb, poly, sizeof(oF) * remaining); memcpy(Q->final_pb + remaining, beta, sizeof(oF) * remaining); }
+    free(keep_buf); free(keep_lv);
     free(poly); free(beta);
     return iter;
 }
+int orc_whir_prove(const oF *poly_in, size_t N, const oF *x, oF *qpoly, oF *a_out, uint8_t *fri_roots, oF *scal, int *checks) {
+    return orc_whir_prove_ex(poly_in, N, x, NULL, NULL, qpoly, a_out, fri_roots, scal, checks, NULL);
+}
 /* matrix: k x w (the committed polynomial, row-major), enc: k x 2w; x: challenge vector (its last log2 k entries pick the rows).
  * P1/P2 transcripts as sumcheck2 (P1: log2(2w) rounds, P2: log2(2w) rounds), whir outputs as orc_whir_prove, I_out: 240 indices. */
-int orc_shockwave_prove(const oF *matrix, const oF *enc, size_t N, int k, const oF *x, int xlen, uint32_t *I_out, oF *q1, oF *r1o, oF *vr1, oF *fin1,
-                        oF *q2, oF *r2o, oF *vr2, oF *fin2, oF *wq, oF *wa, uint8_t *wroots, oF *wscal, int *wchecks, uint8_t *whir_root) {
+/* _ex: also the 240 query replies (k F each: column I[i] of enc) and, given the commitment's tree `levels` (as
+ * orc_shockwave_commit returns it), their paths open_tree_blake(MT, {I[i], 0}, 0) (src/Virgo.cpp:468-472, 503-504), log2(2w) x 32 B
+ * each; plus the WHIR query material (orc_whir_prove_ex). */
+int orc_shockwave_prove_ex(const oF *matrix, const oF *enc, const uint8_t *levels, size_t N, int k, const oF *x, int xlen, uint32_t *I_out, oF *q1, oF *r1o, oF *vr1,
+                           oF *fin1, oF *q2, oF *r2o, oF *vr2, oF *fin2, oF *wq, oF *wa, uint8_t *wroots, oF *wscal, int *wchecks, uint8_t *whir_root,
+                           oF *reply, uint8_t *paths, orc_whir_queries *Q) {
     size_t w = N / (size_t)k, W = 2 * w; int lk = (int)log2((double)k), lgW = (int)log2((double)W);
     oF *beta1 = (oF *)malloc(sizeof(oF) * (size_t)k), *aggr = (oF *)calloc(w, sizeof(oF)), *at = (oF *)calloc(W, sizeof(oF));
     orc_precompute_beta(x + xlen - lk, lk, beta1);
@@ -768,18 +812,26 @@ int orc_shockwave_prove(const oF *matrix, const oF *enc, size_t N, int k, const 
         if (i < w) for (int j = 0; j < k; j++) aggr[i] = f_add(aggr[i], f_mul(beta1[j], matrix[(size_t)j * w + i]));
         for (int j = 0; j < k; j++) at[i] = f_add(at[i], f_mul(beta1[j], enc[(size_t)j * W + i]));
     }
-    if (w > 256) { oF *com = (oF *)malloc(sizeof(oF) * 2 * w); uint8_t *lv = (uint8_t *)malloc(32 * w); size_t c = orc_whir_commit(aggr, w, com, lv); memcpy(whir_root, lv + 32 * (c - 1), 32); free(com); free(lv); }
+    oF *com = NULL; uint8_t *clv = NULL;
+    if (w > 256) { com = (oF *)malloc(sizeof(oF) * 2 * w); clv = (uint8_t *)malloc(32 * w); size_t c = orc_whir_commit(aggr, w, com, clv); memcpy(whir_root, clv + 32 * (c - 1), 32); }
     oF *buff1 = (oF *)calloc(W, sizeof(oF));
     for (int i = 0; i < 240; i++) { I_out[i] = (uint32_t)(rand() % (long)W); }
+    for (int i = 0; i < 240; i++) {
+        if (reply) for (int j = 0; j < k; j++) reply[(size_t)i * k + j] = enc[(size_t)j * W + I_out[i]];
+        if (paths && levels) orc_open_tree_blake(levels, W, I_out[i], 0, 0, paths + (size_t)i * 32 * (size_t)lgW);
+    }
     for (int i = 0; i < 240; i++) buff1[I_out[i]] = fint(1);
     oF p33 = fint(33);
     orc_sumcheck2(at, buff1, W, &p33, q1, r1o, vr1, fin1);
     orc_prove_fft(aggr, w, r1o, q2, r2o, vr2, fin2);                 /* prove_fft(aggr, P1.randomness[0], P1.vr[0]) */
     int iters = 0;
-    if (w / 2 > 256) iters = orc_whir_prove(aggr, w, r2o, wq, wa, wroots, wscal, wchecks);   /* x = P2.randomness[0] minus its last entry: log2 w entries */
-    free(beta1); free(aggr); free(at); free(buff1);
-    (void)lgW;
+    if (w / 2 > 256) iters = orc_whir_prove_ex(aggr, w, r2o, com, clv, wq, wa, wroots, wscal, wchecks, Q);   /* x = P2.randomness[0] minus its last entry: log2 w entries */
+    free(beta1); free(aggr); free(at); free(buff1); free(com); free(clv);
     return iters;
+}
+int orc_shockwave_prove(const oF *matrix, const oF *enc, size_t N, int k, const oF *x, int xlen, uint32_t *I_out, oF *q1, oF *r1o, oF *vr1, oF *fin1,
+                        oF *q2, oF *r2o, oF *vr2, oF *fin2, oF *wq, oF *wa, uint8_t *wroots, oF *wscal, int *wchecks, uint8_t *whir_root) {
+    return orc_shockwave_prove_ex(matrix, enc, NULL, N, k, x, xlen, I_out, q1, r1o, vr1, fin1, q2, r2o, vr2, fin2, wq, wa, wroots, wscal, wchecks, whir_root, NULL, NULL, NULL);
 }
 
 /* ------------------------------------------------------------------------------------------ */

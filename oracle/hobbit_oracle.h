@@ -84,6 +84,13 @@ size_t orc_shockwave_commit(const oF *poly, size_t N, int k, oF *enc_out, uint8_
 void orc_change_form(oF *poly, int logn);
 size_t orc_whir_commit(const oF *poly, size_t N, oF *com_out, uint8_t *levels_out);
 
+/* query material of WHIR's _verify_iteration (see hobbit_oracle.c); every pointer may be NULL */
+typedef struct { int32_t *qidx; oF *qreply; uint8_t *qpaths; oF *final_pb; int32_t *nq; } orc_whir_queries;
+int orc_whir_prove_ex(const oF *poly_in, size_t N, const oF *x, const oF *com, const uint8_t *com_levels, oF *qpoly, oF *a_out, uint8_t *fri_roots,
+                      oF *scal, int *checks, orc_whir_queries *Q);
+int orc_shockwave_prove_ex(const oF *matrix, const oF *enc, const uint8_t *levels, size_t N, int k, const oF *x, int xlen, uint32_t *I_out, oF *q1, oF *r1o, oF *vr1,
+                           oF *fin1, oF *q2, oF *r2o, oF *vr2, oF *fin2, oF *wq, oF *wa, uint8_t *wroots, oF *wscal, int *wchecks, uint8_t *whir_root,
+                           oF *reply, uint8_t *paths, orc_whir_queries *Q);
 int orc_whir_prove(const oF *poly_in, size_t N, const oF *x, oF *qpoly, oF *a_out, uint8_t *fri_roots, oF *scal, int *checks);
 int orc_shockwave_prove(const oF *matrix, const oF *enc, size_t N, int k, const oF *x, int xlen, uint32_t *I_out, oF *q1, oF *r1o, oF *vr1, oF *fin1,
                         oF *q2, oF *r2o, oF *vr2, oF *fin2, oF *wq, oF *wa, uint8_t *wroots, oF *wscal, int *wchecks, uint8_t *whir_root);

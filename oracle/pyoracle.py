@@ -411,35 +411,68 @@ class Oracle(_Base):
         aggr = self.aggregate(p, self.precompute_beta(x[:logK]))
         C = self.compute_tensorcode(aggr, trs, 1).reshape(2 * trs, cols, 2)[trs:].reshape(-1, 2)
         o4 = R1 + logc + R3; r4 = res["r"][o4:o4 + R3]; r5 = res["r"][o4 + R3:o4 + R3 + logc]
-        enc_c, _ = self.shockwave_commit(C, 32)
-        res["sp_c"] = self.shockwave_prove(C, enc_c, 32, r4[:-1])
-        enc_f, _ = self.shockwave_commit(aggr, 32)
+        enc_c, lv_c = self.shockwave_commit(C, 32)
+        res["sp_c"] = self.shockwave_prove(C, enc_c, 32, r4[:-1], lv_c)
+        enc_f, lv_f = self.shockwave_commit(aggr, 32)
         x5 = np.concatenate([r5, r4[logc:logc + R1 - 1]])[:-1]
-        res["sp_f"] = self.shockwave_prove(aggr, enc_f, 32, x5)
+        res["sp_f"] = self.shockwave_prove(aggr, enc_f, 32, x5, lv_f)
         return res
 
-    def whir_prove(self, poly, x):
+    class _WQ(ctypes.Structure):
+        _fields_ = [(n, ctypes.c_void_p) for n in ("qidx", "qreply", "qpaths", "final_pb", "nq")]
+
+    @staticmethod
+    def _wq_buffers():
+        b = dict(qidx=np.zeros(256, np.int32), qreply=np.zeros((256, 16, 2), np.uint64), qpaths=np.zeros(256 * 24 * 32, np.uint8),
+                 final_pb=np.zeros((32, 2), np.uint64), nq=np.zeros(8, np.int32))
+        return b, Oracle._WQ(*[b[n].ctypes.data for n in ("qidx", "qreply", "qpaths", "final_pb", "nq")])
+
+    @staticmethod
+    def whir_query_trim(b, N, iters):
+        """cut the over-allocated query buffers to what `iters` rounds on an N-coefficient polynomial produce"""
+        nq = b["nq"][:iters].copy(); tot = int(nq.sum())
+        pbytes = sum(int(nq[t]) * 32 * (((2 * N) >> t).bit_length() - 1 - 2) for t in range(iters))
+        rem = N >> (4 * iters)
+        return dict(qn=nq, qidx=b["qidx"][:tot].copy(), qreply=b["qreply"][:tot].copy(), qpaths=b["qpaths"][:pbytes].copy(), final_pb=b["final_pb"][:2 * rem].copy())
+
+    def whir_prove(self, poly, x, com=None, com_levels=None):
         p = F(poly).reshape(-1, 2); x = F(x).reshape(-1, 2); N = p.shape[0]
         logN = N.bit_length() - 1
         q = np.zeros((logN + 8, 3, 2), np.uint64); a = np.zeros((logN + 8, 2), np.uint64); roots = np.zeros((logN, 32), np.uint8)
         sc = np.zeros((2, 2), np.uint64); chk = np.zeros(2, np.int32)
-        f = self.lib.orc_whir_prove; f.restype = ctypes.c_int
-        it = f(_p(p), c_sz(N), _p(x), _p(q), _p(a), _p(roots), _p(sc), _p(chk))
-        return dict(iters=np.array([it]), poly=q[:4 * it], a=a[:4 * it], roots=roots[:it], scal=sc, checks=chk)
+        if com is None:
+            com, com_levels = self.whir_commit(p)
+        com = F(com).reshape(-1, 2); lv = np.ascontiguousarray(com_levels, np.uint8)
+        qb, Q = self._wq_buffers()
+        f = self.lib.orc_whir_prove_ex; f.restype = ctypes.c_int
+        it = f(_p(p), c_sz(N), _p(x), _p(com), _p(lv), _p(q), _p(a), _p(roots), _p(sc), _p(chk), ctypes.byref(Q))
+        res = dict(iters=np.array([it]), poly=q[:4 * it], a=a[:4 * it], roots=roots[:it], scal=sc, checks=chk)
+        res.update(self.whir_query_trim(qb, N, it))
+        return res
 
-    def shockwave_prove(self, matrix, enc, k, x):
+    def shockwave_prove(self, matrix, enc, k, x, levels=None):
         m = F(matrix).reshape(-1, 2); e = F(enc).reshape(-1, 2); x = F(x).reshape(-1, 2)
         N = m.shape[0]; w = N // k; W = 2 * w; lgW = W.bit_length() - 1; lw = w.bit_length() - 1
+        if levels is None:
+            _, levels = self.shockwave_commit(m, k)
+        lv = np.ascontiguousarray(levels, np.uint8)
         I = np.zeros(240, np.uint32)
         q1 = np.zeros((lgW, 3, 2), np.uint64); r1 = np.zeros((lgW, 2), np.uint64); vr1 = np.zeros((2, 2), np.uint64); f1 = np.zeros(2, np.uint64)
         q2 = np.zeros((lgW, 3, 2), np.uint64); r2 = np.zeros((lgW, 2), np.uint64); vr2 = np.zeros((2, 2), np.uint64); f2 = np.zeros(2, np.uint64)
         wq = np.zeros((lw + 8, 3, 2), np.uint64); wa = np.zeros((lw + 8, 2), np.uint64); wr = np.zeros((lw + 1, 32), np.uint8)
         ws = np.zeros((2, 2), np.uint64); wc = np.zeros(2, np.int32); wroot = np.zeros(32, np.uint8)
-        f = self.lib.orc_shockwave_prove; f.restype = ctypes.c_int
-        it = f(_p(m), _p(e), c_sz(N), ctypes.c_int(k), _p(x), ctypes.c_int(x.shape[0]), _p(I), _p(q1), _p(r1), _p(vr1), _p(f1), _p(q2), _p(r2), _p(vr2), _p(f2),
-               _p(wq), _p(wa), _p(wr), _p(ws), _p(wc), _p(wroot))
-        return dict(I=I, q1=q1, r1=r1, vr1=vr1, fin1=f1, q2=q2, r2=r2[:lgW - 1], vr2=vr2, fin2=f2, iters=np.array([it]), wq=wq[:4 * it], wa=wa[:4 * it],
-                    wroots=wr[:it], wscal=ws, wchecks=wc, whir_root=wroot)
+        reply = np.zeros((240, k, 2), np.uint64); paths = np.zeros((240, lgW, 32), np.uint8)
+        qb, Q = self._wq_buffers()
+        f = self.lib.orc_shockwave_prove_ex; f.restype = ctypes.c_int
+        it = f(_p(m), _p(e), _p(lv), c_sz(N), ctypes.c_int(k), _p(x), ctypes.c_int(x.shape[0]), _p(I), _p(q1), _p(r1), _p(vr1), _p(f1), _p(q2), _p(r2), _p(vr2), _p(f2),
+               _p(wq), _p(wa), _p(wr), _p(ws), _p(wc), _p(wroot), _p(reply), _p(paths), ctypes.byref(Q))
+        res = dict(I=I, q1=q1, r1=r1, vr1=vr1, fin1=f1, q2=q2, r2=r2[:lgW - 1], vr2=vr2, fin2=f2, iters=np.array([it]), wq=wq[:4 * it], wa=wa[:4 * it],
+                   wroots=wr[:it], wscal=ws, wchecks=wc, whir_root=wroot, reply=reply, paths=paths)
+        if it:
+            res.update(self.whir_query_trim(qb, w, it))
+        else:
+            res.update(qn=np.zeros(0, np.int32), qidx=np.zeros(0, np.int32), qreply=np.zeros((0, 16, 2), np.uint64), qpaths=np.zeros(0, np.uint8), final_pb=np.zeros((0, 2), np.uint64))
+        return res
 
     def read_stream_pc(self, B):
         o = np.zeros((B, 2), np.uint64)

@@ -487,7 +487,8 @@ def test_open_core_vs_oracle(hb, oracle, N, K):
     c.free()
 
 
-SP_KEYS = ("I", "q1", "r1", "vr1", "fin1", "q2", "r2", "vr2", "fin2", "iters", "wq", "wa", "wroots", "wscal", "wchecks", "whir_root")
+SP_KEYS = ("I", "q1", "r1", "vr1", "fin1", "q2", "r2", "vr2", "fin2", "iters", "wq", "wa", "wroots", "wscal", "wchecks", "whir_root",
+           "reply", "paths", "qn", "qidx", "qreply", "qpaths", "final_pb")
 
 
 @pytest.mark.parametrize("N,K", [(1 << 20, 32), (1 << 22, 32)])
@@ -613,7 +614,7 @@ def test_shockwave_prove_vs_oracle(hb, oracle, N, k):
     p = splitmix_field(N, 3)
     enc, lv = oracle.shockwave_commit(p, k)
     x = splitmix_field(N.bit_length() - 1, 4)
-    libc.srandom(9); want = oracle.shockwave_prove(p, enc, k, x)
-    libc.srandom(9); got = hb.shockwave_prove(p, enc, k, x)
+    libc.srandom(9); want = oracle.shockwave_prove(p, enc, k, x, lv)
+    libc.srandom(9); got = hb.shockwave_prove(p, enc, k, x, lv)
     for kk in want:
         assert np.array_equal(got[kk], want[kk]), kk
