@@ -17,6 +17,9 @@ graph _C[100], D[100];
 static hobbit_ctx *g_ctx = nullptr;
 static hobbit_commitment *g_commit = nullptr;
 static int g_commit_K = 0, g_commit_trs = 0; static size_t g_commit_cols = 0;
+static void *g_poly_dev = nullptr; static size_t g_poly_n = 0;      // device copy of the committed polynomial, kept for open_standard
+static hobbit_host_open_transcript g_open;
+hobbit_host_open_transcript &hobbit_host_last_open() { return g_open; }
 
 #define HCHK(call) do { int rc__ = (call); if (rc__ != 0) { printf("Error in %s: %s\n", #call, hobbit_last_error(g_ctx)); exit(-1); } } while (0)
 
@@ -30,6 +33,7 @@ hobbit_ctx *hobbit_host_ctx() {
 }
 void hobbit_host_shutdown() {
     if (g_commit) { hobbit_commitment_free(g_commit); g_commit = nullptr; }
+    if (g_poly_dev) { hobbit_free(g_ctx, g_poly_dev); g_poly_dev = nullptr; g_poly_n = 0; }
     if (g_ctx) { hobbit_ctx_destroy(g_ctx); g_ctx = nullptr; }
 }
 hobbit_commitment *hobbit_host_last_commitment() { return g_commit; }
@@ -203,11 +207,12 @@ void commit_standard(vector<F> &poly, _hash &comm, vector<vector<_hash>> &MT_has
     (void)comm;                                                     // the reference never writes it either
     size_t N = poly.size(), M = N / K;
     if (g_commit) { hobbit_commitment_free(g_commit); g_commit = nullptr; }
-    {
-        DevBuf p(poly.data(), N * sizeof(F));
-        HCHK(hobbit_commit_standard(hobbit_host_ctx(), (const hobbit_F *)p.p, N, K, tensor_row_size, linear_time ? 1 : 0, &g_commit));
-        HCHK(hobbit_sync(g_ctx));
-    }
+    // the device copy of poly is kept: open_standard receives the same vector and would otherwise pay the PCIe upload again
+    if (g_poly_dev) { hobbit_free(hobbit_host_ctx(), g_poly_dev); g_poly_dev = nullptr; }
+    HCHK(hobbit_malloc(hobbit_host_ctx(), N * sizeof(F), &g_poly_dev)); g_poly_n = N;
+    HCHK(hobbit_memcpy_h2d(g_ctx, g_poly_dev, poly.data(), N * sizeof(F)));
+    HCHK(hobbit_commit_standard(g_ctx, (const hobbit_F *)g_poly_dev, N, K, tensor_row_size, linear_time ? 1 : 0, &g_commit));
+    HCHK(hobbit_sync(g_ctx));
     g_commit_K = K; g_commit_trs = tensor_row_size; g_commit_cols = 2 * M / tensor_row_size;
     vector<uint8_t> flat(32 * (2 * M - 1));
     HCHK(hobbit_commitment_levels(g_ctx, g_commit, flat.data()));
@@ -217,6 +222,100 @@ void commit_standard(vector<F> &poly, _hash &comm, vector<vector<_hash>> &MT_has
     _tensor.clear(); _tensor.resize(K);
     const char *mat = getenv("HOBBIT_MATERIALIZE_TENSOR");
     if ((mat && atoi(mat)) || (size_t)4 * N * sizeof(F) <= ((size_t)256 << 20)) hobbit_host_materialize_tensor(_tensor);
+}
+// proof-size accounting of verify_claim_opt_blake (src/merkle_tree.cpp:326-361): 32 B per sibling not yet seen
+static void path_ps(size_t n_leaves, int depth, const vector<size_t> &pos, double &ps) {
+    vector<bool> visited(2 * n_leaves + 2, false);
+    for (size_t p : pos) {
+        size_t pe = n_leaves + p;
+        for (int i = 0; i < depth; i++) {
+            if (visited[pe ^ 1]) break;
+            visited[pe ^ 1] = true; pe /= 2; visited[pe] = true;
+            ps += 32.0 / 1024.0;
+        }
+    }
+}
+static void sumcheck2_ps(int rounds, double &ps) { for (int i = 0; i < rounds; i++) ps += 3 * sizeof(F) / 1024.0; ps += 2 * sizeof(F) / 1024.0; }   // src/sumcheck.cpp:2431,2449
+struct SpBuffers {   // host buffers behind one hobbit_shockwave_out
+    hobbit_host_shockwave_transcript &t; hobbit_shockwave_out o;
+    SpBuffers(hobbit_host_shockwave_transcript &tt, size_t N, int k) : t(tt) {
+        size_t w = N / k, W = 2 * w; int lgW = (int)log2((double)W), lw = (int)log2((double)w);
+        t.I.assign(240, 0); t.q1.assign(3 * lgW, F(0)); t.r1.assign(lgW, F(0)); t.vr1.assign(2, F(0)); t.q2.assign(3 * lgW, F(0)); t.r2.assign(lgW, F(0)); t.vr2.assign(2, F(0));
+        t.wq.assign(3 * (lw + 8), F(0)); t.wa.assign(lw + 8, F(0)); t.wroots.assign(32 * (lw + 1), 0); t.wscal.assign(2, F(0));
+        t.reply.assign(240 * (size_t)k, F(0)); t.paths.assign(240 * (size_t)lgW * 32, 0);
+        t.wqidx.assign(256, 0); t.wqreply.assign(256 * 16, F(0)); t.wqpaths.assign(256 * 24 * 32, 0); t.wfinal.assign(32, F(0)); t.wqn.assign(8, 0);
+        o = hobbit_shockwave_out{t.I.data(), hF(t.q1.data()), hF(t.r1.data()), hF(t.vr1.data()), hF(&t.fin1), hF(t.q2.data()), hF(t.r2.data()), hF(t.vr2.data()), hF(&t.fin2),
+                                 hF(t.wq.data()), hF(t.wa.data()), t.wroots.data(), hF(t.wscal.data()), t.wchecks, t.whir_root, &t.iters,
+                                 hF(t.reply.data()), t.paths.data(), t.wqidx.data(), hF(t.wqreply.data()), t.wqpaths.data(), hF(t.wfinal.data()), t.wqn.data()};
+    }
+};
+// ps of one shockwave_prove (src/Virgo.cpp:435-517) in the reference's order of accumulation
+static void shockwave_ps(const hobbit_host_shockwave_transcript &t, size_t N, int k, double &ps) {
+    size_t w = N / k, W = 2 * w; int lgW = (int)log2((double)W);
+    sumcheck2_ps(lgW, ps); sumcheck2_ps(lgW, ps);                                         // P1, prove_fft
+    if (w / 2 > 256) {                                                                    // _whir_prove (:519-686)
+        size_t q = 0;
+        for (int it = 1; it <= t.iters; it++) {
+            for (int i = 0; i < 4; i++) ps += (3 * sizeof(F)) / 1024.0;
+            size_t size = it == 1 ? 2 * w : (2 * w) >> (it - 1);                          // layer the queries of this round read
+            auto answer = [&](int round) {
+                int n = t.wqn[round];
+                ps += 16.0 * n * sizeof(F) / 1024.0;
+                vector<size_t> pos(t.wqidx.begin() + q, t.wqidx.begin() + q + n);
+                path_ps(size / 4, (int)log2((double)(size / 4)), pos, ps);
+                q += n;
+            };
+            if (it < t.iters) answer(it - 1);
+            else { ps += (w >> (4 * t.iters)) * 2 * sizeof(F) / 1024.0; answer(it - 1); }
+        }
+    } else ps += w * sizeof(F) / 1024.0;
+    ps += 240.0 * k * sizeof(F) / 1024.0;
+    vector<size_t> pos(t.I.begin(), t.I.end());
+    path_ps(W, lgW, pos, ps);
+}
+// src/Our_PC.cpp:604-692.  The prover side runs on the device (hobbit_open_standard: libc draws in the reference's order);
+// the reference's verifier emulation is reduced to its proof-size accounting (ps); vt is the time that accounting took here.
+void open_standard(vector<F> &poly, vector<F> x, vector<vector<_hash>> &Commitment_MT, vector<vector<vector<F>>> &_tensor, int K, double &vt, double &ps) {
+    (void)_tensor;
+    if (!linear_time) { printf("Error: open_standard is built for linear_time (RS x expander) only\n"); exit(-1); }
+    if (!g_commit || g_commit_K != K) { printf("Error: open_standard without a matching commit_standard\n"); exit(-1); }
+    const size_t N = poly.size(), M = N / K;
+    BUFFER_SPACE = M;
+    const int queries = 5900; aggregation_queries = queries;
+    const int trs = g_commit_trs; const size_t cols = g_commit_cols;
+    const int R1 = (int)log2((double)(2 * trs)), logc = (int)log2((double)cols), R3 = R1 + logc, depth = (int)log2((double)M);
+    if (!g_poly_dev || g_poly_n != N || getenv("HOBBIT_HOST_REUPLOAD")) {
+        if (g_poly_dev) hobbit_free(hobbit_host_ctx(), g_poly_dev);
+        HCHK(hobbit_malloc(hobbit_host_ctx(), N * sizeof(F), &g_poly_dev)); g_poly_n = N;
+        HCHK(hobbit_memcpy_h2d(g_ctx, g_poly_dev, poly.data(), N * sizeof(F)));
+    }
+    hobbit_host_open_transcript &t = g_open;
+    t.queries = queries; t.rounds = R1 + logc + 2 * R3 + logc;
+    t.cols.assign(queries, 0); t.rows.assign(queries, 0); t.reply.assign((size_t)queries * K, F(0)); t.paths.assign((size_t)queries * depth * 32, 0);
+    t.qpoly.assign(3 * (size_t)t.rounds, F(0)); t.r.assign(t.rounds, F(0)); t.vr.assign(10, F(0)); t.fin.assign(5, F(0)); t.scalars.assign(5, F(0));
+    SpBuffers bc(t.sp_c, (size_t)trs * cols, 32), bf(t.sp_f, M, 32);
+    hobbit_open_out o{t.cols.data(), t.rows.data(), hF(t.reply.data()), t.paths.data(), hF(t.qpoly.data()), hF(t.r.data()), hF(t.vr.data()), hF(t.fin.data()),
+                      hF(t.scalars.data()), t.checks, t.roots, &bc.o, &bf.o};
+    HCHK(hobbit_open_standard(g_ctx, (const hobbit_F *)g_poly_dev, N, g_commit, hF(x.data()), queries, &o));
+    if (!t.checks[0]) { printf("Error recursion 1\n"); exit(-1); }                         // src/PC_utils.cpp:323-326
+    if (!t.checks[1]) { printf("Error recursion 2\n"); exit(-1); }                         // :364-367
+    if (!t.checks[2]) { printf("Error in fft\n"); exit(-1); }                              // src/sumcheck.cpp:3016-3019
+    for (auto *sp : {&t.sp_c, &t.sp_f}) if (sp->iters && !(sp->wchecks[0] && sp->wchecks[1])) { printf("Error in final verification step\n"); exit(-1); }   // src/Virgo.cpp:562-565, 648-651
+    printf(">>OK\n");
+    auto t0 = std::chrono::steady_clock::now();
+    ps += (double)((size_t)queries * K * sizeof(F)) / 1024.0;                             // :653
+    printf(">> %lf Kb\n", (double)((size_t)queries * K * sizeof(F)) / 1024.0);
+    sumcheck2_ps(R1, ps); sumcheck2_ps(logc, ps); sumcheck2_ps(R3, ps); sumcheck2_ps(R3, ps);   // P1..P4
+    shockwave_ps(t.sp_c, (size_t)trs * cols, 32, ps);
+    sumcheck2_ps(logc, ps);                                                                // P5
+    shockwave_ps(t.sp_f, M, 32, ps);
+    double MT_ps = 0.0;
+    vector<size_t> pos(queries);
+    for (int i = 0; i < queries; i++) pos[i] = (size_t)(t.rows[i] / 4) * cols + t.cols[i];
+    path_ps(Commitment_MT.empty() ? M : Commitment_MT[0].size(), depth, pos, MT_ps);       // :676-679
+    printf("Opening proofs : %lf\n", MT_ps);
+    ps += MT_ps;
+    vt += std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::steady_clock::now() - t0).count();
 }
 void _aggregate_axpy(vector<F> &poly, vector<F> beta1, vector<F> &aggregated_vector, int K) {    // src/Our_PC.cpp:258-272
     size_t M = poly.size() / K;
@@ -408,6 +507,13 @@ void test_PC(size_t N, int option, int K) {
     printf("root ");
     for (int i = 0; i < 32; i++) printf("%02x", MT_hashes.back()[0].arr[i]);
     printf("\n");
+    double vt = 0.0, ps = 0.0;
+    start = std::chrono::steady_clock::now();
+    open_standard(poly, generate_randomness((int)log2((double)poly.size())), MT_hashes, _tensor, K, vt, ps);
+    end = std::chrono::steady_clock::now();
+    double total = commit_time + std::chrono::duration_cast<std::chrono::duration<double>>(end - start).count();
+    std::cout << "Total time: " << total << " seconds" << std::endl;
+    printf("%lf,%lf\n", ps, vt);
 }
 
 // ---- extern "C" hooks so tests can drive the C++ mirror through ctypes -------------------------------
@@ -421,6 +527,26 @@ int hobbit_host_test_pc_root(size_t N, int K, uint8_t *root_out) {
     commit_standard(poly, comm, MT, T, K);
     memcpy(root_out, MT.back()[0].arr, 32);
     return (int)MT.size();
+}
+// commit + open through the C++ mirror on test_PC's inputs; returns the transcript pieces a test compares with the oracle
+int hobbit_host_test_pc_open(size_t N, int K, unsigned seed, uint64_t *qpoly, uint64_t *r, uint32_t *cols_rows, uint8_t *sp_roots /* C_f, C_c, whir_c, whir_f */, int *checks5, double *ps_out) {
+    srandom(1);
+    vector<F> poly = generate_randomness((int)N);
+    linear_time = true; tensor_row_size = (int)(N / (K * 1ULL << 11));
+    expander_init_store(tensor_row_size);
+    _hash comm; vector<vector<_hash>> MT; vector<vector<vector<F>>> T;
+    commit_standard(poly, comm, MT, T, K);
+    vector<F> x = generate_randomness((int)log2((double)N));
+    srandom(seed);
+    double vt = 0, ps = 0;
+    open_standard(poly, x, MT, T, K, vt, ps);
+    hobbit_host_open_transcript &t = hobbit_host_last_open();
+    memcpy(qpoly, t.qpoly.data(), 16 * t.qpoly.size()); memcpy(r, t.r.data(), 16 * t.r.size());
+    for (int i = 0; i < t.queries; i++) { cols_rows[2 * i] = t.cols[i]; cols_rows[2 * i + 1] = t.rows[i]; }
+    memcpy(sp_roots, t.roots, 64); memcpy(sp_roots + 64, t.sp_c.whir_root, 32); memcpy(sp_roots + 96, t.sp_f.whir_root, 32);
+    checks5[0] = t.checks[0]; checks5[1] = t.checks[1]; checks5[2] = t.checks[2]; checks5[3] = t.sp_c.wchecks[0] & t.sp_c.wchecks[1]; checks5[4] = t.sp_f.wchecks[0] & t.sp_f.wchecks[1];
+    *ps_out = ps;
+    return t.rounds;
 }
 int hobbit_host_sumcheck2(const uint64_t *v1, const uint64_t *v2, size_t n, const uint64_t *prev, uint64_t *qpoly, uint64_t *r, uint64_t *vr, uint64_t *fin) {
     vector<F> a(n), b(n); memcpy((void *)a.data(), v1, 16 * n); memcpy((void *)b.data(), v2, 16 * n);

@@ -113,6 +113,20 @@ void compute_tensorcode(vector<F> &message, vector<vector<F>> &tensor);
 /* src/Our_PC.hpp:11-15 */
 void commit_standard(vector<F> &poly, _hash &comm, vector<vector<_hash>> &MT_hashes, vector<vector<vector<F>>> &_tensor, int K);
 void test_PC(size_t N, int option, int K);
+void open_standard(vector<F> &poly, vector<F> x, vector<vector<_hash>> &Commitment_MT, vector<vector<vector<F>>> &_tensor, int K, double &vt, double &ps);
+/* The reference's open_standard returns nothing but vt / ps (it never serialises its proof); the messages the device prover
+ * produced for the last open_standard call are kept here.  Layouts as hobbit_open_out / hobbit_shockwave_out (include/hobbit_hip.h). */
+struct hobbit_host_shockwave_transcript {
+    vector<uint32_t> I; vector<F> q1, r1, vr1, q2, r2, vr2, wq, wa, wscal, reply, wqreply, wfinal; F fin1, fin2;
+    vector<uint8_t> wroots, paths, wqpaths; uint8_t whir_root[32]; vector<int32_t> wqidx, wqn; int wchecks[2] = {0, 0}, iters = 0;
+};
+struct hobbit_host_open_transcript {
+    int queries = 0, rounds = 0;
+    vector<uint32_t> cols, rows; vector<F> reply, qpoly, r, vr, fin, scalars; vector<uint8_t> paths; uint8_t roots[64];
+    int checks[3] = {0, 0, 0};
+    hobbit_host_shockwave_transcript sp_c, sp_f;
+};
+hobbit_host_open_transcript &hobbit_host_last_open();
 /* src/Our_PC.cpp:258-272, 291-305 (file-local helpers of open_standard) */
 void _aggregate_axpy(vector<F> &poly, vector<F> beta1, vector<F> &aggregated_vector, int K);
 void _compute_aggregation_reply(vector<vector<size_t>> &I, vector<vector<F>> &reply, vector<vector<vector<F>>> &_tensor, int K);

@@ -335,6 +335,36 @@ def test_cpp_host_mirror_test_pc_and_sumcheck(oracle):
     lib.hobbit_host_close()
 
 
+def test_host_mirror_open_standard(oracle):
+    """open_standard(poly, x, MT, _tensor, K, vt, ps) of the C++ mirror (reference signature, src/Our_PC.hpp:13) on test_PC's own
+    input sequence: transcripts equal the oracle's open_standard, all of the reference's exit(-1) checks pass, ps is the
+    reference's proof-size accounting."""
+    import ctypes
+    from __graft_entry__ import PKG, build_host
+    build_host()
+    lib = ctypes.CDLL(os.path.join(PKG, "libhobbit_host.so"))
+    libc = ctypes.CDLL(None)
+    N, K, queries, seed = 1 << 20, 32, 5900, 1234
+    trs = N // (K << 11)
+    R1, logc = (2 * trs).bit_length() - 1, 12
+    rounds = R1 + logc + 2 * (R1 + logc) + logc
+    q = np.zeros((rounds, 3, 2), np.uint64); r = np.zeros((rounds, 2), np.uint64); I = np.zeros((queries, 2), np.uint32)
+    roots = np.zeros((4, 32), np.uint8); checks = np.zeros(5, np.int32); ps = ctypes.c_double(0)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.hobbit_host_test_pc_open.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_uint] + [ctypes.c_void_p] * 6
+    assert lib.hobbit_host_test_pc_open(N, K, seed, P(q), P(r), P(I), P(roots), P(checks), ctypes.byref(ps)) == rounds
+    lib.hobbit_host_close()
+    oracle.rng_reset(); poly = oracle.generate_randomness(N); oracle.expander_init_store(trs)
+    x = oracle.generate_randomness(N.bit_length() - 1)
+    libc.srandom(seed); want = oracle.open_standard(poly, K, trs, x, queries)
+    assert checks.tolist() == [1, 1, 1, 1, 1]
+    assert np.array_equal(q, want["poly"]) and np.array_equal(r, want["r"]) and np.array_equal(I, want["I"])
+    assert np.array_equal(roots[:2], want["roots"])
+    assert np.array_equal(roots[2], want["sp_c"]["whir_root"]) and np.array_equal(roots[3], want["sp_f"]["whir_root"])
+    # proof size: at least the replies (5900 x 32 F) plus something for every other message, and well under the tensor itself
+    assert queries * K * 16 / 1024.0 < ps.value < 4 * queries * K * 16 / 1024.0
+
+
 # ---- multi-GPU building blocks on one GPU ------------------------------------------------------
 def test_sharded_commit_hip_ops_world1(hb, oracle):
     """The per-rank GPU operations of the chunk-sharded commit (tensor codes of the local chunks,
