@@ -42,22 +42,20 @@ static int get_twiddles(hobbit_ctx *ctx, int logn, bool inverse, const F **out) 
     m[logn] = d; *out = d; return 0;
 }
 
-// per-pass twiddle tables of k_fft4096: pass with butterfly stride h stores, for k < h,
-//   [wA(k) | wB0(k) | wB1(k) | wC0(k) | wC1(k) | wC2(k) | wC3(k)],  w*(k) = w^((k + s h) * len / (2h,4h,8h))
+// per-pass twiddle tables of k_fft4096 (true radix-8 DIT): the pass with octet stride h stores, for t = 1..7 and k < h,
+//   T[t-1][k] = w^(rev3(t) * k * len / (8h))     (block t of an octet holds the sub-transform of the samples = rev3(t) mod 8)
 static int get_tw8(hobbit_ctx *ctx, bool inverse) {
     const int d = inverse ? 1 : 0;
     if (ctx->tw8[d]) return 0;
     const uint32_t len = 4096;
-    std::vector<F> w(len / 2);
+    std::vector<F> w(len);
     w[0] = fmake(1);
     F w1 = root_of_unity(12); if (inverse) w1 = finv(w1);
-    for (uint32_t i = 1; i < len / 2; i++) w[i] = fmul(w[i - 1], w1);
+    for (uint32_t i = 1; i < len; i++) w[i] = fmul(w[i - 1], w1);
+    static const uint32_t rev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
     std::vector<F> t;
-    for (uint32_t h : {8u, 64u, 512u}) {
-        for (uint32_t k = 0; k < h; k++) t.push_back(w[k * (len / (2 * h))]);
-        for (uint32_t s2 = 0; s2 < 2; s2++) for (uint32_t k = 0; k < h; k++) t.push_back(w[(k + s2 * h) * (len / (4 * h))]);
-        for (uint32_t s4 = 0; s4 < 4; s4++) for (uint32_t k = 0; k < h; k++) t.push_back(w[(k + s4 * h) * (len / (8 * h))]);
-    }
+    for (uint32_t h : {8u, 64u, 512u})
+        for (uint32_t b = 1; b < 8; b++) for (uint32_t k = 0; k < h; k++) t.push_back(w[(rev3[b] * k * (len / (8 * h))) % len]);
     F *dptr = nullptr;
     if (hipMalloc((void **)&dptr, t.size() * sizeof(F)) != hipSuccess) return ctx->fail(HOBBIT_ENOMEM, "twiddle alloc failed");
     HB_CHECK(ctx, hipMemcpy(dptr, t.data(), t.size() * sizeof(F), hipMemcpyHostToDevice));

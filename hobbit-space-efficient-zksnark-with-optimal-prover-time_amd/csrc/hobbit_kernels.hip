@@ -154,8 +154,27 @@ struct Fft4kConst { F w8, w8_3; int w4_plus_i; };
 __device__ __forceinline__ F fmul_w4(const F &a, int plus_i) {   // a * (+i) or a * (-i)
     return plus_i ? fmake(a.im ? P61 - a.im : 0, a.re) : fmake(a.im, a.re ? P61 - a.re : 0);
 }
+// a * w8, w8 = the primitive 8th root of unity of the transform direction.  sqrt(2) = 2^31 in F_p (2^62 = 2), so
+// w8 = 2^30 (1 - i) forward (w4 = -i) and 2^30 (1 + i) inverse: a rotation by 30 bits of (a.re +- a.im), no product at all.
+__device__ __forceinline__ uint64_t rot30p(uint64_t x) { return ((x << 30) & P61) | (x >> 31); }     // x * 2^30 mod 2^61-1, canonical in/out
+__device__ __forceinline__ F fmul_w8(const F &a, int plus_i) {
+    return plus_i ? fmake(rot30p(subp(a.re, a.im)), rot30p(addp(a.re, a.im))) : fmake(rot30p(addp(a.re, a.im)), rot30p(subp(a.im, a.re)));
+}
 __device__ __forceinline__ uint32_t fft_phys(uint32_t i) { return i + (i >> 3); }
 #define HB_BFLY(x, y, w) do { F v__ = fmul(y, w); y = fsub(x, v__); x = fadd(x, v__); } while (0)
+#define HB_BFLY1(x, y) do { F v__ = y; y = fsub(x, v__); x = fadd(x, v__); } while (0)
+// the last two stages of an 8-point DIT DFT on a[0..7] (inputs in bit-reversed order, first stage done): twiddles 1, w4, w8, w8^3
+__device__ __forceinline__ void dft8_tail(F (&a)[8], int plus_i) {
+    F t;
+    HB_BFLY1(a[0], a[2]);
+    t = fmul_w4(a[3], plus_i); a[3] = fsub(a[1], t); a[1] = fadd(a[1], t);
+    HB_BFLY1(a[4], a[6]);
+    t = fmul_w4(a[7], plus_i); a[7] = fsub(a[5], t); a[5] = fadd(a[5], t);
+    HB_BFLY1(a[0], a[4]);
+    t = fmul_w8(a[5], plus_i); a[5] = fsub(a[1], t); a[1] = fadd(a[1], t);
+    t = fmul_w4(a[6], plus_i); a[6] = fsub(a[2], t); a[2] = fadd(a[2], t);
+    t = fmul_w4(fmul_w8(a[7], plus_i), plus_i); a[7] = fsub(a[3], t); a[3] = fadd(a[3], t);
+}
 
 template <bool PADDED>
 __global__ void __launch_bounds__(512)
@@ -168,38 +187,30 @@ k_fft4096(const F *__restrict__ src, size_t src_ld, size_t src_es, F *__restrict
     const F *in = src + (size_t)grp * src_gs + (size_t)r * src_ld;
     F *out = dst + (size_t)grp * dst_gs + (size_t)r * dst_ld;
     const uint32_t tid = threadIdx.x;
+    const int plus_i = cst.w4_plus_i;
     constexpr uint32_t NLOAD = PADDED ? 2048 : 4096;
 #pragma unroll
     for (uint32_t i = 0; i < NLOAD; i += 512) stF(&s[fft_phys(i + tid)], ldF(in + (size_t)(i + tid) * src_es));
     __syncthreads();
     F a[8];
-    {   // ---- pass 0 (h = 1)
+    {   // ---- pass 0 (h = 1): a plain 8-point DFT
         const uint32_t m = __brev(tid) >> 23;                       // rev9(b), b = tid
         a[0] = ldF(&s[fft_phys(m)]); a[2] = ldF(&s[fft_phys(m + 1024)]); a[4] = ldF(&s[fft_phys(m + 512)]); a[6] = ldF(&s[fft_phys(m + 1536)]);
         if (PADDED) { a[1] = a[0]; a[3] = a[2]; a[5] = a[4]; a[7] = a[6]; }       // (u, 0) -> (u, u)
         else {
             a[1] = ldF(&s[fft_phys(m + 2048)]); a[3] = ldF(&s[fft_phys(m + 3072)]); a[5] = ldF(&s[fft_phys(m + 2560)]); a[7] = ldF(&s[fft_phys(m + 3584)]);
-            F t;
-            t = a[1]; a[1] = fsub(a[0], t); a[0] = fadd(a[0], t);
-            t = a[3]; a[3] = fsub(a[2], t); a[2] = fadd(a[2], t);
-            t = a[5]; a[5] = fsub(a[4], t); a[4] = fadd(a[4], t);
-            t = a[7]; a[7] = fsub(a[6], t); a[6] = fadd(a[6], t);
+            HB_BFLY1(a[0], a[1]); HB_BFLY1(a[2], a[3]); HB_BFLY1(a[4], a[5]); HB_BFLY1(a[6], a[7]);
         }
-        F t;
-        t = a[2]; a[2] = fsub(a[0], t); a[0] = fadd(a[0], t);                      // twiddle 1
-        t = fmul_w4(a[3], cst.w4_plus_i); a[3] = fsub(a[1], t); a[1] = fadd(a[1], t);
-        t = a[6]; a[6] = fsub(a[4], t); a[4] = fadd(a[4], t);
-        t = fmul_w4(a[7], cst.w4_plus_i); a[7] = fsub(a[5], t); a[5] = fadd(a[5], t);
-        t = a[4]; a[4] = fsub(a[0], t); a[0] = fadd(a[0], t);
-        HB_BFLY(a[1], a[5], cst.w8);
-        t = fmul_w4(a[6], cst.w4_plus_i); a[6] = fsub(a[2], t); a[2] = fadd(a[2], t);
-        HB_BFLY(a[3], a[7], cst.w8_3);
+        dft8_tail(a, plus_i);
         __syncthreads();                                            // every input has been read
         const uint32_t o = fft_phys(8 * tid);                       // 9*tid: positions 8b..8b+7 are contiguous
 #pragma unroll
         for (int t8 = 0; t8 < 8; t8++) stF(&s[o + t8], a[t8]);
         __syncthreads();
     }
+    // ---- passes 1..3: true radix-8 DIT.  Block t of the stride-h octet holds the sub-transform of the samples = rev3(t) mod 8, so
+    // X[k + m h] = sum_t W_8^{rev3(t) m} (W_{8h}^{rev3(t) k} a[t]): seven general products (tables [7][h], t = 1..7), then the same
+    // product-free 8-point DFT as pass 0 -- 7 instead of 12 products per octet.
 #pragma unroll
     for (int pass = 1; pass <= 3; pass++) {
         const uint32_t h = pass == 1 ? 8u : pass == 2 ? 64u : 512u;
@@ -207,11 +218,10 @@ k_fft4096(const F *__restrict__ src, size_t src_ld, size_t src_es, F *__restrict
         const uint32_t k = tid & (h - 1), j = tid / h, i0 = j * 8 * h + k;
 #pragma unroll
         for (int t8 = 0; t8 < 8; t8++) a[t8] = ldF(&s[fft_phys(i0 + t8 * h)]);
-        const F wA = ldF(tw + k), wB0 = ldF(tw + h + k), wB1 = ldF(tw + 2 * h + k);
-        HB_BFLY(a[0], a[1], wA); HB_BFLY(a[2], a[3], wA); HB_BFLY(a[4], a[5], wA); HB_BFLY(a[6], a[7], wA);
-        HB_BFLY(a[0], a[2], wB0); HB_BFLY(a[1], a[3], wB1); HB_BFLY(a[4], a[6], wB0); HB_BFLY(a[5], a[7], wB1);
-        const F wC0 = ldF(tw + 3 * h + k), wC1 = ldF(tw + 4 * h + k), wC2 = ldF(tw + 5 * h + k), wC3 = ldF(tw + 6 * h + k);
-        HB_BFLY(a[0], a[4], wC0); HB_BFLY(a[1], a[5], wC1); HB_BFLY(a[2], a[6], wC2); HB_BFLY(a[3], a[7], wC3);
+#pragma unroll
+        for (int t8 = 1; t8 < 8; t8++) a[t8] = fmul(a[t8], ldF(tw + (t8 - 1) * h + k));
+        HB_BFLY1(a[0], a[1]); HB_BFLY1(a[2], a[3]); HB_BFLY1(a[4], a[5]); HB_BFLY1(a[6], a[7]);
+        dft8_tail(a, plus_i);
         if (pass < 3) {
 #pragma unroll
             for (int t8 = 0; t8 < 8; t8++) stF(&s[fft_phys(i0 + t8 * h)], a[t8]);
