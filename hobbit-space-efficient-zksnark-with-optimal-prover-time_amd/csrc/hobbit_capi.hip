@@ -155,6 +155,9 @@ void hobbit_ctx_destroy(hobbit_ctx *ctx) {
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->ws2) hipFree(ctx->ws2);
     if (ctx->pin) hipHostFree(ctx->pin);
+    if (ctx->mbox) hipHostFree((void *)ctx->mbox);
+    if (ctx->d_ticket) hipFree(ctx->d_ticket);
+    for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
     if (ctx->ws3) hipFree(ctx->ws3);
     if (ctx->ws4) hipFree(ctx->ws4);
     if (ctx->pinc) hipHostFree(ctx->pinc);
@@ -184,7 +187,7 @@ int hobbit_timer_end_ms(hobbit_ctx *ctx, float *ms) {
     HB_CHECK(ctx, hipEventRecord(ctx->t1, ctx->stream)); HB_CHECK(ctx, hipEventSynchronize(ctx->t1));
     HB_CHECK(ctx, hipEventElapsedTime(ms, ctx->t0, ctx->t1)); return 0;
 }
-int hobbit_profile_enable(hobbit_ctx *ctx, int on) { ctx->prof_on = on != 0; return 0; }
+int hobbit_profile_enable(hobbit_ctx *ctx, int on) { ctx->prof_on = on < 0 ? 0 : on > 2 ? 1 : on; return 0; }
 int hobbit_profile_reset(hobbit_ctx *ctx) { hipStreamSynchronize(ctx->stream); ctx->prof_collect(); ctx->prof.clear(); return 0; }
 int hobbit_profile_get(hobbit_ctx *ctx, const char *kernel, double *total_ms, long long *launches) {
     HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -627,13 +630,18 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
     const F *prev = cF(d_com); const uint8_t *prev_lv = d_com_levels; size_t prev_sz = 2 * N;   // the layer the next query round reads
     WhirQueryCursor qc; std::vector<uint64_t> ridx;
     for (;;) {
+        // the fold challenges a = random() do not depend on the round polynomials (:561), so the four rounds of an iteration are
+        // queued back to back and their coefficients read once
+        F av[4];
         for (int i = 0; i < k; i++) {
             const size_t L = N >> (iter * k + i + 1);
-            const F a = fmake((uint64_t)random());                              // a.push_back(random()) (:561)
-            HB_TRY(launch_whir_round(ctx, poly, beta, L, a, part, coef));
-            HB_CHECK(ctx, hipMemcpyAsync(pin, coef, 3 * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
-            HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-            const F pa = pin[0], pb = pin[1], pc = pin[2];
+            av[i] = fmake((uint64_t)random());                                  // a.push_back(random()) (:561)
+            HB_TRY(launch_whir_round(ctx, poly, beta, L, av[i], part, coef + 3 * i));
+        }
+        HB_CHECK(ctx, hipMemcpyAsync(pin, coef, 12 * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < k; i++) {
+            const F pa = pin[3 * i], pb = pin[3 * i + 1], pc = pin[3 * i + 2], a = av[i];
             if (!feq(fadd(fadd(pa, pb), fadd(pc, pc)), eval)) h_checks[0] = 0;  // "Error in %d" (:562-565)
             eval = fadd(fmul(fadd(fmul(pa, a), pb), a), pc);
             mF(h_qpoly)[3 * nq] = pa; mF(h_qpoly)[3 * nq + 1] = pb; mF(h_qpoly)[3 * nq + 2] = pc; mF(h_a)[nq] = a; nq++;

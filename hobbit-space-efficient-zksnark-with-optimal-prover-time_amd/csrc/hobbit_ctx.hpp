@@ -3,6 +3,7 @@
 // graphs in their device (gather / sliced-ELL) form.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <map>
 #include <string>
 #include <vector>
@@ -53,13 +54,15 @@ struct ProfEntry { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double ms 
 
 }  // namespace hobbit
 
+namespace hobbit { struct Mailbox { F vals[16]; uint32_t flag; uint32_t pad[3]; }; }
+
 struct hobbit_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     std::string err;
     // profiler
-    bool prof_on = false;
+    int prof_on = 0;
     std::map<std::string, hobbit::ProfEntry> prof;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // twiddles: logn -> device table of 2^(logn-1) forward (and inverse) roots
@@ -135,14 +138,24 @@ struct hobbit_ctx {
         err = std::string(what) + ": " + hipGetErrorString(e);
         return HOBBIT_EHIP;
     }
+    // prof_on: 0 off, 1 every launch, 2 only the commit's bulk kernels (a handful of launches per step: the event brackets then
+    // cost nothing measurable, whereas bracketing the ~500 small launches of an open adds milliseconds of host time per step)
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t ev_get() { if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; } hipEvent_t e; hipEventCreate(&e); return e; }
+    static bool prof_bulk(const char *n) {
+        return !strncmp(n, "k_leaf_chain", 12) || !strncmp(n, "k_fft4096", 9) || !strncmp(n, "k_encode", 8) || !strcmp(n, "k_transpose") ||
+               !strncmp(n, "k_inner_digests", 15) || !strncmp(n, "k_chain_digests", 15) || !strcmp(n, "k_aggregate");
+    }
+    bool prof_cur = false;
     void prof_begin(const char *name) {
-        if (!prof_on) return;
-        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        prof_cur = prof_on == 1 || (prof_on == 2 && prof_bulk(name));
+        if (!prof_cur) return;
+        hipEvent_t a = ev_get(), b = ev_get();
         hipEventRecord(a, stream);
         prof[name].ev.emplace_back(a, b);
     }
     void prof_end(const char *name) {
-        if (!prof_on) return;
+        if (!prof_cur) return;
         auto &e = prof[name]; hipEventRecord(e.ev.back().second, stream); e.launches++;
     }
     void prof_collect() {
@@ -150,9 +163,44 @@ struct hobbit_ctx {
             for (auto &p : kv.second.ev) {
                 hipEventSynchronize(p.second);
                 float ms = 0; hipEventElapsedTime(&ms, p.first, p.second);
-                kv.second.ms += ms; hipEventDestroy(p.first); hipEventDestroy(p.second);
+                kv.second.ms += ms; ev_pool.push_back(p.first); ev_pool.push_back(p.second);
             }
             kv.second.ev.clear();
+        }
+    }
+    // ---- mailbox: the one-workgroup reduction kernel of a sumcheck round writes its few coefficients straight into coherent pinned
+    // host memory and then a sequence number; the host spins on that word (HOBBIT_MBOX=sync: sleeps in hipStreamSynchronize)
+    // instead of queueing a copy and synchronising.
+    hobbit::Mailbox *mbox = nullptr; unsigned *d_ticket = nullptr; uint32_t mbox_seq = 0;
+    int mailbox(hobbit::Mailbox **m, unsigned **ticket) {
+        if (!mbox) {
+            if (hipHostMalloc((void **)&mbox, 4096, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { mbox = nullptr; err = "mailbox hipHostMalloc failed"; return HOBBIT_ENOMEM; }
+            memset((void *)mbox, 0, 4096);
+            if (hipMalloc((void **)&d_ticket, 256) != hipSuccess) { err = "mailbox ticket alloc failed"; return HOBBIT_ENOMEM; }
+            if (hipMemsetAsync(d_ticket, 0, 256, stream) != hipSuccess) { err = "mailbox ticket memset failed"; return HOBBIT_EHIP; }
+        }
+        *m = mbox; *ticket = d_ticket; return 0;
+    }
+    // wait until the kernel tagged `seq` has posted; bounded: gives up (error) once the stream has drained without the post
+    int mbox_mode = -1;
+    int mbox_wait(uint32_t seq) {
+        if (mbox_mode < 0) { const char *e = getenv("HOBBIT_MBOX"); mbox_mode = (e && !strcmp(e, "sync")) ? 0 : 1; }
+        if (mbox_mode == 0) {                    // sleep in the runtime; the post is complete when the kernel is
+            int r = hip(hipStreamSynchronize(stream), "mailbox wait");
+            if (r) return r;
+            if (mbox->flag != seq) { err = "mailbox: kernel finished without posting"; return HOBBIT_EHIP; }
+            return 0;
+        }
+        // the runtime queues launches lazily: a query makes it submit what is pending before we start spinning
+        hipError_t q = hipStreamQuery(stream);
+        if (q != hipSuccess && q != hipErrorNotReady) return hip(q, "mailbox wait");
+        for (uint64_t it = 1;; it++) {
+            if (__atomic_load_n(&mbox->flag, __ATOMIC_ACQUIRE) == seq) return 0;
+            if ((it & 0xFFFF) == 0) {
+                q = hipStreamQuery(stream);
+                if (q == hipSuccess) { if (__atomic_load_n(&mbox->flag, __ATOMIC_ACQUIRE) == seq) return 0; err = "mailbox: kernel finished without posting"; return HOBBIT_EHIP; }
+                if (q != hipErrorNotReady) return hip(q, "mailbox wait");
+            }
         }
     }
     int workspace(size_t bytes, void **p) {

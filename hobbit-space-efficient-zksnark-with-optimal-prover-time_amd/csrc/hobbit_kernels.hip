@@ -1065,6 +1065,34 @@ __global__ void __launch_bounds__(256) k_sc_reduce(const F *__restrict__ partial
     block_reduce_store<NC>(c, out);
 }
 
+// The same reduction, posting to the host mailbox: the NC coefficients go straight into coherent pinned host memory, then the
+// launch's sequence number (system-scope release); the host spins on that word instead of queueing a 48-byte copy and sleeping
+// in hipStreamSynchronize.  (Folding this into the round kernel itself -- last workgroup to arrive reduces -- needs an agent-scope
+// release per workgroup, which on this 8-XCD part writes back each XCD's L2: measured 0.16 ms per launch, so it stays a kernel.)
+template <int NC>
+__global__ void __launch_bounds__(256) k_sc_reduce_post(const F *__restrict__ partials, int nblocks, Mailbox *mb, uint32_t seq) {
+    F c[NC];
+#pragma unroll
+    for (int q = 0; q < NC; q++) c[q] = fmake(0);
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
+#pragma unroll
+        for (int q = 0; q < NC; q++) c[q] = fadd(c[q], ldF(partials + (size_t)b * NC + q));
+    __shared__ F red2[NC][16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NC; q++) { F sm = wave_sum(c[q]); if (lane == 0) red2[q][wv] = sm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 0; q < NC; q++) {
+            F sm = red2[q][0];
+            for (int w = 1; w < nw; w++) sm = fadd(sm, red2[q][w]);
+            uint64_t *o = reinterpret_cast<uint64_t *>(&mb->vals[q]);
+            __hip_atomic_store(o, sm.re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(o + 1, sm.im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __hip_atomic_store(&mb->flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // host tail of the 2-product sumcheck: tables a,b of size sz (not yet folded with `rnd` when
 // pending_fold), continuing at round `round` exactly as src/sumcheck.cpp:2401-2452
 static void sc2_host_tail(std::vector<F> &a, std::vector<F> &b, F &rnd, bool pending_fold, int round, int rounds, F *h_qpoly, F *h_r) {
@@ -1178,7 +1206,7 @@ __global__ void __launch_bounds__(256) k_whir_round(F *__restrict__ poly, F *__r
     }
     block_reduce_store<3>(c, partials);
 }
-int launch_whir_round(hobbit_ctx *ctx, F *poly, F *beta, size_t L, F a, F *part, F *coef) {
+int launch_whir_round(hobbit_ctx *ctx, F *poly, F *beta, size_t L, F a, F *part, F *coef) {   // coef: 3 F of this round (device)
     int nb = grid_for(L, 256, 1024);
     HB_LAUNCH(ctx, "k_whir_round", k_whir_round, dim3(nb), dim3(256), 0, poly, beta, L, a, part);
     HB_LAUNCH(ctx, "k_sc_reduce", k_sc_reduce<3>, dim3(1), dim3(256), 0, part, nb, coef);
@@ -1223,8 +1251,8 @@ int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev
     } else {
         size_t szA = n / 2, szB = n / 4;
         F *ws; HB_TRY(ctx->workspace((2 * szA + 2 * szB + (size_t)MAXB * 3 + 4) * sizeof(F), (void **)&ws));
-        F *A1 = ws, *A2 = A1 + szA, *B1 = A2 + szA, *B2 = B1 + szB, *part = B2 + szB, *coef = part + (size_t)MAXB * 3;
-        F *pin; HB_TRY(ctx->pinned(4 * sizeof(F), (void **)&pin));
+        F *A1 = ws, *A2 = A1 + szA, *B1 = A2 + szA, *B2 = B1 + szB, *part = B2 + szB;
+        Mailbox *mb; unsigned *ticket; HB_TRY(ctx->mailbox(&mb, &ticket));
         const F *s1 = v1, *s2 = v2;
         F *d1 = A1, *d2 = A2;
         int i = 0;
@@ -1232,16 +1260,16 @@ int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev
         for (;; i++) {
             size_t L = n >> (i + 1);          // pairs of the round-i tables
             int nb = grid_for(L, 256, MAXB);
+            const uint32_t seq = ++ctx->mbox_seq;
             if (i == 0) HB_LAUNCH(ctx, "k_sc2_poly", k_sc2_poly, dim3(nb), dim3(256), 0, s1, s2, L, part);
             else {
                 HB_LAUNCH(ctx, "k_sc2_fold_poly", k_sc2_fold_poly, dim3(nb), dim3(256), 0, s1, s2, d1, d2, L, rnd, part);
                 s1 = d1; s2 = d2; cur = 2 * L;
                 if (d1 == A1) { d1 = B1; d2 = B2; } else { d1 = A1; d2 = A2; }
             }
-            HB_LAUNCH(ctx, "k_sc_reduce", k_sc_reduce<3>, dim3(1), dim3(256), 0, part, nb, coef);
-            HB_CHECK(ctx, hipMemcpyAsync(pin, coef, 3 * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
-            HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-            for (int q = 0; q < 3; q++) { rnd = mimc_hash(rnd, pin[q]); h_qpoly[3 * i + q] = pin[q]; }
+            HB_LAUNCH(ctx, "k_sc_reduce", k_sc_reduce_post<3>, dim3(1), dim3(256), 0, part, nb, mb, seq);
+            HB_TRY(ctx->mbox_wait(seq));                                  // the last workgroup posts the three coefficients to the host
+            for (int q = 0; q < 3; q++) { const F cq = mb->vals[q]; rnd = mimc_hash(rnd, cq); h_qpoly[3 * i + q] = cq; }
             h_r[i] = rnd;
             if (cur <= 2 * SC_TAIL || i == rounds - 1) break;   // hand the (unfolded) round-i tables to the host
         }

@@ -58,7 +58,7 @@ int hobbit_timer_begin(hobbit_ctx *ctx);
 int hobbit_timer_end_ms(hobbit_ctx *ctx, float *ms);
 /* per-kernel profiling: when enabled every kernel launch is bracketed by HIP events on the
  * context's stream; hobbit_profile_get returns total ms and launch count by kernel name. */
-int hobbit_profile_enable(hobbit_ctx *ctx, int on);
+int hobbit_profile_enable(hobbit_ctx *ctx, int on);   /* 0 off, 1 every launch, 2 only the commit's bulk kernels */
 int hobbit_profile_reset(hobbit_ctx *ctx);
 int hobbit_profile_get(hobbit_ctx *ctx, const char *kernel, double *total_ms, long long *launches);
 int hobbit_profile_names(hobbit_ctx *ctx, char *buf, size_t buflen); /* ';'-separated */
