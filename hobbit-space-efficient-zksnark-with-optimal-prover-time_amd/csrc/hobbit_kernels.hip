@@ -430,22 +430,32 @@ k_encode(const F *__restrict__ src, size_t ld_src, F *__restrict__ dst, size_t l
     F *out = dst + (size_t)blockIdx.x * ld_dst;
     for (uint32_t i = ps.ld_lo + threadIdx.x; i < ps.ld_hi; i += blockDim.x) stF(&cw[i], ldF(in + i));
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    // wave index as a scalar: the slice descriptors below then come through the scalar cache (s_load) instead of a per-lane
+    // global load, and the slice loop is scalar control flow
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
     const uint32_t tl = lane % ENC_SW;
     for (uint32_t s = ps.s_lo; s < ps.s_hi; s++) {
         const EncStep sp = steps[s];
         const F *cin = cw + sp.in_off;
-        for (uint32_t sl = wave; sl < sp.n_slices; sl += nwaves) {
-            const uint32_t base = slice_ptr[sp.slice_base + sl] + lane;
-            const uint32_t iters = slice_width[sp.slice_base + sl] / ENC_SPLIT;    // edge records per lane
-            F acc;
-            if (SMALLW) {
+        if (SMALLW) {
+            // slices of this wave: sl = wave, wave + nwaves, ...  The first group of edge records of the NEXT slice is requested
+            // before the current slice's remainder / fold / shuffle / store, so its L2 latency is off the critical path.
+            uint32_t sl = wave;
+            bool have = sl < sp.n_slices;
+            uint32_t nbase = 0, niters = 0;
+            uint2 en[ENC_UNROLL];
+            if (have) {
+                nbase = slice_ptr[sp.slice_base + sl] + lane; niters = slice_width[sp.slice_base + sl] / ENC_SPLIT;
+                if (niters >= ENC_UNROLL) {
+#pragma unroll
+                    for (int u = 0; u < ENC_UNROLL; u++) en[u] = e32[nbase + u * 64];
+                }
+            }
+            while (have) {
+                const uint32_t base = nbase, iters = niters, cur = sl;
                 Acc96 rl = {0, 0}, rh = {0, 0}, il = {0, 0}, ih = {0, 0};
                 uint32_t j = 0;
                 if (iters >= ENC_UNROLL) {
-                    uint2 en[ENC_UNROLL];
-#pragma unroll
-                    for (int u = 0; u < ENC_UNROLL; u++) en[u] = e32[base + u * 64];
                     for (; j + ENC_UNROLL <= iters; j += ENC_UNROLL) {
                         uint2 e[ENC_UNROLL]; uint4 x[ENC_UNROLL];
 #pragma unroll
@@ -463,24 +473,42 @@ k_encode(const F *__restrict__ src, size_t ld_src, F *__restrict__ dst, size_t l
                         }
                     }
                 }
+                sl += nwaves; have = sl < sp.n_slices;
+                if (have) {                                   // next slice: descriptor + first record group in flight
+                    nbase = slice_ptr[sp.slice_base + sl] + lane; niters = slice_width[sp.slice_base + sl] / ENC_SPLIT;
+                    if (niters >= ENC_UNROLL) {
+#pragma unroll
+                        for (int u = 0; u < ENC_UNROLL; u++) en[u] = e32[nbase + u * 64];
+                    }
+                }
                 for (; j < iters; j++) {                      // remainder (rows are sorted by in-degree: at most ENC_UNROLL-1 records)
                     const uint2 e = e32[base + j * 64];
                     const uint4 x = *reinterpret_cast<const uint4 *>(cin + e.x);
                     acc96_mad(rl, e.y, x.x); acc96_mad(rh, e.y, x.y); acc96_mad(il, e.y, x.z); acc96_mad(ih, e.y, x.w);
                 }
-                acc = fmake(acc_fold(rl, rh), acc_fold(il, ih));
-            } else {
-                acc = fmake(0);
+                F acc = fmake(acc_fold(rl, rh), acc_fold(il, ih));
+#pragma unroll
+                for (int m = ENC_SW; m < 64; m <<= 1) acc = fadd(acc, shfl_xor_F(acc, m));   // combine the lane groups
+                const uint32_t t = slice_out[(sp.slice_base + cur) * ENC_SW + tl];    // outputs are sliced in order of in-degree
+                if (lane < ENC_SW && t != 0xFFFFFFFFu) {
+                    if (ps.direct_out) stF(out + sp.out_off + t, acc); else stF(&cw[sp.out_off + t], acc);
+                }
+            }
+        } else {
+            for (uint32_t sl = wave; sl < sp.n_slices; sl += nwaves) {
+                const uint32_t base = slice_ptr[sp.slice_base + sl] + lane;
+                const uint32_t iters = slice_width[sp.slice_base + sl] / ENC_SPLIT;    // edge records per lane
+                F acc = fmake(0);
                 for (uint32_t j = 0; j < iters; j++) {
                     const uint32_t id = eidx[base + j * 64];
                     acc = fadd(acc, fmul(ldF(cin + id), ldF(ew + base + j * 64)));
                 }
-            }
 #pragma unroll
-            for (int m = ENC_SW; m < 64; m <<= 1) acc = fadd(acc, shfl_xor_F(acc, m));   // combine the lane groups
-            const uint32_t t = slice_out[(sp.slice_base + sl) * ENC_SW + tl];    // outputs are sliced in order of in-degree
-            if (lane < ENC_SW && t != 0xFFFFFFFFu) {
-                if (ps.direct_out) stF(out + sp.out_off + t, acc); else stF(&cw[sp.out_off + t], acc);
+                for (int m = ENC_SW; m < 64; m <<= 1) acc = fadd(acc, shfl_xor_F(acc, m));
+                const uint32_t t = slice_out[(sp.slice_base + sl) * ENC_SW + tl];
+                if (lane < ENC_SW && t != 0xFFFFFFFFu) {
+                    if (ps.direct_out) stF(out + sp.out_off + t, acc); else stF(&cw[sp.out_off + t], acc);
+                }
             }
         }
         __syncthreads();
