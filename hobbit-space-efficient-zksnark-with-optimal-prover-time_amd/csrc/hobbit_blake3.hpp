@@ -15,9 +15,22 @@
 namespace hobbit {
 
 #define HB3_ROTR(x, c) (((x) >> (c)) | ((x) << (32 - (c))))
+// rotr(d ^ a, 16).  On the device: two half-word-select XORs (SDWA, 2-source VALU rate) instead of an XOR plus a v_alignbit_b32,
+// which issues at half rate on this chip (profiles/r01_microbench.txt) -- the leaf chain runs at the VALU issue limit.
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __forceinline__ uint32_t hb3_xor_rot16(uint32_t d, uint32_t a) {
+    uint32_t t;
+    asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t"
+        "v_xor_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "=&v"(t) : "v"(d), "v"(a));
+    return t;
+}
+#define HB3_XROT16(d, a) hb3_xor_rot16(d, a)
+#else
+#define HB3_XROT16(d, a) HB3_ROTR((d) ^ (a), 16)
+#endif
 #define HB3_G(a, b, c, d, mx, my)                                              \
     do {                                                                       \
-        a = a + b + (mx); d = HB3_ROTR(d ^ a, 16); c = c + d; b = HB3_ROTR(b ^ c, 12); \
+        a = a + b + (mx); d = HB3_XROT16(d, a); c = c + d; b = HB3_ROTR(b ^ c, 12); \
         a = a + b + (my); d = HB3_ROTR(d ^ a, 8);  c = c + d; b = HB3_ROTR(b ^ c, 7);  \
     } while (0)
 // one round with message words given in schedule order

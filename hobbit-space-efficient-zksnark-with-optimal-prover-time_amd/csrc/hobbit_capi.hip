@@ -545,8 +545,10 @@ int hobbit_change_form(hobbit_ctx *ctx, hobbit_F *d_poly, int logn) {
     const size_t n = (size_t)1 << logn;
     F *tmp; HB_TRY(ctx->workspace2(n * sizeof(F), (void **)&tmp));
     F *cur = mF(d_poly), *nxt = tmp;
-    for (int l = 0; l < logn; l++) { HB_TRY(launch_change_form_level(ctx, cur, nxt, n, n >> l)); std::swap(cur, nxt); }
+    int l = 0;
+    for (; l < logn && (n >> l) > 4096; l++) { HB_TRY(launch_change_form_level(ctx, cur, nxt, n, n >> l)); std::swap(cur, nxt); }   // block size > 4096: one pass per level
     if (cur != mF(d_poly)) HB_CHECK(ctx, hipMemcpyAsync(d_poly, cur, n * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    if (l < logn) HB_TRY(launch_change_form_tail(ctx, mF(d_poly), n, (uint32_t)(n >> l)));                                           // the rest inside LDS
     return 0;
 }
 int hobbit_whir_commit(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, hobbit_F *d_com, uint8_t *d_levels) {
@@ -622,7 +624,7 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
     HB_CHECK(ctx, hipMemcpyAsync(poly, d_poly, N * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
     HB_TRY(hobbit_eq_table(ctx, h_x, logN, reinterpret_cast<hobbit_F *>(beta)));
     F eval;
-    HB_TRY(launch_matvec_rows(ctx, beta, 1, N, poly, coef));                    // eval = <beta, poly> (:535-538)
+    HB_TRY(launch_dot(ctx, beta, poly, N, part, coef));                         // eval = <beta, poly> (:535-538)
     HB_TRY(hobbit_memcpy_d2h(ctx, &eval, coef, sizeof(F)));
     F *pin; HB_TRY(ctx->pinned(256 * sizeof(F), (void **)&pin));
     int iter = 0, repeats = 100, nq = 0; size_t remaining = 0;
@@ -674,7 +676,7 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
     }
     // final verification step (:641-651)
     F sum;
-    HB_TRY(launch_matvec_rows(ctx, beta, 1, remaining, poly, coef));
+    HB_TRY(launch_dot(ctx, beta, poly, remaining, part, coef));
     HB_TRY(hobbit_memcpy_d2h(ctx, &sum, coef, sizeof(F)));
     h_checks[1] = feq(sum, eval);
     mF(h_scal)[0] = eval; mF(h_scal)[1] = sum;

@@ -604,6 +604,37 @@ __global__ void k_merkle_level(const uint8_t *__restrict__ prev, uint8_t *__rest
         blake3_compress64(m, h); store8w(cur + 32 * i, h);
     }
 }
+// the last levels (n_cur <= 1024 nodes and everything above them) in ONE workgroup: a level per launch is pure launch latency
+// up there (ten launches of a few microseconds of work each, and the opening builds about twenty small trees)
+__global__ void __launch_bounds__(1024) k_merkle_top(const uint8_t *__restrict__ prev, uint8_t *__restrict__ cur, uint32_t n_cur, int quirk) {
+    __shared__ uint32_t buf[2][1024 * 8];
+    const uint32_t tid = threadIdx.x;
+    uint32_t m[16], h[8];
+    if (tid < n_cur) {
+        load8w(prev + 64 * (size_t)tid, m);
+        if (quirk) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) m[8 + j] = m[j];
+        } else load8w(prev + 64 * (size_t)tid + 32, m + 8);
+        blake3_compress64(m, h); store8w(cur + 32 * (size_t)tid, h);
+#pragma unroll
+        for (int j = 0; j < 8; j++) buf[0][tid * 8 + j] = h[j];
+    }
+    uint32_t off = n_cur; int pb = 0;
+    for (uint32_t sz = n_cur / 2; sz >= 1; sz /= 2) {
+        __syncthreads();
+        if (tid < sz) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) m[j] = buf[pb][(2 * tid) * 8 + j];
+#pragma unroll
+            for (int j = 0; j < 8; j++) m[8 + j] = quirk ? m[j] : buf[pb][(2 * tid + 1) * 8 + j];
+            blake3_compress64(m, h); store8w(cur + 32 * (size_t)(off + tid), h);
+#pragma unroll
+            for (int j = 0; j < 8; j++) buf[pb ^ 1][tid * 8 + j] = h[j];
+        }
+        off += sz; pb ^= 1;
+    }
+}
 // Our_PC leaf chain over all K chunks (src/Our_PC.cpp:162-166).  The tensor is codeword-major
 // ([chunk][col][2 trs]), so the 4 field elements of leaf (j, col) are 64 contiguous bytes.  One
 // thread owns one leaf and keeps its Merkle-Damgard state in registers across the chunk loop:
@@ -775,6 +806,36 @@ __global__ void k_change_form_level(const F *__restrict__ in, F *__restrict__ ou
         stF(out + pos + i, a); stF(out + pos + S / 2 + i, fsub(b, a));
     }
 }
+// all levels with block size <= T (T a power of two <= 4096) at once: below that size the recursion stays inside one T-block, so a
+// workgroup takes a T-block through LDS (in place, pairs staged in registers between the two barriers of a level)
+__global__ void __launch_bounds__(256) k_change_form_tail(F *__restrict__ data, uint32_t T) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    F *s = reinterpret_cast<F *>(lds_raw);
+    F *blk = data + (size_t)blockIdx.x * T;
+    for (uint32_t i = threadIdx.x; i < T; i += 256) stF(&s[i], ldF(blk + i));
+    __syncthreads();
+    for (uint32_t S = T; S >= 2; S >>= 1) {
+        F a[8], b[8];                                     // T/2 <= 2048 pairs over 256 threads
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t g = threadIdx.x + 256 * u;
+            if (g < T / 2) { const uint32_t pos = (g / (S / 2)) * S, i = g % (S / 2); a[u] = ldF(&s[pos + 2 * i]); b[u] = ldF(&s[pos + 2 * i + 1]); }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t g = threadIdx.x + 256 * u;
+            if (g < T / 2) { const uint32_t pos = (g / (S / 2)) * S, i = g % (S / 2); stF(&s[pos + i], a[u]); stF(&s[pos + S / 2 + i], fsub(b[u], a[u])); }
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = threadIdx.x; i < T; i += 256) stF(blk + i, ldF(&s[i]));
+}
+int launch_change_form_tail(hobbit_ctx *ctx, F *data, size_t n, uint32_t T) {
+    hipFuncSetAttribute((const void *)k_change_form_tail, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    HB_LAUNCH(ctx, "k_change_form_tail", k_change_form_tail, dim3((unsigned)(n / T)), dim3(256), (size_t)T * 16, data, T);
+    return 0;
+}
 int launch_change_form_level(hobbit_ctx *ctx, const F *in, F *out, size_t n, size_t S) {
     HB_LAUNCH(ctx, "k_change_form_level", k_change_form_level, dim3(grid_for(n / 2, 256)), dim3(256), 0, in, out, n, S);
     return 0;
@@ -806,6 +867,10 @@ int launch_hash_md(hobbit_ctx *ctx, const F *xyzw, const uint8_t *prev, uint8_t 
 int launch_merkle_levels(hobbit_ctx *ctx, uint8_t *levels, size_t n, int quirk) {
     size_t off = 0, tot = n;
     for (size_t sz = n / 2; sz >= 1; sz /= 2) {
+        if (sz <= 1024) {                                   // this level and all above it in one workgroup
+            HB_LAUNCH(ctx, "k_merkle_top", k_merkle_top, dim3(1), dim3(1024), 0, levels + 32 * off, levels + 32 * tot, (uint32_t)sz, quirk);
+            break;
+        }
         HB_LAUNCH(ctx, "k_merkle_level", k_merkle_level, dim3(grid_for(sz, 256)), dim3(256), 0, levels + 32 * off, levels + 32 * tot, sz, quirk);
         off = tot; tot += sz;
     }
@@ -1233,6 +1298,18 @@ __global__ void __launch_bounds__(256) k_whir_round(F *__restrict__ poly, F *__r
         stF(poly + j, fadd(p0, fmul(a, d1))); stF(beta + j, fadd(b0, fmul(a, d2)));
     }
     block_reduce_store<3>(c, partials);
+}
+// <a, b> over n elements: per-workgroup partials (part: >= 1024 F), then one workgroup
+__global__ void __launch_bounds__(256) k_dot(const F *__restrict__ a, const F *__restrict__ b, size_t n, F *__restrict__ partials) {
+    F c[1] = {fmake(0)};
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) c[0] = fadd(c[0], fmul(ldF(a + j), ldF(b + j)));
+    block_reduce_store<1>(c, partials);
+}
+int launch_dot(hobbit_ctx *ctx, const F *a, const F *b, size_t n, F *part, F *out) {
+    int nb = grid_for(n, 256, 1024);
+    HB_LAUNCH(ctx, "k_dot", k_dot, dim3(nb), dim3(256), 0, a, b, n, part);
+    HB_LAUNCH(ctx, "k_sc_reduce", k_sc_reduce<1>, dim3(1), dim3(256), 0, part, nb, out);
+    return 0;
 }
 int launch_whir_round(hobbit_ctx *ctx, F *poly, F *beta, size_t L, F a, F *part, F *coef) {   // coef: 3 F of this round (device)
     int nb = grid_for(L, 256, 1024);

@@ -36,6 +36,8 @@ int launch_transpose_ld(hobbit_ctx *ctx, const F *in, size_t in_gs, size_t in_ld
 int launch_matvec_rows(hobbit_ctx *ctx, const F *Mx, size_t rows, size_t cols, const F *v, F *out);
 int launch_vecmat(hobbit_ctx *ctx, const F *Mx, size_t rows, size_t cols, const F *v, F *out);
 int launch_gather_strided(hobbit_ctx *ctx, const F *src, const uint64_t *d_idx, size_t nq, uint32_t m, size_t bmul, size_t stride, F *out);
+int launch_dot(hobbit_ctx *ctx, const F *a, const F *b, size_t n, F *part, F *out);
+int launch_change_form_tail(hobbit_ctx *ctx, F *data, size_t n, uint32_t T);
 int launch_scatter(hobbit_ctx *ctx, const uint64_t *idx, const F *val, size_t n, F *out);
 int launch_axpy(hobbit_ctx *ctx, F *y, const F *x, F a, size_t n);
 int launch_err_terms(hobbit_ctx *ctx, int kind, const F *const *tables, const int32_t *gate, size_t n, F *h_K);
