@@ -261,24 +261,28 @@ int hobbit_graph_finalize(hobbit_ctx *ctx, long long n, long long *len_out) {
         for (long long i = 0; i < g.L; i++)
             for (int j = 0; j < g.degree; j++) rows[g.nbr[i * g.degree + j]].push_back({(uint32_t)i, g.w[i * g.degree + j]});
         EncStep s; s.in_off = (uint32_t)p.in_off; s.out_off = (uint32_t)p.out_off; s.out_len = (uint32_t)g.R;
-        s.n_slices = (uint32_t)((g.R + ENC_SW - 1) / ENC_SW); s.slice_base = (uint32_t)slice_ptr.size();
+        const uint32_t sw = (uint32_t)g.R >= ENC_WIDE_MIN ? 64u : ENC_SW, split = 64 / sw;
+        // records per output are padded to the lane-group count, and for the wide steps to whole unrolled groups (no remainder loop)
+        const uint32_t pad = sw == 64 ? ENC_UNROLL : split;
+        s.sw = sw; s.out_base = (uint32_t)slice_out.size();
+        s.n_slices = (uint32_t)((g.R + sw - 1) / sw); s.slice_base = (uint32_t)slice_ptr.size();
         std::vector<uint32_t> order((size_t)g.R);
         for (size_t t = 0; t < (size_t)g.R; t++) order[t] = (uint32_t)t;
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rows[a].size() > rows[b].size(); });
         for (uint32_t sl = 0; sl < s.n_slices; sl++) {
             size_t width = 0;
-            for (uint32_t l = 0; l < ENC_SW; l++) { size_t q = (size_t)sl * ENC_SW + l; if (q < (size_t)g.R) width = std::max(width, rows[order[q]].size()); }
-            width = (width + ENC_SPLIT - 1) / ENC_SPLIT * ENC_SPLIT;
+            for (uint32_t l = 0; l < sw; l++) { size_t q = (size_t)sl * sw + l; if (q < (size_t)g.R) width = std::max(width, rows[order[q]].size()); }
+            width = (width + pad - 1) / pad * pad;
             slice_ptr.push_back((uint32_t)pos); slice_width.push_back((uint32_t)width);
-            for (uint32_t l = 0; l < ENC_SW; l++) { size_t q = (size_t)sl * ENC_SW + l; slice_out.push_back(q < (size_t)g.R ? order[q] : 0xFFFFFFFFu); }
+            for (uint32_t l = 0; l < sw; l++) { size_t q = (size_t)sl * sw + l; slice_out.push_back(q < (size_t)g.R ? order[q] : 0xFFFFFFFFu); }
             for (size_t k = 0; k < width; k++)
-                for (uint32_t l = 0; l < ENC_SW; l++) {
-                    size_t q = (size_t)sl * ENC_SW + l;
+                for (uint32_t l = 0; l < sw; l++) {
+                    size_t q = (size_t)sl * sw + l;
                     uint32_t id = 0; F w = fmake(0);
                     if (q < (size_t)g.R && k < rows[order[q]].size()) { id = rows[order[q]][k].first; w = rows[order[q]][k].second; c.n_edges++; }
                     if (c.small_weights) e32.push_back(make_uint2(id, (uint32_t)w.re)); else { eidx.push_back(id); ew.push_back(w); }
                 }
-            pos += width * ENC_SW;
+            pos += width * sw;
         }
         c.steps.push_back(s);
     }

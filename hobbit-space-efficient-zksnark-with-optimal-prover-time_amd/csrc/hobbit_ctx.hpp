@@ -28,7 +28,11 @@ static constexpr uint32_t ENC_UNROLL = 4;              // edge records in flight
 struct EncStep {
     uint32_t in_off, out_off, out_len, n_slices;
     uint32_t slice_base;   // index of this step's first slice in slice_ptr/slice_width
+    uint32_t sw;           // outputs per slice of this step: 64 (one output per lane, no cross-lane combine) for the wide steps,
+                           // ENC_SW (lane groups share an output) for the narrow ones, where a slice per wave would leave waves idle
+    uint32_t out_base;     // index of this step's first entry in slice_out (sw entries per slice)
 };
+static constexpr uint32_t ENC_WIDE_MIN = 512;          // steps with at least this many outputs use sw = 64
 
 struct HostGraph {          // one uploaded level (src/expanders.h:7-16)
     long long L = 0, R = 0;

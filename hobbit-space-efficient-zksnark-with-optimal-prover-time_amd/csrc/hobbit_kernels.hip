@@ -433,10 +433,10 @@ k_encode(const F *__restrict__ src, size_t ld_src, F *__restrict__ dst, size_t l
     // wave index as a scalar: the slice descriptors below then come through the scalar cache (s_load) instead of a per-lane
     // global load, and the slice loop is scalar control flow
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
-    const uint32_t tl = lane % ENC_SW;
     for (uint32_t s = ps.s_lo; s < ps.s_hi; s++) {
         const EncStep sp = steps[s];
         const F *cin = cw + sp.in_off;
+        const uint32_t sw = sp.sw, split = 64 / sw, tl = lane & (sw - 1);      // sw = 64: one output per lane; ENC_SW: lane groups share one
         if (SMALLW) {
             // slices of this wave: sl = wave, wave + nwaves, ...  The first group of edge records of the NEXT slice is requested
             // before the current slice's remainder / fold / shuffle / store, so its L2 latency is off the critical path.
@@ -445,7 +445,7 @@ k_encode(const F *__restrict__ src, size_t ld_src, F *__restrict__ dst, size_t l
             uint32_t nbase = 0, niters = 0;
             uint2 en[ENC_UNROLL];
             if (have) {
-                nbase = slice_ptr[sp.slice_base + sl] + lane; niters = slice_width[sp.slice_base + sl] / ENC_SPLIT;
+                nbase = slice_ptr[sp.slice_base + sl] + lane; niters = slice_width[sp.slice_base + sl] / split;
                 if (niters >= ENC_UNROLL) {
 #pragma unroll
                     for (int u = 0; u < ENC_UNROLL; u++) en[u] = e32[nbase + u * 64];
@@ -475,38 +475,38 @@ k_encode(const F *__restrict__ src, size_t ld_src, F *__restrict__ dst, size_t l
                 }
                 sl += nwaves; have = sl < sp.n_slices;
                 if (have) {                                   // next slice: descriptor + first record group in flight
-                    nbase = slice_ptr[sp.slice_base + sl] + lane; niters = slice_width[sp.slice_base + sl] / ENC_SPLIT;
+                    nbase = slice_ptr[sp.slice_base + sl] + lane; niters = slice_width[sp.slice_base + sl] / split;
                     if (niters >= ENC_UNROLL) {
 #pragma unroll
                         for (int u = 0; u < ENC_UNROLL; u++) en[u] = e32[nbase + u * 64];
                     }
                 }
-                for (; j < iters; j++) {                      // remainder (rows are sorted by in-degree: at most ENC_UNROLL-1 records)
+                for (; j < iters; j++) {                      // remainder (narrow steps only; rows are sorted by in-degree: at most ENC_UNROLL-1 records)
                     const uint2 e = e32[base + j * 64];
                     const uint4 x = *reinterpret_cast<const uint4 *>(cin + e.x);
                     acc96_mad(rl, e.y, x.x); acc96_mad(rh, e.y, x.y); acc96_mad(il, e.y, x.z); acc96_mad(ih, e.y, x.w);
                 }
                 F acc = fmake(acc_fold(rl, rh), acc_fold(il, ih));
-#pragma unroll
-                for (int m = ENC_SW; m < 64; m <<= 1) acc = fadd(acc, shfl_xor_F(acc, m));   // combine the lane groups
-                const uint32_t t = slice_out[(sp.slice_base + cur) * ENC_SW + tl];    // outputs are sliced in order of in-degree
-                if (lane < ENC_SW && t != 0xFFFFFFFFu) {
+                if (sw <= 16) acc = fadd(acc, shfl_xor_F(acc, 16));              // combine the lane groups (uniform branches)
+                if (sw <= 32) acc = fadd(acc, shfl_xor_F(acc, 32));
+                const uint32_t t = slice_out[sp.out_base + cur * sw + tl];       // outputs are sliced in order of in-degree
+                if (lane < sw && t != 0xFFFFFFFFu) {
                     if (ps.direct_out) stF(out + sp.out_off + t, acc); else stF(&cw[sp.out_off + t], acc);
                 }
             }
         } else {
             for (uint32_t sl = wave; sl < sp.n_slices; sl += nwaves) {
                 const uint32_t base = slice_ptr[sp.slice_base + sl] + lane;
-                const uint32_t iters = slice_width[sp.slice_base + sl] / ENC_SPLIT;    // edge records per lane
+                const uint32_t iters = slice_width[sp.slice_base + sl] / split;    // edge records per lane
                 F acc = fmake(0);
                 for (uint32_t j = 0; j < iters; j++) {
                     const uint32_t id = eidx[base + j * 64];
                     acc = fadd(acc, fmul(ldF(cin + id), ldF(ew + base + j * 64)));
                 }
-#pragma unroll
-                for (int m = ENC_SW; m < 64; m <<= 1) acc = fadd(acc, shfl_xor_F(acc, m));
-                const uint32_t t = slice_out[(sp.slice_base + sl) * ENC_SW + tl];
-                if (lane < ENC_SW && t != 0xFFFFFFFFu) {
+                if (sw <= 16) acc = fadd(acc, shfl_xor_F(acc, 16));
+                if (sw <= 32) acc = fadd(acc, shfl_xor_F(acc, 32));
+                const uint32_t t = slice_out[sp.out_base + sl * sw + tl];
+                if (lane < sw && t != 0xFFFFFFFFu) {
                     if (ps.direct_out) stF(out + sp.out_off + t, acc); else stF(&cw[sp.out_off + t], acc);
                 }
             }
@@ -550,7 +550,7 @@ int launch_encode(hobbit_ctx *ctx, const F *src, size_t ld_src, F *dst, size_t l
     // pass B: the remaining steps on the window [n, len)
     EncPass pb = {nn, nn, nn + r0, 1, nsteps, nn + r0, 2 * nn, 0};
     if (c.small_weights) {
-        HB_TRY(launch_encode_pass<true>(ctx, "k_encode_A", src, ld_src, dst, ld_dst, batch, pa, nn, block_for(c, 0, 1, 8)));
+        HB_TRY(launch_encode_pass<true>(ctx, "k_encode_A", src, ld_src, dst, ld_dst, batch, pa, nn, block_for(c, 0, 1, 16)));
         return launch_encode_pass<true>(ctx, "k_encode_B", dst, ld_dst, dst, ld_dst, batch, pb, (uint32_t)c.len - nn, block_for(c, 1, nsteps, 8));
     }
     HB_TRY(launch_encode_pass<false>(ctx, "k_encode_fullw_A", src, ld_src, dst, ld_dst, batch, pa, nn, block_for(c, 0, 1, 8)));
