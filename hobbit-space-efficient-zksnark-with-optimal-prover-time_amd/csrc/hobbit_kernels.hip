@@ -429,7 +429,7 @@ k_encode(const F *__restrict__ src, size_t ld_src, F *__restrict__ dst, size_t l
     const F *in = src + (size_t)blockIdx.x * ld_src;
     F *out = dst + (size_t)blockIdx.x * ld_dst;
     for (uint32_t i = ps.ld_lo + threadIdx.x; i < ps.ld_hi; i += blockDim.x) stF(&cw[i], ldF(in + i));
-    __syncthreads();
+    // (the barrier that publishes the window sits after the first step's first edge-record request: those loads do not touch LDS)
     // wave index as a scalar: the slice descriptors below then come through the scalar cache (s_load) instead of a per-lane
     // global load, and the slice loop is scalar control flow
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
@@ -451,6 +451,7 @@ k_encode(const F *__restrict__ src, size_t ld_src, F *__restrict__ dst, size_t l
                     for (int u = 0; u < ENC_UNROLL; u++) en[u] = e32[nbase + u * 64];
                 }
             }
+            if (s == ps.s_lo) __syncthreads();
             while (have) {
                 const uint32_t base = nbase, iters = niters, cur = sl;
                 Acc96 rl = {0, 0}, rh = {0, 0}, il = {0, 0}, ih = {0, 0};
@@ -495,6 +496,7 @@ k_encode(const F *__restrict__ src, size_t ld_src, F *__restrict__ dst, size_t l
                 }
             }
         } else {
+            if (s == ps.s_lo) __syncthreads();
             for (uint32_t sl = wave; sl < sp.n_slices; sl += nwaves) {
                 const uint32_t base = slice_ptr[sp.slice_base + sl] + lane;
                 const uint32_t iters = slice_width[sp.slice_base + sl] / split;    // edge records per lane
