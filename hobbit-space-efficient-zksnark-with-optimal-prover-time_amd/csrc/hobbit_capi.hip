@@ -702,6 +702,11 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
     return 0;
 }
 // shockwave_prove (src/Virgo.cpp:435-517), prover side
+// workspace4 elements of one shockwave_prove: [0, nested) belongs to the nested whir_commit / whir_prove calls, its own vectors follow
+static size_t shockwave_nested_elems(size_t w) { return 4 * w + whir_scratch_elems(w) + 64; }
+static size_t shockwave_own_elems(size_t w, int k) {
+    return w + 2 * w + 2 * w + 64 + 256 + 256 /* idx */ + 2 * w + 2 * w /* whir_commit outputs: com, levels */ + 240 * (size_t)k /* replies */ + 64;
+}
 int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobbit_F *d_enc, const uint8_t *d_levels, size_t N, int k, const hobbit_F *h_x, int xlen,
                            hobbit_shockwave_out *o) {
     const int lk = ilog2_exact((size_t)k);
@@ -711,8 +716,7 @@ int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobb
     for (int i = 0; i < lk; i++) for (size_t j = ((size_t)1 << i); j-- > 0;) { F t = fmul(cF(h_x)[xlen - lk + (lk - 1 - i)], beta1[j]); beta1[2 * j + 1] = t; beta1[2 * j] = fsub(beta1[j], t); }
     // workspace4 layout: [0, nested) belongs to the nested whir_commit / whir_prove calls (they carve from the start and never ask
     // for more than `nested`, so the buffer is not reallocated under us); our own vectors follow.
-    const size_t nested = 4 * w + whir_scratch_elems(w) + 64;
-    const size_t own = w + W + W + 64 + 256 + 256 /* idx */ + 2 * w + 2 * w /* whir_commit outputs: com, levels */ + 240 * (size_t)k /* replies */ + 64;
+    const size_t nested = shockwave_nested_elems(w), own = shockwave_own_elems(w, k);
     F *base; HB_TRY(ctx->workspace4((nested + own) * sizeof(F), (void **)&base));
     F *mine = base + nested; F *aggr = mine, *at = aggr + w, *b1v = at + W, *dbeta = b1v + W, *ones = dbeta + 64; uint64_t *didx = reinterpret_cast<uint64_t *>(ones + 256);
     F *wcom = ones + 256 + 256; uint8_t *wlv = reinterpret_cast<uint8_t *>(wcom + 2 * w); F *d_rep = wcom + 4 * w;
@@ -1087,7 +1091,14 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
         const size_t sc_need = (3 * big / 2 + 3 * 1024 + 64) * sizeof(F), fft_need = (size_t)2 * nc_el * sizeof(F);
         HB_TRY(ctx->workspace(std::max(sc_need, fft_need), &dummy));
         HB_TRY(ctx->workspace2(std::max(fft_need, (size_t)4 * rows2 * sizeof(F)), &dummy));
+        // the same for the inner provers' scratch and the pinned staging buffer: no buffer is ever grown-and-freed after this point.
+        // (Freeing device memory makes the driver unmap it later and pause the compute queues while it does: a 20+ ms stall that
+        // lands in the NEXT call, measured on the second open of a process.)
+        if (full) HB_TRY(ctx->workspace4((shockwave_nested_elems(nc_el / 32) + shockwave_own_elems(nc_el / 32, 32)) * sizeof(F), &dummy));
+        HB_TRY(ctx->pinned((size_t)queries * (sizeof(F) + 8) + 4096, &dummy));
     }
+    tr.mark("scratch sizing");
+    if (tr.on) fprintf(stderr, "[hobbit open] scratch at entry: ws %zu ws2 %zu ws3 %zu ws4 %zu pin %zu\n", ctx->ws_bytes, ctx->ws2_bytes, ctx->ws3_bytes, ctx->ws4_bytes, ctx->pin_bytes);
     F *d_aggr = arena, *BIG = d_aggr + M, *Tcm = BIG + big, *d_b = Tcm + big, *d_bb = d_b + big, *d_s = d_bb + big, *d_ev = d_s + cols,
       *d_ac = d_ev + cols, *d_b1 = d_ac + rows2;
     F *Mp = BIG, *C = BIG + (size_t)trs * cols;
@@ -1202,6 +1213,7 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     memcpy(x5.data(), Rr, sizeof(hobbit_F) * (size_t)logc); memcpy(x5.data() + logc, r_p4 + logc, sizeof(hobbit_F) * (size_t)(R1 - 1));
     HB_TRY(hobbit_shockwave_prove(ctx, reinterpret_cast<hobbit_F *>(d_aggr), reinterpret_cast<hobbit_F *>(encf), lvf, M, 32, x5.data(), (int)x5.size() - 1, o->sp_f));
     tr.mark("shockwave_prove C_f");
+    if (tr.on) fprintf(stderr, "[hobbit open] scratch at exit:  ws %zu ws2 %zu ws3 %zu ws4 %zu pin %zu\n", ctx->ws_bytes, ctx->ws2_bytes, ctx->ws3_bytes, ctx->ws4_bytes, ctx->pin_bytes);
     return 0;
 }
 int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const hobbit_F *h_x, int queries, hobbit_open_out *o) {

@@ -927,9 +927,24 @@ __global__ void k_aggregate_dev(const F *__restrict__ poly, size_t M, int K, con
         stF(aggr + j, acc);
     }
 }
+// the same with the K <= 64 coefficients passed by value in the kernel arguments (1 KB): no host buffer, no copy, no synchronisation
+struct AggCoef { F b[64]; };
+__global__ void k_aggregate_arg(const F *__restrict__ poly, size_t M, int K, AggCoef beta, F *__restrict__ aggr) {
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < M; j += (size_t)gridDim.x * blockDim.x) {
+        F acc = fmake(0);
+        for (int i = 0; i < K; i++) acc = fadd(acc, fmul(beta.b[i], ldF(poly + (size_t)i * M + j)));
+        stF(aggr + j, acc);
+    }
+}
 int launch_aggregate(hobbit_ctx *ctx, const F *poly, size_t M, int K, const F *h_beta, F *aggr) {
-    // the coefficients are read by the kernel straight from a small pinned (device-visible) host buffer:
-    // no H2D copy, no synchronisation in front of the launch
+    if (K <= 64) {
+        AggCoef cf;
+        for (int i = 0; i < 64; i++) cf.b[i] = i < K ? h_beta[i] : fmake(0);
+        HB_LAUNCH(ctx, "k_aggregate", k_aggregate_arg, dim3(grid_for(M, 256)), dim3(256), 0, poly, M, K, cf, aggr);
+        return 0;
+    }
+    // more chunks than fit the argument block: the coefficients are read by the kernel straight from a small pinned
+    // (device-visible) host buffer
     F *pc; HB_TRY(ctx->pinned_const((size_t)K * sizeof(F), (void **)&pc));
     for (int i = 0; i < K; i++) pc[i] = h_beta[i];
     HB_LAUNCH(ctx, "k_aggregate", k_aggregate_dev, dim3(grid_for(M, 256)), dim3(256), 0, poly, M, K, pc, aggr);
