@@ -12,6 +12,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """HOBBIT_TEST_ORDER=reverse / a number (shuffle seed): run the tests in another order, to catch tests that only pass
+    because an earlier one warmed something up (context, libc generator, oracle globals)."""
+    order = os.environ.get("HOBBIT_TEST_ORDER")
+    if not order:
+        return
+    if order == "reverse":
+        items.reverse()
+    else:
+        import random
+        random.Random(int(order)).shuffle(items)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The plain-C CPU restatement (oracle/hobbit_oracle.c); built on demand with gcc."""
