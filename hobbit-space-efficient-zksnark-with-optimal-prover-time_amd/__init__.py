@@ -682,8 +682,9 @@ class Hobbit:
             n[0, 0] = r; n[0, 1] = tmp[0, 1]
         return out
 
-    def elastic_commit(self, N, B, opt, gcc_arg_order=1):
-        """test_Elastic_PC's commit (src/Elastic_PC.cpp:736-771): opt 1 RSxRS trs=B/2^11, opt 2 RSxexpander trs=B/2^14"""
+    def elastic_commit(self, N, B, opt, gcc_arg_order=1, chunk=None):
+        """test_Elastic_PC's commit (src/Elastic_PC.cpp:736-771): opt 1 RSxRS trs=B/2^11, opt 2 RSxexpander trs=B/2^14.
+        chunk: a DeviceBuffer holding the stream's (repeating) chunk, generated here on the host if None."""
         if opt == 1:
             lin, trs = 0, B >> 11
         else:
@@ -691,7 +692,8 @@ class Hobbit:
             self.expander_init_store(trs)
         e = c_vp()
         self._chk(self.lib.hobbit_elastic_begin(self.ctx, B, trs, lin, gcc_arg_order, ctypes.byref(e)))
-        chunk = self.to_device(self.read_stream_PC(B))
+        if chunk is None:
+            chunk = self.to_device(self.read_stream_PC(B))
         for _ in range(N // B):
             self._chk(self.lib.hobbit_elastic_push(self.ctx, e, chunk.ptr))
         lv = self.alloc(32 * 8 * B)
