@@ -304,6 +304,15 @@ def main():
                          "note": ROOFLINE_NOTES.get(dom, "")},
             "root": root,
         }
+        if dom == "k_leaf_chain" and not sharded:
+            # the binding resource of the dominant kernel: VALU issue.  2023 SIMD-cycles per wave-compression (7 rounds x 8 G x 36 issue
+            # cycles + message/finalisation moves; profiles/r01_microbench.txt), 64 compressions per wave, 1024 SIMDs: the clock at which
+            # the chip would have to issue without a single bubble to finish in the measured time -- compare with the 1.78 GHz it
+            # sustains under this load (2.4 GHz peak)
+            wave_comp = (2.0 * K * (N // K)) / 64.0          # 2 compressions per leaf and chunk
+            cyc = wave_comp * 2023.0 / 1024.0
+            out["roofline"]["binding"] = {"resource": "VALU issue", "simd_cycles_per_launch": cyc,
+                                          "implied_issue_clock_ghz": cyc / (dom_ms * 1e-3) / 1e9, "sustained_clock_ghz": 1.78, "peak_clock_ghz": 2.4}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_logn, K)
             if do_open:
