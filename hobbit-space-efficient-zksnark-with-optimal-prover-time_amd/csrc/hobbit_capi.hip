@@ -1202,9 +1202,7 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     const F a = fmake((uint64_t)random()); o->scalars[3] = *reinterpret_cast<const hobbit_F *>(&a);
     std::vector<hobbit_F> rcat(R3);
     memcpy(rcat.data(), r_p2, sizeof(hobbit_F) * logc); memcpy(rcat.data() + logc, r_p1, sizeof(hobbit_F) * R1);
-    HB_TRY(hobbit_eq_table(ctx, rcat.data(), R3, reinterpret_cast<hobbit_F *>(d_b)));
-    HB_TRY(hobbit_eq_table(ctx, r_p3, R3, reinterpret_cast<hobbit_F *>(d_bb)));
-    HB_TRY(launch_axpy(ctx, d_b, d_bb, a, big));
+    HB_TRY(launch_eq_pair_axpy(ctx, cF(rcat.data()), cF(r_p3), R3, a, d_bb, d_b));      // d_b = beta(r) + a * beta(P3.r), d_bb: scratch
     hobbit_F p312 = {312, 0};
     HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(d_b), reinterpret_cast<hobbit_F *>(BIG), big, &p312, Q, Rr, o->vr + 6, o->fin + 3));
     const hobbit_F *r_p4 = Rr; const F *q4 = cF(Q);

@@ -902,21 +902,65 @@ __global__ void k_eq_step(const F *__restrict__ old, F *__restrict__ nw, size_t 
         stF(nw + 2 * j, fsub(o, t)); stF(nw + 2 * j + 1, t);
     }
 }
+// the first h <= 12 doubling steps in ONE workgroup (table in LDS, pairs staged in registers between the two barriers of a level):
+// up there a level per launch is a dozen launches of a few hundred nanoseconds of work each.  r.b[i] = challenge of level i.
+struct EqHead { F b[12]; };
+__global__ void __launch_bounds__(256) k_eq_head(EqHead r, int h, F *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    F *s = reinterpret_cast<F *>(lds_raw);
+    if (threadIdx.x == 0) s[0] = fmake(1);
+    __syncthreads();
+    for (int i = 0; i < h; i++) {
+        const uint32_t m = 1u << i;
+        F o[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint32_t j = threadIdx.x + 256 * u; if (j < m) o[u] = ldF(&s[j]); }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t j = threadIdx.x + 256 * u;
+            if (j < m) { const F t = fmul(r.b[i], o[u]); stF(&s[2 * j], fsub(o[u], t)); stF(&s[2 * j + 1], t); }
+        }
+        __syncthreads();
+    }
+    for (uint32_t j = threadIdx.x; j < (1u << h); j += 256) stF(out + j, ldF(&s[j]));
+}
+// last doubling step of TWO tables fused with their combination: out = eq(r1) + a * eq(r2)  (src/PC_utils.cpp:344-349), from the
+// two half-size tables o1, o2 and the last challenges c1, c2 -- the full-size tables are never written and read back
+__global__ void k_eq_final_axpy(const F *__restrict__ o1, const F *__restrict__ o2, size_t m, F c1, F c2, F a, F *__restrict__ out) {
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < m; j += (size_t)gridDim.x * blockDim.x) {
+        const F x = ldF(o1 + j), y = ldF(o2 + j), t1 = fmul(c1, x), t2 = fmul(c2, y);
+        stF(out + 2 * j, fadd(fsub(x, t1), fmul(a, fsub(y, t2))));
+        stF(out + 2 * j + 1, fadd(t1, fmul(a, t2)));
+    }
+}
 int launch_eq_table(hobbit_ctx *ctx, const F *h_r, int k, F *d_out) {
-    // ping-pong between d_out (final) and workspace so that the last step lands in d_out
+    // head in one workgroup, then ping-pong between d_out (final) and workspace so that the last step lands in d_out
     size_t n = (size_t)1 << k;
     F *tmp = nullptr;
-    if (k > 0) HB_TRY(ctx->workspace(n / 2 * sizeof(F), (void **)&tmp));
-    F one = fmake(1);
-    F *cur = (k % 2 == 0) ? d_out : tmp;
-    HB_CHECK(ctx, hipMemcpyAsync(cur, &one, sizeof(F), hipMemcpyHostToDevice, ctx->stream));
-    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // `one` is a stack temporary
-    for (int i = 0; i < k; i++) {
+    const int h = k < 12 ? k : 12, rest = k - h;
+    if (rest > 0) HB_TRY(ctx->workspace(n / 2 * sizeof(F), (void **)&tmp));
+    F *cur = (rest % 2 == 0) ? d_out : tmp;
+    EqHead hd;
+    for (int i = 0; i < 12; i++) hd.b[i] = i < h ? h_r[k - 1 - i] : fmake(0);
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void *)k_eq_head, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_set = true; }
+    HB_LAUNCH(ctx, "k_eq_head", k_eq_head, dim3(1), dim3(256), ((size_t)16 << h), hd, h, cur);
+    for (int i = h; i < k; i++) {
         F *nxt = cur == d_out ? tmp : d_out;
         size_t m = (size_t)1 << i;
         HB_LAUNCH(ctx, "k_eq_step", k_eq_step, dim3(grid_for(m, 256)), dim3(256), 0, cur, nxt, m, h_r[k - 1 - i]);
         cur = nxt;
     }
+    return 0;
+}
+// d_out[0..2^k) = eq(r1) + a * eq(r2); d_half: scratch of 2^k elements (the two half-size tables)
+int launch_eq_pair_axpy(hobbit_ctx *ctx, const F *h_r1, const F *h_r2, int k, F a, F *d_half, F *d_out) {
+    if (k < 1) return ctx->fail(HOBBIT_EINVAL, "eq_pair_axpy: k must be >= 1");
+    const size_t m = (size_t)1 << (k - 1);
+    HB_TRY(launch_eq_table(ctx, h_r1 + 1, k - 1, d_half));             // levels 0..k-2 use r[k-1] .. r[1]; the last level uses r[0]
+    HB_TRY(launch_eq_table(ctx, h_r2 + 1, k - 1, d_half + m));
+    HB_LAUNCH(ctx, "k_eq_final_axpy", k_eq_final_axpy, dim3(grid_for(m, 256)), dim3(256), 0, d_half, d_half + m, m, h_r1[0], h_r2[0], a, d_out);
     return 0;
 }
 // aggr[j] = sum_i beta[i] * poly[i*M + j]   (src/Our_PC.cpp:258-272)

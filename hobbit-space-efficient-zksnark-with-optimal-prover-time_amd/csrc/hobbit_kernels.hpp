@@ -38,6 +38,7 @@ int launch_vecmat(hobbit_ctx *ctx, const F *Mx, size_t rows, size_t cols, const 
 int launch_gather_strided(hobbit_ctx *ctx, const F *src, const uint64_t *d_idx, size_t nq, uint32_t m, size_t bmul, size_t stride, F *out);
 int launch_dot(hobbit_ctx *ctx, const F *a, const F *b, size_t n, F *part, F *out);
 int launch_change_form_tail(hobbit_ctx *ctx, F *data, size_t n, uint32_t T);
+int launch_eq_pair_axpy(hobbit_ctx *ctx, const F *h_r1, const F *h_r2, int k, F a, F *d_half, F *d_out);
 int launch_scatter(hobbit_ctx *ctx, const uint64_t *idx, const F *val, size_t n, F *out);
 int launch_axpy(hobbit_ctx *ctx, F *y, const F *x, F a, size_t n);
 int launch_err_terms(hobbit_ctx *ctx, int kind, const F *const *tables, const int32_t *gate, size_t n, F *h_K);
