@@ -727,6 +727,20 @@ class Hobbit:
         self._chk(self.lib.hobbit_sumcheck3(self.ctx, c_vp(p1), c_vp(p2), c_vp(p3), c_sz(n), _hp(pr), _hp(q), _hp(r), _hp(vr), _hp(fin)))
         return dict(poly=q, r=r, vr=vr, fin=fin)
 
+    def prove_gate_consistency_standard(self, L, R, O, add, r):
+        """src/sumcheck.cpp:434-501 (the in-memory gate-consistency prover): a = (1, 1, 1, -1), transcript seeded with F(213), claimed
+        sum 0, mul_gate = 1 - add_gate, beta = precompute_beta(r).  The reference folds its inputs in place and returns nothing;
+        returned here: element 0 of arr_L, arr_R, arr_O, add_gate after the last round."""
+        L, R, O, add = [Fh(v).reshape(-1, 2) for v in (L, R, O, add)]
+        P = np.uint64((1 << 61) - 1)
+        mul = np.stack([(np.uint64(1) + P - add[:, 0]) % P, (P - add[:, 1]) % P], 1).astype(np.uint64)
+        beta = self.precompute_beta(r)
+        a = np.array([[1, 0], [1, 0], [1, 0], [int(P) - 1, 0]], np.uint64)
+        res = self.gate_sumcheck((add, beta, L, R, O, mul), a, np.array([213, 0], np.uint64), np.array([0, 0], np.uint64))
+        return np.stack([res["fin"][2], res["fin"][3], res["fin"][4], res["fin"][0]])
+
+    gate_standard = prove_gate_consistency_standard
+
     def gate_sumcheck(self, tables, a, rand, claimed_sum):
         """degree-4 gate-consistency sumcheck (src/sumcheck.cpp:875-929); tables = (add, beta, L, R, O, mul)"""
         devs = [self._dev_table(t) for t in tables]

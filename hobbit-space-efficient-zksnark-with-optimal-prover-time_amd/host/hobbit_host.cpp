@@ -223,6 +223,22 @@ void commit_standard(vector<F> &poly, _hash &comm, vector<vector<_hash>> &MT_has
     const char *mat = getenv("HOBBIT_MATERIALIZE_TENSOR");
     if ((mat && atoi(mat)) || (size_t)4 * N * sizeof(F) <= ((size_t)256 << 20)) hobbit_host_materialize_tensor(_tensor);
 }
+void prove_gate_consistency_standard(vector<F> &arr_L, vector<F> &arr_R, vector<F> &arr_O, vector<F> &add_gate, vector<F> r, double &vt, double &ps) {
+    (void)vt; (void)ps;                                              // the reference does not touch them either (src/sumcheck.cpp:434-501)
+    const size_t n = arr_L.size(); const int rounds = (int)log2((double)n);
+    vector<F> mul_gate(n), beta;
+    for (size_t i = 0; i < n; i++) mul_gate[i] = F(1) - add_gate[i];
+    precompute_beta(r, beta);
+    DevBuf dA(add_gate.data(), n * sizeof(F)), dB(beta.data(), n * sizeof(F)), dL(arr_L.data(), n * sizeof(F)), dR(arr_R.data(), n * sizeof(F)),
+        dO(arr_O.data(), n * sizeof(F)), dM(mul_gate.data(), n * sizeof(F));
+    F a[4] = {F(1), F(1), F(1), F(0) - F(1)}, rnd = F(213), sum = F(0), fin[6];
+    vector<F> poly(5 * (size_t)rounds), rr(rounds);
+    int ok = 0;
+    HCHK(hobbit_gate_sumcheck(hobbit_host_ctx(), (const hobbit_F *)dA.p, (const hobbit_F *)dB.p, (const hobbit_F *)dL.p, (const hobbit_F *)dR.p, (const hobbit_F *)dO.p,
+                              (const hobbit_F *)dM.p, n, hF(a), hF(&rnd), hF(&sum), hF(poly.data()), hF(rr.data()), hF(fin), &ok));
+    if (!ok) printf("Error in gate consistency 2\n");               // the reference prints and continues (:482-485)
+    add_gate[0] = fin[0]; arr_L[0] = fin[2]; arr_R[0] = fin[3]; arr_O[0] = fin[4];
+}
 // proof-size accounting of verify_claim_opt_blake (src/merkle_tree.cpp:326-361): 32 B per sibling not yet seen
 static void path_ps(size_t n_leaves, int depth, const vector<size_t> &pos, double &ps) {
     vector<bool> visited(2 * n_leaves + 2, false);

@@ -134,6 +134,9 @@ void _compute_aggregation_reply(vector<vector<size_t>> &I, vector<vector<F>> &re
 struct proof generate_2product_sumcheck_proof(vector<F> &_v1, vector<F> &_v2, F previous_r, double &vt, double &ps);
 struct proof _generate_3product_sumcheck_proof(vector<F> &v1, vector<F> &v2, vector<F> &v3, F previous_r, double &vt, double &ps);
 
+/* src/sumcheck.h:89 (src/sumcheck.cpp:434-501).  The reference folds its four inputs in place and returns nothing; here element 0 of
+ * arr_L, arr_R, arr_O, add_gate is set to the fully folded value (all a caller can use) and the rest is left as passed in. */
+void prove_gate_consistency_standard(vector<F> &arr_L, vector<F> &arr_R, vector<F> &arr_O, vector<F> &add_gate, vector<F> r, double &vt, double &ps);
 /* src/sumcheck.h:67,74,78,81 ; src/utils.hpp:24,41 */
 int evaluate_parity_matrix(vector<F> &A, vector<F> &beta1, int Offset, int n, int dep, int &lvl);
 proof prove_linear_code(vector<F> &codeword, int n, double &vt, double &ps);

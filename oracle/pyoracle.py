@@ -207,6 +207,10 @@ class _Base:
         self.lib.orc_gate_sumcheck(*[_p(t) for t in ts], c_sz(n), _p(a), _p(rnd), _p(sm), _p(q), _p(r), _p(fin), _p(chk))
         return dict(poly=q, r=r, fin=fin, rand=rnd, sum=sm, check=chk)
 
+    def gate_standard(self, L, R, O, add, r):
+        """prove_gate_consistency_standard through the gate sumcheck: a = (1, 1, 1, -1), rand = F(213), sum = 0, mul = 1 - add"""
+        return gate_standard_via(self, L, R, O, add, r)[0]
+
     # ---- code-membership / FFT-as-sumcheck helpers
     def evaluate_parity_matrix(self, beta, n):
         b = F(beta).reshape(-1, 2)
@@ -484,6 +488,32 @@ class Oracle(_Base):
         return f(c_sz(N), ctypes.c_int(K))
 
 
+def gate_standard_inputs(n, seed):
+    """consistent gates: selector s in {0,1}; O = L + R where s = 1, L * R where s = 0 (so the claimed sum 0 holds)"""
+    P = (1 << 61) - 1
+    rng = np.random.default_rng(seed)
+    sel = rng.integers(0, 2, n).astype(np.uint64)
+    Lr = rng.integers(0, 1 << 31, n).astype(np.uint64); Rr = rng.integers(0, 1 << 31, n).astype(np.uint64)
+    z = np.zeros(n, np.uint64)
+    L = np.stack([Lr, z], 1); R = np.stack([Rr, z], 1)
+    prod = np.array([(int(a) * int(b)) % P for a, b in zip(Lr, Rr)], np.uint64)
+    O = np.stack([np.where(sel == 1, (Lr + Rr) % np.uint64(P), prod), z], 1)
+    add = np.stack([sel, z], 1)
+    return L, R, O, add
+
+
+def gate_standard_via(be, L, R, O, add, r):
+    """prove_gate_consistency_standard on any backend `be` that has precompute_beta, f_sub and gate_sumcheck"""
+    L, R, O, add = [F(v).reshape(-1, 2) for v in (L, R, O, add)]
+    P = (1 << 61) - 1
+    one = np.zeros_like(add); one[:, 0] = 1
+    mul = np.stack([(one[:, 0] + np.uint64(P) - add[:, 0]) % np.uint64(P), (np.uint64(P) - add[:, 1]) % np.uint64(P)], 1).astype(np.uint64)
+    beta = be.precompute_beta(r)
+    a = np.array([[1, 0], [1, 0], [1, 0], [P - 1, 0]], np.uint64)
+    res = be.gate_sumcheck((add, beta, L, R, O, mul), a, np.array([213, 0], np.uint64), np.array([0, 0], np.uint64))
+    return np.stack([res["fin"][2], res["fin"][3], res["fin"][4], res["fin"][0]]), res
+
+
 class Ref(_Base):
     pfx = "ref_"
 
@@ -551,6 +581,13 @@ class Ref(_Base):
         q, r, vr, fin = self._proof2(rounds)
         self.lib.ref_prove_fft_matrix(_p(m), c_sz(rows), c_sz(cols), _p(rr), _p(ps), _p(q), _p(r), _p(vr), _p(fin))
         return dict(poly=q, r=r, vr=vr, fin=fin)
+
+    def gate_standard(self, L, R, O, add, r):
+        """prove_gate_consistency_standard (src/sumcheck.cpp:434-501): returns the four folded values (L, R, O, add)[0]"""
+        L, R, O, add, r = [F(v).reshape(-1, 2) for v in (L, R, O, add, r)]
+        out = np.zeros((4, 2), np.uint64)
+        self.lib.ref_gate_standard(_p(L), _p(R), _p(O), _p(add), c_sz(L.shape[0]), _p(r), ctypes.c_int(r.shape[0]), _p(out))
+        return out
 
     def read_stream_pc(self, N, B, chunk_idx=0):
         o = np.zeros((B, 2), np.uint64)

@@ -217,6 +217,16 @@ void ref_sumcheck3(const uint64_t *v1, const uint64_t *v2, const uint64_t *v3, s
 }
 
 
+// prove_gate_consistency_standard (src/sumcheck.cpp:434-501): the in-memory degree-4 gate sumcheck (a0 = a1 = a2 = 1, a3 = -1, transcript
+// seeded with F(213), claimed sum 0).  It returns nothing; its inputs are folded in place, so element 0 of each table afterwards is a
+// function of every round's challenge, i.e. of every round polynomial.  out: arr_L[0], arr_R[0], arr_O[0], add_gate[0].
+void ref_gate_standard(const uint64_t *L, const uint64_t *R, const uint64_t *O, const uint64_t *add, size_t n, const uint64_t *r, int k, uint64_t *out) {
+    vector<F> l = vecF(L, n), rr = vecF(R, n), o = vecF(O, n), a = vecF(add, n), rv = vecF(r, k);
+    double vt = 0, ps = 0;
+    prove_gate_consistency_standard(l, rr, o, a, rv, vt, ps);
+    stF(out, l[0]); stF(out + 2, rr[0]); stF(out + 4, o[0]); stF(out + 6, a[0]);
+}
+
 // ---- code-membership / FFT-as-sumcheck helpers (src/sumcheck.cpp:2888-2929, 2975-3027, 3223-3235;
 //      src/utils.cpp:694-775) -------------------------------------------------------------------------
 long long ref_evaluate_parity_matrix(const uint64_t *beta, size_t size_a, long long n, uint64_t *A) {

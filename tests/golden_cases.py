@@ -353,5 +353,16 @@ def case_innerpcs(lib):
     return out
 
 
+def case_gate(lib):
+    """prove_gate_consistency_standard (src/sumcheck.cpp:434-501): the four tables' element 0 after the degree-4 gate sumcheck --
+    a function of every round polynomial through the transcript"""
+    from oracle.pyoracle import gate_standard_inputs
+    out = {}
+    for lg in (1, 3, 8, 12, 14):
+        L, R, O, add = gate_standard_inputs(1 << lg, 40 + lg)
+        out["gs_%d" % lg] = lib.gate_standard(L, R, O, add, splitmix_field(lg, 60 + lg))
+    return out
+
+
 CASES = dict(field=case_field, mimc=case_mimc, blake=case_blake, merkle=case_merkle, graph_encode=case_graph_encode,
-             fft=case_fft, tensorcode=case_tensorcode, commit=case_commit, sumcheck=case_sumcheck, elastic=case_elastic, codeproofs=case_codeproofs, streamfold=case_streamfold, multree=case_multree, innerpcs=case_innerpcs)
+             fft=case_fft, tensorcode=case_tensorcode, commit=case_commit, sumcheck=case_sumcheck, elastic=case_elastic, codeproofs=case_codeproofs, streamfold=case_streamfold, multree=case_multree, innerpcs=case_innerpcs, gate=case_gate)

@@ -601,6 +601,15 @@ def test_open_standard_2e26_selfchecks(hb):
     c.free()
 
 
+def test_gate_standard_vs_golden(hb):
+    """prove_gate_consistency_standard (src/sumcheck.cpp:434-501) against what the real reference produced: pins hobbit_gate_sumcheck"""
+    g = gold("gate")
+    got = golden_cases.case_gate(hb)
+    assert set(got) == set(g.files)
+    for k in g.files:
+        assert np.array_equal(got[k], g[k]), k
+
+
 # ---- degree-4 gate-consistency sumcheck (a22) -------------------------------------------------------
 @pytest.mark.parametrize("logn", [4, 10, 11, 14, 18])
 def test_gate_sumcheck_vs_oracle(hb, oracle, logn):
