@@ -751,6 +751,19 @@ class Hobbit:
         return dict(poly=q, r=r, fin=fin, rand=rnd, sum=sm, check=np.array([chk.value], np.int32))
 
 
+def splitmix_field(n, seed):
+    """n full-range F_{p^2} elements (splitmix64 mod p): the synthetic-input generator of SURVEY.md 8(d), host side
+    (hobbit_fill_splitmix is its device twin)."""
+    P = (1 << 61) - 1
+    idx = np.arange(1, 2 * n + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) * np.uint64(0x632BE59BD9B4E019) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z % np.uint64(P)).reshape(n, 2)
+
+
 # ---- submodule: chunk-sharded multi-GPU commit orchestration --------------------------------
 def _load_parallel():
     name = __name__ + ".parallel"

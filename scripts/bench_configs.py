@@ -8,9 +8,9 @@ import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from __graft_entry__ import load_package
-from oracle.pyoracle import splitmix_field
 
 mod = load_package(); hb = mod.Hobbit(0)
+splitmix_field = mod.splitmix_field
 out = {}
 
 def timed(fn, reps=3, warm=1):

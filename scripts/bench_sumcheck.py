@@ -5,10 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from __graft_entry__ import load_package
 mod = load_package(); hb = mod.Hobbit(0)
+splitmix_field = mod.splitmix_field
 logn = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 n = 1 << logn
 d1 = hb.fill_splitmix(n, 1)
-from oracle.pyoracle import splitmix_field
 d2 = hb.precompute_beta(splitmix_field(logn, 9), keep_on_device=True)
 pr = np.array([33, 0], np.uint64)
 for _ in range(2):
