@@ -3,6 +3,7 @@
 // graphs in their device (gather / sliced-ELL) form.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <string>
@@ -198,9 +199,11 @@ struct hobbit_ctx {
         // the runtime queues launches lazily: a query makes it submit what is pending before we start spinning
         hipError_t q = hipStreamQuery(stream);
         if (q != hipSuccess && q != hipErrorNotReady) return hip(q, "mailbox wait");
+        const auto t_start = std::chrono::steady_clock::now();
         for (uint64_t it = 1;; it++) {
             if (__atomic_load_n(&mbox->flag, __ATOMIC_ACQUIRE) == seq) return 0;
             if ((it & 0xFFFF) == 0) {
+                if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(60)) { err = "mailbox: no post within 60 s (kernel hung?)"; return HOBBIT_EHIP; }
                 q = hipStreamQuery(stream);
                 if (q == hipSuccess) { if (__atomic_load_n(&mbox->flag, __ATOMIC_ACQUIRE) == seq) return 0; err = "mailbox: kernel finished without posting"; return HOBBIT_EHIP; }
                 if (q != hipErrorNotReady) return hip(q, "mailbox wait");
