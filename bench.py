@@ -153,7 +153,7 @@ def main():
                          "commit+opencore stops before the two shockwave_prove calls")
     ap.add_argument("--queries", type=int, default=5900)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-logn", type=int, default=22)
+    ap.add_argument("--cpu-logn", type=int, default=24, help="size of the CPU-baseline sample (2^24: about 17 s of single-thread reference time)")
     args = ap.parse_args()
 
     import torch
