@@ -198,8 +198,8 @@ def main():
         hb.sync()
         last = {}
 
-    do_open = args.phase != "commit" and not sharded
-    full_open = args.phase == "commit+open"
+    do_open = args.phase != "commit"
+    full_open = args.phase == "commit+open" or sharded            # the sharded open is always the full prover side
     import numpy as np
     x_open = np.stack([np.arange(1, args.logn + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15 % ((1 << 61) - 1)) % np.uint64((1 << 61) - 1),
                        np.arange(7, args.logn + 7, dtype=np.uint64) * np.uint64(1234567891011) % np.uint64((1 << 61) - 1)], axis=1)
@@ -208,6 +208,9 @@ def main():
     def step():
         if sharded:
             last["res"] = mod.parallel.sharded_commit(ops_, dist, plan, rank, (d_local.ptr, len(own)))
+            if do_open:
+                ops_.set_local_chunks((d_local.ptr, len(own)))
+                open_last["res"] = mod.parallel.sharded_open(ops_, dist, plan, rank, last["res"], x_open, args.queries)
             ops_._tensor.free()
             return
         c = hb.commit_standard((d_poly, N), K, trs, 1)

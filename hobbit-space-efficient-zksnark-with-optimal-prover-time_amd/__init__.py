@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "hobbit_prove_fft_matrix",
     "hobbit_whir_prove", "hobbit_shockwave_prove",
     "hobbit_batch_3product_sumcheck", "hobbit_mul_tree", "hobbit_shockwave_commit", "hobbit_change_form", "hobbit_whir_commit",
-    "hobbit_open_core", "hobbit_open_standard", "hobbit_gate_sumcheck", "hobbit_compute2p_error_terms", "hobbit_compute3p_error_terms", "hobbit_compute4p_error_terms", "hobbit_fold_axpy",
+    "hobbit_open_core", "hobbit_open_standard", "hobbit_open_from_aggregate", "hobbit_tensor_gather", "hobbit_gate_sumcheck", "hobbit_compute2p_error_terms", "hobbit_compute3p_error_terms", "hobbit_compute4p_error_terms", "hobbit_fold_axpy",
     "hobbit_fold_axpy_i32", "hobbit_batch_prod",
     "hobbit_aggregate", "hobbit_sumcheck2", "hobbit_sumcheck3", "hobbit_fill_splitmix",
 ]
@@ -86,7 +86,7 @@ def load_library(path=LIB_PATH):
         "hobbit_prove_linear_code": [V, V, S, L, V, V, V, V, V], "hobbit_prove_fft": [V, V, S, V, V, V, V, V],
         "hobbit_prove_fft_matrix": [V, V, S, S, V, V, V, V, V],
         "hobbit_gate_sumcheck": [V, V, V, V, V, V, V, S, V, V, V, V, V, V, V],
-        "hobbit_open_core": [V, V, S, V, V, I, V], "hobbit_open_standard": [V, V, S, V, V, I, V],
+        "hobbit_open_core": [V, V, S, V, V, I, V], "hobbit_open_standard": [V, V, S, V, V, I, V], "hobbit_open_from_aggregate": [V, V, S, I, I, I, V], "hobbit_tensor_gather": [V, V, S, I, I, V, V, S, V],
         "hobbit_whir_prove": [V, V, S, V, V, V, V], "hobbit_shockwave_prove": [V, V, V, V, S, I, V, I, V],
         "hobbit_shockwave_commit": [V, V, S, I, V, V], "hobbit_change_form": [V, V, I], "hobbit_whir_commit": [V, V, S, V, V],
         "hobbit_batch_3product_sumcheck": [V, V, V, V, V, I, V, V, V, V], "hobbit_mul_tree": [V, V, S, S, V, V, V, V, V, V, V, V, V, V],
@@ -430,14 +430,25 @@ class Hobbit:
         self.sync()
         return Commitment(self, h, N, K, trs)
 
-    def open_core(self, poly, commitment, x, queries, want_paths=True, full=False):
+    def open_from_aggregate(self, aggr, K, trs, queries=5900):
+        """open_standard's prover side from a given aggregate vector (host array or (DeviceBuffer/ptr, M)); multi-GPU open"""
+        class _C:
+            pass
+        if isinstance(aggr, tuple):
+            ptr, M = aggr; ptr = ptr.ptr if isinstance(ptr, DeviceBuffer) else int(ptr); keep = None
+        else:
+            a = Fh(aggr).reshape(-1, 2); M = a.shape[0]; keep = self.to_device(a); ptr = keep.ptr
+        c = _C(); c.K = K; c.trs = trs; c.M = M; c.cols = 2 * M // trs; c.h = None
+        return self.open_core((ptr, M), c, None, queries, want_paths=False, full=True, _from_aggregate=True)
+
+    def open_core(self, poly, commitment, x, queries, want_paths=True, full=False, _from_aggregate=False):
         """open_standard + recursive_prover_Spielman (host: libc draws in the reference's order); full=False stops before the
         two shockwave_prove calls.  poly: host array or (DeviceBuffer, N)."""
         if isinstance(poly, tuple):
             ptr, N = poly; ptr = ptr.ptr if isinstance(ptr, DeviceBuffer) else int(ptr); keep = None
         else:
             p = Fh(poly).reshape(-1, 2); N = p.shape[0]; keep = self.to_device(p); ptr = keep.ptr
-        c = commitment; x = Fh(x).reshape(-1, 2)
+        c = commitment; x = Fh(x).reshape(-1, 2) if x is not None else None
         R1 = (2 * c.trs).bit_length() - 1; logc = c.cols.bit_length() - 1
         rounds = R1 + logc + 2 * (R1 + logc) + logc
         depth = c.M.bit_length() - 1
@@ -445,7 +456,7 @@ class Hobbit:
 
         class Out(ctypes.Structure):
             _fields_ = [(n, c_vp) for n in names]
-        res = dict(cols=np.zeros(queries, np.uint32), rows=np.zeros(queries, np.uint32), reply=np.zeros((queries, c.K, 2), np.uint64),
+        res = dict(cols=np.zeros(queries, np.uint32), rows=np.zeros(queries, np.uint32), reply=None if _from_aggregate else np.zeros((queries, c.K, 2), np.uint64),
                    paths=np.zeros((queries, depth, 32), np.uint8) if want_paths else None, poly=np.zeros((rounds, 3, 2), np.uint64),
                    r=np.zeros((rounds, 2), np.uint64), vr=np.zeros((5, 2, 2), np.uint64), fin=np.zeros((5, 2), np.uint64),
                    scalars=np.zeros((5, 2), np.uint64), checks=np.zeros(3, np.int32), roots=np.zeros((2, 32), np.uint8))
@@ -457,8 +468,11 @@ class Hobbit:
         else:
             vals += [None, None]
         o = Out(*vals)
-        fn = self.lib.hobbit_open_standard if full else self.lib.hobbit_open_core
-        self._chk(fn(self.ctx, ptr, N, c.h, _hp(x), queries, ctypes.byref(o)))
+        if _from_aggregate:
+            self._chk(self.lib.hobbit_open_from_aggregate(self.ctx, ptr, N, c.K, c.trs, queries, ctypes.byref(o)))
+        else:
+            fn = self.lib.hobbit_open_standard if full else self.lib.hobbit_open_core
+            self._chk(fn(self.ctx, ptr, N, c.h, _hp(x), queries, ctypes.byref(o)))
         res["I"] = np.stack([res["cols"], res["rows"]], axis=1)
         if full:
             res["sp_c"] = self._sp_trim(sp[0][0], c.trs * c.cols, 32); res["sp_f"] = self._sp_trim(sp[1][0], c.M, 32)

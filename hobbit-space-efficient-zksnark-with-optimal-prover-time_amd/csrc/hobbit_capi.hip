@@ -493,6 +493,20 @@ int hobbit_commitment_gather(hobbit_ctx *ctx, const hobbit_commitment *c, const 
     HB_TRY(launch_gather(ctx, c->d_tensor, (size_t)c->cols * c->rows2, c->rows2, c->K, d_rows, d_cols, nq, d_reply));
     return hobbit_memcpy_d2h(ctx, h_reply, d_reply, nq * c->K * sizeof(F));
 }
+// the same gather on a raw tensor shard (codeword-major, `nchunks` chunks of 4M F): the multi-GPU open's replies
+int hobbit_tensor_gather(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M, int nchunks, int trs, const uint32_t *h_rows, const uint32_t *h_cols, size_t nq, hobbit_F *h_reply) {
+    if (nchunks <= 0 || trs <= 0 || M % (size_t)trs) return ctx->fail(HOBBIT_EINVAL, "tensor_gather: bad shard shape");
+    const size_t cols = 2 * M / (size_t)trs, rows2 = 2 * (size_t)trs;
+    for (size_t q = 0; q < nq; q++) if (h_rows[q] >= rows2 || h_cols[q] >= cols) return ctx->fail(HOBBIT_EINVAL, "tensor_gather: query out of range");
+    if (!nq) return 0;
+    uint8_t *buf; size_t rb = ((nq * nchunks * sizeof(F) + 15) / 16) * 16;
+    HB_TRY(ctx->workspace(rb + 8 * nq + 64, (void **)&buf));
+    F *d_reply = reinterpret_cast<F *>(buf); uint32_t *d_rows = reinterpret_cast<uint32_t *>(buf + rb), *d_cols = d_rows + nq;
+    HB_CHECK(ctx, hipMemcpyAsync(d_rows, h_rows, 4 * nq, hipMemcpyHostToDevice, ctx->stream));
+    HB_CHECK(ctx, hipMemcpyAsync(d_cols, h_cols, 4 * nq, hipMemcpyHostToDevice, ctx->stream));
+    HB_TRY(launch_gather(ctx, cF(d_tensor), cols * rows2, (uint32_t)rows2, nchunks, d_rows, d_cols, nq, d_reply));
+    return hobbit_memcpy_d2h(ctx, h_reply, d_reply, nq * nchunks * sizeof(F));
+}
 int hobbit_commitment_paths(hobbit_ctx *ctx, const hobbit_commitment *c, const uint32_t *h_cols, const uint32_t *h_rows, size_t nq, uint8_t *h_paths) {
     std::vector<uint64_t> pos(nq);
     for (size_t q = 0; q < nq; q++) pos[q] = (uint64_t)(h_rows[q] / 4) * c->cols + h_cols[q];   // src/merkle_tree.cpp:309
@@ -1081,18 +1095,23 @@ struct OpenTrace {
         t0 = t1;
     }
 };
-static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const hobbit_F *h_x, int queries, hobbit_open_out *o, bool full) {
-    if (!c || !o || queries <= 0 || (full && (!o->sp_c || !o->sp_f))) return ctx->fail(HOBBIT_EINVAL, "open: bad arguments");
+// With a commitment `c`: the aggregate is computed from d_poly (N = M K coefficients).  With c == NULL (multi-GPU open): d_poly is the
+// M-element aggregate itself, summed by the caller from per-rank partials; dims = {K, trs}; replies and paths are the caller's business.
+static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const int *dims, const hobbit_F *h_x, int queries, hobbit_open_out *o,
+                     bool full) {
+    if ((!c && !dims) || !o || queries <= 0 || (full && (!o->sp_c || !o->sp_f))) return ctx->fail(HOBBIT_EINVAL, "open: bad arguments");
+    if (!c && (o->reply || o->paths)) return ctx->fail(HOBBIT_EINVAL, "open_from_aggregate: replies and paths come from the tensor shards, not from here");
     OpenTrace tr(ctx);
     tr.mark("entry (stream drain)");
-    if (!c->lin) return ctx->fail(HOBBIT_EINVAL, "open_core: only the RS x expander (linear_time) code is built");
-    const int K = c->K, trs = c->trs;
-    const size_t M = c->M, cols = c->cols, rows2 = c->rows2, big = rows2 * cols;
+    if (c && !c->lin) return ctx->fail(HOBBIT_EINVAL, "open_core: only the RS x expander (linear_time) code is built");
+    const int K = c ? c->K : dims[0], trs = c ? c->trs : dims[1];
+    if (K <= 0 || trs < 4 || N % (size_t)K) return ctx->fail(HOBBIT_EINVAL, "open: bad K / trs");
+    const size_t M = N / (size_t)K, cols = 2 * M / (size_t)trs, rows2 = 2 * (size_t)trs, big = rows2 * cols;
     const int logK = ilog2_exact((size_t)K), logc = ilog2_exact(cols), R1 = ilog2_exact(rows2), R3 = R1 + logc;
-    if (logK < 0 || N != M * (size_t)K || logc != 12) return ctx->fail(HOBBIT_EINVAL, "open_core: needs K a power of two and 4096-point row codes");
+    if (logK < 0 || (c && (M != c->M || cols != c->cols)) || logc != 12 || R1 < 0) return ctx->fail(HOBBIT_EINVAL, "open_core: needs K a power of two and 4096-point row codes");
     // beta over the chunk variables (precompute_beta, host: K <= 64 entries) and the r_v[0] draw (:619-623)
     std::vector<F> beta((size_t)K); beta[0] = fmake(1);
-    for (int i = 0; i < logK; i++) for (size_t j = ((size_t)1 << i); j-- > 0;) { F t = fmul(cF(h_x)[logK - 1 - i], beta[j]); beta[2 * j + 1] = t; beta[2 * j] = fsub(beta[j], t); }
+    if (c) for (int i = 0; i < logK; i++) for (size_t j = ((size_t)1 << i); j-- > 0;) { F t = fmul(cF(h_x)[logK - 1 - i], beta[j]); beta[2 * j + 1] = t; beta[2 * j] = fsub(beta[j], t); }
     { F rv0 = fmake((uint64_t)random()); rv0 = fadd(rv0, fmake((uint64_t)rand())); memcpy(&o->scalars[0], &rv0, sizeof(F)); }   // generate_randomness(1)
     // device arena
     F *arena = nullptr;
@@ -1118,7 +1137,8 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
       *d_ac = d_ev + cols, *d_b1 = d_ac + rows2;
     F *Mp = BIG, *C = BIG + (size_t)trs * cols;
     tr.mark("beta + arena");
-    HB_TRY(hobbit_aggregate(ctx, d_poly, N, reinterpret_cast<const hobbit_F *>(beta.data()), K, reinterpret_cast<hobbit_F *>(d_aggr)));   // _aggregate axpy (:258-272)
+    if (c) HB_TRY(hobbit_aggregate(ctx, d_poly, N, reinterpret_cast<const hobbit_F *>(beta.data()), K, reinterpret_cast<hobbit_F *>(d_aggr)));   // _aggregate axpy (:258-272)
+    else HB_CHECK(ctx, hipMemcpyAsync(d_aggr, d_poly, M * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
     // compute_tensorcode(aggr) (:277): M' = row FFTs (row-major), codeword-major copy, expander encode, parity half back to row-major C
     tr.mark("beta, arena, aggregate");
     HB_TRY(fft_rows(ctx, d_aggr, cols / 2, (uint32_t)(cols / 2), Mp, cols, 1, logc, false, 1, (uint32_t)trs, 0, 0));
@@ -1149,8 +1169,8 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     for (int q = 0; q < queries; q++) { qc[q] = (uint32_t)(rand() % (long)cols); qr[q] = (uint32_t)(rand() % (long)rows2); Iv[q] = qc[q] + cols * (uint64_t)qr[q]; }
     if (o->cols) memcpy(o->cols, qc.data(), 4 * (size_t)queries);
     if (o->rows) memcpy(o->rows, qr.data(), 4 * (size_t)queries);
-    if (o->reply) HB_TRY(hobbit_commitment_gather(ctx, c, qr.data(), qc.data(), (size_t)queries, o->reply));
-    if (o->paths) HB_TRY(hobbit_commitment_paths(ctx, c, qc.data(), qr.data(), (size_t)queries, o->paths));
+    if (c && o->reply) HB_TRY(hobbit_commitment_gather(ctx, c, qr.data(), qc.data(), (size_t)queries, o->reply));
+    if (c && o->paths) HB_TRY(hobbit_commitment_paths(ctx, c, qc.data(), qr.data(), (size_t)queries, o->paths));
     tr.mark("queries+gather+paths");
     // recursive_prover_Spielman: s powers (:293-297), aggr_c = [M' | C] . s (:298-309)
     std::vector<F> sv(cols);
@@ -1230,10 +1250,16 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     return 0;
 }
 int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const hobbit_F *h_x, int queries, hobbit_open_out *o) {
-    return open_impl(ctx, d_poly, N, c, h_x, queries, o, false);
+    if (!c) return ctx->fail(HOBBIT_EINVAL, "open_core: null commitment");
+    return open_impl(ctx, d_poly, N, c, nullptr, h_x, queries, o, false);
 }
 int hobbit_open_standard(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const hobbit_F *h_x, int queries, hobbit_open_out *o) {
-    return open_impl(ctx, d_poly, N, c, h_x, queries, o, true);
+    if (!c) return ctx->fail(HOBBIT_EINVAL, "open_standard: null commitment");
+    return open_impl(ctx, d_poly, N, c, nullptr, h_x, queries, o, true);
+}
+int hobbit_open_from_aggregate(hobbit_ctx *ctx, const hobbit_F *d_aggr, size_t M, int K, int trs, int queries, hobbit_open_out *o) {
+    const int dims[2] = {K, trs};
+    return open_impl(ctx, d_aggr, M * (size_t)K, nullptr, dims, nullptr, queries, o, true);
 }
 
 int hobbit_sumcheck2(hobbit_ctx *ctx, const hobbit_F *d_v1, const hobbit_F *d_v2, size_t n, const hobbit_F *prev_r, hobbit_F *h_qpoly,

@@ -81,6 +81,77 @@ def sharded_commit(ops, dist, plan, rank, local_chunks):
     return dict(leaf_range=(lo, hi), subtree=subtree, top=top, root=top[-1])
 
 
+def sharded_open(ops, dist, plan, rank, commit_res, x, queries=5900):
+    """The open of a chunk-sharded commitment (the reference's open_standard, src/Our_PC.cpp:604-661, on one process):
+      1. rank g aggregates ITS chunks with their eq-table coefficients: partial_g = sum_{i = g (mod G)} beta[i] * chunk_i;
+      2. ONE all-gather of the partials (M F each) and a local field sum -> every rank holds the aggregate;
+      3. every rank runs the rest of the open from the aggregate (tensor code of the aggregate, inner commitments, five sumchecks,
+         both shockwave_prove / WHIR proofs): it depends on the aggregate alone, its rounds are sequential and short, so it is
+         replicated, not sharded -- and because every rank draws the same libc sequence, every rank holds the same queries;
+      4. replies reply[q][i] = tensor_i[row_q][col_q] are gathered where chunk i's tensor lives, ONE all-gather;
+      5. the Merkle path of query q comes from the rank that owns its leaf (subtree part, ONE all-gather of padded paths) followed by
+         the top log2 G levels every rank has.
+    `x`: (log2 N, 2) uint64 host array; commit_res: what sharded_commit returned on this rank.  Returns the transcript (as
+    Hobbit.open_standard / open_from_aggregate) with "reply" (queries, K, 2) and "paths" (queries, log2 M, 32) filled in."""
+    import torch
+    G = plan.world
+    own = plan.chunks_of(rank)
+    logK = plan.K.bit_length() - 1
+    beta = ops.eq_table_host(np.asarray(x)[:logK])                       # (K, 2) uint64, host
+    # 1-2. aggregate
+    partial = ops.aggregate_local(np.ascontiguousarray(beta[own]), plan)          # int64 tensor (M, 2) on ops.device
+    parts = [torch.empty_like(partial) for _ in range(G)]
+    if G > 1:
+        dist.all_gather(parts, partial)
+        ops.after_collective()
+    else:
+        parts = [partial]
+    aggr = ops.sum_vectors(parts)
+    # 3. the rest of the open, replicated
+    res = ops.open_from_aggregate(aggr, plan, queries)
+    cols = np.asarray(res["cols"], np.int64); rows = np.asarray(res["rows"], np.int64)
+    # 4. replies
+    mine = ops.gather_local(rows, cols, plan)                                        # int64 tensor (queries, n_own, 2)
+    rep = [torch.empty_like(mine) for _ in range(G)]
+    if G > 1:
+        dist.all_gather(rep, mine)
+        ops.after_collective()
+    else:
+        rep = [mine]
+    reply = np.zeros((queries, plan.K, 2), np.uint64)
+    for h in range(G):
+        r_h = rep[h].cpu().numpy().view(np.uint64)
+        for li, i in enumerate(plan.chunks_of(h)):
+            reply[:, i] = r_h[:, li]
+    res["reply"] = reply
+    # 5. paths: leaf position (row/4) * cols + col (src/merkle_tree.cpp:309); owner = pos // m_local
+    pos = (rows // 4) * plan.cols + cols
+    depth_l = plan.m_local.bit_length() - 1
+    lo, hi = plan.leaf_range(rank)
+    sel = np.nonzero((pos >= lo) & (pos < hi))[0]
+    local_paths = torch.zeros((queries, depth_l, 32), dtype=torch.uint8, device=commit_res["subtree"].device)
+    if len(sel):
+        local_paths[torch.from_numpy(sel).to(local_paths.device)] = ops.subtree_paths(commit_res["subtree"], pos[sel] - lo, plan)
+    allp = [torch.empty_like(local_paths) for _ in range(G)]
+    if G > 1:
+        dist.all_gather(allp, local_paths)
+        ops.after_collective()
+    else:
+        allp = [local_paths]
+    top = np.asarray(commit_res["top"]).reshape(-1, 32)
+    depth_t = G.bit_length() - 1
+    paths = np.zeros((queries, depth_l + depth_t, 32), np.uint8)
+    owner = pos // plan.m_local
+    stacked = np.stack([a.cpu().numpy() for a in allp])                               # (G, queries, depth_l, 32)
+    paths[:, :depth_l] = stacked[owner, np.arange(queries)]
+    off, sz, p = 0, G, owner.copy()
+    for l in range(depth_t):                                                          # siblings in the top levels
+        paths[:, depth_l + l] = top[off + (p ^ 1)]
+        off += sz; sz //= 2; p //= 2
+    res["paths"] = paths
+    return res
+
+
 def assemble_levels(plan, subtrees, top):
     """Rebuild the reference's flat level list (M leaves ... root) from every rank's subtree
     (host arrays, rank order) and the top levels -- used by tests and by rank 0 when a caller
@@ -133,6 +204,52 @@ class HipOps:
     def after_collective(self):
         import torch
         torch.cuda.synchronize(self.device)
+
+    # ---- open
+    def set_local_chunks(self, local_chunks):
+        self._chunks = local_chunks                                  # (device_ptr, n_own)
+
+    def eq_table_host(self, r):
+        return self.hb.precompute_beta(r)
+
+    def aggregate_local(self, coeffs, plan):
+        import torch
+        hb = self.hb
+        ptr, n_own = self._chunks
+        out = torch.empty((plan.M, 2), dtype=torch.int64, device=self.device)
+        hb._chk(hb.lib.hobbit_aggregate(hb.ctx, ptr, plan.M * n_own, coeffs.ctypes.data, n_own, out.data_ptr()))
+        hb.sync()
+        return out
+
+    def sum_vectors(self, parts):
+        hb = self.hb
+        acc = parts[0].clone()
+        for p in parts[1:]:
+            hb._chk(hb.lib.hobbit_f_binop(hb.ctx, 0, acc.data_ptr(), p.data_ptr(), acc.data_ptr(), acc.shape[0]))
+        hb.sync()
+        return acc
+
+    def open_from_aggregate(self, aggr, plan, queries):
+        return self.hb.open_from_aggregate((aggr.data_ptr(), plan.M), plan.K, plan.trs, queries)
+
+    def gather_local(self, rows, cols, plan):
+        """reply[q][li] = tensor shard of local chunk li at (row_q, col_q): the shard is codeword-major, chunk stride 4M"""
+        import torch
+        hb = self.hb
+        n_own = self._chunks[1]
+        r = np.ascontiguousarray(rows, np.uint32); c = np.ascontiguousarray(cols, np.uint32)
+        out = np.zeros((len(r), n_own, 2), np.uint64)
+        hb._chk(hb.lib.hobbit_tensor_gather(hb.ctx, self._tensor.ptr, plan.M, n_own, plan.trs, r.ctypes.data, c.ctypes.data, len(r), out.ctypes.data))
+        return torch.from_numpy(out.view(np.int64)).to(self.device)
+
+    def subtree_paths(self, subtree, local_pos, plan):
+        import torch
+        hb = self.hb
+        pos = np.ascontiguousarray(local_pos, np.uint64)
+        depth = plan.m_local.bit_length() - 1
+        out = np.zeros((len(pos), depth, 32), np.uint8)
+        hb._chk(hb.lib.hobbit_merkle_paths(hb.ctx, subtree.data_ptr(), plan.m_local, pos.ctypes.data, len(pos), out.ctypes.data))
+        return torch.from_numpy(out).to(self.device)
 
 
 def tree_top_host(lib, roots):

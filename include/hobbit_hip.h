@@ -192,6 +192,10 @@ int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobb
 /* tensor codes of `nchunks` consecutive messages of M F each (chunk i at d_msg + i*M), outputs
  * codeword-major per chunk at d_out + i*4M */
 int hobbit_tensorcode_chunks(hobbit_ctx *ctx, const hobbit_F *d_msg, size_t M, int nchunks, int trs, int linear_time, hobbit_F *d_out);
+/* reply[q*nchunks + i] = chunk i of the shard at (row_q, col_q): _compute_aggregation_reply (src/Our_PC.cpp:291-305) on a rank's tensor shard
+ * (as written by hobbit_tensorcode_chunks) */
+int hobbit_tensor_gather(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M, int nchunks, int trs, const uint32_t *h_rows, const uint32_t *h_cols, size_t nq,
+                         hobbit_F *h_reply);
 /* inner leaf digests H(t[4j..4j+3][c]) (src/merkle_tree.cpp:70-75) of nchunks tensors, in leaf
  * order: d_out[(i*M + j*cols + c)*32] */
 int hobbit_inner_digests(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M, int nchunks, int trs, uint8_t *d_out);
@@ -230,6 +234,12 @@ int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
  * out->sp_c / out->sp_f must be set (buffer sizes as hobbit_shockwave_prove).  What the reference runs after that
  * (src/Our_PC.cpp:663-690) is verifier-side accounting whose results are discarded; it is not built. */
 int hobbit_open_standard(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const hobbit_F *h_x, int queries, hobbit_open_out *out);
+/* The same from a given aggregate vector d_aggr (M F) = sum_i beta[i] * chunk_i (src/Our_PC.cpp:258-272) of a commitment with K chunks and
+ * tensor_row_size trs -- the multi-GPU open: each rank aggregates its own chunks, the partials are summed, and everything
+ * after that depends on the aggregate alone.  out->cols / rows receive the queries; out->reply and out->paths must be NULL (replies are
+ * gathered from the ranks' tensor shards, paths from their subtrees).  The evaluation point is not needed: only its chunk variables enter
+ * the opening, through the aggregate. */
+int hobbit_open_from_aggregate(hobbit_ctx *ctx, const hobbit_F *d_aggr, size_t M, int K, int trs, int queries, hobbit_open_out *out);
 
 /* ---- sumchecks ----------------------------------------------------------------------------- */
 /* generate_2product_sumcheck_proof (src/sumcheck.cpp:2391-2460).  Inputs preserved.

@@ -1031,16 +1031,27 @@ void orc_batch_prod(oF *f1, oF *f2, oF *f3, const oF *b1, const oF *b2, const oF
 static void matvec_rows(const oF *Mx, size_t rows, size_t cols, const oF *v, oF *out) {   /* out[i] = sum_j v[j] M[i][j] */
     for (size_t i = 0; i < rows; i++) { oF a = fint(0); for (size_t j = 0; j < cols; j++) a = f_add(a, f_mul(v[j], Mx[i * cols + j])); out[i] = a; }
 }
+/* aggr_in != NULL: the aggregate is given (multi-GPU open: it was summed from per-rank partials); poly / x are then unused */
+static int open_core_impl(const oF *aggr_in, const oF *poly, size_t N, int K, int trs, const oF *x, int queries, uint32_t *I_out, oF *reply_out, const oF *tensor,
+                          oF *scalars_out, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks, uint8_t *roots);
 int orc_open_core(const oF *poly, size_t N, int K, int trs, const oF *x, int queries, uint32_t *I_out, oF *reply_out, const oF *tensor /* K x 2trs x cols, row-major */,
                   oF *scalars_out /* r_v0, s0, s2, a, y1 */, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks, uint8_t *roots /* C_f, C_c (64 B) or NULL */) {
+    return open_core_impl(NULL, poly, N, K, trs, x, queries, I_out, reply_out, tensor, scalars_out, qpoly, r_out, vr, fin, checks, roots);
+}
+int orc_open_core_aggr(const oF *aggr, size_t M, int K, int trs, int queries, uint32_t *I_out, oF *scalars_out, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks,
+                       uint8_t *roots) {
+    return open_core_impl(aggr, NULL, M * (size_t)K, K, trs, NULL, queries, I_out, NULL, NULL, scalars_out, qpoly, r_out, vr, fin, checks, roots);
+}
+static int open_core_impl(const oF *aggr_in, const oF *poly, size_t N, int K, int trs, const oF *x, int queries, uint32_t *I_out, oF *reply_out, const oF *tensor,
+                          oF *scalars_out, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks, uint8_t *roots) {
     size_t M = N / (size_t)K, cols = 2 * M / (size_t)trs, rows2 = 2 * (size_t)trs;
     int logK = (int)log2((double)K), logc = (int)log2((double)cols), R1 = (int)log2((double)rows2);
     /* open_standard: beta over the chunk variables, r_v[0] draw, aggregate */
     oF *beta = (oF *)malloc(sizeof(oF) * (size_t)K);
-    orc_precompute_beta(x, logK, beta);
+    if (!aggr_in) orc_precompute_beta(x, logK, beta);
     oF rv0; orc_generate_randomness(1, &rv0); scalars_out[0] = rv0;
     oF *aggr = (oF *)malloc(sizeof(oF) * M);
-    orc_aggregate(poly, N, beta, K, aggr);
+    if (aggr_in) memcpy(aggr, aggr_in, sizeof(oF) * M); else orc_aggregate(poly, N, beta, K, aggr);
     /* compute_tensorcode(aggr): message half M' (row FFT) and parity half C */
     oF *T = (oF *)malloc(sizeof(oF) * rows2 * cols);
     orc_compute_tensorcode(aggr, M, trs, 1, T);

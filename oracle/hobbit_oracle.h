@@ -113,6 +113,10 @@ void orc_batch_prod(oF *f1, oF *f2, oF *f3, const oF *b1, const oF *b2, const oF
 int orc_open_core(const oF *poly, size_t N, int K, int trs, const oF *x, int queries, uint32_t *I_out, oF *reply_out, const oF *tensor,
                   oF *scalars_out, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks, uint8_t *roots);
 
+/* the same from a given aggregate vector (the multi-GPU open sums it from per-rank partials) */
+int orc_open_core_aggr(const oF *aggr, size_t M, int K, int trs, int queries, uint32_t *I_out, oF *scalars_out, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks,
+                       uint8_t *roots);
+
 /* Elastic_PC streaming commit on the synthetic "test" stream */
 void orc_read_stream_pc(size_t B, oF *out);
 size_t orc_elastic_commit(size_t N, size_t B, int opt, uint8_t *levels_out);

@@ -404,6 +404,25 @@ class Oracle(_Base):
           _p(t) if t is not None else None, _p(sc), _p(q), _p(r), _p(vr), _p(fin), _p(chk), _p(roots))
         return dict(I=I, reply=reply, scalars=sc, poly=q, r=r, vr=vr, fin=fin, checks=chk, roots=roots)
 
+    def open_standard_from_aggregate(self, aggr, K, trs, queries):
+        """open_standard's prover side from a given aggregate (multi-GPU open): no replies (they come from the tensor shards)"""
+        a = F(aggr).reshape(-1, 2); M = a.shape[0]; cols = 2 * M // trs
+        R1 = (2 * trs).bit_length() - 1; logc = cols.bit_length() - 1; R3 = R1 + logc
+        rounds = R1 + logc + 2 * R3 + logc
+        I = np.zeros((queries, 2), np.uint32)
+        sc = np.zeros((5, 2), np.uint64); q = np.zeros((rounds, 3, 2), np.uint64); r = np.zeros((rounds, 2), np.uint64)
+        vr = np.zeros((5, 2, 2), np.uint64); fin = np.zeros((5, 2), np.uint64); chk = np.zeros(3, np.int32); roots = np.zeros((2, 32), np.uint8)
+        f = self.lib.orc_open_core_aggr; f.restype = ctypes.c_int
+        f(_p(a), c_sz(M), ctypes.c_int(K), ctypes.c_int(trs), ctypes.c_int(queries), _p(I), _p(sc), _p(q), _p(r), _p(vr), _p(fin), _p(chk), _p(roots))
+        res = dict(I=I, scalars=sc, poly=q, r=r, vr=vr, fin=fin, checks=chk, roots=roots)
+        C = self.compute_tensorcode(a, trs, 1).reshape(2 * trs, cols, 2)[trs:].reshape(-1, 2)
+        o4 = R1 + logc + R3; r4 = r[o4:o4 + R3]; r5 = r[o4 + R3:o4 + R3 + logc]
+        enc_c, lv_c = self.shockwave_commit(C, 32)
+        res["sp_c"] = self.shockwave_prove(C, enc_c, 32, r4[:-1], lv_c)
+        enc_f, lv_f = self.shockwave_commit(a, 32)
+        res["sp_f"] = self.shockwave_prove(a, enc_f, 32, np.concatenate([r5, r4[logc:logc + R1 - 1]])[:-1], lv_f)
+        return res
+
     def open_standard(self, poly, K, trs, x, queries, tensor=None):
         """Prover side of open_standard (src/Our_PC.cpp:604-661): open_core, then shockwave_prove(C_c, P4.r[:-1])
         (src/PC_utils.cpp:368) and shockwave_prove(C_f, P5.randomness[:-1]) (:385).  The libc generator runs on across the

@@ -44,8 +44,39 @@ class OracleOps:
     def after_collective(self):
         pass
 
+    # ---- open (CPU stand-ins for HipOps' open methods)
+    def set_local_chunks(self, local_chunks):
+        self._chunks = local_chunks
 
-def _worker(rank, world, port, N, K, q):
+    def eq_table_host(self, r):
+        return self.orc.precompute_beta(r)
+
+    def aggregate_local(self, coeffs, plan):
+        flat = np.concatenate(self._chunks)
+        return torch.from_numpy(self.orc.aggregate(flat, coeffs).view(np.int64))
+
+    def sum_vectors(self, parts):
+        acc = parts[0].numpy().view(np.uint64)
+        for p in parts[1:]:
+            acc = self.orc.f_add(acc, p.numpy().view(np.uint64))
+        return torch.from_numpy(np.ascontiguousarray(acc).view(np.int64))
+
+    def open_from_aggregate(self, aggr, plan, queries):
+        res = self.orc.open_standard_from_aggregate(aggr.numpy().view(np.uint64), plan.K, plan.trs, queries)
+        res["cols"] = res["I"][:, 0].copy(); res["rows"] = res["I"][:, 1].copy()
+        return res
+
+    def gather_local(self, rows, cols, plan):
+        ts = [self.orc.compute_tensorcode(m, plan.trs, 1) for m in self._chunks]          # (2trs, cols, 2) row-major each
+        out = np.stack([t[rows, cols] for t in ts], axis=1)                                # (queries, n_own, 2)
+        return torch.from_numpy(np.ascontiguousarray(out).view(np.int64))
+
+    def subtree_paths(self, subtree, local_pos, plan):
+        lv = subtree.numpy()
+        return torch.from_numpy(np.stack([self.orc.open_tree_blake(lv, plan.m_local, int(p), 0, 0) for p in local_pos]))
+
+
+def _worker(rank, world, port, N, K, q, do_open=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -58,8 +89,18 @@ def _worker(rank, world, port, N, K, q):
     plan = mod.parallel.ShardPlan(N, K, trs, world)
     M = plan.M
     local = [poly[i * M:(i + 1) * M] for i in plan.chunks_of(rank)]
-    res = mod.parallel.sharded_commit(OracleOps(orc, mod.load_library()), dist, plan, rank, local)
-    q.put((rank, res["subtree"].numpy(), res["top"], res["root"]))
+    ops = OracleOps(orc, mod.load_library())
+    res = mod.parallel.sharded_commit(ops, dist, plan, rank, local)
+    out = None
+    if do_open:
+        import ctypes
+        x = orc.generate_randomness(N.bit_length() - 1)                  # same point on every rank
+        ctypes.CDLL(None).srandom(2024)                                  # same libc stream on every rank
+        ops.set_local_chunks(local)
+        o = mod.parallel.sharded_open(ops, dist, plan, rank, res, x, 300)
+        out = {k: o[k] for k in ("I", "poly", "r", "vr", "fin", "scalars", "roots", "reply", "paths")}
+        out["sp_c_wq"] = o["sp_c"]["wq"]; out["sp_f_q1"] = o["sp_f"]["q1"]
+    q.put((rank, res["subtree"].numpy(), res["top"], res["root"], out))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -102,6 +143,50 @@ def test_sharded_commit_matches_single_process(oracle, world):
     assert np.array_equal(levels, want)
     for g in got:                                   # every rank ends with the same top levels / root
         assert np.array_equal(g[2], got[0][2]) and np.array_equal(g[3], want[-1])
+
+
+def test_sharded_open_matches_single_process(oracle):
+    """world 2: per-rank partial aggregates + one all-gather, replicated open from the aggregate, replies gathered from the tensor
+    shards, Merkle paths stitched from the owner's subtree and the shared top levels -- everything equal to the single-process
+    open_standard of the same polynomial with the same libc stream."""
+    import ctypes
+    from __graft_entry__ import load_package, build_hip
+    build_hip()
+    world, N, K, queries = 2, 1 << 20, 32, 300
+    trs = N // (K << 11)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, K, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = []
+    import queue as _q
+    import time as _t
+    deadline = _t.time() + 300
+    while len(got) < world:
+        try:
+            got.append(q.get(timeout=2))
+        except _q.Empty:
+            assert all(p.exitcode in (None, 0) for p in procs), "a rank died: exit codes %s" % [p.exitcode for p in procs]
+            assert _t.time() < deadline, "timeout waiting for ranks"
+    got.sort(key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    oracle.rng_reset(); poly = oracle.generate_randomness(N); oracle.expander_init_store(trs)
+    lv, T = oracle.commit_standard(poly, K, trs, 1, want_tensor=True)
+    x = oracle.generate_randomness(N.bit_length() - 1)
+    ctypes.CDLL(None).srandom(2024)
+    want = oracle.open_standard(poly, K, trs, x, queries, tensor=T)
+    M = N // K
+    for g in got:
+        o = g[4]
+        for k in ("I", "poly", "r", "vr", "fin", "scalars", "roots", "reply"):
+            assert np.array_equal(o[k], want[k]), (g[0], k)
+        assert np.array_equal(o["sp_c_wq"], want["sp_c"]["wq"]) and np.array_equal(o["sp_f_q1"], want["sp_f"]["q1"])
+        for qi in (0, 7, 150, queries - 1):
+            assert np.array_equal(o["paths"][qi], oracle.open_tree_blake(lv, M, int(want["I"][qi, 0]), int(want["I"][qi, 1]), 2 * M // trs)), (g[0], qi)
 
 
 def test_shard_plan():

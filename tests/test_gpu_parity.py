@@ -420,6 +420,48 @@ def test_sharded_commit_hip_ops_world1(hb, oracle):
     assert np.array_equal(leaves, want[:M])
 
 
+def test_sharded_open_hip_ops_world1(hb, oracle):
+    """The per-rank GPU operations of the multi-GPU open (local aggregate, field sum of partials, open from the aggregate, replies
+    from the tensor shard, subtree paths) at world size 1 against the single-process hobbit_open_standard and the oracle; the
+    collective pattern is covered by tests/test_dist_gloo.py.  Also emulates two ranks' partial aggregates on the one GPU."""
+    import ctypes
+    import torch
+    from __graft_entry__ import load_package
+    mod = load_package()
+    libc = ctypes.CDLL(None)
+    N, K, queries = 1 << 20, 32, 5900
+    trs = N // (K << 11)
+    oracle.rng_reset(); poly = oracle.generate_randomness(N); oracle.expander_init_store(trs)
+    x = oracle.generate_randomness(N.bit_length() - 1)
+    hb.upload_graphs(trs, graphs_from(oracle, trs))
+    plan = mod.parallel.ShardPlan(N, K, trs, 1)
+    d = hb.to_device(poly)
+    ops = mod.parallel.HipOps(hb, torch.device("cuda", 0))
+    cres = mod.parallel.sharded_commit(ops, None, plan, 0, (d.ptr, K))
+    ops.set_local_chunks((d.ptr, K))
+    libc.srandom(31); got = mod.parallel.sharded_open(ops, None, plan, 0, cres, x, queries)
+    c = hb.commit_standard(poly, K, trs, 1)
+    libc.srandom(31); want = hb.open_standard(poly, c, x, queries, want_paths=True)
+    for k in ("cols", "rows", "reply", "paths", "poly", "r", "vr", "fin", "scalars", "roots", "checks"):
+        assert np.array_equal(got[k], want[k]), k
+    for sp in ("sp_c", "sp_f"):
+        for k in want[sp]:
+            assert np.array_equal(got[sp][k], want[sp][k]), (sp, k)
+    c.free()
+    # two ranks' partial aggregates, summed, equal the aggregate
+    plan2 = mod.parallel.ShardPlan(N, K, trs, 2)
+    M = plan2.M
+    beta = hb.precompute_beta(x[:5])
+    parts = []
+    for r in range(2):
+        own = plan2.chunks_of(r)
+        dl = hb.to_device(np.concatenate([poly[i * M:(i + 1) * M] for i in own]))
+        o2 = mod.parallel.HipOps(hb, torch.device("cuda", 0)); o2.set_local_chunks((dl.ptr, len(own)))
+        parts.append(o2.aggregate_local(np.ascontiguousarray(beta[own]), plan2))
+    total = ops.sum_vectors(parts).cpu().numpy().view(np.uint64)
+    assert np.array_equal(total, oracle.aggregate(poly, beta))
+
+
 # ---- Elastic_PC streaming commit + long-row tensor codes ---------------------------------------
 @pytest.mark.parametrize("opt", [1, 2])
 def test_elastic_commit_vs_golden(hb, opt):
