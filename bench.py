@@ -56,7 +56,7 @@ def measured_traffic(kernel, logn, K):
     only valid for the default 2^28 / K=32 workload."""
     if logn != 28 or K != 32:
         return None
-    path = os.path.join(ROOT, "profiles", "r01_c_hbm_traffic_commit_2e28.json")
+    path = os.path.join(ROOT, "profiles", "r01_e_hbm_traffic_commit_2e28.json")
     try:
         with open(path) as f:
             return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
