@@ -142,6 +142,20 @@ def test_encode_vs_golden(hb, n):
             assert np.array_equal(dg(d), g["enc_%s_%d_dg" % (tag, n)])
 
 
+@pytest.mark.parametrize("n", [2427, 3000, 3333, 4000])
+def test_encode_odd_sizes_vs_oracle(hb, oracle, n):
+    """message lengths that are not powers of two, large enough for the 64-wide slices (>= 512 outputs) with ragged last slices;
+    single-pass (n <= 2560: codeword under 80 KB) and two-pass launches"""
+    oracle.rng_reset(); oracle.expander_init_store(n)
+    hb.upload_graphs(n, graphs_from(oracle, n))
+    x = splitmix_field(2 * n, 70 + n).reshape(2, n, 2)
+    got = hb.encode_monolithic(x)
+    for b in range(2):
+        want, ln = oracle.encode_monolithic(x[b])
+        assert np.array_equal(got[b][:ln], want[:ln]), (n, b)
+        assert not got[b][ln:].any()
+
+
 def test_encode_full_range_weights_vs_golden(hb, oracle):
     g = gold("graph_encode")
     oracle.rng_reset(); oracle.expander_init_store(64)
