@@ -151,29 +151,36 @@ int launch_fft_rows(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_l
 // --------------------------------------------------------------------------------------------
 struct Fft4kConst { F w8, w8_3; int w4_plus_i; };
 
+// Inside the transform, sums live in the quasi-canonical range [0, p] (p itself standing for 0): a + b <= 2p < 2^62 folds with one
+// mask / shift / add and no compare-select; products (fmul) and the w8 rotation accept that range, and the last pass maps p -> 0.
+__device__ __forceinline__ uint64_t addq(uint64_t a, uint64_t b) { const uint64_t s = a + b; return (s & P61) + (s >> 61); }
+__device__ __forceinline__ uint64_t subq(uint64_t a, uint64_t b) { return addq(a, P61 - b); }
+__device__ __forceinline__ F faddq(const F &a, const F &b) { return fmake(addq(a.re, b.re), addq(a.im, b.im)); }
+__device__ __forceinline__ F fsubq(const F &a, const F &b) { return fmake(subq(a.re, b.re), subq(a.im, b.im)); }
+__device__ __forceinline__ F fcanon(const F &a) { return fmake(a.re == P61 ? 0 : a.re, a.im == P61 ? 0 : a.im); }
 __device__ __forceinline__ F fmul_w4(const F &a, int plus_i) {   // a * (+i) or a * (-i)
-    return plus_i ? fmake(a.im ? P61 - a.im : 0, a.re) : fmake(a.im, a.re ? P61 - a.re : 0);
+    return plus_i ? fmake(P61 - a.im, a.re) : fmake(a.im, P61 - a.re);     // [0, p] -> [0, p]: p stands for 0 inside the transform
 }
 // a * w8, w8 = the primitive 8th root of unity of the transform direction.  sqrt(2) = 2^31 in F_p (2^62 = 2), so
 // w8 = 2^30 (1 - i) forward (w4 = -i) and 2^30 (1 + i) inverse: a rotation by 30 bits of (a.re +- a.im), no product at all.
 __device__ __forceinline__ uint64_t rot30p(uint64_t x) { return ((x << 30) & P61) | (x >> 31); }     // x * 2^30 mod 2^61-1, canonical in/out
-__device__ __forceinline__ F fmul_w8(const F &a, int plus_i) {
-    return plus_i ? fmake(rot30p(subp(a.re, a.im)), rot30p(addp(a.re, a.im))) : fmake(rot30p(addp(a.re, a.im)), rot30p(subp(a.im, a.re)));
+__device__ __forceinline__ F fmul_w8(const F &a, int plus_i) {      // quasi-canonical in, quasi-canonical out (rot30p keeps [0, p])
+    return plus_i ? fmake(rot30p(subq(a.re, a.im)), rot30p(addq(a.re, a.im))) : fmake(rot30p(addq(a.re, a.im)), rot30p(subq(a.im, a.re)));
 }
 __device__ __forceinline__ uint32_t fft_phys(uint32_t i) { return i + (i >> 3); }
 #define HB_BFLY(x, y, w) do { F v__ = fmul(y, w); y = fsub(x, v__); x = fadd(x, v__); } while (0)
-#define HB_BFLY1(x, y) do { F v__ = y; y = fsub(x, v__); x = fadd(x, v__); } while (0)
+#define HB_BFLY1(x, y) do { F v__ = y; y = fsubq(x, v__); x = faddq(x, v__); } while (0)
 // the last two stages of an 8-point DIT DFT on a[0..7] (inputs in bit-reversed order, first stage done): twiddles 1, w4, w8, w8^3
 __device__ __forceinline__ void dft8_tail(F (&a)[8], int plus_i) {
     F t;
     HB_BFLY1(a[0], a[2]);
-    t = fmul_w4(a[3], plus_i); a[3] = fsub(a[1], t); a[1] = fadd(a[1], t);
+    t = fmul_w4(a[3], plus_i); a[3] = fsubq(a[1], t); a[1] = faddq(a[1], t);
     HB_BFLY1(a[4], a[6]);
-    t = fmul_w4(a[7], plus_i); a[7] = fsub(a[5], t); a[5] = fadd(a[5], t);
+    t = fmul_w4(a[7], plus_i); a[7] = fsubq(a[5], t); a[5] = faddq(a[5], t);
     HB_BFLY1(a[0], a[4]);
-    t = fmul_w8(a[5], plus_i); a[5] = fsub(a[1], t); a[1] = fadd(a[1], t);
-    t = fmul_w4(a[6], plus_i); a[6] = fsub(a[2], t); a[2] = fadd(a[2], t);
-    t = fmul_w4(fmul_w8(a[7], plus_i), plus_i); a[7] = fsub(a[3], t); a[3] = fadd(a[3], t);
+    t = fmul_w8(a[5], plus_i); a[5] = fsubq(a[1], t); a[1] = faddq(a[1], t);
+    t = fmul_w4(a[6], plus_i); a[6] = fsubq(a[2], t); a[2] = faddq(a[2], t);
+    t = fmul_w4(fmul_w8(a[7], plus_i), plus_i); a[7] = fsubq(a[3], t); a[3] = faddq(a[3], t);
 }
 
 template <bool PADDED>
@@ -229,8 +236,7 @@ k_fft4096(const F *__restrict__ src, size_t src_ld, size_t src_es, F *__restrict
         } else {
 #pragma unroll
             for (int t8 = 0; t8 < 8; t8++) {
-                F v = a[t8];
-                if (do_scale) v = fmul(v, scale);
+                F v = do_scale ? fmul(a[t8], scale) : fcanon(a[t8]);           // canonical out (a product already is)
                 stF(out + (size_t)(i0 + t8 * h) * dst_es, v);
             }
         }
