@@ -599,7 +599,7 @@ SP_KEYS = ("I", "q1", "r1", "vr1", "fin1", "q2", "r2", "vr2", "fin2", "iters", "
            "reply", "paths", "qn", "qidx", "qreply", "qpaths", "final_pb")
 
 
-@pytest.mark.parametrize("N,K", [(1 << 20, 32), (1 << 22, 32), (1 << 24, 32), (1 << 22, 16)])
+@pytest.mark.parametrize("N,K", [(1 << 20, 32), (1 << 22, 32), (1 << 24, 32), (1 << 22, 16), (1 << 23, 64), (1 << 21, 4)])
 def test_open_standard_vs_oracle(hb, oracle, N, K):
     """The whole prover side of open_standard (src/Our_PC.cpp:604-661): the core above followed by
     shockwave_prove(C_c, .) and shockwave_prove(C_f, .) (src/PC_utils.cpp:368,385) with their WHIR proofs; every transcript
