@@ -608,7 +608,7 @@ int hobbit_whir_commit(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, hobbit
 // zero-pad `cur` elements to fsz, change_form, FFT, 16-way regroup, MT_commit_Blake -> root (one FRI layer of _whir_prove,
 // src/Virgo.cpp:581-598).  fp: fsz F transient; keep: the regrouped codeword (fsz F) followed by its Merkle levels (fsz/2 hashes),
 // which the next query round reads.
-static int whir_fri_layer(hobbit_ctx *ctx, const F *d_poly, size_t cur, size_t fsz, F *fp, F *keep, uint8_t *h_root) {
+static int whir_fri_layer(hobbit_ctx *ctx, const F *d_poly, size_t cur, size_t fsz, F *fp, F *keep, uint8_t *d_root) {
     F *buf = keep; uint8_t *lv = reinterpret_cast<uint8_t *>(buf + fsz);
     HB_CHECK(ctx, hipMemsetAsync(fp, 0, fsz * sizeof(F), ctx->stream));
     HB_CHECK(ctx, hipMemcpyAsync(fp, d_poly, cur * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
@@ -618,7 +618,8 @@ static int whir_fri_layer(hobbit_ctx *ctx, const F *d_poly, size_t cur, size_t f
     else HB_TRY(fft_long(ctx, fp, fsz, fsz, fp, lg, false, 1));
     HB_TRY(launch_transpose_ld(ctx, fp, 0, fsz / 16, 16, (uint32_t)(fsz / 16), buf, 0, 16, 1));
     HB_TRY(hobbit_mt_commit_blake(ctx, reinterpret_cast<hobbit_F *>(buf), fsz, lv));
-    return hobbit_memcpy_d2h(ctx, h_root, lv + 32 * (2 * (fsz / 4) - 2), 32);
+    HB_CHECK(ctx, hipMemcpyAsync(d_root, lv + 32 * (2 * (fsz / 4) - 2), 32, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
 }
 // compute_zetas (src/Virgo.cpp:220-236), host side, libc draws in the reference's order
 static void compute_zetas_host(std::vector<F> &z, std::vector<uint64_t> &ridx, int reps, int v, size_t Nq) {
@@ -629,29 +630,16 @@ static void compute_zetas_host(std::vector<F> &z, std::vector<uint64_t> &ridx, i
     for (int i = 0; i < reps; i++) for (int j = 1; j < v; j++) z[(size_t)i * v + j] = fmul(z[(size_t)i * v + j - 1], z[(size_t)i * v + j - 1]);
 }
 // scratch elements hobbit_whir_prove carves from workspace4 AFTER the first 4N (left to a whir_commit of the same polynomial)
+static constexpr size_t WHIR_DIN = 2048 + 128 + 64, WHIR_DRES = 1024;       // F elements: z (100 x <= 20) | pows (<= 100) | indices (<= 128 u64)
 static size_t whir_scratch_elems(size_t N) {
     return 2 * N /* poly, beta */ + 2 * 100 * (N >> 4) /* batched eq tables */ + N /* fp */ + 2 * N + N /* two kept layers */ + 64
-           + 3 * 1024 + 64 + 100 * 32 + 256 + 256 + 256 + 100 * 16 + 64 /* partials, coef, z, y, pows, query idx, replies */;
+           + 3 * 1024 /* partials */ + WHIR_DIN * 6 /* per-iteration inputs z | pows | query indices */ + WHIR_DRES /* coefficients, roots, y, finals */
+           + 256 * 16 /* query replies */ + 8192 /* query paths: < 4096 hashes */ + 64;
 }
-// _verify_iteration's prover part (src/Virgo.cpp:245-275): replies (16 regrouped elements per index) and open_tree_blake(tree, {r,0}, 0)
-struct WhirQueryCursor { size_t q = 0, path_off = 0; int round = 0; };
-static int whir_answer(hobbit_ctx *ctx, hobbit_whir_out *o, WhirQueryCursor &cur, const F *layer, const uint8_t *levels, size_t size, const std::vector<uint64_t> &ridx,
-                       uint64_t *d_idx, F *d_rep) {
-    const size_t n = ridx.size(); const int depth = ilog2_exact(size / 4);
-    if (o->qn) o->qn[cur.round] = (int32_t)n;
-    cur.round++;
-    if (n && layer) {
-        if (o->qidx) for (size_t i = 0; i < n; i++) o->qidx[cur.q + i] = (int32_t)ridx[i];
-        if (o->qreply) {
-            HB_CHECK(ctx, hipMemcpyAsync(d_idx, ridx.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
-            HB_TRY(launch_gather_strided(ctx, layer, d_idx, n, 16, 16, 1, d_rep));
-            HB_TRY(hobbit_memcpy_d2h(ctx, o->qreply + 16 * cur.q, d_rep, n * 16 * sizeof(F)));
-        }
-        if (o->qpaths) HB_TRY(hobbit_merkle_paths(ctx, levels, size / 4, ridx.data(), n, o->qpaths + cur.path_off));
-    }
-    cur.q += n; cur.path_off += n * 32 * (size_t)depth;
-    return 0;
-}
+// _whir_prove (src/Virgo.cpp:519-686).  Nothing the host decides here depends on device data: the fold challenges, the out-of-domain
+// points and the query indices are libc draws, and the running evaluation only feeds the reference's exit(-1) checks.  So the whole
+// proof is queued without a single synchronisation -- host-drawn inputs go through one pinned staging slot per iteration (one
+// async copy each), every result lands in a device result area -- and is read back once at the end, where the checks are replayed.
 int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_F *d_com, const uint8_t *d_com_levels, const hobbit_F *h_x, hobbit_whir_out *o) {
     const int k = 4, logN = ilog2_exact(N);
     if (logN < 9 || logN > 24 || !o) return ctx->fail(HOBBIT_EINVAL, "whir_prove: N must be a power of two in [2^9, 2^24]");
@@ -659,71 +647,77 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
     const size_t curmax = N >> k, sz_front = 4 * N, sz_E = 100 * curmax;
     F *base; HB_TRY(ctx->workspace4((sz_front + whir_scratch_elems(N)) * sizeof(F), (void **)&base));
     F *poly = base + sz_front, *beta = poly + N, *E0 = beta + N, *E1 = E0 + sz_E, *fp = E1 + sz_E, *keepA = fp + N, *keepB = keepA + 2 * N, *part = keepB + N + 64,
-      *coef = part + 3 * 1024, *dz = coef + 64, *dy = dz + 100 * 32, *dpw = dy + 256, *d_rep = dpw + 256 + 256;
-    uint64_t *d_idx = reinterpret_cast<uint64_t *>(dpw + 256);
+      *din = part + 3 * 1024, *dres = din + WHIR_DIN * 6, *d_rep = dres + WHIR_DRES;
+    uint8_t *d_paths = reinterpret_cast<uint8_t *>(d_rep + 256 * 16);
+    // result area: [0] eval0 | per iteration t (stride 128): 12 coefficients, root (2 F), y (100 F) | [900] final sum | [904..) final poly | beta
+    auto res_it = [&](int t) { return dres + 8 + (size_t)t * 128; };
+    F *res_fin = dres + 900;
+    // pinned staging: one slot per iteration, laid out exactly like its device twin (z | pows | indices), then the read-back area
+    uint8_t *pinb; HB_TRY(ctx->pinned((WHIR_DIN * 6 + WHIR_DRES) * sizeof(F), (void **)&pinb));
+    F *pin_in = reinterpret_cast<F *>(pinb), *pin_res = pin_in + WHIR_DIN * 6;
     HB_CHECK(ctx, hipMemcpyAsync(poly, d_poly, N * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
     HB_TRY(hobbit_eq_table(ctx, h_x, logN, reinterpret_cast<hobbit_F *>(beta)));
-    F eval;
-    HB_TRY(launch_dot(ctx, beta, poly, N, part, coef));                         // eval = <beta, poly> (:535-538)
-    HB_TRY(hobbit_memcpy_d2h(ctx, &eval, coef, sizeof(F)));
-    F *pin; HB_TRY(ctx->pinned(256 * sizeof(F), (void **)&pin));
+    HB_TRY(launch_dot(ctx, beta, poly, N, part, dres));                          // eval = <beta, poly> (:535-538)
     int iter = 0, repeats = 100, nq = 0; size_t remaining = 0;
-    h_checks[0] = 1; h_checks[1] = 0;
     const F *prev = cF(d_com); const uint8_t *prev_lv = d_com_levels; size_t prev_sz = 2 * N;   // the layer the next query round reads
-    WhirQueryCursor qc; std::vector<uint64_t> ridx;
+    std::vector<uint64_t> ridx;
+    std::vector<F> a_all; std::vector<std::vector<F>> pw_all;                    // replayed after the read-back
+    size_t q_tot = 0, path_off = 0; int q_round = 0;
+    // _verify_iteration's prover part (:245-275): replies (16 regrouped elements per index) and open_tree_blake(tree, {r,0}, 0), into the
+    // device reply / path areas; `d_idx`: the indices, already on the device
+    auto answer = [&](const uint64_t *d_idx) -> int {
+        const size_t n = ridx.size(); const int depth = ilog2_exact(prev_sz / 4);
+        if (q_round >= 8 || q_tot + n > 256 || path_off + n * 32 * (size_t)depth > 8192 * sizeof(F)) return ctx->fail(HOBBIT_EINVAL, "whir_prove: query buffers too small");
+        if (o->qn) o->qn[q_round] = (int32_t)n;
+        q_round++;
+        if (n && prev) {
+            if (o->qidx) for (size_t i = 0; i < n; i++) o->qidx[q_tot + i] = (int32_t)ridx[i];
+            if (o->qreply) HB_TRY(launch_gather_strided(ctx, prev, d_idx, n, 16, 16, 1, d_rep + 16 * q_tot));
+            if (o->qpaths) HB_TRY(launch_merkle_paths(ctx, prev_lv, prev_sz / 4, d_idx, n, depth, d_paths + path_off));
+        }
+        q_tot += n; path_off += n * 32 * (size_t)depth;
+        return 0;
+    };
     for (;;) {
-        // the fold challenges a = random() do not depend on the round polynomials (:561), so the four rounds of an iteration are
-        // queued back to back and their coefficients read once
-        F av[4];
+        if (iter >= 6) return ctx->fail(HOBBIT_EINVAL, "whir_prove: more iterations than the staging area holds");
         for (int i = 0; i < k; i++) {
             const size_t L = N >> (iter * k + i + 1);
-            av[i] = fmake((uint64_t)random());                                  // a.push_back(random()) (:561)
-            HB_TRY(launch_whir_round(ctx, poly, beta, L, av[i], part, coef + 3 * i));
-        }
-        HB_CHECK(ctx, hipMemcpyAsync(pin, coef, 12 * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
-        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        for (int i = 0; i < k; i++) {
-            const F pa = pin[3 * i], pb = pin[3 * i + 1], pc = pin[3 * i + 2], a = av[i];
-            if (!feq(fadd(fadd(pa, pb), fadd(pc, pc)), eval)) h_checks[0] = 0;  // "Error in %d" (:562-565)
-            eval = fadd(fmul(fadd(fmul(pa, a), pb), a), pc);
-            mF(h_qpoly)[3 * nq] = pa; mF(h_qpoly)[3 * nq + 1] = pb; mF(h_qpoly)[3 * nq + 2] = pc; mF(h_a)[nq] = a; nq++;
+            const F a = fmake((uint64_t)random());                               // a.push_back(random()) (:561)
+            a_all.push_back(a);
+            HB_TRY(launch_whir_round(ctx, poly, beta, L, a, part, res_it(iter) + 3 * i));
         }
         iter++;
         const size_t cur = N >> (k * iter), fsz = (2 * N) >> iter;
-        F *keep = (iter & 1) ? keepA : keepB;                                   // layer sizes halve: odd layers need <= 2N, even <= N elements
-        HB_TRY(whir_fri_layer(ctx, poly, cur, fsz, fp, keep, h_fri_roots + 32 * (iter - 1)));
+        F *keep = (iter & 1) ? keepA : keepB;                                    // layer sizes halve: odd layers need <= 2N, even <= N elements
+        HB_TRY(whir_fri_layer(ctx, poly, cur, fsz, fp, keep, reinterpret_cast<uint8_t *>(res_it(iter - 1) + 12)));
         const int queries = (int)(100.0 / log2((double)fsz / (double)cur));
         if (logN - iter * k <= k) { repeats = queries; remaining = (size_t)1 << (logN - iter * k); break; }
         const int v = logN - iter * k;
         std::vector<F> z; compute_zetas_host(z, ridx, repeats, v, (2 * N) >> (iter + k));
-        HB_CHECK(ctx, hipMemcpyAsync(dz, z.data(), z.size() * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
-        // the `repeats` eq tables side by side, then y = E poly, beta += pows^T E, eval += sum pow_i y_i (:613-633)
+        const F sch = fmake((uint64_t)random());
+        std::vector<F> pw(repeats); { F p = sch; for (int i = 0; i < repeats; i++) { pw[i] = p; p = fmul(p, sch); } }
+        pw_all.push_back(pw);
+        // stage z | pows | indices of this iteration and ship them with one asynchronous copy
+        F *pslot = pin_in + (size_t)(iter - 1) * WHIR_DIN, *dslot = din + (size_t)(iter - 1) * WHIR_DIN;
+        if (z.size() > 2048 || (size_t)repeats > 128 || ridx.size() > 128) return ctx->fail(HOBBIT_EINVAL, "whir_prove: staging slot too small");
+        memcpy(pslot, z.data(), z.size() * sizeof(F)); memcpy(pslot + 2048, pw.data(), pw.size() * sizeof(F)); memcpy(pslot + 2048 + 128, ridx.data(), ridx.size() * 8);
+        HB_CHECK(ctx, hipMemcpyAsync(dslot, pslot, WHIR_DIN * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+        const F *dz = dslot, *dpw = dslot + 2048; const uint64_t *d_idx = reinterpret_cast<const uint64_t *>(dslot + 2048 + 128);
+        // the `repeats` eq tables side by side, then y = E poly, beta += pows^T E (:613-633)
         F *cE = E0, *nE = E1;
         HB_TRY(launch_fill_F(ctx, cE, cur, (size_t)repeats, fmake(1)));
         for (int l = 0; l < v; l++) { HB_TRY(launch_eq_step_batched(ctx, cE, nE, (size_t)1 << l, cur, dz, v, l, repeats)); std::swap(cE, nE); }
-        HB_TRY(launch_matvec_rows(ctx, cE, (size_t)repeats, cur, poly, dy));
-        std::vector<F> y(repeats), pw(repeats);
-        HB_TRY(hobbit_memcpy_d2h(ctx, y.data(), dy, (size_t)repeats * sizeof(F)));
-        const F sch = fmake((uint64_t)random()); F p = sch;
-        for (int i = 0; i < repeats; i++) { pw[i] = p; eval = fadd(eval, fmul(p, y[i])); p = fmul(p, sch); }
-        HB_CHECK(ctx, hipMemcpyAsync(dpw, pw.data(), (size_t)repeats * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+        HB_TRY(launch_matvec_rows(ctx, cE, (size_t)repeats, cur, poly, res_it(iter - 1) + 16));
         HB_TRY(launch_vecmat(ctx, cE, (size_t)repeats, cur, dpw, nE));          // nE[0..cur) = sum_i pow_i E[i]   (uses ctx->workspace for partials)
         HB_TRY(launch_axpy(ctx, beta, nE, fmake(1), cur));
-        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));                       // z / pw are stack-owned host vectors
-        HB_TRY(whir_answer(ctx, o, qc, prev, prev_lv, prev_sz, ridx, d_idx, d_rep));   // _verify_iteration(data, a, r, repeats, iter) (:634)
+        HB_TRY(answer(d_idx));                                                    // _verify_iteration(data, a, r, repeats, iter) (:634)
         prev = keep; prev_lv = reinterpret_cast<const uint8_t *>(keep + fsz); prev_sz = fsz;
         repeats = queries;
     }
-    // final verification step (:641-651)
-    F sum;
-    HB_TRY(launch_dot(ctx, beta, poly, remaining, part, coef));
-    HB_TRY(hobbit_memcpy_d2h(ctx, &sum, coef, sizeof(F)));
-    h_checks[1] = feq(sum, eval);
-    mF(h_scal)[0] = eval; mF(h_scal)[1] = sum;
-    if (o->final_pb) {
-        HB_TRY(hobbit_memcpy_d2h(ctx, o->final_pb, poly, remaining * sizeof(F)));
-        HB_TRY(hobbit_memcpy_d2h(ctx, o->final_pb + remaining, beta, remaining * sizeof(F)));
-    }
+    // final verification step (:641-651): sum = <final_poly, final_beta>
+    HB_TRY(launch_dot(ctx, beta, poly, remaining, part, res_fin));
+    HB_CHECK(ctx, hipMemcpyAsync(res_fin + 4, poly, remaining * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    HB_CHECK(ctx, hipMemcpyAsync(res_fin + 4 + remaining, beta, remaining * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
     {   // closing draws (:652-655) and the last query round (:656), leaving the libc stream where the reference leaves it
         const int lr = ilog2_exact(remaining);
         F cst = fmake(0); for (int i = 0; i < lr; i++) { if (i % 100 == 0) cst = fmake((uint64_t)random()); (void)rand(); }
@@ -731,9 +725,36 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
         std::vector<F> z;
         if (repeats > 0 && lr > 0) {
             compute_zetas_host(z, ridx, repeats, lr, (2 * N) >> (iter * k));
-            HB_TRY(whir_answer(ctx, o, qc, prev, prev_lv, prev_sz, ridx, d_idx, d_rep));
+            if (ridx.size() > 128) return ctx->fail(HOBBIT_EINVAL, "whir_prove: staging slot too small");
+            F *pslot = pin_in + (size_t)5 * WHIR_DIN, *dslot = din + (size_t)5 * WHIR_DIN;     // the last slot: only indices
+            memcpy(pslot + 2048 + 128, ridx.data(), ridx.size() * 8);
+            HB_CHECK(ctx, hipMemcpyAsync(dslot + 2048 + 128, pslot + 2048 + 128, 128 * 8, hipMemcpyHostToDevice, ctx->stream));
+            HB_TRY(answer(reinterpret_cast<const uint64_t *>(dslot + 2048 + 128)));
         }
     }
+    // the one read-back
+    HB_CHECK(ctx, hipMemcpyAsync(pin_res, dres, WHIR_DRES * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+    if (o->qreply && q_tot) HB_CHECK(ctx, hipMemcpyAsync(o->qreply, d_rep, q_tot * 16 * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+    if (o->qpaths && path_off) HB_CHECK(ctx, hipMemcpyAsync(o->qpaths, d_paths, path_off, hipMemcpyDeviceToHost, ctx->stream));
+    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    // replay: round checks ("Error in %d", :562-565), eval updates (:566, :631), final check (:648-651)
+    F eval = pin_res[0];
+    h_checks[0] = 1;
+    for (int t = 0; t < iter; t++) {
+        const F *r = pin_res + 8 + (size_t)t * 128;
+        for (int i = 0; i < k; i++) {
+            const F pa = r[3 * i], pb = r[3 * i + 1], pc = r[3 * i + 2], a = a_all[(size_t)t * k + i];
+            if (!feq(fadd(fadd(pa, pb), fadd(pc, pc)), eval)) h_checks[0] = 0;
+            eval = fadd(fmul(fadd(fmul(pa, a), pb), a), pc);
+            mF(h_qpoly)[3 * nq] = pa; mF(h_qpoly)[3 * nq + 1] = pb; mF(h_qpoly)[3 * nq + 2] = pc; mF(h_a)[nq] = a; nq++;
+        }
+        memcpy(h_fri_roots + 32 * t, r + 12, 32);
+        if (t < (int)pw_all.size()) for (size_t i = 0; i < pw_all[t].size(); i++) eval = fadd(eval, fmul(pw_all[t][i], r[16 + i]));
+    }
+    const F sum = pin_res[900];
+    h_checks[1] = feq(sum, eval);
+    mF(h_scal)[0] = eval; mF(h_scal)[1] = sum;
+    if (o->final_pb) memcpy(o->final_pb, pin_res + 904, 2 * remaining * sizeof(F));
     if (o->iters) *o->iters = iter;
     return 0;
 }
@@ -1136,7 +1157,7 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
         // (Freeing device memory makes the driver unmap it later and pause the compute queues while it does: a 20+ ms stall that
         // lands in the NEXT call, measured on the second open of a process.)
         if (full) HB_TRY(ctx->workspace4((shockwave_nested_elems(nc_el / 32) + shockwave_own_elems(nc_el / 32, 32)) * sizeof(F), &dummy));
-        HB_TRY(ctx->pinned((size_t)queries * (sizeof(F) + 8) + 4096, &dummy));
+        HB_TRY(ctx->pinned(std::max((size_t)queries * (sizeof(F) + 8) + 4096, (WHIR_DIN * 6 + WHIR_DRES) * sizeof(F)), &dummy));
     }
     tr.mark("scratch sizing");
     if (tr.on) fprintf(stderr, "[hobbit open] scratch at entry: ws %zu ws2 %zu ws3 %zu ws4 %zu pin %zu\n", ctx->ws_bytes, ctx->ws2_bytes, ctx->ws3_bytes, ctx->ws4_bytes, ctx->pin_bytes);
