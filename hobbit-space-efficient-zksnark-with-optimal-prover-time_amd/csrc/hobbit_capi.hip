@@ -762,7 +762,7 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
 // workspace4 elements of one shockwave_prove: [0, nested) belongs to the nested whir_commit / whir_prove calls, its own vectors follow
 static size_t shockwave_nested_elems(size_t w) { return 4 * w + whir_scratch_elems(w) + 64; }
 static size_t shockwave_own_elems(size_t w, int k) {
-    return w + 2 * w + 2 * w + 64 + 256 + 256 /* idx */ + 2 * w + 2 * w /* whir_commit outputs: com, levels */ + 240 * (size_t)k /* replies */ + 64;
+    return w + 2 * w + 2 * w + 64 + 256 + 256 /* idx */ + 2 * w + 2 * w /* whir_commit outputs: com, levels */ + 240 * (size_t)k /* replies */ + 240 * 64 /* paths */ + 64;
 }
 int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobbit_F *d_enc, const uint8_t *d_levels, size_t N, int k, const hobbit_F *h_x, int xlen,
                            hobbit_shockwave_out *o) {
@@ -777,14 +777,15 @@ int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobb
     F *base; HB_TRY(ctx->workspace4((nested + own) * sizeof(F), (void **)&base));
     F *mine = base + nested; F *aggr = mine, *at = aggr + w, *b1v = at + W, *dbeta = b1v + W, *ones = dbeta + 64; uint64_t *didx = reinterpret_cast<uint64_t *>(ones + 256);
     F *wcom = ones + 256 + 256; uint8_t *wlv = reinterpret_cast<uint8_t *>(wcom + 2 * w); F *d_rep = wcom + 4 * w;
+    uint8_t *d_pth = reinterpret_cast<uint8_t *>(d_rep + 240 * (size_t)k);
+    // (host vectors handed to asynchronous copies live to the end of this function, which ends synchronised)
     HB_CHECK(ctx, hipMemcpyAsync(dbeta, beta1.data(), (size_t)k * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
-    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     HB_TRY(launch_vecmat(ctx, cF(d_matrix), (size_t)k, w, dbeta, aggr));        // aggr = beta1^T matrix (:444-456)
     HB_TRY(launch_vecmat(ctx, cF(d_enc), (size_t)k, W, dbeta, at));
     const bool committed = w > 256;
     if (committed) {                                                         // whir_commit(aggr, C) (:458-461)
         HB_TRY(hobbit_whir_commit(ctx, reinterpret_cast<hobbit_F *>(aggr), w, reinterpret_cast<hobbit_F *>(wcom), wlv));
-        if (o->whir_root) HB_TRY(hobbit_memcpy_d2h(ctx, o->whir_root, wlv + 32 * (w - 2), 32));
+        if (o->whir_root) HB_CHECK(ctx, hipMemcpyAsync(o->whir_root, wlv + 32 * (w - 2), 32, hipMemcpyDeviceToHost, ctx->stream));
     }
     std::vector<uint64_t> I(240); std::vector<F> one(240, fmake(1));
     for (int i = 0; i < 240; i++) { I[i] = (uint64_t)(rand() % (long)W); if (o->I) o->I[i] = (uint32_t)I[i]; }      // (:463-467)
@@ -794,10 +795,14 @@ int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobb
     HB_TRY(launch_scatter(ctx, didx, ones, 240, b1v));
     if (o->reply) {                                                          // reply[i][j] = encoded_matrix[j][I[i]] (:468-472)
         HB_TRY(launch_gather_strided(ctx, cF(d_enc), didx, 240, (uint32_t)k, 1, W, d_rep));
-        HB_TRY(hobbit_memcpy_d2h(ctx, o->reply, d_rep, 240 * (size_t)k * sizeof(F)));
+        HB_CHECK(ctx, hipMemcpyAsync(o->reply, d_rep, 240 * (size_t)k * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
     }
-    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (o->paths && d_levels) HB_TRY(hobbit_merkle_paths(ctx, d_levels, W, I.data(), 240, o->paths));     // open_tree_blake(data->MT, {I[i],0}, 0) (:503)
+    if (o->paths && d_levels) {                                              // open_tree_blake(data->MT, {I[i],0}, 0) (:503)
+        const int depth = ilog2_exact(W);
+        if (depth > 32) return ctx->fail(HOBBIT_EINVAL, "shockwave_prove: tree too deep for the path buffer");
+        HB_TRY(launch_merkle_paths(ctx, d_levels, W, didx, 240, depth, d_pth));
+        HB_CHECK(ctx, hipMemcpyAsync(o->paths, d_pth, 240 * (size_t)depth * 32, hipMemcpyDeviceToHost, ctx->stream));
+    }
     hobbit_F p33 = {33, 0};
     HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(at), reinterpret_cast<hobbit_F *>(b1v), W, &p33, o->q1, o->r1, o->vr1, o->fin1));         // (:477)
     HB_TRY(hobbit_prove_fft(ctx, reinterpret_cast<hobbit_F *>(aggr), w, o->r1, o->q2, o->r2, o->vr2, o->fin2));                                            // (:478)
@@ -808,6 +813,7 @@ int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobb
         HB_TRY(hobbit_whir_prove(ctx, reinterpret_cast<hobbit_F *>(aggr), w, reinterpret_cast<hobbit_F *>(wcom), wlv, o->r2, &wo));                          // (:480-481)
     }
     if (o->iters) *o->iters = iters;
+    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
@@ -1187,8 +1193,9 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
         HB_TRY(hobbit_shockwave_commit(ctx, reinterpret_cast<hobbit_F *>(d_aggr), M, 32, reinterpret_cast<hobbit_F *>(encf), lvf));
         HB_TRY(hobbit_shockwave_commit(ctx, reinterpret_cast<hobbit_F *>(C), nc_el, 32, reinterpret_cast<hobbit_F *>(encc), lvc));
         if (o->roots) {
-            HB_TRY(hobbit_memcpy_d2h(ctx, o->roots, lvf + 32 * (2 * (2 * M / 32) - 2), 32));
-            HB_TRY(hobbit_memcpy_d2h(ctx, o->roots + 32, lvc + 32 * (2 * (2 * nc_el / 32) - 2), 32));
+            // (asynchronous: complete at the next of the many synchronisation points below)
+            HB_CHECK(ctx, hipMemcpyAsync(o->roots, lvf + 32 * (2 * (2 * M / 32) - 2), 32, hipMemcpyDeviceToHost, ctx->stream));
+            HB_CHECK(ctx, hipMemcpyAsync(o->roots + 32, lvc + 32 * (2 * (2 * nc_el / 32) - 2), 32, hipMemcpyDeviceToHost, ctx->stream));
         }
     }
     tr.mark("shockwave_commit C_f, C_c");
@@ -1238,8 +1245,7 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
         HB_CHECK(ctx, hipMemcpyAsync(tmpv, pin, val.size() * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
         HB_CHECK(ctx, hipMemcpyAsync(tmpi, pin + val.size() * sizeof(F), idx.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         int rc = launch_scatter(ctx, tmpi, tmpv, idx.size(), d_b);
-        hipStreamSynchronize(ctx->stream);                     // the pinned buffer is reused by the sumcheck that follows
-        if (rc) return rc;
+        if (rc) return rc;                                     // (the staging buffer is next written by _whir_prove, many synchronisations later)
     }
     hobbit_F p121 = {121, 0};
     HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(BIG), reinterpret_cast<hobbit_F *>(d_b), big, &p121, Q, Rr, o->vr + 4, o->fin + 2));
