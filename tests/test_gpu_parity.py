@@ -127,6 +127,37 @@ def test_eq_table_large_vs_oracle_and_sum(hb, oracle):
     assert s.tolist() == [1, 0]
 
 
+# ---- error behaviour ---------------------------------------------------------------------------
+def test_invalid_arguments_are_errors_not_crashes(hb, oracle):
+    """C ABI calls return negative HOBBIT_E* codes with a message (the mirror turns them into the reference's printf + exit(-1));
+    nothing is launched on shapes a kernel or its grid does not assume."""
+    import ctypes
+    from __graft_entry__ import load_package
+    E = load_package().HobbitError
+    poly = splitmix_field(1 << 12, 1)
+    d = hb.to_device(poly)
+    h = ctypes.c_void_p()
+    lib, ctx = hb.lib, hb.ctx
+    assert lib.hobbit_commit_standard(ctx, d.ptr, 1 << 12, 3, 4, 1, ctypes.byref(h)) < 0            # K does not divide N
+    assert lib.hobbit_commit_standard(ctx, d.ptr, 1 << 12, 4, 6, 1, ctypes.byref(h)) < 0            # trs not a multiple of 4 dividing N/K
+    assert b"trs" in lib.hobbit_last_error(ctx)
+    assert lib.hobbit_fft_batch(ctx, d.ptr, 25, 1, 1 << 25, 0) < 0                                   # longer than 2^24
+    assert lib.hobbit_fft_batch(ctx, d.ptr, 13, 1, 1 << 13, 1) < 0                                   # long inverse transforms are not built
+    assert lib.hobbit_mt_commit_blake(ctx, d.ptr, 24, d.ptr) < 0                                     # N/4 not a power of two
+    hb.rng_reset(); hb.expander_init_store(64)
+    assert lib.hobbit_encode_batch(ctx, d.ptr, d.ptr, 100, 1, 100, 200) < 0                          # graphs are finalized for n = 64, not 100
+    assert lib.hobbit_encode_batch(ctx, d.ptr, d.ptr, 64, 1, 32, 128) < 0                            # leading dimension shorter than n
+    assert lib.hobbit_sumcheck2(ctx, d.ptr, d.ptr, 1000, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr) < 0      # n not a power of two
+    pos = np.array([1 << 40], np.uint64); out = np.zeros((1, 10, 32), np.uint8)
+    assert lib.hobbit_merkle_paths(ctx, d.ptr, 1 << 10, pos.ctypes.data, 1, out.ctypes.data) < 0     # src/merkle_tree.cpp:310-313: position out of range
+    with pytest.raises(E):
+        hb.shockwave_commit(poly, 3)                                                                 # k must be a power of two in [4, 64]
+    with pytest.raises(E):
+        hb.open_from_aggregate(poly, 32, 6, 10)                                                      # trs must give 4096-point rows
+    # the context is still usable afterwards
+    assert np.array_equal(hb.precompute_beta(splitmix_field(6, 2)), oracle.precompute_beta(splitmix_field(6, 2)))
+
+
 # ---- expander code -------------------------------------------------------------------------
 @pytest.mark.parametrize("n", [4, 13, 14, 16, 64, 100, 256, 1024, 4096])
 def test_encode_vs_golden(hb, n):
