@@ -434,7 +434,15 @@ k_encode(const F *__restrict__ src, size_t ld_src, F *__restrict__ dst, size_t l
     F *cw = reinterpret_cast<F *>(lds_raw) - ps.base;          // cw[i] addresses codeword index i
     const F *in = src + (size_t)blockIdx.x * ld_src;
     F *out = dst + (size_t)blockIdx.x * ld_dst;
-    for (uint32_t i = ps.ld_lo + threadIdx.x; i < ps.ld_hi; i += blockDim.x) stF(&cw[i], ldF(in + i));
+    // window load: eight global loads per thread in flight before the first LDS store (one at a time cost a full memory round
+    // trip per element: 7 400 of pass A's 27 000 cycles per column, measured with s_memtime stamps)
+    for (uint32_t b0 = ps.ld_lo; b0 < ps.ld_hi; b0 += 8 * blockDim.x) {
+        F v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint32_t i = b0 + u * blockDim.x + threadIdx.x; if (i < ps.ld_hi) v[u] = ldF(in + i); }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint32_t i = b0 + u * blockDim.x + threadIdx.x; if (i < ps.ld_hi) stF(&cw[i], v[u]); }
+    }
     // (the barrier that publishes the window sits after the first step's first edge-record request: those loads do not touch LDS)
     // wave index as a scalar: the slice descriptors below then come through the scalar cache (s_load) instead of a per-lane
     // global load, and the slice loop is scalar control flow
