@@ -884,9 +884,7 @@ int hobbit_phi_g(hobbit_ctx *ctx, const hobbit_F *h_rx, int n, const hobbit_F *h
     const F *pm; HB_TRY(get_twiddles(ctx, n, is_ifft != 0, &pm));      // phi_mul[k] = rou^k, k < N/2 (all that is indexed)
     F *g = mF(d_out);
     HB_CHECK(ctx, hipMemsetAsync(g, 0, N * sizeof(F), ctx->stream));
-    F sc[2] = {*cF(h_scale), *cF(h_scale)};
-    HB_CHECK(ctx, hipMemcpyAsync(g, sc, (is_ifft && N > 1 ? 2 : 1) * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
-    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    HB_TRY(launch_fill_F(ctx, g, 1, is_ifft && N > 1 ? 2 : 1, *cF(h_scale)));      // (a kernel argument: no upload to wait for)
     const int last = is_ifft ? n : n - 1;
     for (int i = 1; i <= last; i++) HB_TRY(launch_phi_step(ctx, g, (size_t)1 << (i - 1), n - i, cF(h_rx)[n - i], pm, 0));
     if (!is_ifft) HB_TRY(launch_phi_step(ctx, g, (size_t)1 << (n - 1), 0, cF(h_rx)[0], pm, 1));
