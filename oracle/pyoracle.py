@@ -507,6 +507,59 @@ class Oracle(_Base):
         return f(c_sz(N), ctypes.c_int(K))
 
 
+def _path_ps(n_leaves, depth, pos):
+    """proof-size accounting of verify_claim_opt_blake (src/merkle_tree.cpp:326-361): 32 B per sibling not yet seen"""
+    visited = set(); ps = 0.0
+    for p in pos:
+        pe = n_leaves + int(p)
+        for _ in range(depth):
+            if (pe ^ 1) in visited:
+                break
+            visited.add(pe ^ 1); pe //= 2; visited.add(pe)
+            ps += 32.0 / 1024.0
+    return ps
+
+
+def _sc_ps(rounds):
+    return rounds * 3 * 16.0 / 1024.0 + 2 * 16.0 / 1024.0                 # src/sumcheck.cpp:2431, 2449
+
+
+def _shockwave_ps(sp, N, k):
+    """ps of one shockwave_prove (src/Virgo.cpp:435-517) from its transcript (Oracle.shockwave_prove / Hobbit.shockwave_prove)"""
+    w = N // k; W = 2 * w; lgW = W.bit_length() - 1
+    ps = _sc_ps(lgW) + _sc_ps(lgW)
+    it = int(sp["iters"][0])
+    if w // 2 > 256:
+        q = 0
+        for t in range(1, it + 1):
+            ps += 4 * 3 * 16.0 / 1024.0
+            size = 2 * w if t == 1 else (2 * w) >> (t - 1)
+            n = int(sp["qn"][t - 1])
+            if t == it:
+                ps += (w >> (4 * it)) * 2 * 16.0 / 1024.0
+            ps += 16.0 * n * 16.0 / 1024.0
+            ps += _path_ps(size // 4, (size // 4).bit_length() - 1, sp["qidx"][q:q + n]); q += n
+    else:
+        ps += w * 16.0 / 1024.0
+    ps += 240.0 * k * 16.0 / 1024.0
+    return ps + _path_ps(W, lgW, sp["I"])
+
+
+def open_proof_size(res, N, K, trs, queries=5900):
+    """The `ps` (KB) the reference's open_standard accumulates and test_PC prints (src/Our_PC.cpp:653, 676-683; src/PC_utils.cpp:310-385;
+    src/Virgo.cpp:435-686), recomputed from an open transcript: it depends on every query index drawn from libc across the whole
+    open (through the Merkle-path de-duplication), so it fingerprints the RNG stream end to end."""
+    M = N // K; cols = 2 * M // trs
+    R1 = (2 * trs).bit_length() - 1; logc = cols.bit_length() - 1; R3 = R1 + logc
+    ps = queries * K * 16.0 / 1024.0
+    ps += _sc_ps(R1) + _sc_ps(logc) + _sc_ps(R3) + _sc_ps(R3)
+    ps += _shockwave_ps(res["sp_c"], trs * cols, 32)
+    ps += _sc_ps(logc)
+    ps += _shockwave_ps(res["sp_f"], M, 32)
+    pos = (res["I"][:, 1].astype(np.int64) // 4) * cols + res["I"][:, 0].astype(np.int64)
+    return ps + _path_ps(M, M.bit_length() - 1, pos)
+
+
 def gate_standard_inputs(n, seed):
     """consistent gates: selector s in {0,1}; O = L + R where s = 1, L * R where s = 0 (so the claimed sum 0 holds)"""
     P = (1 << 61) - 1

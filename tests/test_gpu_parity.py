@@ -380,6 +380,23 @@ def test_cpp_host_mirror_test_pc_and_sumcheck(oracle):
     lib.hobbit_host_close()
 
 
+@pytest.mark.parametrize("logN,K", [(20, 32), (20, 16), (22, 32), (24, 32), (26, 32), (28, 32)])
+def test_test_pc_driver_prints_the_reference_proof_size(logN, K):
+    """End to end against the REAL reference binary, up to the north-star size: `./pigeon <logN> 4 <K>` (test_PC, src/Our_PC.cpp:757-826)
+    prints the proof size `ps`, which depends on every query index drawn from libc anywhere in the open (Merkle-path de-duplication in
+    the commitment tree, both shockwave trees and every WHIR layer).  The device-backed C++ mirror's driver must print the same number
+    (fixtures: tests/golden/ps_fingerprints.json, recorded from the reference's stdout)."""
+    import json, subprocess
+    from __graft_entry__ import PKG, build_host
+    build_host()
+    fp = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ps_fingerprints.json")))["test_PC_ps_KB"]
+    r = subprocess.run([os.path.join(PKG, "host", "test_pc"), str(logN), "4", str(K)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    last = r.stdout.strip().splitlines()[-1]                       # "ps,vt" (src/Our_PC.cpp:822)
+    assert float(last.split(",")[0]) == fp["%d,%d" % (logN, K)], last
+    assert ">>OK" in r.stdout
+
+
 def test_ctx_create_leaves_libc_rng_alone():
     """The reference's transcript is a function of the process-wide libc generator; initialising the HIP runtime draws from it
     (measured).  hobbit_ctx_create must hand the caller's stream back untouched -- checked in a fresh process, where context

@@ -46,3 +46,19 @@ def test_open_standard_selfchecks(oracle):
     for sp in ("sp_c", "sp_f"):
         assert res[sp]["wchecks"].tolist() == [1, 1]
         assert int(res[sp]["iters"][0]) >= 1
+
+
+@pytest.mark.parametrize("logN,K", [(20, 32), (20, 16), (22, 32)])
+def test_proof_size_matches_reference_stdout(oracle, logN, K):
+    """End-to-end pin of the open restatement against the REAL reference: the proof size test_PC prints (fingerprints recorded from
+    the reference binary, tests/golden/ps_fingerprints.json) is a function of every query index the open draws from libc -- in
+    open_standard, in both shockwave_prove calls and in every WHIR round -- through the Merkle-path de-duplication.  The restatement,
+    run on test_PC's own input sequence with the generator left alone, must reproduce it to the last bit."""
+    import json, os
+    from oracle.pyoracle import open_proof_size
+    fp = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ps_fingerprints.json")))["test_PC_ps_KB"]
+    N = 1 << logN; trs = N // (K << 11)
+    oracle.rng_reset(); poly = oracle.generate_randomness(N); oracle.expander_init_store(trs)
+    x = oracle.generate_randomness(logN)                      # test_PC's order: poly, graphs, commit, x, open (src/Our_PC.cpp:758-822)
+    res = oracle.open_standard(poly, K, trs, x, 5900)
+    assert open_proof_size(res, N, K, trs) == fp["%d,%d" % (logN, K)]
