@@ -807,7 +807,8 @@ int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobb
     HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(at), reinterpret_cast<hobbit_F *>(b1v), W, &p33, o->q1, o->r1, o->vr1, o->fin1));         // (:477)
     HB_TRY(hobbit_prove_fft(ctx, reinterpret_cast<hobbit_F *>(aggr), w, o->r1, o->q2, o->r2, o->vr2, o->fin2));                                            // (:478)
     int iters = 0;
-    if (w / 2 > 256) {
+    // (:479) aggr.size()/2 > 256 is evaluated after prove_fft doubled aggr in place (src/sumcheck.cpp:2984-2985): the original width w
+    if (committed) {
         // _whir_prove works on a copy of aggr inside its own scratch (from the start of workspace4): aggr and the commitment live beyond it
         hobbit_whir_out wo = {o->wq, o->wa, o->wroots, o->wscal, o->wchecks, &iters, o->wqidx, o->wqreply, o->wqpaths, o->wfinal, o->wqn};
         HB_TRY(hobbit_whir_prove(ctx, reinterpret_cast<hobbit_F *>(aggr), w, reinterpret_cast<hobbit_F *>(wcom), wlv, o->r2, &wo));                          // (:480-481)

@@ -269,7 +269,8 @@ struct SpBuffers {   // host buffers behind one hobbit_shockwave_out
 static void shockwave_ps(const hobbit_host_shockwave_transcript &t, size_t N, int k, double &ps) {
     size_t w = N / k, W = 2 * w; int lgW = (int)log2((double)W);
     sumcheck2_ps(lgW, ps); sumcheck2_ps(lgW, ps);                                         // P1, prove_fft
-    if (w / 2 > 256) {                                                                    // _whir_prove (:519-686)
+    // :479 tests aggr.size()/2 after prove_fft doubled aggr in place (src/sumcheck.cpp:2984-2985): the original width, and :482 adds the doubled one
+    if (w > 256) {                                                                        // _whir_prove (:519-686)
         size_t q = 0;
         for (int it = 1; it <= t.iters; it++) {
             for (int i = 0; i < 4; i++) ps += (3 * sizeof(F)) / 1024.0;
@@ -284,7 +285,7 @@ static void shockwave_ps(const hobbit_host_shockwave_transcript &t, size_t N, in
             if (it < t.iters) answer(it - 1);
             else { ps += (w >> (4 * t.iters)) * 2 * sizeof(F) / 1024.0; answer(it - 1); }
         }
-    } else ps += w * sizeof(F) / 1024.0;
+    } else ps += 2 * w * sizeof(F) / 1024.0;
     ps += 240.0 * k * sizeof(F) / 1024.0;
     vector<size_t> pos(t.I.begin(), t.I.end());
     path_ps(W, lgW, pos, ps);

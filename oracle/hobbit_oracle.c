@@ -825,7 +825,9 @@ int orc_shockwave_prove_ex(const oF *matrix, const oF *enc, const uint8_t *level
     orc_sumcheck2(at, buff1, W, &p33, q1, r1o, vr1, fin1);
     orc_prove_fft(aggr, w, r1o, q2, r2o, vr2, fin2);                 /* prove_fft(aggr, P1.randomness[0], P1.vr[0]) */
     int iters = 0;
-    if (w / 2 > 256) iters = orc_whir_prove_ex(aggr, w, r2o, com, clv, wq, wa, wroots, wscal, wchecks, Q);   /* x = P2.randomness[0] minus its last entry: log2 w entries */
+    /* src/Virgo.cpp:479 tests aggr.size()/2 > 256 AFTER prove_fft, which takes its vector by reference and doubles it
+       (src/sumcheck.cpp:2984-2985): the test is on the original width w, the same as whir_commit's (:458) */
+    if (w > 256) iters = orc_whir_prove_ex(aggr, w, r2o, com, clv, wq, wa, wroots, wscal, wchecks, Q);   /* x = P2.randomness[0] minus its last entry: log2 w entries */
     free(beta1); free(aggr); free(at); free(buff1); free(com); free(clv);
     return iters;
 }

@@ -529,7 +529,7 @@ def _shockwave_ps(sp, N, k):
     w = N // k; W = 2 * w; lgW = W.bit_length() - 1
     ps = _sc_ps(lgW) + _sc_ps(lgW)
     it = int(sp["iters"][0])
-    if w // 2 > 256:
+    if w > 256:                # :479 reads aggr.size()/2 after prove_fft doubled aggr in place (src/sumcheck.cpp:2984-2985)
         q = 0
         for t in range(1, it + 1):
             ps += 4 * 3 * 16.0 / 1024.0
@@ -540,7 +540,7 @@ def _shockwave_ps(sp, N, k):
             ps += 16.0 * n * 16.0 / 1024.0
             ps += _path_ps(size // 4, (size // 4).bit_length() - 1, sp["qidx"][q:q + n]); q += n
     else:
-        ps += w * 16.0 / 1024.0
+        ps += 2 * w * 16.0 / 1024.0        # :482: aggr.size() is the doubled vector
     ps += 240.0 * k * 16.0 / 1024.0
     return ps + _path_ps(W, lgW, sp["I"])
 

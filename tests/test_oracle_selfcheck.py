@@ -48,7 +48,7 @@ def test_open_standard_selfchecks(oracle):
         assert int(res[sp]["iters"][0]) >= 1
 
 
-@pytest.mark.parametrize("logN,K", [(20, 32), (20, 16), (22, 32)])
+@pytest.mark.parametrize("logN,K", [(18, 32), (20, 32), (20, 16), (22, 32)])
 def test_proof_size_matches_reference_stdout(oracle, logN, K):
     """End-to-end pin of the open restatement against the REAL reference: the proof size test_PC prints (fingerprints recorded from
     the reference binary, tests/golden/ps_fingerprints.json) is a function of every query index the open draws from libc -- in
