@@ -151,36 +151,61 @@ int launch_fft_rows(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_l
 // --------------------------------------------------------------------------------------------
 struct Fft4kConst { F w8, w8_3; int w4_plus_i; };
 
-// Inside the transform, sums live in the quasi-canonical range [0, p] (p itself standing for 0): a + b <= 2p < 2^62 folds with one
-// mask / shift / add and no compare-select; products (fmul) and the w8 rotation accept that range, and the last pass maps p -> 0.
-__device__ __forceinline__ uint64_t addq(uint64_t a, uint64_t b) { const uint64_t s = a + b; return (s & P61) + (s >> 61); }
-__device__ __forceinline__ uint64_t subq(uint64_t a, uint64_t b) { return addq(a, P61 - b); }
-__device__ __forceinline__ F faddq(const F &a, const F &b) { return fmake(addq(a.re, b.re), addq(a.im, b.im)); }
-__device__ __forceinline__ F fsubq(const F &a, const F &b) { return fmake(subq(a.re, b.re), subq(a.im, b.im)); }
-__device__ __forceinline__ F fcanon(const F &a) { return fmake(a.re == P61 ? 0 : a.re, a.im == P61 ? 0 : a.im); }
-__device__ __forceinline__ F fmul_w4(const F &a, int plus_i) {   // a * (+i) or a * (-i)
-    return plus_i ? fmake(P61 - a.im, a.re) : fmake(a.im, P61 - a.re);     // [0, p] -> [0, p]: p stands for 0 inside the transform
+// Inside the transform the sums are lazy.  p = 2^61 - 1 leaves three spare bits in a 64-bit word (8p + 7 = 2^64 - 1), exactly the
+// growth of the three add/sub levels of an 8-point DFT: a + b is a plain 64-bit add, a - b is a + (B p - b) with B p the static bound of
+// b, and every output is folded once (mask / shift / add) into [0, p + 7] -- 16 folds per octet instead of 48.  Bounds: the octet's
+// first element comes from LDS in [0, p + 7], the other seven are products (canonical, < p); the first element is always the left
+// operand of its butterflies, so the +7 only rides along: level 1 <= 2p + 7, level 2 <= 4p + 7, level 3 <= 8p + 7.
+// (Same-box A/B at 2^28: 5.56 vs 6.04 ms for the zero-padded rows, 6.26 vs 6.74 ms for full rows.)
+__device__ __forceinline__ uint64_t fold61(uint64_t s) { return (s & P61) + (s >> 61); }            // any u64 -> [0, p + 7], same residue
+__device__ __forceinline__ F ffold(const F &a) { return fmake(fold61(a.re), fold61(a.im)); }
+__device__ __forceinline__ F fcanon(const F &a) {                                                    // any u64 pair -> canonical
+    const uint64_t r = fold61(a.re), i = fold61(a.im);
+    return fmake(r >= P61 ? r - P61 : r, i >= P61 ? i - P61 : i);
+}
+__device__ __forceinline__ F faddl(const F &a, const F &b) { return fmake(a.re + b.re, a.im + b.im); }
+template <int B> __device__ __forceinline__ F fsubl(const F &a, const F &b) {                       // b's components <= B p
+    return fmake(a.re + ((uint64_t)B * P61 - b.re), a.im + ((uint64_t)B * P61 - b.im));
+}
+// a * b for a lazy a (components < 2^62 - 2^10) and a canonical twiddle b.  Same Karatsuba form as fmul, with the offset that keeps
+// ac - bd non-negative doubled: C = p 2^62 >= bd, ac + C < 2^124, ad + bc < 2^124.
+__device__ __forceinline__ F fmul_lz(const F &a, const F &b) {
+    const u128 ac = (u128)a.re * b.re, bd = (u128)a.im * b.im;
+    const u128 all = (u128)(a.re + a.im) * (b.re + b.im);
+    const u128 C = ((u128)P61) << 62;
+    return fmake(red124(ac + C - bd), red124(all - ac - bd));
+}
+template <int B> __device__ __forceinline__ F fmul_w4(const F &a, int plus_i) {   // a * (+i) or a * (-i); components <= B p in and out
+    return plus_i ? fmake((uint64_t)B * P61 - a.im, a.re) : fmake(a.im, (uint64_t)B * P61 - a.re);
 }
 // a * w8, w8 = the primitive 8th root of unity of the transform direction.  sqrt(2) = 2^31 in F_p (2^62 = 2), so
 // w8 = 2^30 (1 - i) forward (w4 = -i) and 2^30 (1 + i) inverse: a rotation by 30 bits of (a.re +- a.im), no product at all.
-__device__ __forceinline__ uint64_t rot30p(uint64_t x) { return ((x << 30) & P61) | (x >> 31); }     // x * 2^30 mod 2^61-1, canonical in/out
-__device__ __forceinline__ F fmul_w8(const F &a, int plus_i) {      // quasi-canonical in, quasi-canonical out (rot30p keeps [0, p])
-    return plus_i ? fmake(rot30p(subq(a.re, a.im)), rot30p(addq(a.re, a.im))) : fmake(rot30p(addq(a.re, a.im)), rot30p(subq(a.im, a.re)));
+__device__ __forceinline__ uint64_t rot30(uint64_t x) {      // x * 2^30 mod p for any u64 x; result < 2^61 + 2^31 <= 2p
+    x = fold61(x);                                           // < 2^62: x = lo31 + hi 2^31, x 2^30 = lo31 2^30 + hi (2^61 = 1)
+    return ((x << 30) & P61) + (x >> 31);
+}
+template <int B> __device__ __forceinline__ F fmul_w8(const F &a, int plus_i) {   // components <= B p (B <= 4) in, <= 2p out
+    const uint64_t s = a.re + a.im;
+    return plus_i ? fmake(rot30(a.re + ((uint64_t)B * P61 - a.im)), rot30(s)) : fmake(rot30(s), rot30(a.im + ((uint64_t)B * P61 - a.re)));
 }
 __device__ __forceinline__ uint32_t fft_phys(uint32_t i) { return i + (i >> 3); }
 #define HB_BFLY(x, y, w) do { F v__ = fmul(y, w); y = fsub(x, v__); x = fadd(x, v__); } while (0)
-#define HB_BFLY1(x, y) do { F v__ = y; y = fsubq(x, v__); x = faddq(x, v__); } while (0)
-// the last two stages of an 8-point DIT DFT on a[0..7] (inputs in bit-reversed order, first stage done): twiddles 1, w4, w8, w8^3
+#define HB_BFLYL(B, x, y) do { F v__ = y; y = fsubl<B>(x, v__); x = faddl(x, v__); } while (0)      /* y <= B p */
+// first stage of the 8-point DIT DFT: right operands canonical
+#define HB_DFT8_HEAD(a) do { HB_BFLYL(1, a[0], a[1]); HB_BFLYL(1, a[2], a[3]); HB_BFLYL(1, a[4], a[5]); HB_BFLYL(1, a[6], a[7]); } while (0)
+// the last two stages of an 8-point DIT DFT on a[0..7] (inputs in bit-reversed order, first stage done): twiddles 1, w4, w8, w8^3.
+// In: a[0], a[1] <= 2p + 7, the rest <= 2p.  Out: <= 8p + 7 = 2^64 - 1, unfolded.
 __device__ __forceinline__ void dft8_tail(F (&a)[8], int plus_i) {
     F t;
-    HB_BFLY1(a[0], a[2]);
-    t = fmul_w4(a[3], plus_i); a[3] = fsubq(a[1], t); a[1] = faddq(a[1], t);
-    HB_BFLY1(a[4], a[6]);
-    t = fmul_w4(a[7], plus_i); a[7] = fsubq(a[5], t); a[5] = faddq(a[5], t);
-    HB_BFLY1(a[0], a[4]);
-    t = fmul_w8(a[5], plus_i); a[5] = fsubq(a[1], t); a[1] = faddq(a[1], t);
-    t = fmul_w4(a[6], plus_i); a[6] = fsubq(a[2], t); a[2] = faddq(a[2], t);
-    t = fmul_w4(fmul_w8(a[7], plus_i), plus_i); a[7] = fsubq(a[3], t); a[3] = faddq(a[3], t);
+    HB_BFLYL(2, a[0], a[2]);
+    t = fmul_w4<2>(a[3], plus_i); a[3] = fsubl<2>(a[1], t); a[1] = faddl(a[1], t);
+    HB_BFLYL(2, a[4], a[6]);
+    t = fmul_w4<2>(a[7], plus_i); a[7] = fsubl<2>(a[5], t); a[5] = faddl(a[5], t);
+    // left operands a[0..3] <= 4p + 7, right operands a[4..7] <= 4p
+    HB_BFLYL(4, a[0], a[4]);
+    t = fmul_w8<4>(a[5], plus_i); a[5] = fsubl<2>(a[1], t); a[1] = faddl(a[1], t);
+    t = fmul_w4<4>(a[6], plus_i); a[6] = fsubl<4>(a[2], t); a[2] = faddl(a[2], t);
+    t = fmul_w4<2>(fmul_w8<4>(a[7], plus_i), plus_i); a[7] = fsubl<2>(a[3], t); a[3] = faddl(a[3], t);
 }
 
 template <bool PADDED>
@@ -196,6 +221,9 @@ k_fft4096(const F *__restrict__ src, size_t src_ld, size_t src_es, F *__restrict
     const uint32_t tid = threadIdx.x;
     const int plus_i = cst.w4_plus_i;
     constexpr uint32_t NLOAD = PADDED ? 2048 : 4096;
+    F w[7];                                                         // the next pass's seven twiddles, requested one pass early (-2 %, same-box A/B)
+#pragma unroll
+    for (int t8 = 0; t8 < 7; t8++) w[t8] = ldF(tw1 + t8 * 8 + (tid & 7));          // pass 1's, in flight over the load and pass 0
 #pragma unroll
     for (uint32_t i = 0; i < NLOAD; i += 512) stF(&s[fft_phys(i + tid)], ldF(in + (size_t)(i + tid) * src_es));
     __syncthreads();
@@ -206,13 +234,13 @@ k_fft4096(const F *__restrict__ src, size_t src_ld, size_t src_es, F *__restrict
         if (PADDED) { a[1] = a[0]; a[3] = a[2]; a[5] = a[4]; a[7] = a[6]; }       // (u, 0) -> (u, u)
         else {
             a[1] = ldF(&s[fft_phys(m + 2048)]); a[3] = ldF(&s[fft_phys(m + 3072)]); a[5] = ldF(&s[fft_phys(m + 2560)]); a[7] = ldF(&s[fft_phys(m + 3584)]);
-            HB_BFLY1(a[0], a[1]); HB_BFLY1(a[2], a[3]); HB_BFLY1(a[4], a[5]); HB_BFLY1(a[6], a[7]);
+            HB_DFT8_HEAD(a);
         }
         dft8_tail(a, plus_i);
         __syncthreads();                                            // every input has been read
         const uint32_t o = fft_phys(8 * tid);                       // 9*tid: positions 8b..8b+7 are contiguous
 #pragma unroll
-        for (int t8 = 0; t8 < 8; t8++) stF(&s[o + t8], a[t8]);
+        for (int t8 = 0; t8 < 8; t8++) stF(&s[o + t8], ffold(a[t8]));
         __syncthreads();
     }
     // ---- passes 1..3: true radix-8 DIT.  Block t of the stride-h octet holds the sub-transform of the samples = rev3(t) mod 8, so
@@ -221,22 +249,27 @@ k_fft4096(const F *__restrict__ src, size_t src_ld, size_t src_es, F *__restrict
 #pragma unroll
     for (int pass = 1; pass <= 3; pass++) {
         const uint32_t h = pass == 1 ? 8u : pass == 2 ? 64u : 512u;
-        const F *tw = pass == 1 ? tw1 : pass == 2 ? tw2 : tw3;
         const uint32_t k = tid & (h - 1), j = tid / h, i0 = j * 8 * h + k;
 #pragma unroll
         for (int t8 = 0; t8 < 8; t8++) a[t8] = ldF(&s[fft_phys(i0 + t8 * h)]);
 #pragma unroll
-        for (int t8 = 1; t8 < 8; t8++) a[t8] = fmul(a[t8], ldF(tw + (t8 - 1) * h + k));
-        HB_BFLY1(a[0], a[1]); HB_BFLY1(a[2], a[3]); HB_BFLY1(a[4], a[5]); HB_BFLY1(a[6], a[7]);
+        for (int t8 = 1; t8 < 8; t8++) a[t8] = fmul_lz(a[t8], w[t8 - 1]);
+        if (pass < 3) {                                    // next pass's twiddles: in flight over this pass's sums, stores and barrier
+            const uint32_t hn = pass == 1 ? 64u : 512u;
+            const F *twn = pass == 1 ? tw2 : tw3;
+#pragma unroll
+            for (int t8 = 0; t8 < 7; t8++) w[t8] = ldF(twn + t8 * hn + (tid & (hn - 1)));
+        }
+        HB_DFT8_HEAD(a);
         dft8_tail(a, plus_i);
         if (pass < 3) {
 #pragma unroll
-            for (int t8 = 0; t8 < 8; t8++) stF(&s[fft_phys(i0 + t8 * h)], a[t8]);
+            for (int t8 = 0; t8 < 8; t8++) stF(&s[fft_phys(i0 + t8 * h)], ffold(a[t8]));
             __syncthreads();
         } else {
 #pragma unroll
             for (int t8 = 0; t8 < 8; t8++) {
-                F v = do_scale ? fmul(a[t8], scale) : fcanon(a[t8]);           // canonical out (a product already is)
+                F v = do_scale ? fmul_lz(ffold(a[t8]), scale) : fcanon(a[t8]);    // canonical out (a product already is)
                 stF(out + (size_t)(i0 + t8 * h) * dst_es, v);
             }
         }
@@ -335,9 +368,37 @@ k_transpose(const F *__restrict__ in, size_t in_gs, size_t in_ld, uint32_t rows,
         if (c < cols && r0 + tx < rows) stF(dst + (size_t)c * ld_out + r0 + tx, ldF(&tile[tx][ty + 8 * i]));
     }
 }
+// Large exact multiples: 64 x 64 tiles, 1 KB contiguous on both sides instead of 512 B (measured at 2^28 on one box: 3.08 vs 3.42 ms;
+// 128 x 32 and 128 x 16 tiles, longer on the write side only, gave 3.42 and 3.47).
+template <int TR, int TC>
+__global__ void __launch_bounds__(256)
+k_transpose_big(const F *__restrict__ in, size_t in_gs, size_t in_ld, F *__restrict__ out, size_t out_gs, size_t ld_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    F *tile = reinterpret_cast<F *>(lds_raw);                              // [TR][TC + 1]
+    const F *src = in + (size_t)blockIdx.z * in_gs;
+    F *dst = out + (size_t)blockIdx.z * out_gs;
+    const uint32_t c0 = blockIdx.x * TC, r0 = blockIdx.y * TR;
+    {
+        const uint32_t tx = threadIdx.x % TC, ty = threadIdx.x / TC;
+#pragma unroll
+        for (int i = 0; i < TR; i += 256 / TC) stF(&tile[(ty + i) * (TC + 1) + tx], ldF(src + (size_t)(r0 + ty + i) * in_ld + c0 + tx));
+    }
+    __syncthreads();
+    {
+        const uint32_t tx = threadIdx.x % TR, ty = threadIdx.x / TR;
+#pragma unroll
+        for (int i = 0; i < TC; i += 256 / TR) stF(dst + (size_t)(c0 + ty + i) * ld_out + r0 + tx, ldF(&tile[tx * (TC + 1) + ty + i]));
+    }
+}
 int launch_transpose_ld(hobbit_ctx *ctx, const F *in, size_t in_gs, size_t in_ld, uint32_t rows, uint32_t cols, F *out, size_t out_gs, size_t ld_out,
                         uint32_t groups) {
     if (!rows || !cols || !groups) return 0;
+    if (rows % 64 == 0 && cols % 64 == 0 && (size_t)rows * cols * groups >= ((size_t)1 << 24)) {
+        const size_t lds = (size_t)64 * 65 * 16;
+        hipFuncSetAttribute((const void *)k_transpose_big<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        HB_LAUNCH(ctx, "k_transpose", (k_transpose_big<64, 64>), dim3(cols / 64, rows / 64, groups), dim3(256), lds, in, in_gs, in_ld, out, out_gs, ld_out);
+        return 0;
+    }
     HB_LAUNCH(ctx, "k_transpose", k_transpose, dim3((cols + 31) / 32, (rows + 31) / 32, groups), dim3(256), 0, in, in_gs, in_ld, rows, cols, out, out_gs,
               ld_out);
     return 0;
