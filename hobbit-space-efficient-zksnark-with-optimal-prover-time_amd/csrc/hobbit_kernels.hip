@@ -75,26 +75,29 @@ int launch_fill_splitmix(hobbit_ctx *ctx, F *o, size_t n, uint64_t seed) {
 // destination may be strided (dst_es = element stride), which is how the row FFT of the tensor
 // code writes straight into the codeword-major tensor.
 // ============================================================================================
+// Short transforms (len < 1024) are packed: a workgroup owns tpw = 1024 / len consecutive rows, so that every radix-4 stage still
+// has one butterfly per thread (a single 256-point row would keep one wave of four busy).
 __global__ void __launch_bounds__(256)
 k_fft_rows(const F *__restrict__ src, size_t src_ld, uint32_t src_len, F *__restrict__ dst, size_t dst_ld, size_t dst_es,
-           int logn, const F *__restrict__ tw, F scale, int do_scale, uint32_t rows_per_group, size_t src_gs, size_t dst_gs) {
+           int logn, const F *__restrict__ tw, F scale, int do_scale, uint32_t rows_per_group, size_t src_gs, size_t dst_gs, uint32_t total_rows,
+           uint32_t tpw) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     F *s = reinterpret_cast<F *>(lds_raw);
     const uint32_t len = 1u << logn;
+    const uint32_t row0 = blockIdx.x * tpw, nrows = min(tpw, total_rows - row0), span = nrows * len;
     // row = (group, r): lets one launch cover K chunks x trs rows with per-chunk base strides
-    const uint32_t grp = blockIdx.x / rows_per_group, r = blockIdx.x % rows_per_group;
-    const F *in = src + (size_t)grp * src_gs + (size_t)r * src_ld;
-    F *out = dst + (size_t)grp * dst_gs + (size_t)r * dst_ld;
-    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+    for (uint32_t e = threadIdx.x; e < span; e += blockDim.x) {
+        const uint32_t t = e >> logn, i = e & (len - 1), row = row0 + t;
+        const F *in = src + (size_t)(row / rows_per_group) * src_gs + (size_t)(row % rows_per_group) * src_ld;
         F v = i < src_len ? ldF(in + i) : fmake(0);
-        stF(&s[__brev(i) >> (32 - logn)], v);
+        stF(&s[(t << logn) + (__brev(i) >> (32 - logn))], v);
     }
     __syncthreads();
     uint32_t h = 1;
     int st = 0;
     if (logn & 1) {   // single radix-2 stage first when the stage count is odd
-        for (uint32_t b = threadIdx.x; b < len / 2; b += blockDim.x) {
-            F u = ldF(&s[2 * b]), v = ldF(&s[2 * b + 1]);   // twiddle w^0 = 1
+        for (uint32_t b = threadIdx.x; b < span / 2; b += blockDim.x) {
+            F u = ldF(&s[2 * b]), v = ldF(&s[2 * b + 1]);   // twiddle w^0 = 1 (pairs never straddle rows)
             stF(&s[2 * b], fadd(u, v)); stF(&s[2 * b + 1], fsub(u, v));
         }
         __syncthreads();
@@ -102,9 +105,10 @@ k_fft_rows(const F *__restrict__ src, size_t src_ld, uint32_t src_len, F *__rest
     }
     for (; st < logn; st += 2, h <<= 2) {
         const uint32_t sA = len / (2 * h), sB = len / (4 * h);   // twiddle strides of the two stages
-        for (uint32_t b = threadIdx.x; b < len / 4; b += blockDim.x) {
+        for (uint32_t g = threadIdx.x; g < span / 4; g += blockDim.x) {
+            const uint32_t t = g >> (logn - 2), b = g & (len / 4 - 1);
             const uint32_t k = b & (h - 1), j = b / h;
-            const uint32_t i0 = j * 4 * h + k;
+            const uint32_t i0 = (t << logn) + j * 4 * h + k;
             F a0 = ldF(&s[i0]), a1 = ldF(&s[i0 + h]), a2 = ldF(&s[i0 + 2 * h]), a3 = ldF(&s[i0 + 3 * h]);
             const F wA = ldF(tw + (size_t)k * sA);
             F t1 = fmul(a1, wA), t3 = fmul(a3, wA);
@@ -116,8 +120,10 @@ k_fft_rows(const F *__restrict__ src, size_t src_ld, uint32_t src_len, F *__rest
         }
         __syncthreads();
     }
-    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
-        F v = ldF(&s[i]);
+    for (uint32_t e = threadIdx.x; e < span; e += blockDim.x) {
+        const uint32_t t = e >> logn, i = e & (len - 1), row = row0 + t;
+        F *out = dst + (size_t)(row / rows_per_group) * dst_gs + (size_t)(row % rows_per_group) * dst_ld;
+        F v = ldF(&s[e]);
         if (do_scale) v = fmul(v, scale);
         stF(out + (size_t)i * dst_es, v);
     }
@@ -126,13 +132,16 @@ k_fft_rows(const F *__restrict__ src, size_t src_ld, uint32_t src_len, F *__rest
 int launch_fft_rows(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_len, F *dst, size_t dst_ld, size_t dst_es,
                     int logn, const F *tw, F scale, int do_scale, uint32_t groups, uint32_t rows_per_group, size_t src_gs, size_t dst_gs) {
     if (logn < 1 || logn > 12) return ctx->fail(HOBBIT_EINVAL, "fft: logn must be in [1,12] for the LDS-resident kernel");
-    size_t lds = (size_t)16 << logn;
     static bool attr_set = false;
     if (!attr_set) { hipFuncSetAttribute((const void *)k_fft_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_set = true; }
-    size_t blocks = (size_t)groups * rows_per_group;
-    if (blocks == 0) return 0;
+    const size_t total = (size_t)groups * rows_per_group;
+    if (total == 0) return 0;
+    if (total >> 32) return ctx->fail(HOBBIT_EINVAL, "fft: too many rows");
+    const uint32_t tpw = logn < 10 ? (1024u >> logn) : 1u;
+    const size_t lds = ((size_t)16 << logn) * tpw;
+    const size_t blocks = (total + tpw - 1) / tpw;
     HB_LAUNCH(ctx, "k_fft_rows", k_fft_rows, dim3((unsigned)blocks), dim3(256), lds, src, src_ld, src_len, dst, dst_ld, dst_es, logn, tw,
-              scale, do_scale, rows_per_group, src_gs, dst_gs);
+              scale, do_scale, rows_per_group, src_gs, dst_gs, (uint32_t)total, tpw);
     return 0;
 }
 
