@@ -123,7 +123,19 @@ static int fft_long(hobbit_ctx *ctx, const F *src, size_t src_ld, size_t src_len
     HB_TRY(launch_fft4096(ctx, t1, 4096, 1, src_len == len ? 4096u : 2048u, t1, 4096, 1, t8, t8 + 7 * 8, t8 + 7 * 8 + 7 * 64, ctx->tw8_w8[d], ctx->tw8_w83[d],
                           ctx->tw8_w4_plus_i[d], fmake(1), 0, batch, R, len, len));
     }
-    HB_TRY(launch_transpose_tw(ctx, t1, len, R, t2, twl, (uint32_t)(len / 2), batch));
+    // inter-stage twiddles as a 2-D table (len entries, built once per length, <= 32 MB) when the batch amortises reading it
+    const F *tw2 = nullptr;
+    if (logn <= 21 && batch >= 8) {
+        auto it = ctx->tw2d_fwd.find(logn);
+        if (it == ctx->tw2d_fwd.end()) {
+            F *d2 = nullptr;
+            if (hipMalloc((void **)&d2, len * sizeof(F)) != hipSuccess) return ctx->fail(HOBBIT_ENOMEM, "twiddle table alloc failed");
+            HB_TRY(launch_build_tw2d(ctx, twl, (uint32_t)(len / 2), R, d2));
+            it = ctx->tw2d_fwd.emplace(logn, d2).first;
+        }
+        tw2 = it->second;
+    }
+    HB_TRY(launch_transpose_tw(ctx, t1, len, R, t2, twl, (uint32_t)(len / 2), tw2, batch));
     HB_TRY(fft_rows(ctx, t2, R, R, t2, R, 1, lr, inverse, 1, (uint32_t)((size_t)batch * 4096), 0, 0));       // scale applied below, not here
     HB_TRY(launch_transpose_ld(ctx, t2, len, R, 4096, R, dst, len, 4096, batch));
     return 0;
@@ -172,6 +184,7 @@ void hobbit_ctx_destroy(hobbit_ctx *ctx) {
     ctx->prof_collect();
     for (auto &kv : ctx->tw_fwd) hipFree(kv.second);
     for (auto &kv : ctx->tw_inv) hipFree(kv.second);
+    for (auto &kv : ctx->tw2d_fwd) hipFree(kv.second);
     for (int d = 0; d < 2; d++) if (ctx->tw8[d]) hipFree(ctx->tw8[d]);
     free_code(ctx->code);
     if (ctx->ws) hipFree(ctx->ws);

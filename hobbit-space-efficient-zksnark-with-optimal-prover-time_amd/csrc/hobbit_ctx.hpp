@@ -72,6 +72,7 @@ struct hobbit_ctx {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // twiddles: logn -> device table of 2^(logn-1) forward (and inverse) roots
     std::map<int, hobbit::F *> tw_fwd, tw_inv;
+    std::map<int, hobbit::F *> tw2d_fwd;          // inter-stage twiddles of the long transforms, [n1][k2] = w^(n1 k2), read coalesced
     // radix-8 per-pass tables of the FFT-4096 kernel ([7][8] | [7][64] | [7][512]), fwd / inv
     hobbit::F *tw8[2] = {nullptr, nullptr};
     hobbit::F tw8_w8[2], tw8_w83[2]; int tw8_w4_plus_i[2] = {0, 0};

@@ -419,8 +419,10 @@ int launch_transpose(hobbit_ctx *ctx, const F *in, size_t in_gs, uint32_t rows, 
 // Long transforms (len = 4096 * R, R up to 4096) by one Cooley-Tukey split, every pass coalesced:
 //   transpose (n2,n1)->(n1,n2) | R x FFT-4096 | twiddle W_len^(n1 k2) fused into the transpose (n1,k2)->(k2,n1)
 //   | 4096 x FFT-R | transpose (k2,k1)->(k1,k2).  This kernel is the middle one.  tw[m] = W_len^m, m < len/2.
+// tw2 != NULL: the twiddles come from a 2-D table tw2[n1 * 4096 + k2] = W_len^(n1 k2), read with the same coalesced pattern as the data
+// (the 1-D lookup tw[n1 k2 mod half] is a 16-byte load per lane from 64 different cache lines: 0.71 -> see DESIGN.md 4).
 __global__ void __launch_bounds__(256)
-k_transpose_tw(const F *__restrict__ in, size_t gs, uint32_t R, F *__restrict__ out, const F *__restrict__ tw, uint32_t half) {
+k_transpose_tw(const F *__restrict__ in, size_t gs, uint32_t R, F *__restrict__ out, const F *__restrict__ tw, uint32_t half, const F *__restrict__ tw2) {
     __shared__ F tile[32][33];
     const F *src = in + (size_t)blockIdx.z * gs;
     F *dst = out + (size_t)blockIdx.z * gs;
@@ -432,7 +434,8 @@ k_transpose_tw(const F *__restrict__ in, size_t gs, uint32_t R, F *__restrict__ 
         if (n1 < R) {
             F v = ldF(src + (size_t)n1 * 4096 + k2);
             const uint32_t m = n1 * k2;                                   // < len = 2*half
-            if (m) { v = fmul(v, ldF(tw + (m & (half - 1)))); if (m >= half) v = fneg(v); }
+            if (tw2) { if (m) v = fmul(v, ldF(tw2 + (size_t)n1 * 4096 + k2)); }
+            else if (m) { v = fmul(v, ldF(tw + (m & (half - 1)))); if (m >= half) v = fneg(v); }
             stF(&tile[ty + 8 * i][tx], v);
         }
     }
@@ -443,8 +446,21 @@ k_transpose_tw(const F *__restrict__ in, size_t gs, uint32_t R, F *__restrict__ 
         if (n1 < R) stF(dst + (size_t)k2 * R + n1, ldF(&tile[tx][ty + 8 * i]));
     }
 }
-int launch_transpose_tw(hobbit_ctx *ctx, const F *in, size_t gs, uint32_t R, F *out, const F *tw, uint32_t half, uint32_t groups) {
-    HB_LAUNCH(ctx, "k_transpose_tw", k_transpose_tw, dim3(4096 / 32, (R + 31) / 32, groups), dim3(256), 0, in, gs, R, out, tw, half);
+__global__ void __launch_bounds__(256)
+k_build_tw2d(const F *__restrict__ tw, uint32_t half, uint32_t R, F *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)R * 4096) return;
+    const uint32_t n1 = (uint32_t)(i >> 12), k2 = (uint32_t)(i & 4095), m = n1 * k2;
+    F v = ldF(tw + (m & (half - 1)));
+    if (m >= half) v = fneg(v);
+    stF(out + i, v);
+}
+int launch_build_tw2d(hobbit_ctx *ctx, const F *tw, uint32_t half, uint32_t R, F *out) {
+    HB_LAUNCH(ctx, "k_build_tw2d", k_build_tw2d, dim3((unsigned)(((size_t)R * 4096 + 255) / 256)), dim3(256), 0, tw, half, R, out);
+    return 0;
+}
+int launch_transpose_tw(hobbit_ctx *ctx, const F *in, size_t gs, uint32_t R, F *out, const F *tw, uint32_t half, const F *tw2, uint32_t groups) {
+    HB_LAUNCH(ctx, "k_transpose_tw", k_transpose_tw, dim3(4096 / 32, (R + 31) / 32, groups), dim3(256), 0, in, gs, R, out, tw, half, tw2);
     return 0;
 }
 

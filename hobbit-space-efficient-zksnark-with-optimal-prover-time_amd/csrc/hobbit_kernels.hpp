@@ -46,7 +46,8 @@ int launch_axpy_i32(hobbit_ctx *ctx, F *y, const int32_t *sel, F a, int one_minu
 int launch_sc3_poly(hobbit_ctx *ctx, const F *s1, const F *s2, const F *s3, size_t L, F *part, F *coef);
 int launch_fold3(hobbit_ctx *ctx, const F *s1, const F *s2, const F *s3, F *d1, F *d2, F *d3, size_t L, F r);
 int launch_mul_layer(hobbit_ctx *ctx, const F *x, size_t n_out, F *in1, F *in2, F *tr);
-int launch_transpose_tw(hobbit_ctx *ctx, const F *in, size_t gs, uint32_t R, F *out, const F *tw, uint32_t half, uint32_t groups);
+int launch_transpose_tw(hobbit_ctx *ctx, const F *in, size_t gs, uint32_t R, F *out, const F *tw, uint32_t half, const F *tw2, uint32_t groups);
+int launch_build_tw2d(hobbit_ctx *ctx, const F *tw, uint32_t half, uint32_t R, F *out);
 int launch_col_digest(hobbit_ctx *ctx, const F *enc, size_t W, int k, int quirk, uint8_t *out);
 int launch_change_form_level(hobbit_ctx *ctx, const F *in, F *out, size_t n, size_t S);
 int launch_whir_round(hobbit_ctx *ctx, F *poly, F *beta, size_t L, F a, F *part, F *coef);
