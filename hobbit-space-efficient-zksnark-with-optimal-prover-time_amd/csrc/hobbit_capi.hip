@@ -135,6 +135,11 @@ static int fft_long(hobbit_ctx *ctx, const F *src, size_t src_ld, size_t src_len
         }
         tw2 = it->second;
     }
+    if (tw2 && lr >= 2 && lr <= 8 && batch <= 65535) {
+        // one pass: twiddle on load, 16 columns x R rows per workgroup, final order on store (t1 -> dst; src was consumed above)
+        const F *twr; HB_TRY(get_twiddles(ctx, lr, inverse, &twr));
+        return launch_fft_cols(ctx, t1, len, lr, dst, tw2, twr, batch);
+    }
     HB_TRY(launch_transpose_tw(ctx, t1, len, R, t2, twl, (uint32_t)(len / 2), tw2, batch));
     HB_TRY(fft_rows(ctx, t2, R, R, t2, R, 1, lr, inverse, 1, (uint32_t)((size_t)batch * 4096), 0, 0));       // scale applied below, not here
     HB_TRY(launch_transpose_ld(ctx, t2, len, R, 4096, R, dst, len, 4096, batch));

@@ -77,28 +77,20 @@ int launch_fill_splitmix(hobbit_ctx *ctx, F *o, size_t n, uint64_t seed) {
 // ============================================================================================
 // Short transforms (len < 1024) are packed: a workgroup owns tpw = 1024 / len consecutive rows, so that every radix-4 stage still
 // has one butterfly per thread (a single 256-point row would keep one wave of four busy).
-__global__ void __launch_bounds__(256)
-k_fft_rows(const F *__restrict__ src, size_t src_ld, uint32_t src_len, F *__restrict__ dst, size_t dst_ld, size_t dst_es,
-           int logn, const F *__restrict__ tw, F scale, int do_scale, uint32_t rows_per_group, size_t src_gs, size_t dst_gs, uint32_t total_rows,
-           uint32_t tpw) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    F *s = reinterpret_cast<F *>(lds_raw);
+// The stages themselves, on `span / len` bit-reversed rows held in LDS.  Element i of a row sits at slot i + i/8 (one pad per eight):
+// the stride-4 and stride-16 butterflies of the first two radix-4 stages then spread over all banks (a plain layout is 4-way
+// conflicted there); the row stride ldr must be >= fft_row_slots(len).
+__device__ __host__ __forceinline__ uint32_t fft_slot(uint32_t i) { return i + (i >> 3); }
+__device__ __host__ __forceinline__ uint32_t fft_row_slots(uint32_t len) { return len + (len >> 3); }
+__device__ __forceinline__ void fft_lds_stages(F *s, int logn, const F *__restrict__ tw, uint32_t span, uint32_t ldr) {
     const uint32_t len = 1u << logn;
-    const uint32_t row0 = blockIdx.x * tpw, nrows = min(tpw, total_rows - row0), span = nrows * len;
-    // row = (group, r): lets one launch cover K chunks x trs rows with per-chunk base strides
-    for (uint32_t e = threadIdx.x; e < span; e += blockDim.x) {
-        const uint32_t t = e >> logn, i = e & (len - 1), row = row0 + t;
-        const F *in = src + (size_t)(row / rows_per_group) * src_gs + (size_t)(row % rows_per_group) * src_ld;
-        F v = i < src_len ? ldF(in + i) : fmake(0);
-        stF(&s[(t << logn) + (__brev(i) >> (32 - logn))], v);
-    }
-    __syncthreads();
     uint32_t h = 1;
     int st = 0;
     if (logn & 1) {   // single radix-2 stage first when the stage count is odd
-        for (uint32_t b = threadIdx.x; b < span / 2; b += blockDim.x) {
-            F u = ldF(&s[2 * b]), v = ldF(&s[2 * b + 1]);   // twiddle w^0 = 1 (pairs never straddle rows)
-            stF(&s[2 * b], fadd(u, v)); stF(&s[2 * b + 1], fsub(u, v));
+        for (uint32_t g = threadIdx.x; g < span / 2; g += blockDim.x) {
+            const uint32_t base = (g >> (logn - 1)) * ldr, i = 2 * (g & (len / 2 - 1));
+            F u = ldF(&s[base + fft_slot(i)]), v = ldF(&s[base + fft_slot(i + 1)]);   // twiddle w^0 = 1
+            stF(&s[base + fft_slot(i)], fadd(u, v)); stF(&s[base + fft_slot(i + 1)], fsub(u, v));
         }
         __syncthreads();
         h = 2; st = 1;
@@ -108,37 +100,91 @@ k_fft_rows(const F *__restrict__ src, size_t src_ld, uint32_t src_len, F *__rest
         for (uint32_t g = threadIdx.x; g < span / 4; g += blockDim.x) {
             const uint32_t t = g >> (logn - 2), b = g & (len / 4 - 1);
             const uint32_t k = b & (h - 1), j = b / h;
-            const uint32_t i0 = (t << logn) + j * 4 * h + k;
-            F a0 = ldF(&s[i0]), a1 = ldF(&s[i0 + h]), a2 = ldF(&s[i0 + 2 * h]), a3 = ldF(&s[i0 + 3 * h]);
+            const uint32_t base = t * ldr, i0 = j * 4 * h + k;
+            const uint32_t p0 = base + fft_slot(i0), p1 = base + fft_slot(i0 + h), p2 = base + fft_slot(i0 + 2 * h), p3 = base + fft_slot(i0 + 3 * h);
+            F a0 = ldF(&s[p0]), a1 = ldF(&s[p1]), a2 = ldF(&s[p2]), a3 = ldF(&s[p3]);
             const F wA = ldF(tw + (size_t)k * sA);
             F t1 = fmul(a1, wA), t3 = fmul(a3, wA);
             F b0 = fadd(a0, t1), b1 = fsub(a0, t1), b2 = fadd(a2, t3), b3 = fsub(a2, t3);
             const F wB0 = ldF(tw + (size_t)k * sB), wB1 = ldF(tw + (size_t)(k + h) * sB);
             F u2 = fmul(b2, wB0), u3 = fmul(b3, wB1);
-            stF(&s[i0], fadd(b0, u2)); stF(&s[i0 + 2 * h], fsub(b0, u2));
-            stF(&s[i0 + h], fadd(b1, u3)); stF(&s[i0 + 3 * h], fsub(b1, u3));
+            stF(&s[p0], fadd(b0, u2)); stF(&s[p2], fsub(b0, u2));
+            stF(&s[p1], fadd(b1, u3)); stF(&s[p3], fsub(b1, u3));
         }
         __syncthreads();
     }
+}
+__global__ void __launch_bounds__(256)
+k_fft_rows(const F *__restrict__ src, size_t src_ld, uint32_t src_len, F *__restrict__ dst, size_t dst_ld, size_t dst_es,
+           int logn, const F *__restrict__ tw, F scale, int do_scale, uint32_t rows_per_group, size_t src_gs, size_t dst_gs, uint32_t total_rows,
+           uint32_t tpw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    F *s = reinterpret_cast<F *>(lds_raw);
+    const uint32_t len = 1u << logn;
+    const uint32_t row0 = blockIdx.x * tpw, nrows = min(tpw, total_rows - row0), span = nrows * len, ldr = fft_row_slots(len);
+    // row = (group, r): lets one launch cover K chunks x trs rows with per-chunk base strides
+    for (uint32_t e = threadIdx.x; e < span; e += blockDim.x) {
+        const uint32_t t = e >> logn, i = e & (len - 1), row = row0 + t;
+        const F *in = src + (size_t)(row / rows_per_group) * src_gs + (size_t)(row % rows_per_group) * src_ld;
+        F v = i < src_len ? ldF(in + i) : fmake(0);
+        stF(&s[t * ldr + fft_slot(__brev(i) >> (32 - logn))], v);
+    }
+    __syncthreads();
+    fft_lds_stages(s, logn, tw, span, ldr);
     for (uint32_t e = threadIdx.x; e < span; e += blockDim.x) {
         const uint32_t t = e >> logn, i = e & (len - 1), row = row0 + t;
         F *out = dst + (size_t)(row / rows_per_group) * dst_gs + (size_t)(row % rows_per_group) * dst_ld;
-        F v = ldF(&s[e]);
+        F v = ldF(&s[t * ldr + fft_slot(i)]);
         if (do_scale) v = fmul(v, scale);
         stF(out + (size_t)i * dst_es, v);
     }
+}
+// The second half of a long transform len = 4096 R in ONE pass (was: twiddle + transpose, 4096 x FFT-R, transpose).  Input
+// y[n1][k2] (R rows of 4096: the R sub-transforms), output X[k1 * 4096 + k2] = sum_n1 W_R^(n1 k1) W_len^(n1 k2) y[n1][k2].
+// A workgroup owns C = 16 adjacent k2 for all n1: loads and stores are 256-byte segments, the twiddles come from the 2-D table
+// tw2[n1][k2] with the same pattern, each of the C columns is one length-R transform in LDS (row stride odd: the column-major
+// fill and drain are bank-conflict-free).
+__global__ void __launch_bounds__(512)
+k_fft_cols(const F *__restrict__ y, size_t gs, int logr, F *__restrict__ out, const F *__restrict__ tw2, const F *__restrict__ twr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    F *s = reinterpret_cast<F *>(lds_raw);
+    constexpr uint32_t C = 16;
+    const uint32_t R = 1u << logr, ldr = fft_row_slots(R) + 1, k20 = blockIdx.x * C;
+    const F *src = y + (size_t)blockIdx.y * gs;
+    F *dst = out + (size_t)blockIdx.y * gs;
+    for (uint32_t e = threadIdx.x; e < C * R; e += blockDim.x) {
+        const uint32_t n1 = e / C, t = e % C;
+        const size_t at = (size_t)n1 * 4096 + k20 + t;
+        F v = ldF(src + at);
+        if (n1) v = fmul(v, ldF(tw2 + at));                               // W_len^(n1 k2); row 0 of the table is all ones
+        stF(&s[t * ldr + fft_slot(__brev(n1) >> (32 - logr))], v);
+    }
+    __syncthreads();
+    fft_lds_stages(s, logr, twr, C * R, ldr);
+    for (uint32_t e = threadIdx.x; e < C * R; e += blockDim.x) {
+        const uint32_t k1 = e / C, t = e % C;
+        stF(dst + (size_t)k1 * 4096 + k20 + t, ldF(&s[t * ldr + fft_slot(k1)]));
+    }
+}
+int launch_fft_cols(hobbit_ctx *ctx, const F *y, size_t gs, int logr, F *out, const F *tw2, const F *twr, uint32_t batch) {
+    if (logr < 2 || logr > 8) return ctx->fail(HOBBIT_EINVAL, "fft_cols: R must be in [4, 256]");
+    const size_t lds = (size_t)16 * (fft_row_slots(1u << logr) + 1) * 16;
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void *)k_fft_cols, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 289 * 16); attr_set = true; }
+    HB_LAUNCH(ctx, "k_fft_cols", k_fft_cols, dim3(4096 / 16, batch), dim3(512), lds, y, gs, logr, out, tw2, twr);
+    return 0;
 }
 
 int launch_fft_rows(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_len, F *dst, size_t dst_ld, size_t dst_es,
                     int logn, const F *tw, F scale, int do_scale, uint32_t groups, uint32_t rows_per_group, size_t src_gs, size_t dst_gs) {
     if (logn < 1 || logn > 12) return ctx->fail(HOBBIT_EINVAL, "fft: logn must be in [1,12] for the LDS-resident kernel");
     static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute((const void *)k_fft_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_set = true; }
+    if (!attr_set) { hipFuncSetAttribute((const void *)k_fft_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 81920); attr_set = true; }
     const size_t total = (size_t)groups * rows_per_group;
     if (total == 0) return 0;
     if (total >> 32) return ctx->fail(HOBBIT_EINVAL, "fft: too many rows");
     const uint32_t tpw = logn < 10 ? (1024u >> logn) : 1u;
-    const size_t lds = ((size_t)16 << logn) * tpw;
+    const size_t lds = (size_t)16 * fft_row_slots(1u << logn) * tpw;
     const size_t blocks = (total + tpw - 1) / tpw;
     HB_LAUNCH(ctx, "k_fft_rows", k_fft_rows, dim3((unsigned)blocks), dim3(256), lds, src, src_ld, src_len, dst, dst_ld, dst_es, logn, tw,
               scale, do_scale, rows_per_group, src_gs, dst_gs, (uint32_t)total, tpw);
