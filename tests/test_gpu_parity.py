@@ -777,6 +777,16 @@ def test_fft_long_vs_oracle(hb, oracle, logn):
     assert np.array_equal(hb.fft(x), oracle.fft(x))
 
 
+@pytest.mark.parametrize("logn", [14, 15, 17, 19, 20])
+def test_fft_long_batched_vs_oracle(hb, oracle, logn):
+    """Batches of >= 8 long transforms take the one-pass second half (k_fft_cols, R = 4 ... 256; R = 128 and 256 are the inner
+    commitments of the 2^28 opening); single ones keep the five-pass form (test above).  Rows 0, 3 and 7 against the oracle, in place."""
+    x = splitmix_field(8 << logn, 930 + logn).reshape(8, 1 << logn, 2)
+    y = hb.fft(x)
+    for b in (0, 3, 7):
+        assert np.array_equal(y[b], oracle.fft(x[b])), (logn, b)
+
+
 def test_innerpcs_vs_golden(hb):
     g = gold("innerpcs")
     got = golden_cases.case_innerpcs(hb)
