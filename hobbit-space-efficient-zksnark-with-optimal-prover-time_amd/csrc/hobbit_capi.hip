@@ -123,9 +123,9 @@ static int fft_long(hobbit_ctx *ctx, const F *src, size_t src_ld, size_t src_len
     HB_TRY(launch_fft4096(ctx, t1, 4096, 1, src_len == len ? 4096u : 2048u, t1, 4096, 1, t8, t8 + 7 * 8, t8 + 7 * 8 + 7 * 64, ctx->tw8_w8[d], ctx->tw8_w83[d],
                           ctx->tw8_w4_plus_i[d], fmake(1), 0, batch, R, len, len));
     }
-    // inter-stage twiddles as a 2-D table (len entries, built once per length, <= 32 MB) when the batch amortises reading it
+    // inter-stage twiddles as a 2-D table (len entries, built once per length, <= 32 MB)
     const F *tw2 = nullptr;
-    if (logn <= 21 && batch >= 8) {
+    if (logn <= 21) {
         auto it = ctx->tw2d_fwd.find(logn);
         if (it == ctx->tw2d_fwd.end()) {
             F *d2 = nullptr;

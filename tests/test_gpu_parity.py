@@ -771,7 +771,7 @@ def test_mul_tree_2e20_vs_oracle(hb, oracle):
 
 
 # ---- long FFTs and the inner PCS commitments of the opening ----------------------------------------
-@pytest.mark.parametrize("logn", [13, 14, 16, 19])
+@pytest.mark.parametrize("logn", [13, 14, 16, 19, 22])       # 22: beyond the 2-D twiddle table, the five-pass form
 def test_fft_long_vs_oracle(hb, oracle, logn):
     x = splitmix_field(1 << logn, 900 + logn)
     assert np.array_equal(hb.fft(x), oracle.fft(x))
@@ -779,8 +779,8 @@ def test_fft_long_vs_oracle(hb, oracle, logn):
 
 @pytest.mark.parametrize("logn", [14, 15, 17, 19, 20])
 def test_fft_long_batched_vs_oracle(hb, oracle, logn):
-    """Batches of >= 8 long transforms take the one-pass second half (k_fft_cols, R = 4 ... 256; R = 128 and 256 are the inner
-    commitments of the 2^28 opening); single ones keep the five-pass form (test above).  Rows 0, 3 and 7 against the oracle, in place."""
+    """Long transforms up to 2^21 take the one-pass second half (k_fft_cols, R = 4 ... 256; R = 128 and 256 are the inner
+    commitments of the 2^28 opening).  Rows 0, 3 and 7 of a batch against the oracle, in place."""
     x = splitmix_field(8 << logn, 930 + logn).reshape(8, 1 << logn, 2)
     y = hb.fft(x)
     for b in (0, 3, 7):
