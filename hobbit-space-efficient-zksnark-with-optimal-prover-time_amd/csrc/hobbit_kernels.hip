@@ -1310,6 +1310,7 @@ int launch_axpy(hobbit_ctx *ctx, F *y, const F *x, F a, size_t n) {
 // to the reference's sequential accumulation.
 // ============================================================================================
 static constexpr size_t SC_TAIL = 1024;      // table size at which the remaining rounds go to the host
+static constexpr size_t SC_DOUBLE_MIN = 16 * SC_TAIL;      // tables at least this large take two rounds per round trip
 
 template <int NC>
 __device__ __forceinline__ void block_reduce_store(F (&c)[NC], F *partials) {
@@ -1352,6 +1353,57 @@ __global__ void __launch_bounds__(256) k_sc2_fold_poly(const F *__restrict__ s1,
         acc_quad(c, x0, x1, y0, y1);
     }
     block_reduce_store<3>(c, partials);
+}
+// Two rounds per transcript round trip.  For a quad (a0..a3) of the round-i tables, X(r, t) = x0(r) + t (x1(r) - x0(r)) with
+// x0 = a0 + r (a1 - a0), x1 = a2 + r (a3 - a2) is bilinear in (r, t); G(r, t) = sum over quads of X(r, t) Y(r, t) is biquadratic and
+// therefore fixed by its nine values on {0, 1, inf}^2 ("inf" = leading coefficient; leading coefficients multiply):
+//   X(0,0) = a0, X(1,0) = a1, X(inf,0) = a1 - a0 | X(0,1) = a2, X(1,1) = a3, X(inf,1) = a3 - a2 | X(0,inf) = a2 - a0, X(1,inf) = a3 - a1,
+//   X(inf,inf) = (a3 - a2) - (a1 - a0).
+// Round i's polynomial is G(r, 0) + G(r, 1); after r = r_i the host has G(r_i, t) at t = 0, 1, inf: round i + 1's polynomial.  Nine
+// products per quad instead of 2 x 4 + 4 over the two rounds, one round trip instead of two, and the tables are read once per two
+// rounds: with FOLD the kernel first folds sixteen elements of the tables two levels up with (r0, r1) into the quad and stores it.
+// Exact field sums: the coefficients are bit-identical to the reference's round-by-round ones (src/sumcheck.cpp:2391-2460).
+// One thread per element of the round-i tables: with FOLD it folds the four elements 4g..4g+3 of the tables two levels up (64
+// contiguous bytes per lane and table, the access pattern of k_sc2_fold_poly) into element g and stores it; the quad is the four
+// adjacent lanes, which exchange values by DPP quad permutes.  Lane q of a quad owns X(q&1, q>>1) = a_q; lanes 1 and 3 also form the
+// r = inf points, lanes 2 and 3 the t = inf points, lane 3 the (inf, inf) point.
+template <int CTRL> __device__ __forceinline__ F quad_perm(const F &v) {
+    F o; uint32_t w[4] = {(uint32_t)v.re, (uint32_t)(v.re >> 32), (uint32_t)v.im, (uint32_t)(v.im >> 32)};
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[k], CTRL, 0xF, 0xF, false);
+    o.re = (uint64_t)w[0] | ((uint64_t)w[1] << 32); o.im = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+    return o;
+}
+template <bool FOLD>
+__global__ void __launch_bounds__(256) k_sc2_double(const F *__restrict__ s1, const F *__restrict__ s2, F *__restrict__ d1, F *__restrict__ d2, size_t Q, F r0,
+                                                    F r1, F *__restrict__ partials) {
+    F acc0 = fmake(0), acc1 = fmake(0), acc2 = fmake(0), acc3 = fmake(0);
+    const int q = threadIdx.x & 3;
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < 4 * Q; g += (size_t)gridDim.x * blockDim.x) {
+        F a, b;
+        if (FOLD) {
+            const F *e = s1 + 4 * g, *h = s2 + 4 * g;
+            F e0 = ldF(e), e1 = ldF(e + 1), e2 = ldF(e + 2), e3 = ldF(e + 3);
+            F f0 = fadd(e0, fmul(r0, fsub(e1, e0))), f1 = fadd(e2, fmul(r0, fsub(e3, e2)));
+            a = fadd(f0, fmul(r1, fsub(f1, f0)));
+            F h0 = ldF(h), h1 = ldF(h + 1), h2 = ldF(h + 2), h3 = ldF(h + 3);
+            F k0 = fadd(h0, fmul(r0, fsub(h1, h0))), k1 = fadd(h2, fmul(r0, fsub(h3, h2)));
+            b = fadd(k0, fmul(r1, fsub(k1, k0)));
+            stF(d1 + g, a); stF(d2 + g, b);
+        } else { a = ldF(s1 + g); b = ldF(s2 + g); }
+        acc0 = fadd(acc0, fmul(a, b));                                                   // (0,0) (1,0) (0,1) (1,1) on lanes 0..3
+        const F an = quad_perm<0xA0>(a), bn = quad_perm<0xA0>(b);                        // lanes 1, 3 <- lanes 0, 2
+        const F da = fsub(a, an), db = fsub(b, bn);                                      // lanes 1, 3: a1 - a0, a3 - a2
+        acc1 = fadd(acc1, fmul(da, db));                                                 // (inf,0) on lane 1, (inf,1) on lane 3
+        const F a2 = quad_perm<0x44>(a), b2 = quad_perm<0x44>(b);                        // lanes 2, 3 <- lanes 0, 1
+        acc2 = fadd(acc2, fmul(fsub(a, a2), fsub(b, b2)));                               // (0,inf) on lane 2, (1,inf) on lane 3
+        const F da2 = quad_perm<0x44>(da), db2 = quad_perm<0x44>(db);                    // lane 3 <- lane 1's differences
+        acc3 = fadd(acc3, fmul(fsub(da, da2), fsub(db, db2)));                           // (inf,inf) on lane 3
+    }
+    const F z = fmake(0);
+    F c[9] = {q == 0 ? acc0 : z, q == 1 ? acc0 : z, q == 1 ? acc1 : z, q == 2 ? acc0 : z, q == 3 ? acc0 : z, q == 3 ? acc1 : z,
+              q == 2 ? acc2 : z, q == 3 ? acc2 : z, q == 3 ? acc3 : z};
+    block_reduce_store<9>(c, partials);
 }
 // reduce the per-workgroup partials to NC coefficients
 template <int NC>
@@ -1562,13 +1614,51 @@ int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev
         sc2_host_tail(ta, tb, rnd, false, 0, rounds, h_qpoly, h_r);
     } else {
         size_t szA = n / 2, szB = n / 4;
-        F *ws; HB_TRY(ctx->workspace((2 * szA + 2 * szB + (size_t)MAXB * 3 + 4) * sizeof(F), (void **)&ws));
+        F *ws; HB_TRY(ctx->workspace((2 * szA + 2 * szB + (size_t)MAXB * 9 + 4) * sizeof(F), (void **)&ws));
         F *A1 = ws, *A2 = A1 + szA, *B1 = A2 + szA, *B2 = B1 + szB, *part = B2 + szB;
         Mailbox *mb; unsigned *ticket; HB_TRY(ctx->mailbox(&mb, &ticket));
         const F *s1 = v1, *s2 = v2;
         F *d1 = A1, *d2 = A2;
         int i = 0;
         size_t cur = n;                       // size of the tables s1/s2 point at
+        // ---- large tables: two rounds per round trip (k_sc2_double) ----
+        if (n >= SC_DOUBLE_MIN) {
+            const F *S1 = v1, *S2 = v2; size_t S_size = n;            // the materialised tables: level i - 2 (or the inputs)
+            F *D1 = B1, *D2 = B2;                                     // T_2 has n/4 elements: fits B; later levels fit either
+            bool pend = false; F pr0 = fmake(0), pr1 = fmake(0);      // (r_{i-2}, r_{i-1}): still to be applied to S
+            while ((n >> i) >= SC_DOUBLE_MIN) {
+                const size_t Q = (n >> i) / 4;
+                const int nb = grid_for(4 * Q, 256, MAXB);
+                const uint32_t seq = ++ctx->mbox_seq;
+                if (!pend) HB_LAUNCH(ctx, "k_sc2_double", k_sc2_double<false>, dim3(nb), dim3(256), 0, S1, S2, (F *)nullptr, (F *)nullptr, Q, pr0, pr1, part);
+                else {
+                    HB_LAUNCH(ctx, "k_sc2_double", k_sc2_double<true>, dim3(nb), dim3(256), 0, S1, S2, D1, D2, Q, pr0, pr1, part);
+                    S1 = D1; S2 = D2; S_size = 4 * Q;
+                    if (D1 == B1) { D1 = A1; D2 = A2; } else { D1 = B1; D2 = B2; }
+                }
+                HB_LAUNCH(ctx, "k_sc_reduce", k_sc_reduce_post<9>, dim3(1), dim3(256), 0, part, nb, mb, seq);
+                HB_TRY(ctx->mbox_wait(seq));
+                F G[9]; for (int q = 0; q < 9; q++) G[q] = mb->vals[q];            // G(r, t) at (0,0) (1,0) (inf,0) | (0,1) (1,1) (inf,1) | (0,inf) (1,inf) (inf,inf)
+                // round i: G(r, 0) + G(r, 1) as (a, b, c) from its values at r = inf, 1, 0
+                F p0[3]; p0[0] = fadd(G[2], G[5]); p0[2] = fadd(G[0], G[3]); p0[1] = fsub(fsub(fadd(G[1], G[4]), p0[0]), p0[2]);
+                for (int q = 0; q < 3; q++) { rnd = mimc_hash(rnd, p0[q]); h_qpoly[3 * i + q] = p0[q]; }
+                h_r[i] = rnd;
+                const F r = rnd, rr = fmul(r, r);
+                F v[3];                                                             // G(r_i, t) at t = 0, 1, inf
+                for (int k = 0; k < 3; k++) { const F cc = G[3 * k], aa = G[3 * k + 2], bb = fsub(fsub(G[3 * k + 1], aa), cc); v[k] = fadd(cc, fadd(fmul(r, bb), fmul(rr, aa))); }
+                const F p1[3] = {v[2], fsub(fsub(v[1], v[2]), v[0]), v[0]};         // round i + 1: (a, b, c)
+                for (int q = 0; q < 3; q++) { rnd = mimc_hash(rnd, p1[q]); h_qpoly[3 * (i + 1) + q] = p1[q]; }
+                h_r[i + 1] = rnd;
+                pend = true; pr0 = r; pr1 = rnd; i += 2;
+            }
+            // bridge to the round-by-round loop: it expects s = T_{i-1} and rnd = r_{i-1}.  S = T_{i-2}: fold it once with r_{i-2}
+            // (the polynomial this launch also sums is round i-1's, already known: its partials are not reduced).
+            F *b1 = (S1 == A1) ? B1 : A1, *b2 = (S1 == A1) ? B2 : A2;
+            const size_t L = S_size / 4;
+            HB_LAUNCH(ctx, "k_sc2_fold_poly", k_sc2_fold_poly, dim3(grid_for(L, 256, MAXB)), dim3(256), 0, S1, S2, b1, b2, L, pr0, part);
+            s1 = b1; s2 = b2; cur = 2 * L;
+            if (b1 == A1) { d1 = B1; d2 = B2; } else { d1 = A1; d2 = A2; }
+        }
         for (;; i++) {
             size_t L = n >> (i + 1);          // pairs of the round-i tables
             int nb = grid_for(L, 256, MAXB);
