@@ -1048,6 +1048,14 @@ __global__ void k_eq_step(const F *__restrict__ old, F *__restrict__ nw, size_t 
         stF(nw + 2 * j, fsub(o, t)); stF(nw + 2 * j + 1, t);
     }
 }
+// two doubling steps in one pass (levels with challenges ra, then rb): old[j] -> new[4j .. 4j+3]; the intermediate level is never stored
+__global__ void k_eq_step2(const F *__restrict__ old, F *__restrict__ nw, size_t m, F ra, F rb) {
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < m; j += (size_t)gridDim.x * blockDim.x) {
+        const F o = ldF(old + j), t = fmul(ra, o), x0 = fsub(o, t);
+        const F u0 = fmul(rb, x0), u1 = fmul(rb, t);
+        stF(nw + 4 * j, fsub(x0, u0)); stF(nw + 4 * j + 1, u0); stF(nw + 4 * j + 2, fsub(t, u1)); stF(nw + 4 * j + 3, u1);
+    }
+}
 // the first h <= 12 doubling steps in ONE workgroup (table in LDS, pairs staged in registers between the two barriers of a level):
 // up there a level per launch is a dozen launches of a few hundred nanoseconds of work each.  r.b[i] = challenge of level i.
 struct EqHead { F b[12]; };
@@ -1086,16 +1094,18 @@ int launch_eq_table(hobbit_ctx *ctx, const F *h_r, int k, F *d_out) {
     F *tmp = nullptr;
     const int h = k < 12 ? k : 12, rest = k - h;
     if (rest > 0) HB_TRY(ctx->workspace(n / 2 * sizeof(F), (void **)&tmp));
-    F *cur = (rest % 2 == 0) ? d_out : tmp;
+    const int launches = rest / 2 + rest % 2;                       // one single step if `rest` is odd, then two levels per pass
+    F *cur = (launches % 2 == 0) ? d_out : tmp;
     EqHead hd;
     for (int i = 0; i < 12; i++) hd.b[i] = i < h ? h_r[k - 1 - i] : fmake(0);
     static bool attr_set = false;
     if (!attr_set) { hipFuncSetAttribute((const void *)k_eq_head, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_set = true; }
     HB_LAUNCH(ctx, "k_eq_head", k_eq_head, dim3(1), dim3(256), ((size_t)16 << h), hd, h, cur);
-    for (int i = h; i < k; i++) {
+    for (int i = h; i < k;) {
         F *nxt = cur == d_out ? tmp : d_out;
         size_t m = (size_t)1 << i;
-        HB_LAUNCH(ctx, "k_eq_step", k_eq_step, dim3(grid_for(m, 256)), dim3(256), 0, cur, nxt, m, h_r[k - 1 - i]);
+        if ((k - i) % 2) { HB_LAUNCH(ctx, "k_eq_step", k_eq_step, dim3(grid_for(m, 256)), dim3(256), 0, cur, nxt, m, h_r[k - 1 - i]); i += 1; }
+        else { HB_LAUNCH(ctx, "k_eq_step", k_eq_step2, dim3(grid_for(m, 256)), dim3(256), 0, cur, nxt, m, h_r[k - 1 - i], h_r[k - 2 - i]); i += 2; }
         cur = nxt;
     }
     return 0;
