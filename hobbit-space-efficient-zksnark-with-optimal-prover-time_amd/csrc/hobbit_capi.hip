@@ -723,8 +723,9 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
         const F *dz = dslot, *dpw = dslot + 2048; const uint64_t *d_idx = reinterpret_cast<const uint64_t *>(dslot + 2048 + 128);
         // the `repeats` eq tables side by side, then y = E poly, beta += pows^T E (:613-633)
         F *cE = E0, *nE = E1;
-        HB_TRY(launch_fill_F(ctx, cE, cur, (size_t)repeats, fmake(1)));
-        for (int l = 0; l < v; l++) { HB_TRY(launch_eq_step_batched(ctx, cE, nE, (size_t)1 << l, cur, dz, v, l, repeats)); std::swap(cE, nE); }
+        const int hd = v < 11 ? v : 11;                                           // levels 0..hd-1 of every table in one launch
+        HB_TRY(launch_eq_head_batched(ctx, cE, cur, dz, v, hd, repeats));
+        for (int l = hd; l < v; l++) { HB_TRY(launch_eq_step_batched(ctx, cE, nE, (size_t)1 << l, cur, dz, v, l, repeats)); std::swap(cE, nE); }
         HB_TRY(launch_matvec_rows(ctx, cE, (size_t)repeats, cur, poly, res_it(iter - 1) + 16));
         HB_TRY(launch_vecmat(ctx, cE, (size_t)repeats, cur, dpw, nE));          // nE[0..cur) = sum_i pow_i E[i]   (uses ctx->workspace for partials)
         HB_TRY(launch_axpy(ctx, beta, nE, fmake(1), cur));

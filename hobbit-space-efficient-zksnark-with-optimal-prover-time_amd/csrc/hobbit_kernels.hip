@@ -1596,6 +1596,34 @@ __global__ void k_eq_step_batched(const F *__restrict__ old, F *__restrict__ nw,
         stF(n + 2 * j, fsub(x, t)); stF(n + 2 * j + 1, t);
     }
 }
+// the first h <= 11 levels of every table in one launch (one workgroup per table, table in LDS): a level per launch is latency only up there
+__global__ void __launch_bounds__(256) k_eq_head_batched(F *__restrict__ out, size_t ld, const F *__restrict__ z, int v, int h) {
+    __shared__ F s[2048];
+    const F *zz = z + (size_t)blockIdx.x * v;
+    if (threadIdx.x == 0) s[0] = fmake(1);
+    __syncthreads();
+    for (int i = 0; i < h; i++) {
+        const uint32_t m = 1u << i;
+        const F r = ldF(zz + (v - 1 - i));
+        F o[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t j = threadIdx.x + 256 * u; if (j < m) o[u] = ldF(&s[j]); }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t j = threadIdx.x + 256 * u;
+            if (j < m) { const F t = fmul(r, o[u]); stF(&s[2 * j], fsub(o[u], t)); stF(&s[2 * j + 1], t); }
+        }
+        __syncthreads();
+    }
+    F *n = out + (size_t)blockIdx.x * ld;
+    for (uint32_t j = threadIdx.x; j < (1u << h); j += 256) stF(n + j, ldF(&s[j]));
+}
+int launch_eq_head_batched(hobbit_ctx *ctx, F *out, size_t ld, const F *z, int v, int h, int reps) {
+    if (h < 0 || h > 11 || h > v) return ctx->fail(HOBBIT_EINVAL, "eq_head_batched: 0 <= h <= min(v, 11)");
+    HB_LAUNCH(ctx, "k_eq_step_batched", k_eq_head_batched, dim3(reps), dim3(256), 0, out, ld, z, v, h);
+    return 0;
+}
 int launch_eq_step_batched(hobbit_ctx *ctx, const F *old, F *nw, size_t m, size_t ld, const F *z, int v, int level, int reps) {
     HB_LAUNCH(ctx, "k_eq_step_batched", k_eq_step_batched, dim3(grid_for(m, 256, 256), reps), dim3(256), 0, old, nw, m, ld, z, v, level);
     return 0;

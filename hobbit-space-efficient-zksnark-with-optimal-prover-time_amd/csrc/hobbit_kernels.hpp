@@ -53,6 +53,7 @@ int launch_col_digest(hobbit_ctx *ctx, const F *enc, size_t W, int k, int quirk,
 int launch_change_form_level(hobbit_ctx *ctx, const F *in, F *out, size_t n, size_t S);
 int launch_whir_round(hobbit_ctx *ctx, F *poly, F *beta, size_t L, F a, F *part, F *coef);
 int launch_eq_step_batched(hobbit_ctx *ctx, const F *old, F *nw, size_t m, size_t ld, const F *z, int v, int level, int reps);
+int launch_eq_head_batched(hobbit_ctx *ctx, F *out, size_t ld, const F *z, int v, int h, int reps);
 int launch_fill_F(hobbit_ctx *ctx, F *p, size_t stride, size_t n, F v);
 int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev_r, F *h_qpoly, F *h_r, F *h_vr, F *h_final);
 int launch_gate_sumcheck(hobbit_ctx *ctx, const F *const tabs[6], size_t n, const F *h_a, F *h_rand, F *h_sum, F *h_poly, F *h_r, F *h_final, int *h_check);
