@@ -904,9 +904,14 @@ int hobbit_phi_g(hobbit_ctx *ctx, const hobbit_F *h_rx, int n, const hobbit_F *h
     const F *pm; HB_TRY(get_twiddles(ctx, n, is_ifft != 0, &pm));      // phi_mul[k] = rou^k, k < N/2 (all that is indexed)
     F *g = mF(d_out);
     HB_CHECK(ctx, hipMemsetAsync(g, 0, N * sizeof(F), ctx->stream));
-    HB_TRY(launch_fill_F(ctx, g, 1, is_ifft && N > 1 ? 2 : 1, *cF(h_scale)));      // (a kernel argument: no upload to wait for)
     const int last = is_ifft ? n : n - 1;
-    for (int i = 1; i <= last; i++) HB_TRY(launch_phi_step(ctx, g, (size_t)1 << (i - 1), n - i, cF(h_rx)[n - i], pm, 0));
+    int first = 1;
+    if (!is_ifft && last >= 2) {                                       // the first levels in one workgroup: a level per launch is latency only up there
+        const int hd = last < 11 ? last : 11;
+        HB_TRY(launch_phi_head(ctx, g, n, hd, cF(h_rx), *cF(h_scale), pm));
+        first = hd + 1;
+    } else HB_TRY(launch_fill_F(ctx, g, 1, is_ifft && N > 1 ? 2 : 1, *cF(h_scale)));      // (a kernel argument: no upload to wait for)
+    for (int i = first; i <= last; i++) HB_TRY(launch_phi_step(ctx, g, (size_t)1 << (i - 1), n - i, cF(h_rx)[n - i], pm, 0));
     if (!is_ifft) HB_TRY(launch_phi_step(ctx, g, (size_t)1 << (n - 1), 0, cF(h_rx)[0], pm, 1));
     return 0;
 }

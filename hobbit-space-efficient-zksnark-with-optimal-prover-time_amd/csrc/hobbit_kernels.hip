@@ -1215,6 +1215,31 @@ __global__ void k_phi_step(F *__restrict__ g, size_t half, int m, F rx, const F 
         stF(g + b, fmul(gl, fadd(t1, t2)));
     }
 }
+// levels 1..h (h <= 11) of the forward table in one workgroup: g[0] = scale, then h in-place doubling levels in LDS.  rx.b[i-1] = the
+// challenge of level i (= h_rx[n - i]).
+__global__ void __launch_bounds__(256) k_phi_head(F *__restrict__ g, int n, int h, EqHead rx, F scale, const F *__restrict__ pm) {
+    __shared__ F s[2048];
+    if (threadIdx.x == 0) s[0] = scale;
+    __syncthreads();
+    for (int i = 1; i <= h; i++) {
+        const uint32_t half = 1u << (i - 1);
+        const F r = rx.b[i - 1], t1 = fsub(fmake(1), r);
+        for (uint32_t b = threadIdx.x; b < half; b += 256) {
+            const F t2 = fmul(r, ldF(pm + ((size_t)b << (n - i)))), gl = ldF(&s[b]);
+            stF(&s[b ^ half], fmul(gl, fsub(t1, t2)));
+            stF(&s[b], fmul(gl, fadd(t1, t2)));
+        }
+        __syncthreads();
+    }
+    for (uint32_t j = threadIdx.x; j < (1u << h); j += 256) stF(g + j, ldF(&s[j]));
+}
+int launch_phi_head(hobbit_ctx *ctx, F *g, int n, int h, const F *h_rx, F scale, const F *pm) {
+    if (h < 1 || h > 11 || h >= n) return ctx->fail(HOBBIT_EINVAL, "phi_head: 1 <= h <= min(11, n - 1)");
+    EqHead rx;
+    for (int i = 1; i <= 12; i++) rx.b[i - 1] = i <= h ? h_rx[n - i] : fmake(0);
+    HB_LAUNCH(ctx, "k_phi_step", k_phi_head, dim3(1), dim3(256), 0, g, n, h, rx, scale, pm);
+    return 0;
+}
 int launch_phi_step(hobbit_ctx *ctx, F *g, size_t half, int m, F rx, const F *pm, int last_only) {
     HB_LAUNCH(ctx, "k_phi_step", k_phi_step, dim3(grid_for(half, 256)), dim3(256), 0, g, half, m, rx, pm, last_only);
     return 0;

@@ -30,6 +30,7 @@ int launch_tensor_row(hobbit_ctx *ctx, const F *chunk, uint32_t rows2, uint32_t 
 int launch_eval_fold(hobbit_ctx *ctx, const F *v, F *o, size_t L, F r);
 int launch_csr_gather(hobbit_ctx *ctx, const uint32_t *rowptr, const uint32_t *idx, const F *w, const F *x, F *y, size_t rows);
 int launch_phi_step(hobbit_ctx *ctx, F *g, size_t half, int m, F rx, const F *pm, int last_only);
+int launch_phi_head(hobbit_ctx *ctx, F *g, int n, int h, const F *h_rx, F scale, const F *pm);
 int launch_fold_rows(hobbit_ctx *ctx, const F *in, F *out, size_t out_rows, size_t cols, F r);
 int launch_transpose_ld(hobbit_ctx *ctx, const F *in, size_t in_gs, size_t in_ld, uint32_t rows, uint32_t cols, F *out, size_t out_gs, size_t ld_out,
                         uint32_t groups);
