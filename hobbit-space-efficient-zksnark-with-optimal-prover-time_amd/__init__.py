@@ -38,6 +38,8 @@ ABI_SYMBOLS = [
     "hobbit_commitment_tensor_dev", "hobbit_commitment_levels", "hobbit_commitment_root", "hobbit_commitment_tensor_row",
     "hobbit_commitment_gather", "hobbit_commitment_path", "hobbit_commitment_paths",
     "hobbit_elastic_begin", "hobbit_elastic_push", "hobbit_elastic_finish", "hobbit_elastic_free",
+    "hobbit_elastic_open_begin", "hobbit_elastic_open_aggregate_push", "hobbit_elastic_open_aggregate_finish", "hobbit_elastic_open_reply_push",
+    "hobbit_elastic_open_finish", "hobbit_elastic_open_free", "hobbit_generate_randomness",
     "hobbit_tensorcode_chunks", "hobbit_inner_digests", "hobbit_chain_digests", "hobbit_blake3_64_host",
     "hobbit_parity_matrix", "hobbit_phi_g", "hobbit_prepare_matrix_cols", "hobbit_prove_linear_code", "hobbit_prove_fft",
     "hobbit_prove_fft_matrix",
@@ -95,6 +97,9 @@ def load_library(path=LIB_PATH):
         "hobbit_fold_axpy_i32": [V, V, V, V, I, S], "hobbit_batch_prod": [V, V, V, V, V, V, V, I, S, V, V, V, V, V, V],
         "hobbit_elastic_begin": [V, S, I, I, I, V], "hobbit_elastic_push": [V, V, V], "hobbit_elastic_finish": [V, V, V],
         "hobbit_elastic_free": [V],
+        "hobbit_elastic_open_begin": [V, S, S, I, V, I, V], "hobbit_elastic_open_aggregate_push": [V, V, V], "hobbit_elastic_open_aggregate_finish": [V, V],
+        "hobbit_elastic_open_reply_push": [V, V, V], "hobbit_elastic_open_finish": [V, V, V, V], "hobbit_elastic_open_free": [V],
+        "hobbit_generate_randomness": [S, V],
         "hobbit_tensorcode_chunks": [V, V, S, I, I, I, V], "hobbit_inner_digests": [V, V, S, I, I, V],
         "hobbit_chain_digests": [V, V, S, I, S, V], "hobbit_blake3_64_host": [V, V, S],
     }
@@ -288,11 +293,7 @@ class Hobbit:
     def generate_randomness(self, n):
         """src/utils.cpp:873-883 (host-side, libc)"""
         out = np.zeros((n, 2), np.uint64)
-        c = 0
-        for i in range(n):
-            if i % 100 == 0:
-                c = self._libc.random()
-            out[i, 0] = (c + self._libc.rand()) % P
+        self.lib.hobbit_generate_randomness(c_sz(n), _hp(out))
         return out
 
     def _draw(self, L, R, d):
@@ -696,7 +697,56 @@ class Hobbit:
             n[0, 0] = r; n[0, 1] = tmp[0, 1]
         return out
 
-    def elastic_commit(self, N, B, opt, gcc_arg_order=1, chunk=None):
+    def read_stream(self, B):
+        """default branch of read_stream (src/witness_stream.cpp:2348-2352): v[i] = F(i % 1024 + 1); what Elastic_PC::open's two
+        passes read for the "test" descriptor"""
+        out = np.zeros((B, 2), np.uint64)
+        out[:, 0] = np.arange(B, dtype=np.uint64) % np.uint64(1024) + np.uint64(1)
+        return out
+
+    def elastic_open(self, N, B, x, queries=700, commit_levels=None, chunk=None, shockwave=True):
+        """Elastic_PC::open, option 1 (src/Elastic_PC.cpp:625-726), prover side.  commit_levels: DeviceBuffer with the commitment tree
+        (hobbit_elastic_finish) or None; chunk: DeviceBuffer of the (repeating) read_stream chunk, built here if None."""
+        x = Fh(x).reshape(-1, 2)
+        trs = B >> 11; cols = 4096; K = N // B
+        logc = 12; logr = (2 * trs).bit_length() - 1; logt = logr - 1
+        e = c_vp()
+        self._chk(self.lib.hobbit_elastic_open_begin(self.ctx, N, B, trs, _hp(x), queries, ctypes.byref(e)))
+        try:
+            if chunk is None:
+                chunk = self.to_device(self.read_stream(B))
+            for _ in range(K):
+                self._chk(self.lib.hobbit_elastic_open_aggregate_push(self.ctx, e, chunk.ptr))
+            self._chk(self.lib.hobbit_elastic_open_aggregate_finish(self.ctx, e))
+            for _ in range(K):
+                self._chk(self.lib.hobbit_elastic_open_reply_push(self.ctx, e, chunk.ptr))
+            maxr = (2048 * 2 * trs).bit_length() - 1 + logr + (logt + logc) + logc
+            depth = (4 * B).bit_length() - 1
+            res = dict(cols=np.zeros(queries, np.uint32), rows=np.zeros(queries, np.uint32), rv0=np.zeros(2, np.uint64), reply=np.zeros((queries, K, 2), np.uint64),
+                       reply_len=np.zeros(1, np.int32), paths=np.zeros((queries, depth, 32), np.uint8) if commit_levels is not None else None,
+                       cf_root=np.zeros(32, np.uint8), ncols=np.zeros(1, np.int32), poly=np.zeros((maxr, 3, 2), np.uint64), r=np.zeros((maxr, 2), np.uint64),
+                       vr=np.zeros((4, 2, 2), np.uint64), fin=np.zeros((4, 2), np.uint64), checks=np.zeros(2, np.int32), rx=np.zeros((logc + logt, 2), np.uint64))
+            names = ("cols", "rows", "rv0", "reply", "reply_len", "paths", "cf_root", "ncols", "poly", "r", "vr", "fin", "checks", "rx")
+
+            class Out(ctypes.Structure):
+                _fields_ = [(n, c_vp) for n in names + ("sp_f",)]
+            sp = self._sp_buffers(B, 32) if shockwave else None
+            o = Out(*([(res[k].ctypes.data if res[k] is not None else None) for k in names] + [ctypes.addressof(sp[1]) if sp else None]))
+            lv = commit_levels.ptr if isinstance(commit_levels, DeviceBuffer) else commit_levels
+            self._chk(self.lib.hobbit_elastic_open_finish(self.ctx, e, lv, ctypes.byref(o)))
+        finally:
+            self.lib.hobbit_elastic_open_free(e)
+        nc = int(res["ncols"][0]); np2 = 1 << max(nc - 1, 0).bit_length()
+        rounds = (np2 * 2 * trs).bit_length() - 1 + logr + (logt + logc) + logc
+        res["poly"] = res["poly"][:rounds]; res["r"] = res["r"][:rounds]
+        rl = int(res["reply_len"][0])
+        res["reply"] = res["reply"].reshape(-1, 2)[:queries * rl].reshape(queries, rl, 2)
+        res["I"] = np.stack([res["cols"], res["rows"]], axis=1)
+        if sp:
+            res["sp_f"] = self._sp_trim(sp[0], B, 32)
+        return res
+
+    def elastic_commit(self, N, B, opt, gcc_arg_order=1, chunk=None, keep_levels=False):
         """test_Elastic_PC's commit (src/Elastic_PC.cpp:736-771): opt 1 RSxRS trs=B/2^11, opt 2 RSxexpander trs=B/2^14.
         chunk: a DeviceBuffer holding the stream's (repeating) chunk, generated here on the host if None."""
         if opt == 1:
@@ -714,7 +764,7 @@ class Hobbit:
         self._chk(self.lib.hobbit_elastic_finish(self.ctx, e, lv.ptr))
         out = self.to_host(lv, (8 * B - 1, 32), np.uint8)
         self.lib.hobbit_elastic_free(e)
-        return out
+        return (out, lv) if keep_levels else out
 
     # ---- sumchecks (reference names: src/sumcheck.cpp:2391, 1974)
     def _dev_table(self, v):

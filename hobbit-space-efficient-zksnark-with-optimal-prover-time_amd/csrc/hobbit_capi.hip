@@ -247,6 +247,10 @@ int hobbit_profile_names(hobbit_ctx *ctx, char *buf, size_t buflen) {
 void hobbit_mimc(const hobbit_F *x, const hobbit_F *k, hobbit_F *out) { *mF(out) = mimc_hash(*cF(x), *cF(k)); }
 void hobbit_f_mul_host(const hobbit_F *a, const hobbit_F *b, hobbit_F *o, size_t n) { for (size_t i = 0; i < n; i++) mF(o)[i] = fmul(cF(a)[i], cF(b)[i]); }
 void hobbit_f_inv_host(const hobbit_F *a, hobbit_F *o, size_t n) { for (size_t i = 0; i < n; i++) mF(o)[i] = finv(cF(a)[i]); }
+void hobbit_generate_randomness(size_t n, hobbit_F *h_out) {       // src/utils.cpp:873-883
+    F cst = fmake(0);
+    for (size_t i = 0; i < n; i++) { if (i % 100 == 0) cst = fmake((uint64_t)random()); mF(h_out)[i] = fadd(cst, fmake((uint64_t)rand())); }
+}
 int hobbit_f_binop(hobbit_ctx *ctx, int op, const hobbit_F *a, const hobbit_F *b, hobbit_F *o, size_t n) {
     if (op < 0 || op > 2) return ctx->fail(HOBBIT_EINVAL, "f_binop: op must be 0,1,2");
     if (!n) return 0;
@@ -1134,6 +1138,170 @@ int hobbit_mul_tree(hobbit_ctx *ctx, const hobbit_F *d_input, size_t vectors, si
     }
     memcpy(h_final_r, r.data(), sizeof(F) * r.size()); *mF(h_final_eval) = sum;
     if (layers_out) *layers_out = layers;
+    return 0;
+}
+
+// ---- Elastic_PC open, RS x RS (test_Elastic_PC option 1): src/Elastic_PC.cpp:625-726 ---------------------------------
+// The stream stays with the host, as in the commit: pass 2 (aggregate, :316-347) and pass 3 (compute_aggregation_reply /
+// update_reply, :487-533, 59-111) receive the chunks as device buffers, in stream order.
+struct hobbit_elastic_open {
+    hobbit_ctx *ctx; size_t N, B, K; int trs, queries; uint32_t cols, rows2;
+    std::vector<F> beta; std::vector<uint32_t> qc, qr, ucols, qci; F rv0;
+    size_t n_aggr, n_reply; bool committed;
+    F *d_aggr, *d_T, *d_G, *d_reply, *d_encf; uint8_t *d_lvf; uint32_t *d_ucols; uint64_t *d_pick; int *d_nz;
+};
+// precompute_beta (src/utils.cpp:251-296) on the host for a handful of variables
+static void host_eq_table(const F *r, int k, std::vector<F> &out) {
+    out.assign((size_t)1 << k, fmake(0)); out[0] = fmake(1);
+    for (int i = 0; i < k; i++) for (size_t j = ((size_t)1 << i); j-- > 0;) { F t = fmul(r[k - 1 - i], out[j]); out[2 * j + 1] = t; out[2 * j] = fsub(out[j], t); }
+}
+void hobbit_elastic_open_free(hobbit_elastic_open *e) {
+    if (!e) return;
+    hipStreamSynchronize(e->ctx->stream);
+    for (void *p : {(void *)e->d_aggr, (void *)e->d_T, (void *)e->d_G, (void *)e->d_reply, (void *)e->d_encf, (void *)e->d_lvf, (void *)e->d_ucols, (void *)e->d_pick, (void *)e->d_nz})
+        if (p) hipFree(p);
+    delete e;
+}
+int hobbit_elastic_open_begin(hobbit_ctx *ctx, size_t N, size_t B, int trs, const hobbit_F *h_x, int queries, hobbit_elastic_open **out) {
+    if (!out) return HOBBIT_EINVAL;
+    *out = nullptr;
+    if (trs <= 0 || ilog2_exact(B) < 0 || ilog2_exact((size_t)trs) < 0 || B % (size_t)trs || 2 * B / (size_t)trs != 4096 || 2 * trs > 4096)
+        return ctx->fail(HOBBIT_EINVAL, "elastic_open: needs trs = B/2^11 (4096-point row codes) and 2*trs <= 4096");
+    if (N % B || ilog2_exact(N / B) < 0 || queries <= 0 || !h_x) return ctx->fail(HOBBIT_EINVAL, "elastic_open: N/B must be a power of two");
+    hobbit_elastic_open *e = new hobbit_elastic_open();
+    e->ctx = ctx; e->N = N; e->B = B; e->K = N / B; e->trs = trs; e->queries = queries; e->cols = 4096; e->rows2 = (uint32_t)(2 * trs);
+    e->n_aggr = e->n_reply = 0; e->committed = false;
+    e->d_aggr = e->d_T = e->d_G = e->d_reply = e->d_encf = nullptr; e->d_lvf = nullptr; e->d_ucols = nullptr; e->d_pick = nullptr; e->d_nz = nullptr;
+    host_eq_table(cF(h_x), ilog2_exact(e->K), e->beta);                                                     // precompute_beta(x1, beta) (:638-643)
+    e->rv0 = fadd(fmake((uint64_t)random()), fmake((uint64_t)rand()));                                      // r_v[0] = generate_randomness(1)[0] (:645)
+    e->qc.resize(queries); e->qr.resize(queries);
+    for (int q = 0; q < queries; q++) { e->qc[q] = (uint32_t)(rand() % (long)e->cols); e->qr[q] = (uint32_t)(rand() % (long)e->rows2); }   // (:650-655)
+    e->ucols = e->qc; std::sort(e->ucols.begin(), e->ucols.end()); e->ucols.erase(std::unique(e->ucols.begin(), e->ucols.end()), e->ucols.end());
+    const size_t nc = e->ucols.size();
+    e->qci.resize(queries); std::vector<uint64_t> pick(queries);
+    for (int q = 0; q < queries; q++) {
+        e->qci[q] = (uint32_t)(std::lower_bound(e->ucols.begin(), e->ucols.end(), e->qc[q]) - e->ucols.begin());
+        pick[q] = (uint64_t)e->qci[q] * e->rows2 + e->qr[q];
+    }
+    bool ok = hipMalloc((void **)&e->d_aggr, B * sizeof(F)) == hipSuccess && hipMalloc((void **)&e->d_T, (size_t)trs * 4096 * sizeof(F)) == hipSuccess &&
+              hipMalloc((void **)&e->d_G, nc * e->rows2 * sizeof(F)) == hipSuccess && hipMalloc((void **)&e->d_reply, e->K * (size_t)queries * sizeof(F)) == hipSuccess &&
+              hipMalloc((void **)&e->d_encf, 2 * B * sizeof(F)) == hipSuccess && hipMalloc((void **)&e->d_lvf, 64 * (2 * B / 32)) == hipSuccess &&
+              hipMalloc((void **)&e->d_ucols, nc * 4) == hipSuccess && hipMalloc((void **)&e->d_pick, (size_t)queries * 8) == hipSuccess &&
+              hipMalloc((void **)&e->d_nz, e->K * sizeof(int)) == hipSuccess;
+    if (!ok) { hobbit_elastic_open_free(e); return ctx->fail(HOBBIT_ENOMEM, "elastic_open_begin: allocation failed"); }
+    HB_CHECK(ctx, hipMemsetAsync(e->d_aggr, 0, B * sizeof(F), ctx->stream));
+    HB_CHECK(ctx, hipMemsetAsync(e->d_nz, 0, e->K * sizeof(int), ctx->stream));
+    HB_CHECK(ctx, hipMemcpyAsync(e->d_ucols, e->ucols.data(), nc * 4, hipMemcpyHostToDevice, ctx->stream));
+    HB_CHECK(ctx, hipMemcpyAsync(e->d_pick, pick.data(), (size_t)queries * 8, hipMemcpyHostToDevice, ctx->stream));
+    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));                                                        // `pick` is a local
+    *out = e;
+    return 0;
+}
+int hobbit_elastic_open_aggregate_push(hobbit_ctx *ctx, hobbit_elastic_open *e, const hobbit_F *d_chunk) {
+    if (e->n_aggr >= e->K || e->committed) return ctx->fail(HOBBIT_ESTATE, "elastic_open: more aggregate chunks than N/B");
+    HB_TRY(launch_axpy(ctx, e->d_aggr, cF(d_chunk), e->beta[e->n_aggr], e->B));                             // aggregated_vector[j] += beta1[i]*buff[j] (:330-333)
+    e->n_aggr++;
+    return 0;
+}
+int hobbit_elastic_open_aggregate_finish(hobbit_ctx *ctx, hobbit_elastic_open *e) {
+    if (e->n_aggr != e->K) return ctx->fail(HOBBIT_ESTATE, "elastic_open: aggregate pass incomplete");
+    HB_TRY(hobbit_shockwave_commit(ctx, reinterpret_cast<hobbit_F *>(e->d_aggr), e->B, 32, reinterpret_cast<hobbit_F *>(e->d_encf), e->d_lvf));   // C_f (:343-346)
+    e->committed = true;
+    return 0;
+}
+int hobbit_elastic_open_reply_push(hobbit_ctx *ctx, hobbit_elastic_open *e, const hobbit_F *d_chunk) {
+    if (e->n_reply >= e->K) return ctx->fail(HOBBIT_ESTATE, "elastic_open: more reply chunks than N/B");
+    const size_t i = e->n_reply, half = e->B / (size_t)e->trs; const uint32_t nc = (uint32_t)e->ucols.size();
+    HB_TRY(launch_any_nonzero(ctx, cF(d_chunk), e->B, e->d_nz + i));                                        // an all-zero chunk appends nothing (:510-517)
+    // update_reply (:59-111): rows to twice their length, then each queried column (trs entries, zero-padded) to 2*trs, its queried row kept
+    HB_TRY(fft_rows(ctx, cF(d_chunk), half, (uint32_t)half, e->d_T, e->cols, 1, 12, false, 1, (uint32_t)e->trs, 0, 0));
+    HB_TRY(launch_gather_cols(ctx, e->d_T, e->cols, (uint32_t)e->trs, e->d_ucols, nc, e->d_G, e->rows2));
+    HB_TRY(fft_rows(ctx, e->d_G, e->rows2, (uint32_t)e->trs, e->d_G, e->rows2, 1, ilog2_exact(e->rows2), false, 1, nc, 0, 0));
+    HB_TRY(launch_gather_strided(ctx, e->d_G, e->d_pick, (size_t)e->queries, 1, 1, 0, e->d_reply + i * (size_t)e->queries));
+    e->n_reply++;
+    return 0;
+}
+int hobbit_elastic_open_finish(hobbit_ctx *ctx, hobbit_elastic_open *e, const uint8_t *d_commit_levels, hobbit_elastic_open_out *o) {
+    if (!o || !e->committed || e->n_reply != e->K) return ctx->fail(HOBBIT_ESTATE, "elastic_open_finish: the aggregate and reply passes must be complete");
+    const size_t B = e->B, trs = (size_t)e->trs, cols = e->cols, rows2 = e->rows2, half = B / trs, nq = (size_t)e->queries, nc = e->ucols.size();
+    const int logc = 12, logr = ilog2_exact(rows2), logt = logr - 1;
+    if (o->cols) memcpy(o->cols, e->qc.data(), 4 * nq);
+    if (o->rows) memcpy(o->rows, e->qr.data(), 4 * nq);
+    if (o->rv0) *mF(o->rv0) = e->rv0;
+    if (o->ncols) *o->ncols = (int)nc;
+    if (o->cf_root) HB_CHECK(ctx, hipMemcpyAsync(o->cf_root, e->d_lvf + 32 * (2 * (2 * B / 32) - 2), 32, hipMemcpyDeviceToHost, ctx->stream));
+    {   // replies: one entry per non-zero chunk, in stream order
+        std::vector<int> nz(e->K); std::vector<F> rep(e->K * nq);
+        HB_CHECK(ctx, hipMemcpyAsync(nz.data(), e->d_nz, e->K * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HB_CHECK(ctx, hipMemcpyAsync(rep.data(), e->d_reply, e->K * nq * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        size_t filled = 0;
+        for (size_t i = 0; i < e->K; i++) if (nz[i]) filled++;
+        if (o->reply) { size_t f = 0; for (size_t i = 0; i < e->K; i++) if (nz[i]) { for (size_t q = 0; q < nq; q++) mF(o->reply)[q * filled + f] = rep[i * nq + q]; f++; } }
+        if (o->reply_len) *o->reply_len = (int)filled;
+    }
+    if (o->paths && d_commit_levels) {                                                                      // open_tree_blake(Commitment_MT, I[i], 2B/trs) (:684-687)
+        std::vector<uint64_t> pos(nq);
+        for (size_t q = 0; q < nq; q++) pos[q] = (uint64_t)(e->qr[q] / 4) * cols + e->qc[q];
+        HB_TRY(paths_common(ctx, d_commit_levels, 4 * B, pos.data(), nq, o->paths));
+    }
+    // ---- recursive_prover_RS (src/PC_utils.cpp:396-512) ----
+    size_t np2 = 1; while (np2 < nc) np2 <<= 1;
+    const int R0 = ilog2_exact(np2 * rows2);
+    F *arena; HB_TRY(ctx->workspace3((2 * B + np2 * trs + 2 * np2 * rows2 + 2 * B + 4096 + 64) * sizeof(F), (void **)&arena));
+    F *out1 = arena, *sel = out1 + 2 * B, *out3 = sel + np2 * trs, *bt = out3 + np2 * rows2, *b2 = bt + np2 * rows2, *stage = b2 + 2 * B;
+    HB_TRY(fft_rows(ctx, e->d_aggr, half, (uint32_t)half, out1, cols, 1, logc, false, 1, (uint32_t)trs, 0, 0));                  // out_1 (:406-420)
+    HB_CHECK(ctx, hipMemsetAsync(sel, 0, (np2 * trs + 2 * np2 * rows2 + 2 * B) * sizeof(F), ctx->stream));                         // sel | out3 | bt | b2
+    HB_TRY(launch_gather_cols(ctx, out1, cols, (uint32_t)trs, e->d_ucols, (uint32_t)nc, sel, trs));                                // selected_collumns (:422-431)
+    HB_TRY(fft_rows(ctx, sel, trs, (uint32_t)trs, out3, rows2, 1, logr, false, 1, (uint32_t)nc, 0, 0));                            // out_3 (:436-452)
+    std::vector<F> rq(nq);
+    { F cst = fmake(0); for (size_t i = 0; i < nq; i++) { if (i % 100 == 0) cst = fmake((uint64_t)random()); rq[i] = fadd(cst, fmake((uint64_t)rand())); } }   // r = generate_randomness(I.size()) (:459)
+    {   // beta (:461-470): the sorted column walk is paired with the UNSORTED query rows, duplicates accumulate
+        std::vector<uint32_t> cs(e->qc); std::sort(cs.begin(), cs.end());
+        std::map<uint64_t, F> acc; size_t counter = 0;
+        for (size_t i = 0; i < nq; i++) {
+            if (e->ucols[counter] != cs[i]) counter++;
+            const uint64_t at = counter * rows2 + e->qr[i];
+            auto it = acc.find(at);
+            if (it == acc.end()) acc[at] = rq[i]; else it->second = fadd(it->second, rq[i]);
+        }
+        uint8_t *pin; HB_TRY(ctx->pinned(std::max(nq * (sizeof(F) + 8) + 64, (size_t)2048 * sizeof(F)), (void **)&pin));
+        F *pv = reinterpret_cast<F *>(pin); uint64_t *pi = reinterpret_cast<uint64_t *>(pin + nq * sizeof(F));
+        size_t n = 0; for (auto &kv : acc) { pi[n] = kv.first; pv[n] = kv.second; n++; }
+        F *dv = stage; uint64_t *di = reinterpret_cast<uint64_t *>(stage + nq);
+        if (2 * nq > 4096) return ctx->fail(HOBBIT_EINVAL, "elastic_open: too many queries for the staging area");
+        HB_CHECK(ctx, hipMemcpyAsync(dv, pv, n * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+        HB_CHECK(ctx, hipMemcpyAsync(di, pi, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        HB_TRY(launch_scatter(ctx, di, dv, n, bt));
+    }
+    hobbit_F p323 = {323, 0};
+    hobbit_F *Q = o->qpoly, *Rr = o->r;
+    HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(out3), reinterpret_cast<hobbit_F *>(bt), np2 * rows2, &p323, Q, Rr, o->vr, o->fin));          // P0 (:474)
+    const hobbit_F *r0 = Rr; Q += 3 * R0; Rr += R0;
+    HB_TRY(hobbit_prove_fft_matrix(ctx, reinterpret_cast<hobbit_F *>(sel), np2, trs, r0, Q, Rr, o->vr + 2, o->fin + 1));                                       // P2 (:480)
+    { const F *q2 = cF(Q); o->checks[0] = feq(fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])), cF(o->vr)[0]); }                                                   // src/sumcheck.cpp:3016-3019
+    const hobbit_F *r2 = Rr; Q += 3 * logr; Rr += logr;
+    // r_point: P2.randomness[0] (its logr sumcheck challenges, then r1 = P0.r[logr..]) from index log2(trs) on (:482-485)
+    std::vector<F> rpt; rpt.push_back(cF(r2)[logt]);
+    for (int i = logr; i < R0; i++) rpt.push_back(cF(r0)[i]);
+    std::vector<F> rb; host_eq_table(rpt.data(), (int)rpt.size(), rb);
+    {   // beta[collumns[i] + j*cols] = r[i] (:489-496)
+        uint8_t *pin; HB_TRY(ctx->pinned(2048 * sizeof(F), (void **)&pin));
+        if (nc > 2048) return ctx->fail(HOBBIT_EINVAL, "elastic_open: more than 2048 distinct columns");
+        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));                                    // (the staging buffer's previous contents have been consumed: sumcheck2 synchronised)
+        memcpy(pin, rb.data(), nc * sizeof(F));
+        HB_CHECK(ctx, hipMemcpyAsync(stage, pin, nc * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+        HB_TRY(launch_spread_cols(ctx, e->d_ucols, stage, (uint32_t)nc, (uint32_t)trs, cols, b2));
+    }
+    HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(out1), reinterpret_cast<hobbit_F *>(b2), trs * cols, &p323, Q, Rr, o->vr + 4, o->fin + 2));     // P3 (:498)
+    const hobbit_F *r3 = Rr; Q += 3 * (logt + logc); Rr += logt + logc;
+    HB_TRY(hobbit_prove_fft_matrix(ctx, reinterpret_cast<hobbit_F *>(e->d_aggr), trs, half, r3, Q, Rr, o->vr + 6, o->fin + 3));                               // P5 (:503)
+    { const F *q5 = cF(Q); o->checks[1] = feq(fadd(fadd(q5[0], q5[1]), fadd(q5[2], q5[2])), cF(o->vr)[4]); }
+    // r_x = P5.randomness[0]: its sumcheck challenges, then r1 = P3.r[logc .. logc + log2 trs) (src/sumcheck.cpp:3021-3023)
+    std::vector<hobbit_F> rx((size_t)logc + (size_t)logt);
+    memcpy(rx.data(), Rr, sizeof(hobbit_F) * (size_t)logc); memcpy(rx.data() + logc, r3 + logc, sizeof(hobbit_F) * (size_t)logt);
+    if (o->rx) memcpy(o->rx, rx.data(), sizeof(hobbit_F) * rx.size());
+    if (o->sp_f) HB_TRY(hobbit_shockwave_prove(ctx, reinterpret_cast<hobbit_F *>(e->d_aggr), reinterpret_cast<hobbit_F *>(e->d_encf), e->d_lvf, B, 32, rx.data(), (int)rx.size(), o->sp_f));   // (:507)
     return 0;
 }
 

@@ -1996,4 +1996,42 @@ int launch_sumcheck3(hobbit_ctx *ctx, const F *v1, const F *v2, const F *v3, siz
     return 0;
 }
 
+// ============================================================================================
+// Elastic_PC open helpers (src/Elastic_PC.cpp:59-111 update_reply, :510-517 zero-chunk test; src/PC_utils.cpp:422-496)
+// ============================================================================================
+// *flag |= (some element of v is non-zero)
+__global__ void k_any_nonzero(const F *__restrict__ v, size_t n, int *__restrict__ flag) {
+    int nz = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { const F a = ldF(v + i); nz |= (a.re | a.im) != 0; }
+    if (__any(nz) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+int launch_any_nonzero(hobbit_ctx *ctx, const F *v, size_t n, int *d_flag) {
+    HB_LAUNCH(ctx, "k_any_nonzero", k_any_nonzero, dim3(grid_for(n, 256, 1024)), dim3(256), 0, v, n, d_flag);
+    return 0;
+}
+// G[c*ldG + j] = T[j*ld + cols[c]], j < nrows: the queried columns of a row-major matrix, one per output row
+__global__ void k_gather_cols(const F *__restrict__ T, size_t ld, uint32_t nrows, const uint32_t *__restrict__ cols, uint32_t ncols, F *__restrict__ G, size_t ldG) {
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= (size_t)ncols * nrows) return;
+    const uint32_t c = (uint32_t)(t / nrows), j = (uint32_t)(t % nrows);
+    stF(G + (size_t)c * ldG + j, ldF(T + (size_t)j * ld + cols[c]));
+}
+int launch_gather_cols(hobbit_ctx *ctx, const F *T, size_t ld, uint32_t nrows, const uint32_t *d_cols, uint32_t ncols, F *G, size_t ldG) {
+    if (!ncols || !nrows) return 0;
+    HB_LAUNCH(ctx, "k_gather_cols", k_gather_cols, dim3((unsigned)(((size_t)ncols * nrows + 255) / 256)), dim3(256), 0, T, ld, nrows, d_cols, ncols, G, ldG);
+    return 0;
+}
+// out[cols[i] + j*ld] = vals[i], j < nrows: a column indicator weighted per column (recursive_prover_RS's second beta, src/PC_utils.cpp:489-496)
+__global__ void k_spread_cols(const uint32_t *__restrict__ cols, const F *__restrict__ vals, uint32_t ncols, uint32_t nrows, size_t ld, F *__restrict__ out) {
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= (size_t)ncols * nrows) return;
+    const uint32_t j = (uint32_t)(t / ncols), i = (uint32_t)(t % ncols);
+    stF(out + (size_t)j * ld + cols[i], ldF(vals + i));
+}
+int launch_spread_cols(hobbit_ctx *ctx, const uint32_t *d_cols, const F *d_vals, uint32_t ncols, uint32_t nrows, size_t ld, F *out) {
+    if (!ncols || !nrows) return 0;
+    HB_LAUNCH(ctx, "k_spread_cols", k_spread_cols, dim3((unsigned)(((size_t)ncols * nrows + 255) / 256)), dim3(256), 0, d_cols, d_vals, ncols, nrows, ld, out);
+    return 0;
+}
+
 }  // namespace hobbit

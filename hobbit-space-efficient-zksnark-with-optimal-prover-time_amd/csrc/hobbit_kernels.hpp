@@ -59,4 +59,7 @@ int launch_fill_F(hobbit_ctx *ctx, F *p, size_t stride, size_t n, F v);
 int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev_r, F *h_qpoly, F *h_r, F *h_vr, F *h_final);
 int launch_gate_sumcheck(hobbit_ctx *ctx, const F *const tabs[6], size_t n, const F *h_a, F *h_rand, F *h_sum, F *h_poly, F *h_r, F *h_final, int *h_check);
 int launch_sumcheck3(hobbit_ctx *ctx, const F *v1, const F *v2, const F *v3, size_t n, F prev_r, F *h_cpoly, F *h_r, F *h_vr, F *h_final);
+int launch_any_nonzero(hobbit_ctx *ctx, const F *v, size_t n, int *d_flag);
+int launch_gather_cols(hobbit_ctx *ctx, const F *T, size_t ld, uint32_t nrows, const uint32_t *d_cols, uint32_t ncols, F *G, size_t ldG);
+int launch_spread_cols(hobbit_ctx *ctx, const uint32_t *d_cols, const F *d_vals, uint32_t ncols, uint32_t nrows, size_t ld, F *out);
 }  // namespace hobbit

@@ -38,6 +38,7 @@ extern "C" {
 typedef struct hobbit_ctx hobbit_ctx;
 typedef struct hobbit_commitment hobbit_commitment;
 typedef struct hobbit_elastic hobbit_elastic;
+typedef struct hobbit_elastic_open hobbit_elastic_open;
 typedef struct { uint64_t re, im; } hobbit_F;
 
 /* ---- context, memory, timing ------------------------------------------------------------- */
@@ -67,6 +68,9 @@ int hobbit_profile_names(hobbit_ctx *ctx, char *buf, size_t buflen); /* ';'-sepa
 void hobbit_mimc(const hobbit_F *x, const hobbit_F *k, hobbit_F *out);           /* mimc_hash */
 void hobbit_f_mul_host(const hobbit_F *a, const hobbit_F *b, hobbit_F *out, size_t n);
 void hobbit_f_inv_host(const hobbit_F *a, hobbit_F *out, size_t n);
+/* generate_randomness (src/utils.cpp:873-883), host side, on the process-wide libc generator: every 100 elements c = random(),
+ * element = F(c) + F(rand()) */
+void hobbit_generate_randomness(size_t n, hobbit_F *h_out);
 /* element-wise device ops (test surface for the device field arithmetic): op 0 add, 1 sub, 2 mul */
 int hobbit_f_binop(hobbit_ctx *ctx, int op, const hobbit_F *d_a, const hobbit_F *d_b, hobbit_F *d_out, size_t n);
 
@@ -240,6 +244,41 @@ int hobbit_open_standard(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, cons
  * gathered from the ranks' tensor shards, paths from their subtrees).  The evaluation point is not needed: only its chunk variables enter
  * the opening, through the aggregate. */
 int hobbit_open_from_aggregate(hobbit_ctx *ctx, const hobbit_F *d_aggr, size_t M, int K, int trs, int queries, hobbit_open_out *out);
+
+/* ---- Elastic_PC open, RS x RS (src/Elastic_PC.cpp:625-726 open; test_Elastic_PC option 1) ------------------- */
+/* The reference streams the data three times: commit, aggregate (:316-347) and compute_aggregation_reply (:487-533).  As in the
+ * commit the stream stays with the host and every B-element chunk arrives as a device buffer, in stream order, once per pass.
+ *   begin            : beta over the chunk variables (h_x[0 .. log2(N/B))), then the libc draws in the reference's order:
+ *                      r_v[0] (generate_randomness(1)), `queries` x (rand() % cols, rand() % 2trs)            (:638-655)
+ *   aggregate_push   : aggr += beta[i] * chunk_i                                                               (:327-334)
+ *   aggregate_finish : C_f = shockwave_commit(aggr, 32)                                                        (:343-346)
+ *   reply_push       : update_reply (:59-111): rows RS-encoded, each queried column RS-encoded, the queried entry appended to
+ *                      that query's reply; an all-zero chunk appends nothing (:510-517)
+ *   finish           : replies, Merkle paths (open_tree_blake(Commitment_MT, I[i], 2B/trs), :684-687; d_commit_levels = the
+ *                      (8B-1) x 32 B tree hobbit_elastic_finish wrote, or NULL), then recursive_prover_RS
+ *                      (src/PC_utils.cpp:396-512): P0, P2 = prove_fft_matrix, P3, P5 = prove_fft_matrix, shockwave_prove(C_f, r_x).
+ * Only trs = B/2^11 (4096-point row codes) with linear_time = false is built: option 2's update_reply_spielman (:431-485) reads
+ * past a vector in the reference (rows >= tensor_row_size index a tensor_row_size-long copy, :465-478) and has no defined result.
+ * The MT_commit_Blake over every reply (:677-680) and verify_claim_opt_blake are verifier-side accounting whose results are
+ * discarded; they are not run.
+ * All hobbit_elastic_open_out pointers are host buffers (NULL = not wanted, except qpoly/r/vr/fin/checks):
+ *   cols, rows : queries x u32;  rv0 : 1 F;  reply : queries x reply_len F (reply_len = non-zero chunks <= N/B);
+ *   paths : queries x log2(4B) x 32 B;  cf_root : 32 B;  ncols : distinct queried columns;
+ *   qpoly / r : P0, P2, P3, P5 back to back, rounds log2(np2 * 2trs), log2(2trs), log2(2B), 12 (np2 = ncols rounded up to a
+ *               power of two);  vr : 4 x 2 F;  fin : 4 F;
+ *   checks[2] : prove_fft_matrix's exit(-1) sum checks for P2 and P5 (src/sumcheck.cpp:3016-3019), 1 = holds;
+ *   rx : r_x = P5.randomness[0], 12 + log2(trs) F;  sp_f : transcript of shockwave_prove(C_f, r_x) (NULL: not run). */
+typedef struct {
+    uint32_t *cols, *rows; hobbit_F *rv0; hobbit_F *reply; int *reply_len; uint8_t *paths; uint8_t *cf_root; int *ncols;
+    hobbit_F *qpoly, *r, *vr, *fin; int *checks; hobbit_F *rx;
+    hobbit_shockwave_out *sp_f;
+} hobbit_elastic_open_out;
+int hobbit_elastic_open_begin(hobbit_ctx *ctx, size_t N, size_t B, int trs, const hobbit_F *h_x, int queries, hobbit_elastic_open **out);
+int hobbit_elastic_open_aggregate_push(hobbit_ctx *ctx, hobbit_elastic_open *e, const hobbit_F *d_chunk);
+int hobbit_elastic_open_aggregate_finish(hobbit_ctx *ctx, hobbit_elastic_open *e);
+int hobbit_elastic_open_reply_push(hobbit_ctx *ctx, hobbit_elastic_open *e, const hobbit_F *d_chunk);
+int hobbit_elastic_open_finish(hobbit_ctx *ctx, hobbit_elastic_open *e, const uint8_t *d_commit_levels, hobbit_elastic_open_out *out);
+void hobbit_elastic_open_free(hobbit_elastic_open *e);
 
 /* ---- sumchecks ----------------------------------------------------------------------------- */
 /* generate_2product_sumcheck_proof (src/sumcheck.cpp:2391-2460).  Inputs preserved.

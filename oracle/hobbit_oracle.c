@@ -1176,6 +1176,140 @@ size_t orc_elastic_commit(size_t N, size_t B, int opt, uint8_t *levels_out) {
     return create_tree(levels_out, T);
 }
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* Elastic_PC open, RS x RS (test_Elastic_PC option 1): src/Elastic_PC.cpp:625-726 with         */
+/* aggregate (:316-347), compute_aggregation_reply + update_reply (:487-533, 59-111) and          */
+/* recursive_prover_RS (src/PC_utils.cpp:396-512) up to its closing shockwave_prove(C_f, r_x),     */
+/* which the caller composes (orc_shockwave_prove_ex) with the libc generator running on.         */
+/* Passes 2 and 3 read the stream through read_stream, whose default branch serves the "test"     */
+/* descriptor: v[i] = F(i % 1024 + 1) (src/witness_stream.cpp:2348-2352), every chunk alike.       */
+/* Option 2 (RS x expander) is NOT restated: update_reply_spielman (:431-485) indexes a            */
+/* tensor_row_size-long copy of the un-encoded column with rows >= tensor_row_size (:465-478),     */
+/* a read past the vector -- there is no defined result to be bit-exact with.                      */
+/* ------------------------------------------------------------------------------------------ */
+void orc_read_stream(size_t B, oF *out) { for (size_t i = 0; i < B; i++) out[i] = fint((uint64_t)(i % 1024) + 1); }
+
+void orc_elastic_aggregate(size_t N, size_t B, const oF *beta, oF *aggr_out, uint8_t *cf_root) {
+    oF *buff = (oF *)malloc(sizeof(oF) * B);
+    memset(aggr_out, 0, sizeof(oF) * B);
+    for (size_t i = 0; i < N / B; i++) {                 /* :327-334 */
+        orc_read_stream(B, buff);
+        for (size_t j = 0; j < B; j++) aggr_out[j] = f_add(aggr_out[j], f_mul(beta[i], buff[j]));
+    }
+    if (cf_root) {                                       /* C_f = shockwave_commit(buff = aggr, 32) (:343-346) */
+        oF *enc = (oF *)malloc(sizeof(oF) * 2 * B); uint8_t *lv = (uint8_t *)malloc(64 * (2 * B / 32) * 2);
+        size_t cnt = orc_shockwave_commit(aggr_out, B, 32, enc, lv); memcpy(cf_root, lv + 32 * (cnt - 1), 32);
+        free(enc); free(lv);
+    }
+    free(buff);
+}
+/* update_reply (:59-111, !linear_time): rows FFT'd to twice their length, then per query the queried column (tensor_row_size entries,
+ * zero-padded to twice that) is transformed and its queried row appended.  A chunk that is all zero is skipped (:510-517): nothing is
+ * appended for it.  reply: nq x (N/B) row-major; returns the number of entries appended per query. */
+size_t orc_elastic_reply(size_t N, size_t B, const uint64_t *Iq, size_t nq, oF *reply) {
+    const size_t trs = B >> 11, half = B / trs, cols = 2 * half, K = N / B;
+    const int logc = (int)log2((double)cols), logr = (int)log2((double)(2 * trs));
+    oF *buff = (oF *)malloc(sizeof(oF) * B), *T = (oF *)malloc(sizeof(oF) * trs * cols), *col = (oF *)malloc(sizeof(oF) * 2 * trs);
+    size_t filled = 0;
+    for (size_t i = 0; i < K; i++) {
+        orc_read_stream(B, buff);
+        int nz = 0;
+        for (size_t j = 0; j < B; j++) if (!fis0(buff[j])) { nz = 1; break; }
+        if (!nz) continue;
+        memset(T, 0, sizeof(oF) * trs * cols);
+        for (size_t r = 0; r < trs; r++) { memcpy(T + r * cols, buff + r * half, sizeof(oF) * half); orc_fft_cached(T + r * cols, logc, 0); }
+        for (size_t q = 0; q < nq; q++) {
+            memset(col, 0, sizeof(oF) * 2 * trs);
+            for (size_t r = 0; r < trs; r++) col[r] = T[r * cols + Iq[2 * q]];
+            orc_fft(col, logr, 0);
+            reply[q * K + filled] = col[Iq[2 * q + 1]];
+        }
+        filled++;
+    }
+    free(buff); free(T); free(col);
+    return filled;
+}
+static int cmp_sz(const void *a, const void *b) { size_t x = *(const size_t *)a, y = *(const size_t *)b; return x < y ? -1 : x > y; }
+static size_t next_pow2(size_t l) { size_t p = 1; while (p < l) p <<= 1; return p; }
+/* qpoly / r_out / vr / fin hold P0, P2, P3, P5 back to back (rounds R0 = log2(np2 * 2trs), log2(2trs), log2(2B), 12); rx = P5.randomness.
+ * checks[0]: P2's claimed sum == P0.vr[0]; checks[1]: P5's == P3.vr[0] (prove_fft_matrix's own exit(-1) tests, src/sumcheck.c:3016-3019).
+ * commit_levels: the commitment tree (4B leaves) or NULL; paths: queries x log2(4B) hashes. */
+int orc_elastic_open_rs(size_t N, size_t B, const oF *x, int queries, const uint8_t *commit_levels, uint32_t *I_out, oF *rv0_out, oF *aggr_out, uint8_t *cf_root,
+                        oF *reply_out, uint8_t *paths_out, int *ncols_out, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks, oF *rx_out) {
+    const size_t trs = B >> 11, half = B / trs, cols = 2 * half, rows2 = 2 * trs, K = N / B;
+    const int logK = (int)log2((double)K), logc = (int)log2((double)cols), logr = (int)log2((double)rows2), logt = (int)log2((double)trs);
+    /* open (:625-655): beta over the chunk variables, r_v[0], the queries */
+    oF *beta = (oF *)malloc(sizeof(oF) * K);
+    orc_precompute_beta(x, logK, beta);
+    orc_generate_randomness(1, rv0_out);
+    uint64_t *Iq = (uint64_t *)malloc(sizeof(uint64_t) * 2 * (size_t)queries);
+    for (int q = 0; q < queries; q++) {
+        Iq[2 * q] = (uint64_t)(rand() % (long)cols); Iq[2 * q + 1] = (uint64_t)(rand() % (long)rows2);
+        I_out[2 * q] = (uint32_t)Iq[2 * q]; I_out[2 * q + 1] = (uint32_t)Iq[2 * q + 1];
+    }
+    orc_elastic_aggregate(N, B, beta, aggr_out, cf_root);
+    if (reply_out) orc_elastic_reply(N, B, Iq, (size_t)queries, reply_out);
+    if (commit_levels && paths_out) {                     /* open_tree_blake(Commitment_MT, I[i], 2B/trs) (:684-687) */
+        const int depth = (int)log2((double)(4 * B));
+        for (int q = 0; q < queries; q++) orc_open_tree_blake(commit_levels, 4 * B, Iq[2 * q], Iq[2 * q + 1], cols, paths_out + (size_t)q * depth * 32);
+    }
+    /* recursive_prover_RS (src/PC_utils.cpp:396-512) */
+    size_t *cs = (size_t *)malloc(sizeof(size_t) * (size_t)queries);
+    for (int q = 0; q < queries; q++) cs[q] = Iq[2 * q];
+    qsort(cs, (size_t)queries, sizeof(size_t), cmp_sz);                       /* I_sorted's first entries / I_t (:128-142) */
+    size_t *col = (size_t *)malloc(sizeof(size_t) * (size_t)queries), nc = 0;
+    for (int q = 0; q < queries; q++) if (q == 0 || cs[q] != cs[q - 1]) col[nc++] = cs[q];
+    const size_t np2 = next_pow2(nc);
+    if (ncols_out) *ncols_out = (int)nc;
+    oF *out1 = (oF *)calloc(trs * cols, sizeof(oF));                          /* rows of the aggregate, RS-encoded (:406-420) */
+    for (size_t i = 0; i < trs; i++) { memcpy(out1 + i * cols, aggr_out + i * half, sizeof(oF) * half); orc_fft_cached(out1 + i * cols, logc, 0); }
+    oF *sel = (oF *)calloc(np2 * trs, sizeof(oF)), *out3 = (oF *)calloc(np2 * rows2, sizeof(oF));
+    for (size_t i = 0; i < nc; i++) {                                         /* selected columns and their codewords (:422-452) */
+        for (size_t j = 0; j < trs; j++) { sel[i * trs + j] = out1[j * cols + col[i]]; out3[i * rows2 + j] = sel[i * trs + j]; }
+        orc_fft_cached(out3 + i * rows2, logr, 0);
+    }
+    oF *bt = (oF *)calloc(np2 * rows2, sizeof(oF));
+    oF *rq = (oF *)malloc(sizeof(oF) * (size_t)queries);
+    orc_generate_randomness(queries, rq);                                     /* (:459) */
+    {   size_t counter = 0;                                                   /* (:461-470): the sorted column walk indexes the UNSORTED rows */
+        for (int i = 0; i < queries; i++) {
+            if (col[counter] != cs[i]) counter++;
+            const size_t at = counter * rows2 + Iq[2 * i + 1];
+            bt[at] = f_add(bt[at], rq[i]);
+        } }
+    const int R0 = (int)log2((double)(np2 * rows2));
+    oF p323 = fint(323);
+    size_t qo = 0, ro = 0;
+    oF *q0 = qpoly, *r0 = r_out;
+    orc_sumcheck2(out3, bt, np2 * rows2, &p323, q0, r0, vr, fin);             /* P0 (:474) */
+    qo += 3 * (size_t)R0; ro += (size_t)R0;
+    oF *q2 = qpoly + qo, *r2 = r_out + ro;
+    orc_prove_fft_matrix(sel, np2, trs, r0, q2, r2, vr + 2, fin + 1);        /* P2 (:480) */
+    { oF c = f_add(f_add(q2[0], q2[1]), f_add(q2[2], q2[2])); checks[0] = (c.re == vr[0].re && c.im == vr[0].im); }
+    qo += 3 * (size_t)logr; ro += (size_t)logr;
+    /* P2.randomness[0] = sumcheck challenges (logr) | r1 = P0.r[logr ..]; r_point = entries from index log2(trs) on (:482-485) */
+    const int np = 1 + (R0 - logr);
+    oF *rpt = (oF *)malloc(sizeof(oF) * (size_t)np);
+    rpt[0] = r2[logt];
+    for (int i = 0; i < R0 - logr; i++) rpt[1 + i] = r0[logr + i];
+    oF *rb = (oF *)malloc(sizeof(oF) * ((size_t)1 << np));
+    orc_precompute_beta(rpt, np, rb);
+    oF *b2 = (oF *)calloc(trs * cols, sizeof(oF));                            /* (:489-496) */
+    for (size_t i = 0; i < nc; i++) for (size_t j = 0; j < trs; j++) b2[col[i] + j * cols] = rb[i];
+    oF *q3 = qpoly + qo, *r3 = r_out + ro;
+    orc_sumcheck2(out1, b2, trs * cols, &p323, q3, r3, vr + 4, fin + 2);      /* P3 (:498) */
+    qo += 3 * (size_t)(logt + logc); ro += (size_t)(logt + logc);
+    oF *q5 = qpoly + qo, *r5 = r_out + ro;
+    orc_prove_fft_matrix(aggr_out, trs, half, r3, q5, r5, vr + 6, fin + 3);  /* P5 (:503) */
+    { oF c = f_add(f_add(q5[0], q5[1]), f_add(q5[2], q5[2])); checks[1] = (c.re == vr[4].re && c.im == vr[4].im); }
+    /* r_x = P5.randomness[0] = its sumcheck challenges (logc) followed by r1 = P3.r[logc .. logc + log2 trs) (src/sumcheck.cpp:3021-3023) */
+    memcpy(rx_out, r5, sizeof(oF) * (size_t)logc);
+    memcpy(rx_out + logc, r3 + logc, sizeof(oF) * (size_t)logt);
+    free(beta); free(Iq); free(cs); free(col); free(out1); free(sel); free(out3); free(bt); free(rq); free(rpt); free(rb); free(b2);
+    return R0 + logr + (logt + logc) + logc;
+}
+
 /* test_PC(N, 4, K) inputs (src/Our_PC.cpp:757-813) + timed commit_standard */
 double orc_time_commit_standard(size_t N, int K) {
     srandom(1);

@@ -121,6 +121,13 @@ int orc_open_core_aggr(const oF *aggr, size_t M, int K, int trs, int queries, ui
 void orc_read_stream_pc(size_t B, oF *out);
 size_t orc_elastic_commit(size_t N, size_t B, int opt, uint8_t *levels_out);
 
+/* Elastic_PC open, RS x RS (option 1; option 2's update_reply_spielman is undefined behaviour in the reference, see hobbit_oracle.c) */
+void orc_read_stream(size_t B, oF *out);
+void orc_elastic_aggregate(size_t N, size_t B, const oF *beta, oF *aggr_out, uint8_t *cf_root);
+size_t orc_elastic_reply(size_t N, size_t B, const uint64_t *Iq, size_t nq, oF *reply);
+int orc_elastic_open_rs(size_t N, size_t B, const oF *x, int queries, const uint8_t *commit_levels, uint32_t *I_out, oF *rv0_out, oF *aggr_out, uint8_t *cf_root,
+                        oF *reply_out, uint8_t *paths_out, int *ncols_out, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks, oF *rx_out);
+
 /* cpu_baseline helper: generate test_PC's inputs and time commit_standard (seconds) */
 double orc_time_commit_standard(size_t N, int K);
 

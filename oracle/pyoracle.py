@@ -326,6 +326,25 @@ class _Base:
         return o[:cnt]
 
 
+
+    # ---- Elastic_PC open, RS x RS: stream passes 2 and 3 (src/Elastic_PC.cpp:316-347, 487-533)
+    def read_stream(self, B):
+        o = np.zeros((B, 2), np.uint64)
+        self.fn("read_stream")(c_sz(B), _p(o))
+        return o
+
+    def elastic_aggregate(self, N, B, beta):
+        b = F(beta).reshape(-1, 2)
+        aggr = np.zeros((B, 2), np.uint64); root = np.zeros(32, np.uint8)
+        self.fn("elastic_aggregate")(c_sz(N), c_sz(B), _p(b), _p(aggr), _p(root))
+        return aggr, root
+
+    def elastic_reply(self, N, B, I):
+        Iq = np.ascontiguousarray(I, np.uint64).reshape(-1, 2)
+        reply = np.zeros((Iq.shape[0], N // B, 2), np.uint64)
+        self.fn("elastic_reply")(c_sz(N), c_sz(B), _p(Iq), c_sz(Iq.shape[0]), _p(reply))
+        return reply
+
 class Oracle(_Base):
     pfx = "orc_"
 
@@ -439,6 +458,38 @@ class Oracle(_Base):
         enc_f, lv_f = self.shockwave_commit(aggr, 32)
         x5 = np.concatenate([r5, r4[logc:logc + R1 - 1]])[:-1]
         res["sp_f"] = self.shockwave_prove(aggr, enc_f, 32, x5, lv_f)
+        return res
+
+
+    def aggregate_roots(self, poly, beta, trs):
+        """_aggregate (src/Our_PC.cpp:258-289): the aggregate and the roots of C_f / C_c"""
+        aggr = self.aggregate(poly, beta)
+        M = aggr.shape[0]; cols = 2 * M // trs
+        C = self.compute_tensorcode(aggr, trs, 1).reshape(2 * trs, cols, 2)[trs:].reshape(-1, 2)
+        return aggr, np.stack([self.shockwave_commit(aggr, 32)[1][-1], self.shockwave_commit(C, 32)[1][-1]])
+
+    def elastic_open(self, N, B, x, queries=700, commit_levels=None, want_reply=True):
+        """Prover side of Elastic_PC::open, option 1 (src/Elastic_PC.cpp:625-726): orc_elastic_open_rs, then shockwave_prove(C_f, r_x)
+        (src/PC_utils.cpp:507) with the libc generator running on, as Oracle.open_standard does for Our_PC."""
+        x = F(x).reshape(-1, 2)
+        trs = B >> 11; cols = 2 * B // trs; K = N // B
+        logc = cols.bit_length() - 1; logr = (2 * trs).bit_length() - 1; logt = trs.bit_length() - 1
+        maxr = (1024 * 2 * trs).bit_length() - 1 + logr + (logt + logc) + logc
+        I = np.zeros((queries, 2), np.uint32); rv0 = np.zeros(2, np.uint64); aggr = np.zeros((B, 2), np.uint64); root = np.zeros(32, np.uint8)
+        reply = np.zeros((queries, K, 2), np.uint64) if want_reply else None
+        depth = (4 * B).bit_length() - 1
+        lv = np.ascontiguousarray(commit_levels, np.uint8) if commit_levels is not None else None
+        paths = np.zeros((queries, depth, 32), np.uint8) if lv is not None else None
+        nc = ctypes.c_int()
+        q = np.zeros((maxr, 3, 2), np.uint64); r = np.zeros((maxr, 2), np.uint64); vr = np.zeros((4, 2, 2), np.uint64); fin = np.zeros((4, 2), np.uint64)
+        chk = np.zeros(2, np.int32); rx = np.zeros((logc + logt, 2), np.uint64)
+        f = self.lib.orc_elastic_open_rs; f.restype = ctypes.c_int
+        rounds = f(c_sz(N), c_sz(B), _p(x), ctypes.c_int(queries), _p(lv) if lv is not None else None, _p(I), _p(rv0), _p(aggr), _p(root),
+                   _p(reply) if reply is not None else None, _p(paths) if paths is not None else None, ctypes.byref(nc), _p(q), _p(r), _p(vr), _p(fin), _p(chk), _p(rx))
+        res = dict(I=I, rv0=rv0, aggr=aggr, cf_root=root, reply=reply, paths=paths, ncols=np.array([nc.value]), poly=q[:rounds], r=r[:rounds], vr=vr, fin=fin,
+                   checks=chk, rx=rx)
+        enc_f, lv_f = self.shockwave_commit(aggr, 32)
+        res["sp_f"] = self.shockwave_prove(aggr, enc_f, 32, rx, lv_f)
         return res
 
     class _WQ(ctypes.Structure):
@@ -630,6 +681,14 @@ class Ref(_Base):
         self.lib.ref_aggregate(_p(p), c_sz(p.shape[0]), _p(b), ctypes.c_int(K), ctypes.c_int(trs), ctypes.c_int(lin), _p(o))
         return o
 
+
+
+    def aggregate_roots(self, poly, beta, trs):
+        p = F(poly).reshape(-1, 2); b = F(beta).reshape(-1, 2)
+        K = b.shape[0]
+        o = np.zeros((p.shape[0] // K, 2), np.uint64); roots = np.zeros((2, 32), np.uint8)
+        self.lib.ref_aggregate_roots(_p(p), c_sz(p.shape[0]), _p(b), ctypes.c_int(K), ctypes.c_int(trs), _p(o), _p(roots))
+        return o, roots
 
     def prove_linear_code(self, codeword, n, seed):
         """returns (r1 the reference drew from the libc generator seeded with `seed`, proof)"""

@@ -43,6 +43,13 @@ void batch_prod(vector<vector<F>> &fold_buff1, vector<vector<F>> &fold_buff2, ve
                 vector<vector<F>> &remaining_betas, vector<F> a, int i, double &vt, double &ps);                                            // :1093
 struct proof batch_3product_sumcheck(vector<vector<F>> &arr1, vector<vector<F>> &arr2, vector<vector<F>> &arr3, vector<F> a, double &vt, double &ps);   // :275
 
+// src/Elastic_PC.cpp:315, 316, 487: the query list is a file-scope global there; aggregate / compute_aggregation_reply are not in the header
+extern vector<vector<size_t>> I;
+extern int aggregation_queries;                                                                                                              // src/Elastic_PC.cpp:10
+void aggregate(stream_descriptor fd, vector<F> beta1, vector<F> random_points, vector<vector<_hash>> &MT_hashes, vector<F> &aggregated_vector,
+               vector<vector<F>> &aggregated_tensor);                                                                                        // src/Elastic_PC.cpp:316
+void compute_aggregation_reply(stream_descriptor fd, vector<vector<size_t>> &I, vector<vector<F>> &reply);                                  // src/Elastic_PC.cpp:487
+
 static_assert(sizeof(F) == 16, "fieldElement must be 16 bytes");
 static_assert(sizeof(_hash) == 32, "_hash must be 32 bytes");
 
@@ -186,6 +193,21 @@ void ref_compute_aggregation_reply(const uint64_t *I, size_t nq, int K, uint64_t
 }
 void ref_release_commit(void) { g_MT.clear(); g_MT.shrink_to_fit(); g_tensor.clear(); g_tensor.shrink_to_fit(); }
 
+
+// test_PC(N,4,K)'s commitment from a fresh-process generator state, run entirely inside the library (no numpy copy of a
+// 4 GiB polynomial): srandom(1); poly = generate_randomness(N); expander_init_store(N/(K*2^11)); commit_standard
+// (src/Our_PC.cpp:757-816).  Leaves g_MT / g_tensor alive for ref_open_tree_blake / ref_tensor_get.
+size_t ref_test_pc_commit(size_t N, int K, uint8_t *levels_out) {
+    srandom(1);
+    vector<F> poly = generate_randomness((int)N);
+    linear_time = true; tensor_row_size = (int)(N / ((size_t)K << 11));
+    __encode_initialized = false;
+    expander_init_store(tensor_row_size);
+    _hash comm; g_MT.clear(); g_tensor.clear();
+    commit_standard(poly, comm, g_MT, g_tensor, K);
+    return flatten_levels(g_MT, levels_out);
+}
+
 // aggregation axpy only (src/Our_PC.cpp:258-272): aggr[j] = sum_i beta[i]*poly[i*M+j].
 // The reference function continues into shockwave_commit; we call the real function and free
 // what it allocates.
@@ -196,6 +218,18 @@ void ref_aggregate(const uint64_t *poly, size_t N, const uint64_t *beta, int K, 
     memcpy(aggr_out, aggr.data(), 16 * aggr.size());
     delete C_f; C_f = nullptr;
     if (linear_time) { delete C_c; C_c = nullptr; }
+}
+
+
+// _aggregate as above, also handing back the roots of the two inner commitments it makes (src/Our_PC.cpp:274-287):
+// roots[0..32) = C_f (shockwave_commit(aggr, 32)), roots[32..64) = C_c (shockwave_commit(parity half of the aggregate's tensor code, 32)).
+void ref_aggregate_roots(const uint64_t *poly, size_t N, const uint64_t *beta, int K, int trs, uint64_t *aggr_out, uint8_t *roots) {
+    tensor_row_size = trs; linear_time = true;
+    vector<F> p = vecF(poly, N), b = vecF(beta, K), rv(K, F(1)), aggr; vector<vector<F>> at;
+    _aggregate(p, b, rv, aggr, at, true, K);
+    memcpy(aggr_out, aggr.data(), 16 * aggr.size());
+    memcpy(roots, C_f->MT.back()[0].arr, 32); memcpy(roots + 32, C_c->MT.back()[0].arr, 32);
+    delete C_f; C_f = nullptr; delete C_c; C_c = nullptr;
 }
 
 // ---- sumchecks (src/sumcheck.cpp:2391-2460, 1974-2058) ------------------------------------------
@@ -377,6 +411,37 @@ void ref_read_stream_pc(size_t N, size_t B, size_t chunk_idx, uint64_t *out) {
     vector<F> buf(B);
     for (size_t i = 0; i <= chunk_idx; i++) read_stream_PC(fd, buf.data(), (int)B);
     memcpy(out, buf.data(), 16 * B);
+}
+
+
+// ---- Elastic_PC open, RS x RS (opt 1): the two stream passes that do not reach SHA3 (src/Elastic_PC.cpp:316-347, 487-533, 59-111) ----
+// read_stream's default branch (src/witness_stream.cpp:2348-2352) serves the "test" descriptor: v[i] = F(i % 1024 + 1), every chunk alike.
+void ref_read_stream(size_t B, uint64_t *out) {
+    stream_descriptor fd; fd.name = "test"; fd.size = B; fd.pos = 0;
+    vector<F> buf(B); read_stream(fd, buf, (int)B);
+    memcpy(out, buf.data(), 16 * B);
+}
+// aggregate() with linear_time = false: aggr[j] = sum_i beta[i] * chunk_i[j], then C_f = shockwave_commit(aggr, 32) (root handed back).
+void ref_elastic_aggregate(size_t N, size_t B, const uint64_t *beta, uint64_t *aggr_out, uint8_t *cf_root) {
+    BUFFER_SPACE = B; linear_time = false; tensor_row_size = (int)(B >> 11);
+    stream_descriptor fd; fd.name = "test"; fd.size = N; fd.pos = 0;
+    size_t K = N / B;
+    vector<F> b = vecF(beta, K), rv(K, F(1)), aggr; vector<vector<F>> at; vector<vector<_hash>> MT;
+    aggregate(fd, b, rv, MT, aggr, at);
+    memcpy(aggr_out, aggr.data(), 16 * aggr.size());
+    memcpy(cf_root, C_f->MT.back()[0].arr, 32);
+    delete C_f; C_f = nullptr;
+}
+// compute_aggregation_reply() with linear_time = false (update_reply): Iq = nq x (col, row); reply: nq x (N/B) (every chunk of the
+// "test" stream is non-zero, so no chunk is skipped).
+void ref_elastic_reply(size_t N, size_t B, const uint64_t *Iq, size_t nq, uint64_t *reply) {
+    BUFFER_SPACE = B; linear_time = false; tensor_row_size = (int)(B >> 11); aggregation_queries = (int)nq;
+    stream_descriptor fd; fd.name = "test"; fd.size = N; fd.pos = 0;
+    vector<vector<size_t>> II(nq); for (size_t q = 0; q < nq; q++) II[q] = {(size_t)Iq[2 * q], (size_t)Iq[2 * q + 1]};
+    vector<vector<F>> r;
+    compute_aggregation_reply(fd, II, r);
+    size_t K = N / B;
+    for (size_t q = 0; q < nq; q++) memcpy(reply + 2 * q * K, r[q].data(), 16 * r[q].size());
 }
 
 // whole-driver timing hook for bench.py's cpu_baseline ("reference" kind): commit only.

@@ -188,6 +188,12 @@ def case_commit(lib):
         out[key + "paths"] = np.stack(paths)
         if lib.__class__.__name__ == "Ref":
             lib.release_commit()
+        if K == 32:
+            # _aggregate (src/Our_PC.cpp:258-289) on test_PC's own evaluation point (drawn after the commit, :822): the aggregate and
+            # the roots of its two inner commitments C_f, C_c
+            x = lib.generate_randomness(N.bit_length() - 1)
+            aggr, roots = lib.aggregate_roots(poly, lib.precompute_beta(x[:5]), trs)
+            out[key + "aggr_dg"] = dg(aggr); out[key + "cfcc"] = roots
     # full-range polynomial (img != 0 everywhere), 2^18 / K=32 and RSxRS (linear_time=false, trs=4)
     poly = splitmix_field(1 << 18, 77)
     for lin in (0, 1):
@@ -236,6 +242,44 @@ def case_elastic(lib):
         out["el_%d_root" % opt] = lv[-1].copy()
         out["el_%d_leaves_dg" % opt] = dg(lv[:T - 1])
         out["el_%d_upper_dg" % opt] = dg(lv[T:])
+    return out
+
+
+ELASTIC_OPEN_CASES = ((1 << 18, 1 << 14), (1 << 19, 1 << 16))
+
+
+def elastic_open_inputs(N, B, nq=700, seed=901):
+    """Elastic_PC::open's own draws (src/Elastic_PC.cpp:645-655) from a seeded libc generator: x (splitmix), then r_v[0] =
+    generate_randomness(1) (one random(), one rand()), then nq x (rand() % cols, rand() % 2trs).  Returns (x, I)."""
+    import ctypes
+    libc = ctypes.CDLL(None); libc.random.restype = ctypes.c_long
+    trs = B >> 11; cols = 2 * B // trs
+    x = splitmix_field(N.bit_length() - 1, 900)
+    libc.srandom(seed); libc.random(); libc.rand()
+    I = np.zeros((nq, 2), np.uint64)
+    for q in range(nq):
+        I[q, 0] = libc.rand() % cols; I[q, 1] = libc.rand() % (2 * trs)
+    return x, I
+
+
+def elastic_open_queries(B, nq, seed):
+    trs = B >> 11
+    return np.random.default_rng(seed).integers(0, [2 * B // trs, 2 * trs], (nq, 2)).astype(np.uint64)
+
+
+def case_elastic_open(lib):
+    """Elastic_PC::open option 1 (RS x RS), the two stream passes that do not reach SHA3: aggregate (src/Elastic_PC.cpp:316-347: axpy over
+    the read_stream default "test" stream + shockwave_commit) and compute_aggregation_reply / update_reply (:487-533, 59-111), on the
+    chunk coefficients and queries open() itself derives (:638-655)"""
+    out = {}
+    for (N, B) in ELASTIC_OPEN_CASES:
+        key = "eo_%d_%d_" % (N, B)
+        x, I = elastic_open_inputs(N, B)
+        aggr, root = lib.elastic_aggregate(N, B, lib.precompute_beta(x[:(N // B).bit_length() - 1]))
+        out[key + "aggr_dg"] = dg(aggr); out[key + "aggr_s"] = samp(aggr); out[key + "cf_root"] = root
+        rep = lib.elastic_reply(N, B, I)
+        out[key + "I_dg"] = dg(I); out[key + "reply_dg"] = dg(rep); out[key + "reply_s"] = samp(rep.reshape(-1, 2))
+    out["read_stream"] = dg(lib.read_stream(4096))
     return out
 
 
@@ -364,5 +408,5 @@ def case_gate(lib):
     return out
 
 
-CASES = dict(field=case_field, mimc=case_mimc, blake=case_blake, merkle=case_merkle, graph_encode=case_graph_encode,
+CASES = dict(elastic_open=case_elastic_open, field=case_field, mimc=case_mimc, blake=case_blake, merkle=case_merkle, graph_encode=case_graph_encode,
              fft=case_fft, tensorcode=case_tensorcode, commit=case_commit, sumcheck=case_sumcheck, elastic=case_elastic, codeproofs=case_codeproofs, streamfold=case_streamfold, multree=case_multree, innerpcs=case_innerpcs, gate=case_gate)

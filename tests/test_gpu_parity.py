@@ -26,6 +26,37 @@ def gold(name):
     return np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
 
 
+def rehash_path(hb, node, pos, path):
+    """Walk one open_tree_blake sibling path (src/merkle_tree.cpp:308-324) up to the root with create_tree_blake's left|left rule
+    (:275-280): a parent is H(L | L) with L the EVEN node of the pair -- the running node when its position is even, the sibling the
+    path carries when it is odd.  (So an odd leaf never reaches the root: that is the reference's tree, kept bit for bit.)"""
+    import ctypes
+    node = np.ascontiguousarray(node, np.uint8).copy()
+    for lvl in range(path.shape[0]):
+        L = node if pos % 2 == 0 else path[lvl]
+        blk = np.concatenate([L, L]).astype(np.uint8); out = np.zeros(32, np.uint8)
+        hb.lib.hobbit_blake3_64_host(blk.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), 1)
+        node = out; pos //= 2
+    return node
+
+
+def leaf_from_tensor(hb, c, col, row):
+    """the commitment's leaf for query (col,row): hash_double_field_element_merkle_damgard_blake chained over the K chunks on rows
+    4j..4j+3 of the column (src/Our_PC.cpp:162-166), recomputed on the HOST from gathered tensor entries"""
+    import ctypes
+    j = row // 4
+    t = c.gather(np.arange(4 * j, 4 * j + 4), np.full(4, col))          # (4, K, 2)
+    prev = np.zeros(32, np.uint8)
+    for i in range(c.K):
+        blk = np.ascontiguousarray(t[:, i, :]).view(np.uint8).reshape(64)
+        inner = np.zeros(32, np.uint8)
+        hb.lib.hobbit_blake3_64_host(blk.ctypes.data_as(ctypes.c_void_p), inner.ctypes.data_as(ctypes.c_void_p), 1)
+        blk2 = np.concatenate([inner, prev]); out = np.zeros(32, np.uint8)
+        hb.lib.hobbit_blake3_64_host(blk2.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), 1)
+        prev = out
+    return prev
+
+
 def graphs_from(oracle, n):
     lv, dep, m = {}, 0, n
     while m > 13:
@@ -395,6 +426,12 @@ def test_test_pc_driver_prints_the_reference_proof_size(logN, K):
     last = r.stdout.strip().splitlines()[-1]                       # "ps,vt" (src/Our_PC.cpp:822)
     assert float(last.split(",")[0]) == fp["%d,%d" % (logN, K)], last
     assert ">>OK" in r.stdout
+    # the commitment root the driver prints, against the REAL reference's commit_standard on the same inputs (oracle/_ref fixtures:
+    # tests/golden/commit.npz for 2^18 / 2^20, tests/golden/bigroot_2e<logN>.npz from oracle/gen_big_roots.py for 2^22 ... 2^28)
+    if logN <= 20 or os.path.exists(os.path.join(GOLD, "bigroot_2e%d.npz" % logN)):
+        want = gold("commit")["c_%d_%d_root" % (1 << logN, K)] if logN <= 20 else gold("bigroot_2e%d" % logN)["root"]
+        line = [l for l in r.stdout.splitlines() if l.startswith("root ")]
+        assert line and line[0].split()[1] == want.tobytes().hex(), line
 
 
 def test_ctx_create_leaves_libc_rng_alone():
@@ -700,9 +737,25 @@ def test_open_standard_2e26_selfchecks(hb):
         col, row = int(a["I"][q, 0]), int(a["I"][q, 1])
         for i in (0, K - 1):
             assert np.array_equal(a["reply"][q, i], c.tensor_row(i, row)[col])
-    # a Merkle path re-hashes to the root: leaf (row/4, col) -> root with the reference's left|left quirk
+    # Merkle paths really re-hash to the root: the leaf is recomputed on the host from the four tensor rows of all K chunks, then
+    # walked up with the reference's left|left rule (even positions only: an odd node never feeds its parent in that tree)
     root = c.root()
     assert a["paths"].shape == (5900, (N // K).bit_length() - 1, 32) and root.shape == (32,)
+    done = 0
+    for q in range(5900):
+        col, row = int(a["I"][q, 0]), int(a["I"][q, 1])
+        pos = (row // 4) * 4096 + col
+        leaf = leaf_from_tensor(hb, c, col, row)
+        if pos % 2 == 0:
+            assert np.array_equal(rehash_path(hb, leaf, pos, a["paths"][q]), root), q
+            done += 1
+        else:
+            # odd leaf: the path's first sibling is the even neighbour, which does chain to the root; the leaf itself must still be the stored one
+            assert np.array_equal(rehash_path(hb, a["paths"][q][0], pos - 1, a["paths"][q]), root), q
+            assert np.array_equal(c.open_tree_blake(col - 1, row)[0], leaf), q          # sibling path of the even neighbour starts with this leaf
+        if q >= 40 and done >= 3:
+            break
+    assert done >= 3
     c.free()
 
 
@@ -827,3 +880,142 @@ def test_shockwave_prove_vs_oracle(hb, oracle, N, k):
     libc.srandom(9); got = hb.shockwave_prove(p, enc, k, x, lv)
     for kk in want:
         assert np.array_equal(got[kk], want[kk]), kk
+
+
+# ---- reference-anchored values at the C3 / north-star sizes -------------------------------------------------------------
+@pytest.mark.parametrize("logN", [22, 24, 26, 28])
+def test_commit_standard_vs_reference_big(hb, logN):
+    """commit_standard on test_PC(2^logN, 4, 32)'s exact inputs (libc-drawn polynomial and graphs) against the REAL reference's
+    output at that size (oracle/gen_big_roots.py ran oracle/_ref's commit_standard once: 167 s at 2^26, ~11 min at 2^28 on one core):
+    root, sha256 of every Merkle level, 64 sampled leaves, 64 sampled tensor entries, five open_tree_blake paths."""
+    from oracle.gen_big_roots import sample_plan
+    import hashlib
+    if not os.path.exists(os.path.join(GOLD, "bigroot_2e%d.npz" % logN)):
+        pytest.skip("fixture bigroot_2e%d not generated" % logN)
+    g = gold("bigroot_2e%d" % logN)
+    N, K = 1 << logN, 32
+    M, trs, leaves, chunk, row, col, qs = sample_plan(logN)
+    hb.rng_reset()
+    poly = hb.generate_randomness(N)                          # src/Our_PC.cpp:758
+    hb.expander_init_store(trs)                               # :813
+    d = hb.to_device(poly); del poly
+    c = hb.commit_standard((d, N), K, trs, 1)
+    assert np.array_equal(c.root(), g["root"])
+    lv = c.levels()
+    off, sz, dgs = 0, M, []
+    while sz >= 1:
+        dgs.append(np.frombuffer(hashlib.sha256(lv[off:off + sz].tobytes()).digest(), np.uint8)); off += sz; sz //= 2
+    assert np.array_equal(np.stack(dgs), g["level_dg"])
+    assert np.array_equal(lv[leaves], g["leaves_s"])
+    del lv
+    for i in range(len(chunk)):
+        assert np.array_equal(c.gather([row[i]], [col[i]])[0, chunk[i]], g["tensor_s"][i]), i
+    for i, (cc, rr) in enumerate(qs):
+        assert np.array_equal(c.open_tree_blake(cc, rr), g["paths"][i]), i
+    c.free(); d.free()
+
+
+def test_aggregate_roots_vs_golden(hb):
+    """_aggregate's inner commitments C_f / C_c (src/Our_PC.cpp:274-287) on test_PC's own inputs and evaluation point: the `roots` the
+    open returns against the roots the REAL reference's _aggregate produced (tests/golden/commit.npz, c_*_cfcc)"""
+    g = gold("commit")
+    for N in (1 << 18, 1 << 20):
+        K = 32; trs = N // (K << 11)
+        hb.rng_reset(); poly = hb.generate_randomness(N); hb.expander_init_store(trs)
+        c = hb.commit_standard(poly, K, trs, 1)
+        x = hb.generate_randomness(N.bit_length() - 1)
+        res = hb.open_core(poly, c, x, 5900, want_paths=False)
+        assert np.array_equal(res["roots"], g["c_%d_32_cfcc" % N]), N
+        c.free()
+
+
+# ---- Elastic_PC open, option 1 (RS x RS) ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,B", golden_cases.ELASTIC_OPEN_CASES)
+def test_elastic_open_passes_vs_golden(hb, N, B):
+    """aggregate + C_f and compute_aggregation_reply / update_reply of Elastic_PC::open against what the REAL reference's functions
+    returned (tests/golden/elastic_open.npz): the queries open() draws, the root of C_f (a function of the whole aggregate), the replies"""
+    import ctypes
+    g = gold("elastic_open"); key = "eo_%d_%d_" % (N, B)
+    x, I = golden_cases.elastic_open_inputs(N, B)
+    ctypes.CDLL(None).srandom(901)
+    res = hb.elastic_open(N, B, x, 700, shockwave=False)
+    assert np.array_equal(dg(res["I"].astype(np.uint64)), g[key + "I_dg"])
+    assert np.array_equal(res["cf_root"], g[key + "cf_root"])
+    assert res["reply"].shape == (700, N // B, 2)
+    assert np.array_equal(dg(res["reply"]), g[key + "reply_dg"])
+    assert res["checks"].tolist() == [1, 1]
+
+
+@pytest.mark.parametrize("logN,logB", [(18, 14), (20, 16), (22, 18), (22, 20), (21, 13)])
+def test_elastic_open_vs_oracle(hb, oracle, logN, logB):
+    """The whole prover side of Elastic_PC::open option 1 on test_Elastic_PC's sequence (commit, x = generate_randomness(log N), open):
+    queries, replies, Merkle paths of the commitment, the four sumcheck transcripts of recursive_prover_RS and shockwave_prove(C_f, r_x)
+    with its WHIR proof, bit-exact against the oracle; the reference's exit(-1) checks hold on both."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    N, B = 1 << logN, 1 << logB
+    oracle.rng_reset(); lv = oracle.elastic_commit(N, B, 1)
+    x = oracle.generate_randomness(logN)
+    libc.srandom(99); want = oracle.elastic_open(N, B, x, 700, lv)
+    got_lv, dlv = hb.elastic_commit(N, B, 1, keep_levels=True)
+    T = 4 * B
+    assert np.array_equal(got_lv[:T - 1], lv[:T - 1]) and np.array_equal(got_lv[T:], lv[T:])
+    libc.srandom(99); got = hb.elastic_open(N, B, x, 700, commit_levels=dlv)
+    assert want["checks"].tolist() == [1, 1] and got["checks"].tolist() == [1, 1]
+    assert int(got["ncols"][0]) == int(want["ncols"][0]) and int(got["reply_len"][0]) == N // B
+    for k in ("I", "rv0", "cf_root", "reply", "poly", "r", "vr", "fin", "rx"):
+        assert np.array_equal(got[k], want[k]), k
+    # leaf 4B-1 is undefined in the reference; no path of the opening reaches it as a sibling unless position 4B-2 is queried (it is not:
+    # positions are (row/4)*cols + col < B)
+    assert np.array_equal(got["paths"], want["paths"])
+    has_whir = int(want["sp_f"]["iters"][0]) > 0
+    assert want["sp_f"]["wchecks"].tolist() == ([1, 1] if has_whir else [0, 0])
+    for k in SP_KEYS:
+        assert np.array_equal(got["sp_f"][k], want["sp_f"][k]), k
+
+
+def test_elastic_open_skips_zero_chunks(hb, oracle):
+    """compute_aggregation_reply appends nothing for an all-zero chunk (src/Elastic_PC.cpp:510-517): push zero chunks 1 and 2 of 4"""
+    import ctypes
+    N, B = 1 << 16, 1 << 14
+    x = splitmix_field(16, 5)
+    ch = hb.to_device(hb.read_stream(B)); z = hb.to_device(np.zeros((B, 2), np.uint64))
+    e = ctypes.c_void_p()
+    ctypes.CDLL(None).srandom(7)
+    hb._chk(hb.lib.hobbit_elastic_open_begin(hb.ctx, N, B, B >> 11, x.ctypes.data_as(ctypes.c_void_p), 64, ctypes.byref(e)))
+    for b in (ch, z, z, ch):
+        hb._chk(hb.lib.hobbit_elastic_open_aggregate_push(hb.ctx, e, b.ptr))
+    hb._chk(hb.lib.hobbit_elastic_open_aggregate_finish(hb.ctx, e))
+    for b in (ch, z, z, ch):
+        hb._chk(hb.lib.hobbit_elastic_open_reply_push(hb.ctx, e, b.ptr))
+    rl = np.zeros(1, np.int32); rep = np.zeros((64, 4, 2), np.uint64)
+    q = np.zeros((64, 3, 2), np.uint64); r = np.zeros((64, 2), np.uint64); vr = np.zeros((4, 2, 2), np.uint64); fin = np.zeros((4, 2), np.uint64); chk = np.zeros(2, np.int32)
+    names = ("cols", "rows", "rv0", "reply", "reply_len", "paths", "cf_root", "ncols", "poly", "r", "vr", "fin", "checks", "rx", "sp_f")
+
+    class Out(ctypes.Structure):
+        _fields_ = [(n, ctypes.c_void_p) for n in names]
+    o = Out(None, None, None, rep.ctypes.data, rl.ctypes.data, None, None, None, q.ctypes.data, r.ctypes.data, vr.ctypes.data, fin.ctypes.data, chk.ctypes.data, None, None)
+    hb._chk(hb.lib.hobbit_elastic_open_finish(hb.ctx, e, None, ctypes.byref(o)))
+    hb.lib.hobbit_elastic_open_free(e)
+    assert rl[0] == 2 and chk.tolist() == [1, 1]
+    rep = rep.reshape(-1, 2)[:128].reshape(64, 2, 2)
+    assert np.array_equal(rep[:, 0], rep[:, 1]) and rep.any()
+
+
+# ---- C5: Elastic_PC streaming commit at 2^30 on one GPU (and 2^26), against the REAL reference ---------------------------------
+@pytest.mark.parametrize("logN,opt", [(26, 1), (26, 2), (30, 1), (30, 2)])
+def test_elastic_commit_vs_reference_big(hb, logN, opt):
+    """test_Elastic_PC's commit with B = 2^20 (opt 1: RS x RS, trs = 512; opt 2: 32768-point rows x expander, trs = 64) against the
+    REAL reference's root and level digests (oracle/gen_elastic_roots.py ran oracle/_ref once per case; 2^30 took ~35 min per option).
+    The stream's chunk is generated once on the host and stays resident (the reference's "test" stream repeats one chunk)."""
+    import glob
+    name = "elastic_root_%d_20_%d" % (logN, opt)
+    if not os.path.exists(os.path.join(GOLD, name + ".npz")):
+        pytest.skip("fixture %s not generated" % name)
+    g = gold(name)
+    N, B = 1 << logN, 1 << 20
+    hb.rng_reset()
+    lv = hb.elastic_commit(N, B, opt)
+    T = 4 * B
+    assert np.array_equal(lv[-1], g["root"])
+    assert np.array_equal(dg(lv[:T - 1]), g["leaves_dg"]) and np.array_equal(dg(lv[T:]), g["upper_dg"])

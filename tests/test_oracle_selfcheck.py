@@ -62,3 +62,23 @@ def test_proof_size_matches_reference_stdout(oracle, logN, K):
     x = oracle.generate_randomness(logN)                      # test_PC's order: poly, graphs, commit, x, open (src/Our_PC.cpp:758-822)
     res = oracle.open_standard(poly, K, trs, x, 5900)
     assert open_proof_size(res, N, K, trs) == fp["%d,%d" % (logN, K)]
+
+
+@pytest.mark.parametrize("logN,logB", [(18, 14), (20, 16)])
+def test_elastic_open_selfchecks(oracle, logN, logB):
+    """Elastic_PC::open option 1 on test_Elastic_PC's own sequence (commit, x = generate_randomness(log N), open): prove_fft_matrix's two
+    exit(-1) sum checks inside recursive_prover_RS (P2 against P0.vr[0], P5 against P3.vr[0]), the closing shockwave_prove's WHIR
+    checks, and the structure of the replies (one entry per chunk; every chunk of the default stream is alike, so the columns agree)."""
+    N, B = 1 << logN, 1 << logB
+    oracle.rng_reset()
+    lv = oracle.elastic_commit(N, B, 1)
+    x = oracle.generate_randomness(logN)
+    res = oracle.elastic_open(N, B, x, 700, lv)
+    assert res["checks"].tolist() == [1, 1]
+    assert res["sp_f"]["wchecks"].tolist() == [1, 1]
+    assert res["reply"].shape == (700, N // B, 2)
+    assert np.array_equal(res["reply"][:, 0], res["reply"][:, -1])
+    assert 0 < int(res["ncols"][0]) <= 700
+    # a Merkle path of the commitment re-hashes to its root (left|left rule: the sibling is carried, the parent hashes the left child twice)
+    depth = (4 * B).bit_length() - 1
+    assert res["paths"].shape == (700, depth, 32)

@@ -8,7 +8,7 @@ import golden_cases
 from oracle.pyoracle import splitmix_field
 
 
-@pytest.mark.parametrize("name", ["field", "mimc", "blake", "merkle", "fft", "sumcheck"])
+@pytest.mark.parametrize("name", ["field", "mimc", "blake", "merkle", "fft", "sumcheck", "elastic_open"])
 def test_case_agrees(oracle, ref, name):
     a = golden_cases.CASES[name](oracle); b = golden_cases.CASES[name](ref)
     for k in a:
@@ -35,3 +35,13 @@ def test_commit_2e18_full_tensor(oracle, ref):
     lv2, t2 = ref.commit_standard(poly, 32, trs, 1, want_tensor=True)
     ref.release_commit()
     assert np.array_equal(lv1, lv2) and np.array_equal(t1, t2)
+
+
+def test_elastic_open_passes_other_shape(oracle, ref):
+    """aggregate / compute_aggregation_reply of Elastic_PC::open (option 1) at a shape outside the fixtures"""
+    N, B = 1 << 17, 1 << 13
+    beta = splitmix_field(N // B, 5)
+    a1, r1 = oracle.elastic_aggregate(N, B, beta); a2, r2 = ref.elastic_aggregate(N, B, beta)
+    assert np.array_equal(a1, a2) and np.array_equal(r1, r2)
+    I = golden_cases.elastic_open_queries(B, 333, 7)
+    assert np.array_equal(oracle.elastic_reply(N, B, I), ref.elastic_reply(N, B, I))
