@@ -492,7 +492,94 @@ void commit(stream_descriptor fd, _hash &comm, vector<vector<_hash>> &MT_hashes)
     MT_hashes.resize(levels);
     for (size_t l = 0, sz = T; l < levels; l++, sz /= 2) { MT_hashes[l].resize(sz); lv.to_host(MT_hashes[l].data(), 32 * sz, 32 * off); off += sz; }
 }
-void test_Elastic_PC_commit(size_t N, int option) {                 // src/Elastic_PC.cpp:736-771 (commit phase)
+void read_stream(stream_descriptor &fd, vector<F> &v, int size) {   // src/witness_stream.cpp:2106, default branch :2348-2352
+    if (fd.name == "input" || fd.name == "circuit" || fd.name == "witness" || fd.name == "transcript_stream" || fd.name.find("lookup") == 0 ||
+        fd.name.find("wiring_consistency_check") == 0) { printf("Error: stream '%s' belongs to the witness generator (out of scope)\n", fd.name.c_str()); exit(-1); }
+    for (int i = 0; i < size; i++) v[i] = F((i % 1024) + 1);
+}
+static hobbit_host_elastic_transcript g_eopen;
+hobbit_host_elastic_transcript &hobbit_host_last_elastic_open() { return g_eopen; }
+// src/Elastic_PC.cpp:625-726, !linear_time (RS x RS).  Prover side on the device (hobbit_elastic_open_*: libc draws in the reference's
+// order, the stream re-read twice through read_stream as the reference does); the verifier emulation is reduced to its ps accounting.
+void open(stream_descriptor fd, vector<F> x, vector<vector<_hash>> &Commitment_MT, double &vt, double &ps) {
+    if (linear_time) {
+        // update_reply_spielman (:431-485) indexes a tensor_row_size-long copy of the un-encoded column with rows >= tensor_row_size
+        // (:465-478): a read past the vector in the reference itself -- no defined result to reproduce
+        printf("Error: Elastic_PC::open with linear_time (option 2) is undefined in the reference (update_reply_spielman reads past its vector); not built\n");
+        exit(-1);
+    }
+    const int queries = 700; aggregation_queries = queries;
+    const size_t B = BUFFER_SPACE, K = fd.size / B; const int trs = tensor_row_size;
+    const int logc = 12, logr = (int)log2((double)(2 * trs)), logt = logr - 1, depth = (int)log2((double)(4 * B));
+    hobbit_elastic_open *e = nullptr;
+    HCHK(hobbit_elastic_open_begin(hobbit_host_ctx(), fd.size, B, trs, hF(x.data()), queries, &e));
+    vector<F> buff(B); DevBuf d(B * sizeof(F));
+    for (size_t i = 0; i < K; i++) {                                 // aggregate (:327-334)
+        read_stream(fd, buff, (int)B);
+        HCHK(hobbit_memcpy_h2d(g_ctx, d.p, buff.data(), B * sizeof(F)));
+        HCHK(hobbit_elastic_open_aggregate_push(g_ctx, e, (const hobbit_F *)d.p));
+    }
+    HCHK(hobbit_elastic_open_aggregate_finish(g_ctx, e));
+    for (size_t i = 0; i < K; i++) {                                 // compute_aggregation_reply (:506-531)
+        read_stream(fd, buff, (int)B);
+        HCHK(hobbit_memcpy_h2d(g_ctx, d.p, buff.data(), B * sizeof(F)));
+        HCHK(hobbit_elastic_open_reply_push(g_ctx, e, (const hobbit_F *)d.p));
+    }
+    // the commitment tree, flat, back on the device for the paths
+    size_t tot = 0; for (auto &l : Commitment_MT) tot += l.size();
+    DevBuf lv(32 * tot);
+    { size_t off = 0; for (auto &l : Commitment_MT) { HCHK(hobbit_memcpy_h2d(g_ctx, (uint8_t *)lv.p + 32 * off, l.data(), 32 * l.size())); off += l.size(); } }
+    hobbit_host_elastic_transcript &t = g_eopen;
+    const int maxr = 11 + logr + logr + (logt + logc) + logc;
+    t.queries = queries; t.cols.assign(queries, 0); t.rows.assign(queries, 0); t.reply.assign((size_t)queries * K, F(0)); t.paths.assign((size_t)queries * depth * 32, 0);
+    t.qpoly.assign(3 * (size_t)maxr, F(0)); t.r.assign(maxr, F(0)); t.vr.assign(8, F(0)); t.fin.assign(4, F(0)); t.rx.assign(logc + logt, F(0));
+    SpBuffers bf(t.sp_f, B, 32);
+    hobbit_elastic_open_out o{t.cols.data(), t.rows.data(), hF(&t.rv0), hF(t.reply.data()), &t.reply_len, t.paths.data(), t.cf_root, &t.ncols,
+                              hF(t.qpoly.data()), hF(t.r.data()), hF(t.vr.data()), hF(t.fin.data()), t.checks, hF(t.rx.data()), &bf.o};
+    HCHK(hobbit_elastic_open_finish(g_ctx, e, tot == 8 * B - 1 ? (const uint8_t *)lv.p : nullptr, &o));
+    hobbit_elastic_open_free(e);
+    if (!t.checks[0] || !t.checks[1]) { printf("Error in fft\n"); exit(-1); }                                   // src/sumcheck.cpp:3016-3019
+    if (t.sp_f.iters && !(t.sp_f.wchecks[0] && t.sp_f.wchecks[1])) { printf("Error in final verification step\n"); exit(-1); }
+    auto t0 = std::chrono::steady_clock::now();
+    size_t np2 = 1; while (np2 < (size_t)t.ncols) np2 <<= 1;
+    t.rounds = (int)log2((double)(np2 * 2 * trs)) + logr + (logt + logc) + logc;
+    double MT_ps = 0.0;
+    vector<size_t> pos(queries);
+    for (int i = 0; i < queries; i++) pos[i] = (size_t)(t.rows[i] / 4) * 4096 + t.cols[i];
+    path_ps(4 * B, depth, pos, MT_ps);                                                                          // (:684-688)
+    ps += (double)((size_t)queries * (size_t)t.reply_len * sizeof(F)) / 1024.0;                                 // (:701)
+    sumcheck2_ps((int)log2((double)(np2 * 2 * trs)), ps); sumcheck2_ps(logr, ps); sumcheck2_ps(logt + logc, ps); sumcheck2_ps(logc, ps);   // P0, P2, P3, P5
+    shockwave_ps(t.sp_f, B, 32, ps);
+    ps += MT_ps;
+    vt += std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::steady_clock::now() - t0).count();
+    for (auto &l : Commitment_MT) { l.clear(); vector<_hash>(l).swap(l); }                                      // (:691-696)
+    Commitment_MT.clear();
+    printf("PC : ps = %lf, vt = %lf\n", ps, vt);
+}
+void test_Elastic_PC(size_t N, int option) {                        // src/Elastic_PC.cpp:736-771
+    _hash comm; vector<vector<_hash>> MT_hashes;
+    stream_descriptor commit_data; commit_data.name = "test"; commit_data.size = N;
+    if (option == 1) { linear_time = false; tensor_row_size = (int)(BUFFER_SPACE / (1ULL << 11)); }
+    else if (option == 2) { linear_time = true; int K = (int)(N / BUFFER_SPACE); tensor_row_size = (int)(N / (K * 1ULL << 14)); printf("> %d\n", tensor_row_size); expander_init_store(tensor_row_size); }
+    else { printf("Error: option %d (the Brakedown streaming baseline) is a comparison baseline, not built\n", option); exit(-1); }
+    auto start = std::chrono::steady_clock::now();
+    commit(commit_data, comm, MT_hashes);
+    auto end = std::chrono::steady_clock::now();
+    double elapsed = std::chrono::duration_cast<std::chrono::duration<double>>(end - start).count();
+    std::cout << "Commit time: " << elapsed << " seconds" << std::endl;
+    if (option == 1) printf("Commitment finished\n");
+    printf("root ");
+    for (int i = 0; i < 32; i++) printf("%02x", MT_hashes.back()[0].arr[i]);
+    printf("\n");
+    if (option == 2) return;                                         // its open is undefined in the reference (see open())
+    double vt = 0.0, ps = 0.0;
+    start = std::chrono::steady_clock::now();
+    open(commit_data, generate_randomness((int)log2((double)N)), MT_hashes, vt, ps);
+    end = std::chrono::steady_clock::now();
+    elapsed += std::chrono::duration_cast<std::chrono::duration<double>>(end - start).count();
+    printf("Total prover time : %lf\n", elapsed);
+}
+void test_Elastic_PC_commit(size_t N, int option) {                 // commit phase only (kept for callers that time the commit alone)
     _hash comm; vector<vector<_hash>> MT_hashes;
     stream_descriptor commit_data; commit_data.name = "test"; commit_data.size = N;
     if (option == 1) { linear_time = false; tensor_row_size = (int)(BUFFER_SPACE / (1ULL << 11)); }
@@ -585,6 +672,24 @@ int hobbit_host_elastic_root(size_t N, size_t B, int option, uint8_t *root_out) 
     commit(fd, comm, MT);
     memcpy(root_out, MT.back()[0].arr, 32);
     return (int)MT.size();
+}
+// test_Elastic_PC(N, 1) through the mirror from a fresh generator state; hands back root, queries, replies and the four transcripts
+int hobbit_host_elastic_open(size_t N, size_t B, uint8_t *root_out, uint32_t *cols_rows, uint64_t *reply, uint64_t *qpoly, uint64_t *r, int *checks, double *ps_out) {
+    srandom(1);
+    BUFFER_SPACE = B; linear_time = false; tensor_row_size = (int)(B >> 11);
+    _hash comm; vector<vector<_hash>> MT;
+    stream_descriptor fd; fd.name = "test"; fd.size = N;
+    commit(fd, comm, MT);
+    memcpy(root_out, MT.back()[0].arr, 32);
+    double vt = 0, ps = 0;
+    open(fd, generate_randomness((int)log2((double)N)), MT, vt, ps);
+    hobbit_host_elastic_transcript &t = hobbit_host_last_elastic_open();
+    for (int i = 0; i < t.queries; i++) { cols_rows[2 * i] = t.cols[i]; cols_rows[2 * i + 1] = t.rows[i]; }
+    memcpy(reply, t.reply.data(), 16 * (size_t)t.queries * t.reply_len);
+    memcpy(qpoly, t.qpoly.data(), 16 * 3 * (size_t)t.rounds); memcpy(r, t.r.data(), 16 * (size_t)t.rounds);
+    checks[0] = t.checks[0]; checks[1] = t.checks[1]; checks[2] = t.sp_f.wchecks[0] & t.sp_f.wchecks[1];
+    *ps_out = ps;
+    return t.rounds;
 }
 void hobbit_host_close(void) { hobbit_host_shutdown(); }
 }

@@ -159,6 +159,17 @@ struct stream_descriptor {
 void read_stream_PC(stream_descriptor &fd, F *v, int size);      /* synthetic default stream only (src/witness_stream.cpp:2405-2411) */
 void commit(stream_descriptor fd, _hash &comm, vector<vector<_hash>> &MT_hashes);
 void init_commitment(bool mod);
+void read_stream(stream_descriptor &fd, vector<F> &v, int size);  /* default branch only (src/witness_stream.cpp:2348-2352) */
+void open(stream_descriptor fd, vector<F> x, vector<vector<_hash>> &Commitment_MT, double &vt, double &ps);   /* !linear_time (RS x RS) */
+void test_Elastic_PC(size_t N, int option);                     /* src/Elastic_PC.cpp:736-771: options 1 (commit + open) and 2 (commit; its open is undefined in the reference) */
+/* the messages of the last Elastic open (the reference returns only vt / ps); layouts as hobbit_elastic_open_out */
+struct hobbit_host_elastic_transcript {
+    int queries = 0, rounds = 0, reply_len = 0, ncols = 0;
+    vector<uint32_t> cols, rows; vector<F> reply, qpoly, r, vr, fin, rx; vector<uint8_t> paths; uint8_t cf_root[32]; F rv0;
+    int checks[2] = {0, 0};
+    hobbit_host_shockwave_transcript sp_f;
+};
+hobbit_host_elastic_transcript &hobbit_host_last_elastic_open();
 void test_Elastic_PC_commit(size_t N, int option);              /* commit phase of test_Elastic_PC (src/Elastic_PC.cpp:736-771) */
 
 /* Not in the reference: the 16 GiB `_tensor` of a 2^28 commit stays on the device.

@@ -10,7 +10,7 @@ int main(int argc, char **argv) {
     init_hash();
     if (std::string(argv[1]) == "elastic") {          // src/main.cpp:1177-1178: BUFFER_SPACE = 1<<argv[2]; test_Elastic_PC(1<<argv[1], argv[3])
         BUFFER_SPACE = 1ULL << atoi(argv[3]);
-        test_Elastic_PC_commit(1ULL << atoi(argv[2]), argc > 4 ? atoi(argv[4]) : 1);
+        test_Elastic_PC(1ULL << atoi(argv[2]), argc > 4 ? atoi(argv[4]) : 1);
     } else
         test_PC(1ULL << atoi(argv[1]), atoi(argv[2]), atoi(argv[3]));
     hobbit_host_shutdown();

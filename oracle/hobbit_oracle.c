@@ -1189,12 +1189,28 @@ size_t orc_elastic_commit(size_t N, size_t B, int opt, uint8_t *levels_out) {
 /* a read past the vector -- there is no defined result to be bit-exact with.                      */
 /* ------------------------------------------------------------------------------------------ */
 void orc_read_stream(size_t B, oF *out) { for (size_t i = 0; i < B; i++) out[i] = fint((uint64_t)(i % 1024) + 1); }
+/* Stream model for the streaming provers.  kind 0: the reference's default branch (every read alike).  kind 1 (tests only, no
+ * counterpart in the reference): read number c since the last reset returns splitmix_field(n, seed + c) -- full-range values that
+ * differ from read to read, so that chunk-order mistakes cannot hide behind a repeating stream. */
+static int g_stream_kind = 0; static uint64_t g_stream_seed = 0, g_stream_count = 0;
+void orc_stream_config(int kind, uint64_t seed) { g_stream_kind = kind; g_stream_seed = seed; g_stream_count = 0; }
+static void stream_reset(void) { g_stream_count = 0; }
+static void stream_read(oF *dst, size_t n) {
+    if (g_stream_kind == 0) { orc_read_stream(n, dst); return; }
+    const uint64_t sd = g_stream_seed + g_stream_count++;
+    for (size_t i = 0; i < 2 * n; i++) {
+        uint64_t z = sd * 0x632BE59BD9B4E019ULL + (uint64_t)(i + 1) * 0x9E3779B97F4A7C15ULL;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; z ^= z >> 31;
+        if (i & 1) dst[i / 2].im = z % P61; else dst[i / 2].re = z % P61;
+    }
+}
 
 void orc_elastic_aggregate(size_t N, size_t B, const oF *beta, oF *aggr_out, uint8_t *cf_root) {
     oF *buff = (oF *)malloc(sizeof(oF) * B);
     memset(aggr_out, 0, sizeof(oF) * B);
+    stream_reset();
     for (size_t i = 0; i < N / B; i++) {                 /* :327-334 */
-        orc_read_stream(B, buff);
+        stream_read(buff, B);
         for (size_t j = 0; j < B; j++) aggr_out[j] = f_add(aggr_out[j], f_mul(beta[i], buff[j]));
     }
     if (cf_root) {                                       /* C_f = shockwave_commit(buff = aggr, 32) (:343-346) */
@@ -1212,8 +1228,9 @@ size_t orc_elastic_reply(size_t N, size_t B, const uint64_t *Iq, size_t nq, oF *
     const int logc = (int)log2((double)cols), logr = (int)log2((double)(2 * trs));
     oF *buff = (oF *)malloc(sizeof(oF) * B), *T = (oF *)malloc(sizeof(oF) * trs * cols), *col = (oF *)malloc(sizeof(oF) * 2 * trs);
     size_t filled = 0;
+    stream_reset();
     for (size_t i = 0; i < K; i++) {
-        orc_read_stream(B, buff);
+        stream_read(buff, B);
         int nz = 0;
         for (size_t j = 0; j < B; j++) if (!fis0(buff[j])) { nz = 1; break; }
         if (!nz) continue;
@@ -1308,6 +1325,256 @@ int orc_elastic_open_rs(size_t N, size_t B, const oF *x, int queries, const uint
     memcpy(rx_out + logc, r3 + logc, sizeof(oF) * (size_t)logt);
     free(beta); free(Iq); free(cs); free(col); free(out1); free(sel); free(out3); free(bt); free(rq); free(rpt); free(rb); free(b2);
     return R0 + logr + (logt + logc) + logc;
+}
+
+
+/* ------------------------------------------------------------------------------------------ */
+/* Streaming (space-efficient) sumcheck drivers of the multiplication-tree prover:              */
+/* read_mul_tree_layer / read_mul_tree_data (src/witness_stream.cpp:2413-2510, the branch for     */
+/* every stream but "wiring_consistency_check"), generate_claims_opt (src/sumcheck.cpp:1014-1054), */
+/* generate_3product_sumcheck_beta_stream_batch_optimized (:1150-1393) and                         */
+/* prove_multiplication_tree_stream_shallow (:1746-1915) without commit_layers / open_layers.      */
+/* ------------------------------------------------------------------------------------------ */
+/* v[0 .. size): products of 2^layer consecutive stream elements; one read of 2*size elements fills size/2^layer entries of each half */
+static void read_mul_tree_layer(oF *v, size_t size, int layer) {
+    const size_t seg = (size_t)1 << layer;
+    oF *tmp = (oF *)malloc(sizeof(oF) * 2 * size);
+    for (size_t i = 0; i < size; i++) v[i] = fint(1);
+    size_t counter = 0;
+    while (counter != size / 2) {
+        stream_read(tmp, 2 * size);
+        for (size_t i = 0; i < size / seg; i++) {
+            for (size_t j = 0; j < seg; j++) v[counter] = f_mul(v[counter], tmp[i * seg + j]);
+            for (size_t j = 0; j < seg; j++) v[counter + size / 2] = f_mul(v[counter + size / 2], tmp[i * seg + j + size]);
+            counter++;
+        }
+    }
+    free(tmp);
+}
+/* V[0]: `size` products of 2^layer consecutive elements (lower half from the first half of every read, upper half from its second
+ * half); V[i] (i >= 1): products of 2^distance consecutive entries of V[i-1] */
+static void read_mul_tree_data(oF **V, const size_t *vlen, int batches, size_t size, int layer, int distance) {
+    const size_t seg = (size_t)1 << layer;
+    oF *tmp = (oF *)malloc(sizeof(oF) * size);
+    size_t counter = 0;
+    while (counter != size / 2) {
+        stream_read(tmp, size);
+        for (size_t i = 0; i < size / (2 * seg); i++) {
+            oF a = tmp[i * seg], b = tmp[i * seg + size / 2];
+            for (size_t j = 1; j < seg; j++) { a = f_mul(a, tmp[i * seg + j]); b = f_mul(b, tmp[i * seg + j + size / 2]); }
+            V[0][counter] = a; V[0][counter + size / 2] = b; counter++;
+        }
+    }
+    const size_t off = (size_t)1 << distance;
+    for (int i = 1; i < batches; i++)
+        for (size_t j = 0; j < vlen[i]; j++) { oF a = fint(1); for (size_t k = 0; k < off; k++) a = f_mul(a, V[i - 1][off * j + k]); V[i][j] = a; }
+    free(tmp);
+}
+void orc_read_mul_tree_layer(size_t size, int layer, oF *out) { stream_reset(); read_mul_tree_layer(out, size, layer); }
+/* V levels back to back in `out` (4B, 4B >> distance, ...) */
+void orc_read_mul_tree_data(size_t size, int layer, int distance, int batches, oF *out) {
+    oF *V[16]; size_t vlen[16]; size_t o = 0;
+    for (int i = 0; i < batches; i++) { V[i] = out + o; vlen[i] = size >> (i * distance); o += vlen[i]; }
+    stream_reset(); read_mul_tree_data(V, vlen, batches, size, layer, distance);
+}
+/* r: batches x rlen (row-major); new_r: batches rows, row i of 1 + (logB - i*distance) + log2(R) entries (stride new_r_ld);
+ * transcript: P1 (batch_3product_sumcheck: rounds1 = logB rounds of 4 F), P2 (2-product over R: 3 F per round).
+ * checks: [0] every K_partial == old_claims ("Error in sumcheck 0", printed only), [1] P1's claim == Kf, [2] sum b.vr == P2's claim. */
+int orc_sumcheck3_stream_batch(size_t fd_size, size_t B, const oF *r, int rlen, int batches, int distance, int layer_id, const oF *old_claims, int n_old,
+                               oF *new_claims, oF *new_r, int new_r_ld, oF *cpoly1, oF *r1, oF *vr1, oF *qpoly2, oF *r2, oF *vr2, oF *fin2, oF *R_out, int *checks) {
+    const size_t size = fd_size >> layer_id; const int logB = (int)log2((double)B);
+    oF *f1[16], *f2[16], *f3[16], *b1[16], *b2[16], *b3[16], *rb[16], *V[16]; size_t sz[16] = {0}, vlen[16] = {0}, rbn[16] = {0};
+    for (int i = 0; i < batches; i++) {
+        sz[i] = B >> (i * distance); vlen[i] = (4 * B) >> (i * distance);
+        f1[i] = (oF *)malloc(sizeof(oF) * sz[i]); f2[i] = (oF *)malloc(sizeof(oF) * sz[i]); f3[i] = (oF *)malloc(sizeof(oF) * sz[i]);
+        b1[i] = (oF *)malloc(sizeof(oF) * sz[i]); b2[i] = (oF *)malloc(sizeof(oF) * sz[i]); b3[i] = (oF *)malloc(sizeof(oF) * sz[i]);
+        V[i] = (oF *)malloc(sizeof(oF) * vlen[i]);
+        const int n_init = logB - i * distance, n_rem = (int)log2((double)(size / 2)) - i * distance - n_init;
+        orc_precompute_beta(r + (size_t)i * rlen, n_init, b3[i]); memcpy(f3[i], b3[i], sizeof(oF) * sz[i]);
+        rbn[i] = (size_t)1 << n_rem; rb[i] = (oF *)malloc(sizeof(oF) * rbn[i]);
+        orc_precompute_beta(r + (size_t)i * rlen + n_init, n_rem, rb[i]);
+    }
+    const size_t nch = size / (4 * B), half = rbn[0] / 2;
+    stream_reset();
+    read_mul_tree_data(V, vlen, batches, 4 * B, layer_id, distance);
+    oF Kp[16], a[16];
+    for (int i = 0; i < batches; i++) {
+        Kp[i] = fint(0);
+        for (size_t j = 0; j < sz[i]; j++) { f1[i][j] = V[i][2 * j]; f2[i][j] = V[i][2 * j + 1]; }
+        for (size_t j = 0; j < sz[i]; j++) Kp[i] = f_add(Kp[i], f_mul(f_mul(f1[i][j], f2[i][j]), f3[i][j]));
+    }
+    orc_generate_randomness(batches, a);
+    oF Kf = fint(0);
+    size_t nR = 1; oF *R = (oF *)malloc(sizeof(oF) * (2 * nch + 1)); R[0] = fint(1);
+    for (int i = 0; i < batches; i++) { Kf = f_add(Kf, f_mul(a[i], Kp[i])); Kp[i] = f_mul(Kp[i], rb[i][0]); }
+    /* one batch_prod step (src/sumcheck.cpp:1093-1136) on the chunk halves currently in b1/b2, remaining_betas index idx */
+#define BATCH_PROD_STEP(idx) do {                                                                                               \
+        oF K1 = fint(0), K2 = fint(0), K3[16], rnd = R[nR - 1];                                                                 \
+        for (int j = 0; j < batches; j++) { oF K[3] = {fint(0), fint(0), fint(0)};                                              \
+            orc_batch_prod_terms(b1[j], b2[j], b3[j], f1[j], f2[j], f3[j], sz[j], K);                                           \
+            K1 = f_add(K1, f_mul(a[j], K[0])); K2 = f_add(K2, f_mul(a[j], K[1])); K3[j] = K[2]; }                               \
+        rnd = mimc_hash(K1, rnd); rnd = mimc_hash(K2, rnd);                                                                     \
+        for (int j = 0; j < batches; j++) rnd = mimc_hash(K3[j], rnd);                                                          \
+        { oF x1 = rnd, x2 = f_mul(rnd, x1), x3 = f_mul(rnd, x2);                                                                \
+          for (int j = 0; j < batches; j++) { Kp[j] = f_add(Kp[j], f_mul(rb[j][idx], K3[j])); Kf = f_add(Kf, f_mul(f_mul(x3, a[j]), K3[j])); } \
+          Kf = f_add(Kf, f_add(f_mul(x2, K2), f_mul(x1, K1))); }                                                                \
+        R[nR++] = rnd;                                                                                                          \
+        for (int j = 0; j < batches; j++) { orc_fold_axpy(f1[j], b1[j], &rnd, sz[j]); orc_fold_axpy(f2[j], b2[j], &rnd, sz[j]); orc_fold_axpy(f3[j], b3[j], &rnd, sz[j]); } \
+    } while (0)
+#define LOAD_HALF(second) do { for (int j = 0; j < batches; j++) for (size_t k = 0; k < sz[j]; k++) {                          \
+        b1[j][k] = V[j][2 * k + ((second) ? 2 * sz[j] : 0)]; b2[j][k] = V[j][2 * k + 1 + ((second) ? 2 * sz[j] : 0)]; } } while (0)
+    LOAD_HALF(1); BATCH_PROD_STEP(half);
+    for (size_t i = 1; i < nch; i++) {
+        read_mul_tree_data(V, vlen, batches, 4 * B, layer_id, distance);
+        LOAD_HALF(0); BATCH_PROD_STEP(i);
+        LOAD_HALF(1); BATCH_PROD_STEP(i + half);
+    }
+    stream_reset();
+    checks[0] = 1;
+    for (int i = 0; i < n_old; i++) if (Kp[i].re != old_claims[i].re || Kp[i].im != old_claims[i].im) checks[0] = 0;
+    /* P1 = batch_3product_sumcheck(fold_buff1, fold_buff2, fold_buff3, a) on concatenated tables */
+    size_t tot = 0; for (int i = 0; i < batches; i++) tot += sz[i];
+    oF *t1 = (oF *)malloc(sizeof(oF) * tot), *t2 = (oF *)malloc(sizeof(oF) * tot), *t3 = (oF *)malloc(sizeof(oF) * tot);
+    { size_t o = 0; for (int i = 0; i < batches; i++) { memcpy(t1 + o, f1[i], sizeof(oF) * sz[i]); memcpy(t2 + o, f2[i], sizeof(oF) * sz[i]); memcpy(t3 + o, f3[i], sizeof(oF) * sz[i]); o += sz[i]; } }
+    const int rounds1 = orc_batch_3product_sumcheck(t1, t2, t3, sz, batches, a, cpoly1, r1, vr1);
+    { oF c = f_add(f_add(f_add(cpoly1[0], cpoly1[1]), f_add(cpoly1[2], cpoly1[3])), cpoly1[3]); checks[1] = (c.re == Kf.re && c.im == Kf.im); }
+    /* Partial_Evals pass (:1315-1340) */
+    oF *PE = (oF *)calloc(2 * (size_t)batches * nR, sizeof(oF));
+    for (int k = 0; k < batches; k++) orc_precompute_beta(r1, (int)log2((double)sz[k]), b3[k]);          /* beta[k] (b3 reused) */
+    for (size_t i = 0; i < nch; i++) {
+        read_mul_tree_data(V, vlen, batches, 4 * B, layer_id, distance);
+        for (int k = 0; k < batches; k++) {
+            oF *p0 = PE + (size_t)(2 * k) * nR, *p1 = PE + (size_t)(2 * k + 1) * nR;
+            for (size_t j = 0; j < vlen[k] / 4; j++) {
+                p0[i] = f_add(p0[i], f_mul(b3[k][j], V[k][2 * j])); p0[i + nR / 2] = f_add(p0[i + nR / 2], f_mul(b3[k][j], V[k][2 * j + vlen[k] / 2]));
+                p1[i] = f_add(p1[i], f_mul(b3[k][j], V[k][2 * j + 1])); p1[i + nR / 2] = f_add(p1[i + nR / 2], f_mul(b3[k][j], V[k][2 * j + 1 + vlen[k] / 2]));
+            }
+        }
+    }
+    /* permute_partial_evals (:1137-1148): only R is permuted (even entries, then odd) */
+    oF *Rp = (oF *)malloc(sizeof(oF) * nR);
+    for (size_t i = 0; i < nR / 2; i++) { Rp[i] = R[2 * i]; Rp[nR / 2 + i] = R[2 * i + 1]; }
+    memcpy(R_out, Rp, sizeof(oF) * nR);
+    oF bb[32]; orc_generate_randomness(2 * batches, bb);
+    oF *ae = (oF *)calloc(nR, sizeof(oF));
+    for (int i = 0; i < 2 * batches; i++) for (size_t j = 0; j < nR; j++) ae[j] = f_add(ae[j], f_mul(bb[i], PE[(size_t)i * nR + j]));
+    oF zero = fint(0);
+    orc_sumcheck2(Rp, ae, nR, &zero, qpoly2, r2, vr2, fin2);                                              /* previous_r = the never-updated local rand = F(0) */
+    { oF sum = fint(0);
+      for (int i = 0; i < batches; i++) { sum = f_add(sum, f_mul(bb[2 * i], vr1[3 * i])); sum = f_add(sum, f_mul(bb[2 * i + 1], vr1[3 * i + 1])); }
+      oF c = f_add(f_add(qpoly2[0], qpoly2[1]), f_add(qpoly2[2], qpoly2[2])); checks[2] = (c.re == sum.re && c.im == sum.im); }
+    const int lR = (int)log2((double)nR);
+    const oF pad = fint((uint64_t)random());
+    for (int i = 0; i < batches; i++) {
+        oF *row = new_r + (size_t)i * new_r_ld; int n = 0;
+        row[n++] = pad;
+        for (int j = 0; j < logB - i * distance; j++) row[n++] = r1[j];
+        for (int j = 0; j < lR; j++) row[n++] = r2[j];
+        oF e0, e1; orc_evaluate_vector(PE + (size_t)(2 * i) * nR, nR, r2, lR, &e0); orc_evaluate_vector(PE + (size_t)(2 * i + 1) * nR, nR, r2, lR, &e1);
+        new_claims[i] = f_add(f_mul(f_sub(fint(1), pad), e0), f_mul(pad, e1));
+    }
+    for (int i = 0; i < batches; i++) { free(f1[i]); free(f2[i]); free(f3[i]); free(b1[i]); free(b2[i]); free(b3[i]); free(rb[i]); free(V[i]); }
+    free(R); free(Rp); free(t1); free(t2); free(t3); free(PE); free(ae);
+    (void)rounds1;
+    return (int)nR;
+#undef BATCH_PROD_STEP
+#undef LOAD_HALF
+}
+
+
+/* generate_claims_opt (src/sumcheck.cpp:1014-1054) */
+void orc_generate_claims_opt(size_t fd_size, size_t B, const oF *r, int batches, int layer_id, int distance, oF *claims) {
+    const size_t size = fd_size >> layer_id; const int logB = (int)log2((double)B);
+    oF *beta[16], *rb[16], *V[16]; size_t vlen[16] = {0}, rbn[16] = {0};
+    for (int i = 0; i < batches; i++) {
+        const int n_init = logB - i * distance, n_rem = (int)log2((double)(size / 2)) - i * distance - n_init;
+        vlen[i] = (4 * B) >> (i * distance); V[i] = (oF *)malloc(sizeof(oF) * vlen[i]);
+        beta[i] = (oF *)malloc(sizeof(oF) * ((size_t)1 << n_init)); orc_precompute_beta(r, n_init, beta[i]);
+        rbn[i] = (size_t)1 << n_rem; rb[i] = (oF *)malloc(sizeof(oF) * rbn[i]); orc_precompute_beta(r + n_init, n_rem, rb[i]);
+        claims[i] = fint(0);
+    }
+    stream_reset();
+    for (size_t i = 0; i < size / (4 * B); i++) {
+        read_mul_tree_data(V, vlen, batches, 4 * B, layer_id, distance);
+        for (int j = 0; j < batches; j++)
+            for (size_t k = 0; k < vlen[j] / 4; k++) {
+                claims[j] = f_add(claims[j], f_mul(f_mul(f_mul(rb[j][i], beta[j][k]), V[j][2 * k]), V[j][2 * k + 1]));
+                claims[j] = f_add(claims[j], f_mul(f_mul(f_mul(rb[j][i + rbn[j] / 2], beta[j][k]), V[j][2 * k + vlen[j] / 2]), V[j][2 * k + 1 + vlen[j] / 2]));
+            }
+    }
+    for (int i = 0; i < batches; i++) { free(beta[i]); free(rb[i]); free(V[i]); }
+}
+
+/* prove_gate_consistency (src/sumcheck.cpp:796-975) over a caller-supplied trace: chunk i = elements [i*B, (i+1)*B) of L, R, O (field
+ * elements) and S (int selectors; 1 = addition gate), n_chunks = tr.size / BUFFER_SPACE.  read_trace itself belongs to the witness
+ * generator (Seval / witness_stream.cpp) and is out of scope; NOT pinned against oracle/_ref as a whole for that reason -- its pieces are
+ * (compute{2,3,4}p_error_terms: streamfold.npz; the degree-4 loop through prove_gate_consistency_standard: gate.npz; sumcheck2).
+ * Outputs: R (n_chunks challenges, R[0] = 1), a (4), gate sumcheck transcript (poly: logB x 5, gr: logB), fin6 (the six folded values
+ * add, beta, L, R, O, mul), Peval (6 x n_chunks), b (6), P (q2: lR x 3, r2, vr2, fin2).
+ * checks: [0] "Error in gate consistency 1" held for every chunk, [1] "... 2" for every round, [2] "... 3". */
+void orc_gate_consistency_stream(const oF *L, const oF *Rt, const oF *O, const int32_t *S, size_t n_chunks, size_t B, const oF *r, oF *R_out, oF *a_out, oF *poly, oF *gr,
+                                 oF *fin6, oF *Peval, oF *b_out, oF *q2, oF *r2, oF *vr2, oF *fin2, int *checks) {
+    const int logB = (int)log2((double)B);
+    oF *beta = (oF *)malloc(sizeof(oF) * B), *fb = (oF *)malloc(sizeof(oF) * B), *fL = (oF *)malloc(sizeof(oF) * B), *fR = (oF *)malloc(sizeof(oF) * B),
+       *fO = (oF *)malloc(sizeof(oF) * B), *fa = (oF *)malloc(sizeof(oF) * B), *fm = (oF *)malloc(sizeof(oF) * B);
+    orc_precompute_beta(r, logB, beta); memcpy(fb, beta, sizeof(oF) * B);
+    memcpy(fL, L, sizeof(oF) * B); memcpy(fR, Rt, sizeof(oF) * B); memcpy(fO, O, sizeof(oF) * B);
+    for (size_t i = 0; i < B; i++) { fa[i] = fint((uint64_t)(int64_t)S[i]); fm[i] = f_sub(fint(1), fa[i]); }
+    oF rnd = fint(0), KO = fint(0), KL = fint(0), KR = fint(0), KM = fint(0);
+    for (size_t i = 0; i < B; i++) {
+        KO = f_add(KO, f_mul(beta[i], fO[i])); KL = f_add(KL, f_mul(f_mul(beta[i], fL[i]), fa[i]));
+        KR = f_add(KR, f_mul(f_mul(beta[i], fR[i]), fa[i])); KM = f_add(KM, f_mul(f_mul(f_mul(beta[i], fR[i]), fL[i]), fm[i]));
+    }
+    R_out[0] = fint(1); checks[0] = 1;
+    for (size_t c = 1; c < n_chunks; c++) {
+        const oF *bL = L + c * B, *bR = Rt + c * B, *bO = O + c * B; const int32_t *bS = S + c * B;
+        oF K2[2] = {fint(0), fint(0)}, KLs[3] = {fint(0), fint(0), fint(0)}, KRs[3] = {fint(0), fint(0), fint(0)}, K4[4] = {fint(0), fint(0), fint(0), fint(0)};
+        orc_err2p(bO, beta, fO, fb, B, K2);
+        orc_err3p(bL, bS, fL, fa, fb, beta, B, KLs);
+        orc_err3p(bR, bS, fR, fa, fb, beta, B, KRs);
+        orc_err4p(bL, bR, beta, bS, fL, fR, fb, fm, B, K4);
+        { oF t = f_sub(f_add(f_add(K4[3], KLs[2]), KRs[2]), K2[1]); if (!fis0(t)) checks[0] = 0; }
+        rnd = mimc_hash(K2[0], rnd); rnd = mimc_hash(K2[1], rnd);
+        rnd = mimc_hash(KLs[0], rnd); rnd = mimc_hash(KLs[1], rnd); rnd = mimc_hash(KLs[2], rnd);
+        rnd = mimc_hash(KRs[0], rnd); rnd = mimc_hash(KRs[1], rnd); rnd = mimc_hash(KRs[2], rnd);
+        R_out[c] = rnd;
+        oF x1 = rnd, x2 = f_mul(rnd, x1), x3 = f_mul(rnd, x2), x4 = f_mul(rnd, x3);
+        KO = f_add(KO, f_add(f_mul(x1, K2[0]), f_mul(x2, K2[1])));
+        KL = f_add(KL, f_add(f_add(f_mul(x1, KLs[0]), f_mul(x2, KLs[1])), f_mul(x3, KLs[2])));
+        KR = f_add(KR, f_add(f_add(f_mul(x1, KRs[0]), f_mul(x2, KRs[1])), f_mul(x3, KRs[2])));
+        KM = f_add(KM, f_add(f_add(f_mul(x1, K4[0]), f_mul(x2, K4[1])), f_add(f_mul(x3, K4[2]), f_mul(x4, K4[3]))));
+        for (size_t j = 0; j < B; j++) {
+            oF s = fint((uint64_t)(int64_t)bS[j]);
+            fa[j] = f_add(fa[j], f_mul(rnd, s)); fL[j] = f_add(fL[j], f_mul(rnd, bL[j])); fR[j] = f_add(fR[j], f_mul(rnd, bR[j]));
+            fO[j] = f_add(fO[j], f_mul(rnd, bO[j])); fm[j] = f_add(fm[j], f_mul(rnd, f_sub(fint(1), s))); fb[j] = f_add(fb[j], f_mul(rnd, beta[j]));
+        }
+    }
+    orc_generate_randomness(4, a_out);
+    oF sum = f_add(f_add(f_mul(a_out[0], KL), f_mul(a_out[1], KR)), f_add(f_mul(a_out[2], KM), f_mul(KO, a_out[3])));
+    orc_gate_sumcheck(fa, fb, fL, fR, fO, fm, B, a_out, &rnd, &sum, poly, gr, fin6, &checks[1]);
+    /* Peval pass (:949-959) */
+    oF *b1 = (oF *)malloc(sizeof(oF) * B);
+    orc_precompute_beta(gr, logB, b1);
+    for (size_t i = 0; i < 6 * n_chunks; i++) Peval[i] = fint(0);
+    for (size_t c = 0; c < n_chunks; c++)
+        for (size_t j = 0; j < B; j++) {
+            oF s = fint((uint64_t)(int64_t)S[c * B + j]);
+            Peval[0 * n_chunks + c] = f_add(Peval[0 * n_chunks + c], f_mul(b1[j], L[c * B + j]));
+            Peval[1 * n_chunks + c] = f_add(Peval[1 * n_chunks + c], f_mul(b1[j], Rt[c * B + j]));
+            Peval[2 * n_chunks + c] = f_add(Peval[2 * n_chunks + c], f_mul(b1[j], O[c * B + j]));
+            Peval[3 * n_chunks + c] = f_add(Peval[3 * n_chunks + c], f_mul(b1[j], s));
+            Peval[4 * n_chunks + c] = f_add(Peval[4 * n_chunks + c], f_mul(b1[j], f_sub(fint(1), s)));
+            Peval[5 * n_chunks + c] = f_add(Peval[5 * n_chunks + c], f_mul(b1[j], beta[j]));
+        }
+    orc_generate_randomness(6, b_out);
+    oF *pe = (oF *)calloc(n_chunks, sizeof(oF));
+    for (size_t j = 0; j < n_chunks; j++) for (int i = 0; i < 6; i++) pe[j] = f_add(pe[j], f_mul(b_out[i], Peval[(size_t)i * n_chunks + j]));
+    orc_sumcheck2(R_out, pe, n_chunks, &rnd, q2, r2, vr2, fin2);
+    /* sum = fold_L[0]*b0 + fold_R[0]*b1 + fold_O[0]*b2 + b3*fold_add[0] + b4*fold_mul[0] + b5*fold_beta[0]; fin6 = add, beta, L, R, O, mul */
+    { oF sm = f_add(f_add(f_mul(fin6[2], b_out[0]), f_mul(fin6[3], b_out[1])), f_add(f_mul(fin6[4], b_out[2]), f_mul(b_out[3], fin6[0])));
+      sm = f_add(sm, f_add(f_mul(b_out[4], fin6[5]), f_mul(b_out[5], fin6[1])));
+      oF c = f_add(f_add(q2[0], q2[1]), f_add(q2[2], q2[2])); checks[2] = (c.re == sm.re && c.im == sm.im); }
+    free(beta); free(fb); free(fL); free(fR); free(fO); free(fa); free(fm); free(b1); free(pe);
 }
 
 /* test_PC(N, 4, K) inputs (src/Our_PC.cpp:757-813) + timed commit_standard */

@@ -128,6 +128,17 @@ size_t orc_elastic_reply(size_t N, size_t B, const uint64_t *Iq, size_t nq, oF *
 int orc_elastic_open_rs(size_t N, size_t B, const oF *x, int queries, const uint8_t *commit_levels, uint32_t *I_out, oF *rv0_out, oF *aggr_out, uint8_t *cf_root,
                         oF *reply_out, uint8_t *paths_out, int *ncols_out, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks, oF *rx_out);
 
+/* streaming sumcheck drivers (see hobbit_oracle.c) */
+void orc_stream_config(int kind, uint64_t seed);
+void orc_read_mul_tree_layer(size_t size, int layer, oF *out);
+void orc_read_mul_tree_data(size_t size, int layer, int distance, int batches, oF *out);
+int orc_sumcheck3_stream_batch(size_t fd_size, size_t B, const oF *r, int rlen, int batches, int distance, int layer_id, const oF *old_claims, int n_old,
+                               oF *new_claims, oF *new_r, int new_r_ld, oF *cpoly1, oF *r1, oF *vr1, oF *qpoly2, oF *r2, oF *vr2, oF *fin2, oF *R_out, int *checks);
+
+void orc_generate_claims_opt(size_t fd_size, size_t B, const oF *r, int batches, int layer_id, int distance, oF *claims);
+void orc_gate_consistency_stream(const oF *L, const oF *Rt, const oF *O, const int32_t *S, size_t n_chunks, size_t B, const oF *r, oF *R_out, oF *a_out, oF *poly, oF *gr,
+                                 oF *fin6, oF *Peval, oF *b_out, oF *q2, oF *r2, oF *vr2, oF *fin2, int *checks);
+
 /* cpu_baseline helper: generate test_PC's inputs and time commit_standard (seconds) */
 double orc_time_commit_standard(size_t N, int K);
 

@@ -492,6 +492,100 @@ class Oracle(_Base):
         res["sp_f"] = self.shockwave_prove(aggr, enc_f, 32, rx, lv_f)
         return res
 
+
+    # ---- streaming multiplication-tree prover (src/sumcheck.cpp:1014-1054, 1150-1393; src/witness_stream.cpp:2413-2510)
+    def stream_config(self, kind=0, seed=0):
+        """kind 0: the reference's default stream (every read alike); kind 1: read c = splitmix_field(n, seed + c) (tests only)"""
+        self.lib.orc_stream_config(ctypes.c_int(kind), ctypes.c_uint64(seed))
+
+    def read_mul_tree_layer(self, fd_size, size, layer):
+        o = np.zeros((size, 2), np.uint64)
+        self.lib.orc_read_mul_tree_layer(c_sz(size), ctypes.c_int(layer), _p(o))
+        return o
+
+    def read_mul_tree_data(self, fd_size, size, layer, distance, batches):
+        tot = sum(size >> (i * distance) for i in range(batches))
+        o = np.zeros((tot, 2), np.uint64)
+        self.lib.orc_read_mul_tree_data(c_sz(size), ctypes.c_int(layer), ctypes.c_int(distance), ctypes.c_int(batches), _p(o))
+        return o
+
+    def sumcheck3_stream_batch(self, fd_size, B, r, batches, distance, layer_id, old_claims, full=False):
+        """generate_3product_sumcheck_beta_stream_batch_optimized; r: (batches, rlen, 2).  Returns dict(new_claims, new_r[, transcripts])"""
+        r = F(r); rlen = r.shape[1]; oc = F(old_claims).reshape(-1, 2)
+        size = fd_size >> layer_id; logB = B.bit_length() - 1; nR = size // (2 * B); lR = nR.bit_length() - 1
+        ld = 1 + logB + lR
+        nc = np.zeros((batches, 2), np.uint64); nr = np.zeros((batches, ld, 2), np.uint64)
+        c1 = np.zeros((logB, 4, 2), np.uint64); r1 = np.zeros((logB, 2), np.uint64); vr1 = np.zeros((batches, 3, 2), np.uint64)
+        q2 = np.zeros((lR, 3, 2), np.uint64); r2 = np.zeros((lR, 2), np.uint64); vr2 = np.zeros((2, 2), np.uint64); f2 = np.zeros(2, np.uint64)
+        R = np.zeros((nR, 2), np.uint64); chk = np.zeros(3, np.int32)
+        f = self.lib.orc_sumcheck3_stream_batch; f.restype = ctypes.c_int
+        f(c_sz(fd_size), c_sz(B), _p(r), ctypes.c_int(rlen), ctypes.c_int(batches), ctypes.c_int(distance), ctypes.c_int(layer_id), _p(oc), ctypes.c_int(oc.shape[0]),
+          _p(nc), _p(nr), ctypes.c_int(ld), _p(c1), _p(r1), _p(vr1), _p(q2), _p(r2), _p(vr2), _p(f2), _p(R), _p(chk))
+        rows = [nr[i, :1 + logB - i * distance + lR].copy() for i in range(batches)]
+        out = dict(new_claims=nc, new_r=rows)
+        if full:
+            out.update(cpoly1=c1, r1=r1, vr1=vr1, qpoly2=q2, r2=r2, vr2=vr2, fin2=f2, R=R, checks=chk)
+        return out
+
+
+
+    def generate_claims_opt(self, fd_size, B, r, batches, layer_id, distance):
+        r = F(r).reshape(-1, 2); c = np.zeros((batches, 2), np.uint64)
+        self.lib.orc_generate_claims_opt(c_sz(fd_size), c_sz(B), _p(r), ctypes.c_int(batches), ctypes.c_int(layer_id), ctypes.c_int(distance), _p(c))
+        return c
+
+    def field_prod(self, v):
+        """product of the entries of v (n a power of two)"""
+        v = F(v).reshape(-1, 2).copy()
+        while v.shape[0] > 1:
+            v = self.f_mul(v[0::2], v[1::2])
+        return v[0]
+
+    def mul_tree_stream_shallow(self, fd_size, B, vectors, size, previous_r, distance, prev_x, naive=True):
+        """prove_multiplication_tree_stream_shallow (src/sumcheck.cpp:1746-1915) without commit_layers / open_layers (they end in
+        Elastic_PC commit / open over "PC_layer" streams): composition of the restated pieces, libc draws in the reference's order.
+        Returns dict(output, tree=<mul_tree transcript>, steps=[per streaming sumcheck: the full transcript dict])."""
+        assert size * vectors > 2 * B, "in-memory case (src/sumcheck.cpp:1755-1774): call mul_tree on read_stream's data directly"
+        layers = ((size * vectors) // (2 * B)).bit_length() - 1
+        if layers % distance != 0 and layers > distance:
+            layers = distance + layers - (layers % distance)
+        n1 = fd_size >> layers
+        buff1 = self.read_mul_tree_layer(fd_size, n1, layers)
+        inp = buff1.reshape(vectors, n1 // vectors, 2)
+        tree = self.mul_tree(inp, previous_r, prev_x)
+        out = dict(output=np.stack([self.field_prod(inp[i]) for i in range(vectors)]), tree=tree, steps=[], layers=layers)
+        if layers == 0:
+            return out
+        lt = n1.bit_length() - 1
+        old_claims = tree["final_eval"].reshape(1, 2); old_r = [tree["final_r"][:lt]]
+        if layers <= distance or naive:
+            for i in range(layers - 1, -1, -1):
+                st = self.sumcheck3_stream_batch(fd_size, B, np.stack(old_r), 1, 1, i, old_claims, full=True)
+                out["steps"].append(st); old_claims = st["new_claims"]; old_r = st["new_r"]
+        else:
+            batches = layers // distance
+            extra = self.generate_randomness(((size * vectors) >> distance).bit_length() - 1 - lt)
+            r_temp = np.concatenate([tree["final_r"][:lt], extra])
+            old_r = [r_temp] * batches
+            old_claims = self.generate_claims_opt(fd_size, B, r_temp, batches, distance - 1, distance)
+            out["claims0"] = old_claims
+            for i in range(distance - 1, -1, -1):
+                ln = min(len(x) for x in old_r)
+                rr = np.stack([np.concatenate([x, np.zeros((max(len(y) for y in old_r) - len(x), 2), np.uint64)]) for x in old_r])
+                st = self.sumcheck3_stream_batch(fd_size, B, rr, batches, distance, i, old_claims, full=True)
+                out["steps"].append(st); old_claims = st["new_claims"]; old_r = st["new_r"]
+        return out
+
+    def gate_consistency_stream(self, L, R, O, S, B, r):
+        """prove_gate_consistency (src/sumcheck.cpp:796-975) over a caller-supplied trace (chunks of B)"""
+        L, R, O = [F(v).reshape(-1, 2) for v in (L, R, O)]; S = np.ascontiguousarray(S, np.int32); r = F(r).reshape(-1, 2)
+        nch = L.shape[0] // B; logB = B.bit_length() - 1; lR = nch.bit_length() - 1
+        out = dict(R=np.zeros((nch, 2), np.uint64), a=np.zeros((4, 2), np.uint64), poly=np.zeros((logB, 5, 2), np.uint64), gr=np.zeros((logB, 2), np.uint64),
+                   fin6=np.zeros((6, 2), np.uint64), Peval=np.zeros((6, nch, 2), np.uint64), b=np.zeros((6, 2), np.uint64), q2=np.zeros((lR, 3, 2), np.uint64),
+                   r2=np.zeros((lR, 2), np.uint64), vr2=np.zeros((2, 2), np.uint64), fin2=np.zeros(2, np.uint64), checks=np.zeros(3, np.int32))
+        self.lib.orc_gate_consistency_stream(_p(L), _p(R), _p(O), _p(S), c_sz(nch), c_sz(B), _p(r), *[_p(out[k]) for k in ("R", "a", "poly", "gr", "fin6", "Peval", "b", "q2", "r2", "vr2", "fin2", "checks")])
+        return out
+
     class _WQ(ctypes.Structure):
         _fields_ = [(n, ctypes.c_void_p) for n in ("qidx", "qreply", "qpaths", "final_pb", "nq")]
 
@@ -611,6 +705,18 @@ def open_proof_size(res, N, K, trs, queries=5900):
     return ps + _path_ps(M, M.bit_length() - 1, pos)
 
 
+def elastic_open_proof_size(res, N, B, queries=700):
+    """The `ps` (KB) Elastic_PC::open accumulates for option 1 (src/Elastic_PC.cpp:701, 716; src/PC_utils.cpp:474-507), from a transcript"""
+    trs = B >> 11; cols = 4096
+    logr = (2 * trs).bit_length() - 1; logt = logr - 1
+    nc = int(res["ncols"][0]); np2 = 1 << max(nc - 1, 0).bit_length()
+    ps = queries * res["reply"].shape[1] * 16.0 / 1024.0
+    ps += _sc_ps((np2 * 2 * trs).bit_length() - 1) + _sc_ps(logr) + _sc_ps(logt + 12) + _sc_ps(12)
+    ps += _shockwave_ps(res["sp_f"], B, 32)
+    pos = (res["I"][:, 1].astype(np.int64) // 4) * cols + res["I"][:, 0].astype(np.int64)
+    return ps + _path_ps(4 * B, (4 * B).bit_length() - 1, pos)
+
+
 def gate_standard_inputs(n, seed):
     """consistent gates: selector s in {0,1}; O = L + R where s = 1, L * R where s = 0 (so the claimed sum 0 holds)"""
     P = (1 << 61) - 1
@@ -689,6 +795,39 @@ class Ref(_Base):
         o = np.zeros((p.shape[0] // K, 2), np.uint64); roots = np.zeros((2, 32), np.uint8)
         self.lib.ref_aggregate_roots(_p(p), c_sz(p.shape[0]), _p(b), ctypes.c_int(K), ctypes.c_int(trs), _p(o), _p(roots))
         return o, roots
+
+
+    def read_mul_tree_layer(self, fd_size, size, layer):
+        o = np.zeros((size, 2), np.uint64)
+        self.lib.ref_read_mul_tree_layer(c_sz(fd_size), c_sz(size), ctypes.c_int(layer), _p(o))
+        return o
+
+    def read_mul_tree_data(self, fd_size, size, layer, distance, batches):
+        tot = sum(size >> (i * distance) for i in range(batches))
+        o = np.zeros((tot, 2), np.uint64)
+        self.lib.ref_read_mul_tree_data(c_sz(fd_size), c_sz(size), ctypes.c_int(layer), ctypes.c_int(distance), ctypes.c_int(batches), _p(o))
+        return o
+
+    def generate_claims_opt(self, fd_size, B, r, batches, layer_id, distance):
+        r = F(r).reshape(-1, 2); c = np.zeros((batches, 2), np.uint64)
+        self.lib.ref_generate_claims_opt(c_sz(fd_size), c_sz(B), _p(r), ctypes.c_int(r.shape[0]), ctypes.c_int(batches), ctypes.c_int(layer_id), ctypes.c_int(distance), _p(c))
+        return c
+
+    def sumcheck3_stream_batch(self, fd_size, B, r, batches, distance, layer_id, old_claims, full=False):
+        r = F(r); rlen = r.shape[1]; oc = F(old_claims).reshape(-1, 2)
+        size = fd_size >> layer_id; logB = B.bit_length() - 1; nR = size // (2 * B); lR = nR.bit_length() - 1
+        ld = 1 + logB + lR
+        nc = np.zeros((batches, 2), np.uint64); nr = np.zeros((batches, ld, 2), np.uint64)
+        self.lib.ref_sumcheck3_stream_batch(c_sz(fd_size), c_sz(B), _p(r), ctypes.c_int(rlen), ctypes.c_int(batches), ctypes.c_int(distance), ctypes.c_int(layer_id),
+                                            _p(oc), ctypes.c_int(oc.shape[0]), _p(nc), _p(nr), ctypes.c_int(ld))
+        return dict(new_claims=nc, new_r=[nr[i, :1 + logB - i * distance + lR].copy() for i in range(batches)])
+
+    def mul_tree_stream_shallow(self, fd_size, B, vectors, size, previous_r, distance, prev_x):
+        pr = F(previous_r).reshape(2); px = F(prev_x).reshape(-1, 2)
+        o = np.zeros((vectors, 2), np.uint64)
+        f = self.lib.ref_mul_tree_stream_shallow; f.restype = ctypes.c_int
+        n = f(c_sz(fd_size), c_sz(B), ctypes.c_int(vectors), c_sz(size), _p(pr), ctypes.c_int(distance), _p(px), ctypes.c_int(px.shape[0]), _p(o))
+        return o[:n]
 
     def prove_linear_code(self, codeword, n, seed):
         """returns (r1 the reference drew from the libc generator seeded with `seed`, proof)"""

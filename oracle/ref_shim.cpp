@@ -50,6 +50,10 @@ void aggregate(stream_descriptor fd, vector<F> beta1, vector<F> random_points, v
                vector<vector<F>> &aggregated_tensor);                                                                                        // src/Elastic_PC.cpp:316
 void compute_aggregation_reply(stream_descriptor fd, vector<vector<size_t>> &I, vector<vector<F>> &reply);                                  // src/Elastic_PC.cpp:487
 
+void generate_3product_sumcheck_beta_stream_batch_optimized(stream_descriptor fd, vector<vector<F>> r, int batches, int distance, int layer_id, vector<F> old_claims,
+                                                            vector<F> &new_claims, vector<vector<F>> &new_r, double &vt, double &ps);      // src/sumcheck.cpp:1150
+void generate_claims_opt(stream_descriptor fd, vector<F> r, vector<F> &claims, int batches, int layer_id, int distance);                      // src/sumcheck.cpp:1014
+
 static_assert(sizeof(F) == 16, "fieldElement must be 16 bytes");
 static_assert(sizeof(_hash) == 32, "_hash must be 32 bytes");
 
@@ -442,6 +446,49 @@ void ref_elastic_reply(size_t N, size_t B, const uint64_t *Iq, size_t nq, uint64
     compute_aggregation_reply(fd, II, r);
     size_t K = N / B;
     for (size_t q = 0; q < nq; q++) memcpy(reply + 2 * q * K, r[q].data(), 16 * r[q].size());
+}
+
+
+// ---- streaming multiplication-tree prover on the "test" stream (read_stream's default branch) -------------------------------
+void ref_read_mul_tree_layer(size_t fd_size, size_t size, int layer, uint64_t *out) {                 // src/witness_stream.cpp:2413-2456
+    stream_descriptor fd; fd.name = "test"; fd.size = fd_size; fd.pos = 0;
+    vector<F> v(size); read_mul_tree_layer(fd, v, (int)size, layer);
+    memcpy(out, v.data(), 16 * size);
+}
+void ref_read_mul_tree_data(size_t fd_size, size_t size, int layer, int distance, int batches, uint64_t *out) {   // :2458-2510
+    stream_descriptor fd; fd.name = "test"; fd.size = fd_size; fd.pos = 0;
+    vector<vector<F>> V(batches); for (int i = 0; i < batches; i++) V[i].resize(size >> (i * distance));
+    read_mul_tree_data(fd, V, (int)size, layer, distance);
+    size_t o = 0; for (int i = 0; i < batches; i++) { memcpy(out + 2 * o, V[i].data(), 16 * V[i].size()); o += V[i].size(); }
+}
+void ref_generate_claims_opt(size_t fd_size, size_t B, const uint64_t *r, int rlen, int batches, int layer_id, int distance, uint64_t *claims) {   // src/sumcheck.cpp:1014-1054
+    BUFFER_SPACE = B;
+    stream_descriptor fd; fd.name = "test"; fd.size = fd_size; fd.pos = 0;
+    vector<F> c; generate_claims_opt(fd, vecF(r, rlen), c, batches, layer_id, distance);
+    memcpy(claims, c.data(), 16 * c.size());
+}
+// generate_3product_sumcheck_beta_stream_batch_optimized (src/sumcheck.cpp:1150-1393): draws a, b and the pad challenge from libc
+// (seed first); hands back the new claims and new_r rows (row i: 1 + (log2 B - i*distance) + log2(size/2B) entries at stride ld).
+// Exits the process if one of its own checks ("Error in sumcheck 1/2") fails.
+void ref_sumcheck3_stream_batch(size_t fd_size, size_t B, const uint64_t *r, int rlen, int batches, int distance, int layer_id, const uint64_t *old_claims, int n_old,
+                                uint64_t *new_claims, uint64_t *new_r, int ld) {
+    BUFFER_SPACE = B;
+    stream_descriptor fd; fd.name = "test"; fd.size = fd_size; fd.pos = 0;
+    vector<vector<F>> rr(batches), nr; for (int i = 0; i < batches; i++) rr[i] = vecF(r + 2 * (size_t)i * rlen, rlen);
+    vector<F> nc(batches, F(0)); double vt = 0, ps = 0;
+    generate_3product_sumcheck_beta_stream_batch_optimized(fd, rr, batches, distance, layer_id, vecF(old_claims, n_old), nc, nr, vt, ps);
+    memcpy(new_claims, nc.data(), 16 * nc.size());
+    for (size_t i = 0; i < nr.size(); i++) memcpy(new_r + 2 * i * ld, nr[i].data(), 16 * nr[i].size());
+}
+// prove_multiplication_tree_stream_shallow (src/sumcheck.cpp:1746-1915), naive = true (no commit_layers / open_layers: those end in
+// SHA3): returns P1.output (the `vectors` products).  Everything after the in-memory tree is self-checked inside (exit(-1)).
+int ref_mul_tree_stream_shallow(size_t fd_size, size_t B, int vectors, size_t size, const uint64_t *previous_r, int distance, const uint64_t *prev_x, int nx, uint64_t *out) {
+    BUFFER_SPACE = B;
+    stream_descriptor fd; fd.name = "test"; fd.size = fd_size; fd.pos = 0;
+    double vt = 0, ps = 0;
+    vector<F> o = prove_multiplication_tree_stream_shallow(fd, vectors, (int)size, ldF(previous_r), distance, vecF(prev_x, nx), true, vt, ps);
+    memcpy(out, o.data(), 16 * o.size());
+    return (int)o.size();
 }
 
 // whole-driver timing hook for bench.py's cpu_baseline ("reference" kind): commit only.

@@ -283,6 +283,42 @@ def case_elastic_open(lib):
     return out
 
 
+STREAM_SHAPES = ((1 << 15, 1 << 10, 0, 1, 1), (1 << 15, 1 << 10, 2, 1, 1), (1 << 15, 1 << 10, 1, 2, 2), (1 << 17, 1 << 10, 1, 3, 2), (1 << 18, 1 << 12, 0, 1, 1))
+
+
+def stream_batch_inputs(fd_size, B, layer_id, batches, distance):
+    size = fd_size >> layer_id
+    rlen = (size // 2).bit_length() - 1
+    return splitmix_field(batches * rlen, 50 + layer_id).reshape(batches, rlen, 2), splitmix_field(batches, 60)
+
+
+def case_streamdrv(lib):
+    """Streaming multiplication-tree prover on the reference's default "test" stream: read_mul_tree_layer / read_mul_tree_data
+    (src/witness_stream.cpp:2413-2510), generate_claims_opt (src/sumcheck.cpp:1014-1054),
+    generate_3product_sumcheck_beta_stream_batch_optimized (:1150-1393: new claims and challenge rows, functions of every transcript
+    message and libc draw in it) and prove_multiplication_tree_stream_shallow's output (:1746-1915)"""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    out = {}
+    for layer in (1, 2, 4):
+        out["layer_%d" % layer] = dg(lib.read_mul_tree_layer(1 << 16, 1 << 11, layer))
+    for (layer, dist, bt) in ((0, 1, 1), (2, 1, 1), (1, 2, 2), (0, 3, 3)):
+        out["data_%d_%d_%d" % (layer, dist, bt)] = dg(lib.read_mul_tree_data(1 << 16, 1 << 12, layer, dist, bt))
+    for (fd, B, layer_id, batches, dist) in STREAM_SHAPES:
+        rr, oc = stream_batch_inputs(fd, B, layer_id, batches, dist)
+        libc.srandom(5)
+        res = lib.sumcheck3_stream_batch(fd, B, rr, batches, dist, layer_id, oc)
+        key = "gsb_%d_%d_%d_%d_%d_" % (fd, B, layer_id, batches, dist)
+        out[key + "claims"] = res["new_claims"]
+        for i, row in enumerate(res["new_r"]):
+            out[key + "r%d" % i] = row
+    out["claims_opt"] = lib.generate_claims_opt(1 << 16, 1 << 10, splitmix_field(16, 70), 2, 1, 2)
+    libc.srandom(11)
+    o = lib.mul_tree_stream_shallow(1 << 15, 1 << 10, 8, 1 << 12, np.array([32, 0], np.uint64), 5, splitmix_field(3, 9))
+    out["shallow_out"] = o["output"] if isinstance(o, dict) else o
+    return out
+
+
 def case_codeproofs(lib):
     """evaluate_parity_matrix / prove_linear_code / phiGInit / prepare_matrix / prove_fft / prove_fft_matrix
     (src/sumcheck.cpp:2888-2929, 3223-3235, 2975-3027; src/utils.cpp:694-775)"""
@@ -408,5 +444,5 @@ def case_gate(lib):
     return out
 
 
-CASES = dict(elastic_open=case_elastic_open, field=case_field, mimc=case_mimc, blake=case_blake, merkle=case_merkle, graph_encode=case_graph_encode,
+CASES = dict(streamdrv=case_streamdrv, elastic_open=case_elastic_open, field=case_field, mimc=case_mimc, blake=case_blake, merkle=case_merkle, graph_encode=case_graph_encode,
              fft=case_fft, tensorcode=case_tensorcode, commit=case_commit, sumcheck=case_sumcheck, elastic=case_elastic, codeproofs=case_codeproofs, streamfold=case_streamfold, multree=case_multree, innerpcs=case_innerpcs, gate=case_gate)

@@ -1019,3 +1019,28 @@ def test_elastic_commit_vs_reference_big(hb, logN, opt):
     T = 4 * B
     assert np.array_equal(lv[-1], g["root"])
     assert np.array_equal(dg(lv[:T - 1]), g["leaves_dg"]) and np.array_equal(dg(lv[T:]), g["upper_dg"])
+
+
+def test_host_mirror_test_elastic_pc(oracle):
+    """test_Elastic_PC(2^18, 1) through the C++ mirror (commit(stream_descriptor), open(stream_descriptor), read_stream, the reference's
+    signatures): root, queries, replies, sumcheck transcripts and the proof size against the oracle run on the same libc sequence"""
+    import ctypes
+    from __graft_entry__ import PKG, build_host
+    from oracle.pyoracle import elastic_open_proof_size
+    build_host()
+    lib = ctypes.CDLL(os.path.join(PKG, "libhobbit_host.so"))
+    N, B = 1 << 18, 1 << 14
+    oracle.rng_reset(); lv = oracle.elastic_commit(N, B, 1)
+    x = oracle.generate_randomness(18)
+    want = oracle.elastic_open(N, B, x, 700, lv)
+    root = np.zeros(32, np.uint8); I = np.zeros((700, 2), np.uint32); reply = np.zeros((700, N // B, 2), np.uint64)
+    q = np.zeros((64, 3, 2), np.uint64); r = np.zeros((64, 2), np.uint64); chk = np.zeros(3, np.int32); ps = ctypes.c_double()
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.hobbit_host_elastic_open.argtypes = [ctypes.c_size_t, ctypes.c_size_t] + [ctypes.c_void_p] * 7
+    rounds = lib.hobbit_host_elastic_open(N, B, P(root), P(I), P(reply), P(q), P(r), P(chk), ctypes.byref(ps))
+    lib.hobbit_host_close()
+    assert np.array_equal(root, lv[-1]) and chk.tolist() == [1, 1, 1]
+    assert rounds == want["poly"].shape[0]
+    assert np.array_equal(I, want["I"]) and np.array_equal(reply, want["reply"])
+    assert np.array_equal(q[:rounds], want["poly"]) and np.array_equal(r[:rounds], want["r"])
+    assert ps.value == elastic_open_proof_size(want, N, B)

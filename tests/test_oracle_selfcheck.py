@@ -82,3 +82,37 @@ def test_elastic_open_selfchecks(oracle, logN, logB):
     # a Merkle path of the commitment re-hashes to its root (left|left rule: the sibling is carried, the parent hashes the left child twice)
     depth = (4 * B).bit_length() - 1
     assert res["paths"].shape == (700, depth, 32)
+
+
+@pytest.mark.parametrize("distance,naive", [(5, True), (2, False), (1, True)])
+def test_mul_tree_stream_shallow_selfchecks(oracle, distance, naive):
+    """prove_multiplication_tree_stream_shallow restated (layers <= distance, the config-4 shape; the batched path; the naive path) on a
+    stream whose reads all differ (stream kind 1: no counterpart in the reference, which repeats one chunk): every streaming sumcheck's
+    K_partial must equal the claim handed down by the previous layer ("Error in sumcheck 0"), P1's claim the folded Kf ("... 1"), and
+    sum b.vr P2's claim ("... 2")."""
+    import ctypes
+    B, vectors, size = 1 << 10, 8, 1 << 12
+    oracle.stream_config(1, 4000)
+    try:
+        ctypes.CDLL(None).srandom(3)
+        res = oracle.mul_tree_stream_shallow(vectors * size, B, vectors, size, np.array([32, 0], np.uint64), distance, splitmix_field(3, 9), naive=naive)
+    finally:
+        oracle.stream_config(0, 0)
+    assert len(res["steps"]) == (min(distance, 4) if not naive else 4)
+    for st in res["steps"]:
+        assert st["checks"].tolist() == [1, 1, 1]
+
+
+def test_gate_consistency_stream_selfchecks(oracle):
+    """prove_gate_consistency's chunk loop, degree-4 sumcheck and Peval pass (src/sumcheck.cpp:796-975) on consistent synthetic gates:
+    'Error in gate consistency 1/2/3' must all hold; a corrupted output column must trip check 1."""
+    from oracle.pyoracle import gate_standard_inputs
+    B, nch = 1 << 8, 8
+    parts = [gate_standard_inputs(B, 100 + c) for c in range(nch)]
+    L, R, O = [np.concatenate([p[i] for p in parts]) for i in range(3)]
+    S = np.concatenate([p[3][:, 0] for p in parts]).astype(np.int32)
+    res = oracle.gate_consistency_stream(L, R, O, S, B, splitmix_field(8, 3))
+    assert res["checks"].tolist() == [1, 1, 1]
+    assert np.array_equal(res["R"][0], np.array([1, 0], np.uint64))
+    O2 = O.copy(); O2[3 * B + 5, 0] ^= np.uint64(1)
+    assert oracle.gate_consistency_stream(L, R, O2, S, B, splitmix_field(8, 3))["checks"][0] == 0
