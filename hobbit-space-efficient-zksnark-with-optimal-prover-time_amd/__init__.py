@@ -40,6 +40,8 @@ ABI_SYMBOLS = [
     "hobbit_elastic_begin", "hobbit_elastic_push", "hobbit_elastic_finish", "hobbit_elastic_free",
     "hobbit_elastic_open_begin", "hobbit_elastic_open_aggregate_push", "hobbit_elastic_open_aggregate_finish", "hobbit_elastic_open_reply_push",
     "hobbit_elastic_open_finish", "hobbit_elastic_open_free", "hobbit_generate_randomness",
+    "hobbit_read_mul_tree_layer", "hobbit_read_mul_tree_data", "hobbit_generate_claims_opt", "hobbit_sumcheck3_stream_batch", "hobbit_mul_tree_stream_shallow",
+    "hobbit_gate_consistency_stream",
     "hobbit_tensorcode_chunks", "hobbit_inner_digests", "hobbit_chain_digests", "hobbit_blake3_64_host",
     "hobbit_parity_matrix", "hobbit_phi_g", "hobbit_prepare_matrix_cols", "hobbit_prove_linear_code", "hobbit_prove_fft",
     "hobbit_prove_fft_matrix",
@@ -100,6 +102,9 @@ def load_library(path=LIB_PATH):
         "hobbit_elastic_open_begin": [V, S, S, I, V, I, V], "hobbit_elastic_open_aggregate_push": [V, V, V], "hobbit_elastic_open_aggregate_finish": [V, V],
         "hobbit_elastic_open_reply_push": [V, V, V], "hobbit_elastic_open_finish": [V, V, V, V], "hobbit_elastic_open_free": [V],
         "hobbit_generate_randomness": [S, V],
+        "hobbit_read_mul_tree_layer": [V, V, V, S, I, V], "hobbit_read_mul_tree_data": [V, V, V, S, I, I, I, V],
+        "hobbit_generate_claims_opt": [V, V, V, S, S, V, I, I, I, I, V], "hobbit_sumcheck3_stream_batch": [V, V, V, S, S, V, I, I, I, I, V, I, V],
+        "hobbit_mul_tree_stream_shallow": [V, V, V, S, S, I, S, V, I, V, I, V], "hobbit_gate_consistency_stream": [V, V, V, S, S, V, V],
         "hobbit_tensorcode_chunks": [V, V, S, I, I, I, V], "hobbit_inner_digests": [V, V, S, I, I, V],
         "hobbit_chain_digests": [V, V, S, I, S, V], "hobbit_blake3_64_host": [V, V, S],
     }
@@ -745,6 +750,137 @@ class Hobbit:
         if sp:
             res["sp_f"] = self._sp_trim(sp[0], B, 32)
         return res
+
+    # ---- streaming provers over a chunk source (src/sumcheck.cpp:796-975, 1014-1054, 1150-1393, 1746-1915) ----
+    CHUNK_FN = ctypes.CFUNCTYPE(c_int, c_vp, c_sz, ctypes.POINTER(c_vp))
+    TRACE_FN = ctypes.CFUNCTYPE(c_int, c_vp, c_sz, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp))
+
+    def chunk_source(self, kind=0, seed=0):
+        """A hobbit_chunk_source for tests / benches.  kind 0: the reference's default stream (read_stream: v[i] = F(i % 1024 + 1), every
+        read alike; one resident buffer per read size).  kind 1: read c since the last reset = splitmix_field(n, seed + c), generated on
+        the host and uploaded per read.  Keep the returned object alive while the library may call it."""
+        st = dict(c=0, resident={}, live=[])
+
+        def fn(user, n, out):
+            try:
+                if n == 0:
+                    st["c"] = 0
+                    return 0
+                if kind == 0:
+                    if n not in st["resident"]:
+                        st["resident"][n] = self.to_device(self.read_stream(n))
+                    out[0] = st["resident"][n].ptr
+                else:
+                    buf = self.to_device(splitmix_field(n, seed + st["c"])); st["c"] += 1
+                    st["live"].append(buf); del st["live"][:-3]
+                    out[0] = buf.ptr
+                return 0
+            except Exception:            # an exception must not unwind through the C caller
+                import traceback; traceback.print_exc()
+                return 1
+        cb = self.CHUNK_FN(fn); cb._state = st
+        return cb
+
+    def trace_source(self, L, R, O, S, B):
+        """hobbit_trace_source over host arrays (chunk c = elements [c*B, (c+1)*B)), resident on the device"""
+        dl, dr, do = [self.to_device(Fh(v).reshape(-1, 2)) for v in (L, R, O)]; ds = self.to_device(np.ascontiguousarray(S, np.int32))
+        st = dict(c=0)
+
+        def fn(user, n, pl, pr, po, ps):
+            if n == 0:
+                st["c"] = 0
+                return 0
+            c = st["c"]; st["c"] += 1
+            if n != B or (c + 1) * B * 16 > dl.nbytes:
+                return 1
+            pl[0] = dl.ptr + 16 * c * B; pr[0] = dr.ptr + 16 * c * B; po[0] = do.ptr + 16 * c * B; ps[0] = ds.ptr + 4 * c * B
+            return 0
+        cb = self.TRACE_FN(fn); cb._keep = (dl, dr, do, ds)
+        return cb
+
+    def read_mul_tree_layer(self, src, size, layer):
+        o = self.alloc(16 * size)
+        self._chk(self.lib.hobbit_read_mul_tree_layer(self.ctx, ctypes.cast(src, c_vp), None, size, layer, o.ptr))
+        return self.to_host(o, (size, 2), np.uint64)
+
+    def read_mul_tree_data(self, src, size, layer, distance, batches):
+        tot = sum(size >> (i * distance) for i in range(batches))
+        o = self.alloc(16 * tot)
+        self._chk(self.lib.hobbit_read_mul_tree_data(self.ctx, ctypes.cast(src, c_vp), None, size, layer, distance, batches, o.ptr))
+        return self.to_host(o, (tot, 2), np.uint64)
+
+    def generate_claims_opt(self, src, fd_size, B, r, batches, layer_id, distance):
+        r = Fh(r).reshape(-1, 2); c = np.zeros((batches, 2), np.uint64)
+        self._chk(self.lib.hobbit_generate_claims_opt(self.ctx, ctypes.cast(src, c_vp), None, fd_size, B, _hp(r), r.shape[0], batches, layer_id, distance, _hp(c)))
+        return c
+
+    class _S3(ctypes.Structure):
+        _fields_ = [("new_claims", c_vp), ("new_r", c_vp), ("new_r_ld", c_int), ("cpoly1", c_vp), ("r1", c_vp), ("vr1", c_vp), ("qpoly2", c_vp), ("r2", c_vp), ("vr2", c_vp),
+                    ("fin2", c_vp), ("R", c_vp), ("checks", c_vp)]
+
+    def _s3_buffers(self, fd_size, B, batches, layer_id):
+        size = fd_size >> layer_id; logB = B.bit_length() - 1; nR = size // (2 * B); lR = nR.bit_length() - 1; ld = 1 + logB + lR
+        b = dict(new_claims=np.zeros((batches, 2), np.uint64), new_r=np.zeros((batches, ld, 2), np.uint64), cpoly1=np.zeros((logB, 4, 2), np.uint64),
+                 r1=np.zeros((logB, 2), np.uint64), vr1=np.zeros((batches, 3, 2), np.uint64), qpoly2=np.zeros((lR, 3, 2), np.uint64), r2=np.zeros((lR, 2), np.uint64),
+                 vr2=np.zeros((2, 2), np.uint64), fin2=np.zeros(2, np.uint64), R=np.zeros((nR, 2), np.uint64), checks=np.zeros(3, np.int32))
+        st = self._S3(b["new_claims"].ctypes.data, b["new_r"].ctypes.data, ld, *[b[k].ctypes.data for k in ("cpoly1", "r1", "vr1", "qpoly2", "r2", "vr2", "fin2", "R", "checks")])
+        return b, st, ld
+
+    @staticmethod
+    def _s3_result(b, B, batches, distance, ld):
+        logB = B.bit_length() - 1; lR = ld - 1 - logB
+        out = dict(b); out["new_r"] = [b["new_r"][i, :1 + logB - i * distance + lR].copy() for i in range(batches)]
+        return out
+
+    def sumcheck3_stream_batch(self, src, fd_size, B, r, batches, distance, layer_id, old_claims):
+        """generate_3product_sumcheck_beta_stream_batch_optimized; r: (batches, rlen, 2)"""
+        r = Fh(r); rlen = r.shape[1]; oc = Fh(old_claims).reshape(-1, 2)
+        b, st, ld = self._s3_buffers(fd_size, B, batches, layer_id)
+        self._chk(self.lib.hobbit_sumcheck3_stream_batch(self.ctx, ctypes.cast(src, c_vp), None, fd_size, B, _hp(r), rlen, batches, distance, layer_id, _hp(oc), oc.shape[0], ctypes.byref(st)))
+        return self._s3_result(b, B, batches, distance, ld)
+
+    def mul_tree_stream_shallow(self, src, fd_size, B, vectors, size, previous_r, distance, prev_x, naive=True):
+        """prove_multiplication_tree_stream_shallow without commit_layers / open_layers"""
+        total = size * vectors
+        layers = max((total // (2 * B)).bit_length() - 1, 0)
+        if layers % distance != 0 and layers > distance:
+            layers = distance + layers - (layers % distance)
+        n1 = (fd_size >> layers) if total > 2 * B else total
+        sz = n1 // vectors; lt = n1.bit_length() - 1; depth = sz.bit_length() - 1; nr = sum(range(lt))
+        tree = dict(output=np.zeros((vectors, 2), np.uint64), poly=np.zeros((nr + 1, 4, 2), np.uint64), r=np.zeros((nr + 1, 2), np.uint64), vr=np.zeros((depth, 3, 2), np.uint64),
+                    fin=np.zeros((depth, 2), np.uint64), final_r=np.zeros((lt, 2), np.uint64), out_eval=np.zeros(2, np.uint64), final_eval=np.zeros(2, np.uint64),
+                    layers=np.zeros(1, np.int32))
+        if layers <= distance or naive:
+            plan = [(1, 1, i) for i in range(layers - 1, -1, -1)]
+        else:
+            plan = [(layers // distance, distance, i) for i in range(distance - 1, -1, -1)]
+        bufs = [self._s3_buffers(fd_size, B, bt, lid) for (bt, d, lid) in plan] if total > 2 * B else []
+        arr = (self._S3 * max(len(bufs), 1))(*[x[1] for x in bufs])
+        nst = ctypes.c_int(0); claims0 = np.zeros((16, 2), np.uint64); sl = ctypes.c_int(0)
+
+        class MO(ctypes.Structure):
+            _fields_ = [(n, c_vp) for n in ("output", "cpoly", "r", "vr", "fin", "final_r", "out_eval", "final_eval", "layers", "steps")] + [("max_steps", c_int), ("n_steps", c_vp), ("claims0", c_vp), ("stream_layers", c_vp)]
+        mo = MO(*[tree[k].ctypes.data for k in ("output", "poly", "r", "vr", "fin", "final_r", "out_eval", "final_eval", "layers")], ctypes.addressof(arr), len(bufs),
+                ctypes.addressof(nst), claims0.ctypes.data, ctypes.addressof(sl))
+        pr = Fh(previous_r).reshape(2); px = Fh(prev_x).reshape(-1, 2)
+        self._chk(self.lib.hobbit_mul_tree_stream_shallow(self.ctx, ctypes.cast(src, c_vp), None, fd_size, B, vectors, size, _hp(pr), distance, _hp(px), int(naive), ctypes.byref(mo)))
+        L = int(tree["layers"][0])
+        tree.update(vr=tree["vr"][:L], fin=tree["fin"][:L], layers=np.array([L]))
+        steps = [self._s3_result(bufs[i][0], B, plan[i][0], plan[i][1], bufs[i][2]) for i in range(nst.value)]
+        return dict(output=tree["output"], tree=tree, steps=steps, layers=sl.value, claims0=claims0)
+
+    def gate_consistency_stream(self, tsrc, n_chunks, B, r):
+        r = Fh(r).reshape(-1, 2); logB = B.bit_length() - 1; lR = n_chunks.bit_length() - 1
+        out = dict(R=np.zeros((n_chunks, 2), np.uint64), a=np.zeros((4, 2), np.uint64), poly=np.zeros((logB, 5, 2), np.uint64), gr=np.zeros((logB, 2), np.uint64),
+                   fin6=np.zeros((6, 2), np.uint64), Peval=np.zeros((6, n_chunks, 2), np.uint64), b=np.zeros((6, 2), np.uint64), q2=np.zeros((lR, 3, 2), np.uint64),
+                   r2=np.zeros((lR, 2), np.uint64), vr2=np.zeros((2, 2), np.uint64), fin2=np.zeros(2, np.uint64), checks=np.zeros(3, np.int32))
+        names = ("R", "a", "poly", "gr", "fin6", "Peval", "b", "q2", "r2", "vr2", "fin2", "checks")
+
+        class GO(ctypes.Structure):
+            _fields_ = [(n, c_vp) for n in names]
+        go = GO(*[out[k].ctypes.data for k in names])
+        self._chk(self.lib.hobbit_gate_consistency_stream(self.ctx, ctypes.cast(tsrc, c_vp), None, n_chunks, B, _hp(r), ctypes.byref(go)))
+        return out
 
     def elastic_commit(self, N, B, opt, gcc_arg_order=1, chunk=None, keep_levels=False):
         """test_Elastic_PC's commit (src/Elastic_PC.cpp:736-771): opt 1 RSxRS trs=B/2^11, opt 2 RSxexpander trs=B/2^14.

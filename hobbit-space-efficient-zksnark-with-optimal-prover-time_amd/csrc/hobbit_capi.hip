@@ -1092,8 +1092,17 @@ int hobbit_batch_3product_sumcheck(hobbit_ctx *ctx, const hobbit_F *d_t1, const 
 }
 
 // ---- prove_multiplication_tree_new (src/sumcheck.cpp:35-257), power-of-two vectors x size ---------------------
+static int mul_tree_impl(hobbit_ctx *ctx, const hobbit_F *d_input, size_t vectors, size_t size, const hobbit_F *h_previous_r, const hobbit_F *h_prev_x,
+                         hobbit_F *h_cpoly, hobbit_F *h_r, hobbit_F *h_vr, hobbit_F *h_fin, hobbit_F *h_final_r, hobbit_F *h_out_eval, hobbit_F *h_final_eval, int *layers_out,
+                         hobbit_F *h_output);
 int hobbit_mul_tree(hobbit_ctx *ctx, const hobbit_F *d_input, size_t vectors, size_t size, const hobbit_F *h_previous_r, const hobbit_F *h_prev_x,
                     hobbit_F *h_cpoly, hobbit_F *h_r, hobbit_F *h_vr, hobbit_F *h_fin, hobbit_F *h_final_r, hobbit_F *h_out_eval, hobbit_F *h_final_eval, int *layers_out) {
+    return mul_tree_impl(ctx, d_input, vectors, size, h_previous_r, h_prev_x, h_cpoly, h_r, h_vr, h_fin, h_final_r, h_out_eval, h_final_eval, layers_out, nullptr);
+}
+// h_output (nullable): Proof.output = the `vectors` products (top layer of the tree)
+static int mul_tree_impl(hobbit_ctx *ctx, const hobbit_F *d_input, size_t vectors, size_t size, const hobbit_F *h_previous_r, const hobbit_F *h_prev_x,
+                         hobbit_F *h_cpoly, hobbit_F *h_r, hobbit_F *h_vr, hobbit_F *h_fin, hobbit_F *h_final_r, hobbit_F *h_out_eval, hobbit_F *h_final_eval, int *layers_out,
+                         hobbit_F *h_output) {
     const int depth = ilog2_exact(size), lv = ilog2_exact(vectors);
     if (depth < 1 || lv < 0) return ctx->fail(HOBBIT_EINVAL, "mul_tree: vectors and size must be powers of two (the host mirror pads as the reference does)");
     const size_t total = vectors * size;
@@ -1104,6 +1113,7 @@ int hobbit_mul_tree(hobbit_ctx *ctx, const hobbit_F *d_input, size_t vectors, si
       for (int i = 0; i < depth; i++) { len /= 2; lo[i] = o; HB_TRY(launch_mul_layer(ctx, src, len, in1 + o, in2 + o, tr + o)); src = tr + o; o += len; } }
     F previous_r = *cF(h_previous_r), sum;
     std::vector<F> r; int layers = 0; size_t qo = 0, ro = 0;
+    if (h_output) HB_TRY(hobbit_memcpy_d2h(ctx, h_output, tr + lo[depth - 1], vectors * sizeof(F)));
     if (vectors == 1) {
         F top; HB_TRY(hobbit_memcpy_d2h(ctx, &top, tr + lo[depth - 1], sizeof(F)));
         previous_r = mimc_hash(previous_r, top); sum = top;
@@ -1302,6 +1312,365 @@ int hobbit_elastic_open_finish(hobbit_ctx *ctx, hobbit_elastic_open *e, const ui
     memcpy(rx.data(), Rr, sizeof(hobbit_F) * (size_t)logc); memcpy(rx.data() + logc, r3 + logc, sizeof(hobbit_F) * (size_t)logt);
     if (o->rx) memcpy(o->rx, rx.data(), sizeof(hobbit_F) * rx.size());
     if (o->sp_f) HB_TRY(hobbit_shockwave_prove(ctx, reinterpret_cast<hobbit_F *>(e->d_aggr), reinterpret_cast<hobbit_F *>(e->d_encf), e->d_lvf, B, 32, rx.data(), (int)rx.size(), o->sp_f));   // (:507)
+    return 0;
+}
+
+// ---- streaming (space-efficient) provers over a caller-supplied chunk source -------------------------------------------------
+struct StreamSrc { hobbit_chunk_source fn; void *user; };
+static int src_next(hobbit_ctx *ctx, const StreamSrc &s, size_t n, const F **d) {
+    const hobbit_F *p = nullptr;
+    if (!s.fn || s.fn(s.user, n, &p) != 0 || (n && !p)) return ctx->fail(HOBBIT_EINVAL, "chunk source failed");
+    *d = cF(p); return 0;
+}
+static int src_reset(hobbit_ctx *ctx, const StreamSrc &s) { const F *d; return src_next(ctx, s, 0, &d); }   // reset_stream (src/witness_stream.cpp:228-234)
+// evaluate_vector (src/utils.cpp:789-802) on a handful of host values
+static F host_eval_vector(std::vector<F> v, const F *r, int k) {
+    for (int i = 0; i < k; i++) { size_t L = v.size() / 2; for (size_t j = 0; j < L; j++) v[j] = fadd(v[2 * j], fmul(r[i], fsub(v[2 * j + 1], v[2 * j]))); v.resize(L); }
+    return v[0];
+}
+// read_mul_tree_layer (src/witness_stream.cpp:2413-2456, every stream but "wiring_consistency_check"): d_out[0..size) = products of
+// 2^layer consecutive elements; one read of 2*size elements fills size/2^layer entries of each half.  layer >= 1.
+static int dev_read_mul_tree_layer(hobbit_ctx *ctx, const StreamSrc &src, size_t size, int layer, F *d_out) {
+    if (layer < 1 || ((size_t)1 << layer) > size) return ctx->fail(HOBBIT_EINVAL, "read_mul_tree_layer: needs 1 <= layer <= log2(size) (the reference indexes past its vector for layer 0)");
+    const uint32_t seg = 1u << layer; const size_t per = size / seg;
+    for (size_t counter = 0; counter < size / 2; counter += per) {
+        const F *ch; HB_TRY(src_next(ctx, src, 2 * size, &ch));
+        HB_TRY(launch_seg_prod(ctx, ch, seg, per, d_out + counter));
+        HB_TRY(launch_seg_prod(ctx, ch + size, seg, per, d_out + counter + size / 2));
+    }
+    return 0;
+}
+// read_mul_tree_data (:2458-2510): V[0] = `size` products of 2^layer consecutive elements (lower half from the first half of every read,
+// upper half from its second half), V[i] = products of 2^distance consecutive entries of V[i-1]
+static int dev_read_mul_tree_data(hobbit_ctx *ctx, const StreamSrc &src, F *const *V, const size_t *vlen, int batches, size_t size, int layer, int distance) {
+    const uint32_t seg = 1u << layer; const size_t per = size / (2 * (size_t)seg);
+    if (!per) return ctx->fail(HOBBIT_EINVAL, "read_mul_tree_data: 2^layer too large for the read size");
+    for (size_t counter = 0; counter < size / 2; counter += per) {
+        const F *ch; HB_TRY(src_next(ctx, src, size, &ch));
+        HB_TRY(launch_seg_prod(ctx, ch, seg, per, V[0] + counter));
+        HB_TRY(launch_seg_prod(ctx, ch + size / 2, seg, per, V[0] + counter + size / 2));
+    }
+    for (int i = 1; i < batches; i++) HB_TRY(launch_seg_prod(ctx, V[i - 1], 1u << distance, vlen[i], V[i]));
+    return 0;
+}
+int hobbit_read_mul_tree_layer(hobbit_ctx *ctx, hobbit_chunk_source source, void *user, size_t size, int layer, hobbit_F *d_out) {
+    StreamSrc src{source, user};
+    HB_TRY(src_reset(ctx, src));
+    return dev_read_mul_tree_layer(ctx, src, size, layer, mF(d_out));
+}
+int hobbit_read_mul_tree_data(hobbit_ctx *ctx, hobbit_chunk_source source, void *user, size_t size, int layer, int distance, int batches, hobbit_F *d_out) {
+    if (batches < 1 || batches > 16 || distance < 0) return ctx->fail(HOBBIT_EINVAL, "read_mul_tree_data: 1 <= batches <= 16");
+    StreamSrc src{source, user};
+    F *V[16]; size_t vlen[16]; size_t o = 0;
+    for (int i = 0; i < batches; i++) { V[i] = mF(d_out) + o; vlen[i] = size >> (i * distance); o += vlen[i]; }
+    HB_TRY(src_reset(ctx, src));
+    return dev_read_mul_tree_data(ctx, src, V, vlen, batches, size, layer, distance);
+}
+// shared set-up of generate_claims_opt / the streaming 3-product sumcheck: per batch the table sizes and the eq table over the chunk index (host)
+struct StreamPlan {
+    int batches, logB; size_t size, nch, tot, vtot;
+    size_t sz[16], off[16], vlen[16], voff[16]; int n_init[16]; std::vector<F> rb[16];
+};
+static int stream_plan(hobbit_ctx *ctx, StreamPlan &P, size_t fd_size, size_t B, const F *h_r, int rlen, int rstride, int batches, int distance, int layer_id) {
+    if (batches < 1 || batches > 16 || distance < 1 || layer_id < 0) return ctx->fail(HOBBIT_EINVAL, "streaming sumcheck: bad batches / distance / layer");
+    P.batches = batches; P.size = fd_size >> layer_id; P.logB = ilog2_exact(B);
+    if (P.logB < 1 || ilog2_exact(P.size) < 0 || P.size < 4 * B) return ctx->fail(HOBBIT_EINVAL, "streaming sumcheck: needs power-of-two sizes with size >= 4*BUFFER_SPACE");
+    P.nch = P.size / (4 * B); P.tot = P.vtot = 0;
+    const int lhalf = ilog2_exact(P.size / 2);
+    for (int i = 0; i < batches; i++) {
+        const int n_init = P.logB - i * distance, n_rem = lhalf - i * distance - n_init;
+        if (n_init < 1 || n_rem < 1 || n_init + n_rem > rlen) return ctx->fail(HOBBIT_EINVAL, "streaming sumcheck: challenge vector too short for this batch");
+        P.n_init[i] = n_init;
+        P.sz[i] = B >> (i * distance); P.vlen[i] = (4 * B) >> (i * distance); P.off[i] = P.tot; P.voff[i] = P.vtot; P.tot += P.sz[i]; P.vtot += P.vlen[i];
+        host_eq_table(h_r + (size_t)i * rstride + n_init, n_rem, P.rb[i]);
+    }
+    return 0;
+}
+// generate_claims_opt (src/sumcheck.cpp:1014-1054): one challenge vector r for every batch
+int hobbit_generate_claims_opt(hobbit_ctx *ctx, hobbit_chunk_source source, void *user, size_t fd_size, size_t B, const hobbit_F *h_r, int rlen, int batches, int layer_id,
+                               int distance, hobbit_F *h_claims) {
+    StreamSrc src{source, user}; StreamPlan P;
+    HB_TRY(stream_plan(ctx, P, fd_size, B, cF(h_r), rlen, 0, batches, distance, layer_id));
+    const size_t nres = 2 * P.nch * (size_t)batches;
+    F *base; HB_TRY(ctx->workspace4((2 * P.vtot + P.tot + 1024 + nres + 64) * sizeof(F), (void **)&base));
+    F *Vb = base, *EO = Vb + P.vtot, *beta = EO + P.vtot, *part = beta + P.tot, *dres = part + 1024;
+    F *V[16]; for (int i = 0; i < batches; i++) V[i] = Vb + P.voff[i];
+    for (int i = 0; i < batches; i++) HB_TRY(hobbit_eq_table(ctx, h_r, P.n_init[i], reinterpret_cast<hobbit_F *>(beta + P.off[i])));
+    HB_TRY(src_reset(ctx, src));
+    for (size_t c = 0; c < P.nch; c++) {
+        HB_TRY(dev_read_mul_tree_data(ctx, src, V, P.vlen, batches, 4 * B, layer_id, distance));
+        for (int j = 0; j < batches; j++) {
+            F *E = EO + P.voff[j], *O = E + 2 * P.sz[j];                         // evens | odds, each 2*sz: [first half | second half]
+            HB_TRY(launch_deinterleave(ctx, V[j], 2 * P.sz[j], E, O));
+            HB_TRY(launch_dot_gen(ctx, beta + P.off[j], E, 1, O, P.sz[j], part, dres + (2 * c) * batches + j));
+            HB_TRY(launch_dot_gen(ctx, beta + P.off[j], E + P.sz[j], 1, O + P.sz[j], P.sz[j], part, dres + (2 * c + 1) * batches + j));
+        }
+    }
+    std::vector<F> res(nres);
+    HB_TRY(hobbit_memcpy_d2h(ctx, res.data(), dres, nres * sizeof(F)));
+    for (int j = 0; j < batches; j++) {
+        F cl = fmake(0); const size_t hb = P.rb[j].size() / 2;
+        for (size_t c = 0; c < P.nch; c++) { cl = fadd(cl, fmul(P.rb[j][c], res[(2 * c) * batches + j])); cl = fadd(cl, fmul(P.rb[j][c + hb], res[(2 * c + 1) * batches + j])); }
+        mF(h_claims)[j] = cl;
+    }
+    return src_reset(ctx, src);
+}
+// generate_3product_sumcheck_beta_stream_batch_optimized (src/sumcheck.cpp:1150-1393)
+int hobbit_sumcheck3_stream_batch(hobbit_ctx *ctx, hobbit_chunk_source source, void *user, size_t fd_size, size_t B, const hobbit_F *h_r, int rlen, int batches, int distance,
+                                  int layer_id, const hobbit_F *h_old_claims, int n_old, hobbit_stream3_out *o) {
+    if (!o || n_old > batches) return ctx->fail(HOBBIT_EINVAL, "sumcheck3_stream_batch: bad arguments");
+    StreamSrc src{source, user}; StreamPlan P;
+    HB_TRY(stream_plan(ctx, P, fd_size, B, cF(h_r), rlen, rlen, batches, distance, layer_id));
+    const size_t nR = 2 * P.nch, half = P.rb[0].size() / 2, npe = 2 * (size_t)batches * nR;
+    // device tables: V | evens/odds scratch | fold1,2,3 | buff1,2,3 (each `tot`, batch j at off[j]) | partials | results
+    F *base; HB_TRY(ctx->workspace4((2 * P.vtot + 6 * P.tot + 1024 + npe + 2 * nR + 64) * sizeof(F), (void **)&base));
+    F *Vb = base, *EO = Vb + P.vtot, *f1 = EO + P.vtot, *f2 = f1 + P.tot, *f3 = f2 + P.tot, *b1 = f3 + P.tot, *b2 = b1 + P.tot, *b3 = b2 + P.tot, *part = b3 + P.tot,
+      *dres = part + 1024, *dR = dres + npe + 16;
+    F *V[16]; for (int i = 0; i < batches; i++) V[i] = Vb + P.voff[i];
+    for (int i = 0; i < batches; i++) HB_TRY(hobbit_eq_table(ctx, h_r + (size_t)i * rlen, P.n_init[i], reinterpret_cast<hobbit_F *>(b3 + P.off[i])));   // buff3 = beta(initial_r) (:1171)
+    HB_CHECK(ctx, hipMemcpyAsync(f3, b3, P.tot * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));                                                       // fold_buff3 = buff3
+    HB_TRY(src_reset(ctx, src));
+    HB_TRY(dev_read_mul_tree_data(ctx, src, V, P.vlen, batches, 4 * B, layer_id, distance));                                                              // (:1187)
+    std::vector<F> Kp(batches), a(batches);
+    for (int i = 0; i < batches; i++) {                                              // fold_buff1/2 = the first half's pairs; K_partial = sum f1 f2 f3 (:1194-1202)
+        HB_TRY(launch_deinterleave(ctx, V[i], P.sz[i], f1 + P.off[i], f2 + P.off[i]));
+        HB_TRY(launch_dot_gen(ctx, f1 + P.off[i], f2 + P.off[i], 1, f3 + P.off[i], P.sz[i], part, dres + i));
+    }
+    HB_TRY(hobbit_memcpy_d2h(ctx, Kp.data(), dres, (size_t)batches * sizeof(F)));
+    { F cst = fmake(0); for (int i = 0; i < batches; i++) { if (i % 100 == 0) cst = fmake((uint64_t)random()); a[i] = fadd(cst, fmake((uint64_t)rand())); } }          // a = generate_randomness(batches)
+    F Kf = fmake(0);
+    std::vector<F> R; R.push_back(fmake(1));
+    for (int i = 0; i < batches; i++) { Kf = fadd(Kf, fmul(a[i], Kp[i])); Kp[i] = fmul(Kp[i], P.rb[i][0]); }
+    auto load_half = [&](int second) -> int {
+        for (int j = 0; j < batches; j++) HB_TRY(launch_deinterleave(ctx, V[j] + (second ? 2 * P.sz[j] : 0), P.sz[j], b1 + P.off[j], b2 + P.off[j]));
+        return 0;
+    };
+    auto batch_prod_step = [&](size_t idx) -> int {                                   // batch_prod (:1093-1136)
+        F K1 = fmake(0), K2 = fmake(0); std::vector<F> K3(batches);
+        for (int j = 0; j < batches; j++) {
+            const size_t q = P.off[j];
+            const F *t[8] = {b1 + q, b2 + q, b3 + q, f1 + q, f2 + q, f3 + q, nullptr, nullptr}; F k[4];
+            HB_TRY(launch_err_terms(ctx, 13, t, nullptr, P.sz[j], k));
+            K1 = fadd(K1, fmul(a[j], k[0])); K2 = fadd(K2, fmul(a[j], k[1])); K3[j] = k[2];
+        }
+        F rnd = mimc_hash(K1, R.back()); rnd = mimc_hash(K2, rnd);
+        for (int j = 0; j < batches; j++) rnd = mimc_hash(K3[j], rnd);
+        const F x1 = rnd, x2 = fmul(rnd, x1), x3 = fmul(rnd, x2);
+        for (int j = 0; j < batches; j++) { Kp[j] = fadd(Kp[j], fmul(P.rb[j][idx], K3[j])); Kf = fadd(Kf, fmul(fmul(x3, a[j]), K3[j])); }
+        Kf = fadd(Kf, fadd(fmul(x2, K2), fmul(x1, K1)));
+        R.push_back(rnd);
+        HB_TRY(launch_axpy(ctx, f1, b1, rnd, P.tot)); HB_TRY(launch_axpy(ctx, f2, b2, rnd, P.tot));
+        return launch_axpy(ctx, f3, b3, rnd, P.tot);
+    };
+    HB_TRY(load_half(1)); HB_TRY(batch_prod_step(half));                              // (:1216-1222)
+    for (size_t i = 1; i < P.nch; i++) {                                              // (:1223-1241)
+        HB_TRY(dev_read_mul_tree_data(ctx, src, V, P.vlen, batches, 4 * B, layer_id, distance));
+        HB_TRY(load_half(0)); HB_TRY(batch_prod_step(i));
+        HB_TRY(load_half(1)); HB_TRY(batch_prod_step(i + half));
+    }
+    HB_TRY(src_reset(ctx, src));
+    o->checks[0] = 1;
+    for (int i = 0; i < n_old; i++) if (!feq(Kp[i], cF(h_old_claims)[i])) o->checks[0] = 0;                                                              // "Error in sumcheck 0" (printed only, :1246-1251)
+    // P1 = batch_3product_sumcheck(fold_buff1, fold_buff2, fold_buff3, a) (:1264); "Error in sumcheck 1" (:1280-1283)
+    std::vector<size_t> lens(batches); for (int i = 0; i < batches; i++) lens[i] = P.sz[i];
+    HB_TRY(hobbit_batch_3product_sumcheck(ctx, reinterpret_cast<hobbit_F *>(f1), reinterpret_cast<hobbit_F *>(f2), reinterpret_cast<hobbit_F *>(f3), lens.data(), batches,
+                                          reinterpret_cast<hobbit_F *>(a.data()), o->cpoly1, o->r1, o->vr1));
+    { const F *q0 = cF(o->cpoly1); o->checks[1] = feq(fadd(fadd(fadd(q0[0], q0[1]), fadd(q0[2], q0[3])), q0[3]), Kf); }
+    // Partial_Evals pass (:1303-1340): beta[k] over P1's first log2(sizes[k]) challenges
+    for (int k = 0; k < batches; k++) HB_TRY(hobbit_eq_table(ctx, o->r1, ilog2_exact(P.sz[k]), reinterpret_cast<hobbit_F *>(b3 + P.off[k])));
+    for (size_t i = 0; i < P.nch; i++) {
+        HB_TRY(dev_read_mul_tree_data(ctx, src, V, P.vlen, batches, 4 * B, layer_id, distance));
+        for (int k = 0; k < batches; k++) {
+            const F *bt = b3 + P.off[k]; const size_t n = P.sz[k], h2 = P.vlen[k] / 2;
+            F *p0 = dres + (size_t)(2 * k) * nR, *p1 = dres + (size_t)(2 * k + 1) * nR;
+            HB_TRY(launch_dot_gen(ctx, bt, V[k], 2, nullptr, n, part, p0 + i));
+            HB_TRY(launch_dot_gen(ctx, bt, V[k] + h2, 2, nullptr, n, part, p0 + i + nR / 2));
+            HB_TRY(launch_dot_gen(ctx, bt, V[k] + 1, 2, nullptr, n, part, p1 + i));
+            HB_TRY(launch_dot_gen(ctx, bt, V[k] + 1 + h2, 2, nullptr, n, part, p1 + i + nR / 2));
+        }
+    }
+    HB_TRY(src_reset(ctx, src));
+    std::vector<F> PE(npe);
+    HB_TRY(hobbit_memcpy_d2h(ctx, PE.data(), dres, npe * sizeof(F)));
+    std::vector<F> Rp(nR);                                                              // permute_partial_evals (:1137-1148): only R moves
+    for (size_t i = 0; i < nR / 2; i++) { Rp[i] = R[2 * i]; Rp[nR / 2 + i] = R[2 * i + 1]; }
+    if (o->R) memcpy(o->R, Rp.data(), nR * sizeof(F));
+    std::vector<F> bb(2 * (size_t)batches), ae(nR, fmake(0));
+    { F cst = fmake(0); for (size_t i = 0; i < bb.size(); i++) { if (i % 100 == 0) cst = fmake((uint64_t)random()); bb[i] = fadd(cst, fmake((uint64_t)rand())); } }   // b = generate_randomness(2*batches)
+    for (size_t i = 0; i < bb.size(); i++) for (size_t j = 0; j < nR; j++) ae[j] = fadd(ae[j], fmul(bb[i], PE[i * nR + j]));
+    HB_TRY(hobbit_memcpy_h2d(ctx, dR, Rp.data(), nR * sizeof(F)));
+    HB_TRY(hobbit_memcpy_h2d(ctx, dR + nR, ae.data(), nR * sizeof(F)));
+    hobbit_F zero = {0, 0};                                                             // previous_r = the local `rand`, never updated: F(0) (:1207, 1351)
+    HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(dR), reinterpret_cast<hobbit_F *>(dR + nR), nR, &zero, o->qpoly2, o->r2, o->vr2, o->fin2));
+    {   // "Error in sumcheck 2" (:1356-1365)
+        F sum = fmake(0); const F *vr1 = cF(o->vr1), *q2 = cF(o->qpoly2);
+        for (int i = 0; i < batches; i++) { sum = fadd(sum, fmul(bb[2 * i], vr1[3 * i])); sum = fadd(sum, fmul(bb[2 * i + 1], vr1[3 * i + 1])); }
+        o->checks[2] = feq(fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])), sum);
+    }
+    const int lR = ilog2_exact(nR);
+    const F pad = fmake((uint64_t)random());                                            // (:1368)
+    for (int i = 0; i < batches; i++) {
+        F *row = mF(o->new_r) + (size_t)i * o->new_r_ld; int n = 0;
+        if (1 + P.n_init[i] + lR > o->new_r_ld) return ctx->fail(HOBBIT_EINVAL, "sumcheck3_stream_batch: new_r_ld too small");
+        row[n++] = pad;
+        for (int j = 0; j < P.n_init[i]; j++) row[n++] = cF(o->r1)[j];
+        for (int j = 0; j < lR; j++) row[n++] = cF(o->r2)[j];
+        const F e0 = host_eval_vector(std::vector<F>(PE.begin() + (size_t)(2 * i) * nR, PE.begin() + (size_t)(2 * i + 1) * nR), cF(o->r2), lR);
+        const F e1 = host_eval_vector(std::vector<F>(PE.begin() + (size_t)(2 * i + 1) * nR, PE.begin() + (size_t)(2 * i + 2) * nR), cF(o->r2), lR);
+        mF(o->new_claims)[i] = fadd(fmul(fsub(fmake(1), pad), e0), fmul(pad, e1));      // (:1383-1386)
+    }
+    return 0;
+}
+// prove_multiplication_tree_stream_shallow (src/sumcheck.cpp:1746-1915) without commit_layers / open_layers
+int hobbit_mul_tree_stream_shallow(hobbit_ctx *ctx, hobbit_chunk_source source, void *user, size_t fd_size, size_t B, int vectors, size_t size, const hobbit_F *h_previous_r,
+                                   int distance, const hobbit_F *h_prev_x, int naive, hobbit_mul_stream_out *o) {
+    if (!o || vectors < 1 || distance < 1 || ilog2_exact((size_t)vectors) < 0 || ilog2_exact(size) < 0) return ctx->fail(HOBBIT_EINVAL, "mul_tree_stream_shallow: vectors and size must be powers of two");
+    StreamSrc src{source, user};
+    const size_t total = size * (size_t)vectors;
+    if (o->n_steps) *o->n_steps = 0;
+    if (total <= 2 * B) {                                                               // in memory (:1755-1774)
+        HB_TRY(src_reset(ctx, src));
+        const F *ch; HB_TRY(src_next(ctx, src, total, &ch));
+        return mul_tree_impl(ctx, reinterpret_cast<const hobbit_F *>(ch), (size_t)vectors, size, h_previous_r, h_prev_x, o->cpoly, o->r, o->vr, o->fin, o->final_r, o->out_eval,
+                             o->final_eval, o->layers, o->output);
+    }
+    int layers = ilog2_exact(total / (2 * B));
+    if (layers < 0) return ctx->fail(HOBBIT_EINVAL, "mul_tree_stream_shallow: size*vectors/(2*BUFFER_SPACE) must be a power of two");
+    if (layers % distance != 0 && layers > distance) layers = distance + layers - (layers % distance);       // (:1779-1793)
+    if (o->stream_layers) *o->stream_layers = layers;
+    const size_t n1 = fd_size >> layers;
+    if (n1 < (size_t)vectors * 2) return ctx->fail(HOBBIT_EINVAL, "mul_tree_stream_shallow: product layer smaller than the vector count");
+    F *buff1; HB_TRY(ctx->workspace4(n1 * sizeof(F), (void **)&buff1));
+    HB_TRY(src_reset(ctx, src));
+    HB_TRY(dev_read_mul_tree_layer(ctx, src, n1, layers, buff1));                       // (:1805-1810)
+    HB_TRY(mul_tree_impl(ctx, reinterpret_cast<hobbit_F *>(buff1), (size_t)vectors, n1 / (size_t)vectors, h_previous_r, h_prev_x, o->cpoly, o->r, o->vr, o->fin, o->final_r,
+                         o->out_eval, o->final_eval, o->layers, o->output));
+    HB_TRY(src_reset(ctx, src));
+    if (layers == 0) return 0;
+    const int lt = ilog2_exact(n1);
+    std::vector<hobbit_F> claims(16), nclaims(16);
+    int steps = 0;
+    auto run_step = [&](const hobbit_F *r, int rlen, int batches, int dist, int layer_id, int n_old) -> int {
+        if (steps >= o->max_steps) return ctx->fail(HOBBIT_EINVAL, "mul_tree_stream_shallow: more streaming sumchecks than max_steps");
+        hobbit_stream3_out *st = &o->steps[steps];
+        HB_TRY(hobbit_sumcheck3_stream_batch(ctx, source, user, fd_size, B, r, rlen, batches, dist, layer_id, claims.data(), n_old, st));
+        for (int i = 0; i < batches; i++) claims[i] = st->new_claims[i];
+        steps++; if (o->n_steps) *o->n_steps = steps;
+        return 0;
+    };
+    if (layers <= distance || naive) {                                                  // (:1849-1865)
+        claims[0] = *o->final_eval;
+        std::vector<hobbit_F> cur(o->final_r, o->final_r + lt);
+        for (int i = layers - 1; i >= 0; i--) {
+            HB_TRY(run_step(cur.data(), (int)cur.size(), 1, 1, i, 1));
+            const hobbit_stream3_out *st = &o->steps[steps - 1];
+            const int n = 1 + ilog2_exact(B) + ilog2_exact((fd_size >> i) / (2 * B));
+            cur.assign(st->new_r, st->new_r + n);
+        }
+    } else {                                                                            // (:1866-1908)
+        const int batches = layers / distance;
+        const int want = ilog2_exact(total >> distance);
+        std::vector<hobbit_F> r_temp(o->final_r, o->final_r + lt);
+        { F cst = fmake(0); for (int i = 0; i < want - lt; i++) { if (i % 100 == 0) cst = fmake((uint64_t)random()); F v = fadd(cst, fmake((uint64_t)rand())); r_temp.push_back(*reinterpret_cast<hobbit_F *>(&v)); } }
+        HB_TRY(hobbit_generate_claims_opt(ctx, source, user, fd_size, B, r_temp.data(), (int)r_temp.size(), batches, distance - 1, distance, claims.data()));
+        if (o->claims0) memcpy(o->claims0, claims.data(), sizeof(hobbit_F) * (size_t)batches);
+        int ld = (int)r_temp.size();
+        std::vector<hobbit_F> cur((size_t)batches * ld);
+        for (int b = 0; b < batches; b++) memcpy(cur.data() + (size_t)b * ld, r_temp.data(), sizeof(hobbit_F) * (size_t)ld);
+        for (int i = distance - 1; i >= 0; i--) {
+            HB_TRY(run_step(cur.data(), ld, batches, distance, i, batches));
+            const hobbit_stream3_out *st = &o->steps[steps - 1];
+            ld = st->new_r_ld;
+            cur.assign(st->new_r, st->new_r + (size_t)batches * ld);
+        }
+    }
+    return 0;
+}
+// prove_gate_consistency (src/sumcheck.cpp:796-975) over a caller-supplied trace source (read_trace belongs to the witness generator)
+int hobbit_gate_consistency_stream(hobbit_ctx *ctx, hobbit_trace_source source, void *user, size_t n_chunks, size_t B, const hobbit_F *h_r, hobbit_gate_stream_out *o) {
+    const int logB = ilog2_exact(B), lR = ilog2_exact(n_chunks);
+    if (!o || !source || logB < 1 || lR < 1) return ctx->fail(HOBBIT_EINVAL, "gate_consistency_stream: BUFFER_SPACE and the chunk count must be powers of two, chunks >= 2");
+    auto next = [&](size_t n, const F **L, const F **R, const F **O, const int32_t **S) -> int {
+        const hobbit_F *l = nullptr, *r = nullptr, *oo = nullptr; const int32_t *s = nullptr;
+        if (source(user, n, &l, &r, &oo, &s) != 0 || (n && (!l || !r || !oo || !s))) return ctx->fail(HOBBIT_EINVAL, "trace source failed");
+        *L = cF(l); *R = cF(r); *O = cF(oo); *S = s; return 0;
+    };
+    const F *bL, *bR, *bO; const int32_t *bS;
+    F *base; HB_TRY(ctx->workspace4((8 * B + 1024 + 6 * n_chunks + 2 * n_chunks + 64) * sizeof(F), (void **)&base));
+    F *beta = base, *fb = beta + B, *fL = fb + B, *fR = fL + B, *fO = fR + B, *fa = fO + B, *fm = fa + B, *tmp = fm + B, *part = tmp + B, *dres = part + 1024, *dR = dres + 6 * n_chunks + 16;
+    HB_TRY(hobbit_eq_table(ctx, h_r, logB, reinterpret_cast<hobbit_F *>(beta)));
+    HB_CHECK(ctx, hipMemcpyAsync(fb, beta, B * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    HB_TRY(next(0, &bL, &bR, &bO, &bS));
+    HB_TRY(next(B, &bL, &bR, &bO, &bS));
+    HB_CHECK(ctx, hipMemcpyAsync(fL, bL, B * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    HB_CHECK(ctx, hipMemcpyAsync(fR, bR, B * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    HB_CHECK(ctx, hipMemcpyAsync(fO, bO, B * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    HB_TRY(launch_i32_to_F(ctx, bS, 0, B, fa)); HB_TRY(launch_i32_to_F(ctx, bS, 1, B, fm));
+    // Kf_O, Kf_L, Kf_R, Kf_M (:818-826)
+    HB_TRY(launch_dot_gen(ctx, beta, fO, 1, nullptr, B, part, dres));
+    HB_TRY(launch_dot_gen(ctx, beta, fL, 1, fa, B, part, dres + 1));
+    HB_TRY(launch_dot_gen(ctx, beta, fR, 1, fa, B, part, dres + 2));
+    HB_TRY(launch_f_binop(ctx, 2, fR, fL, tmp, B));
+    HB_TRY(launch_dot_gen(ctx, beta, tmp, 1, fm, B, part, dres + 3));
+    F K0[4]; HB_TRY(hobbit_memcpy_d2h(ctx, K0, dres, 4 * sizeof(F)));
+    F KO = K0[0], KL = K0[1], KR = K0[2], KM = K0[3], rnd = fmake(0);
+    std::vector<F> R; R.push_back(fmake(1));
+    o->checks[0] = 1;
+    for (size_t c = 1; c < n_chunks; c++) {
+        HB_TRY(next(B, &bL, &bR, &bO, &bS));
+        F k2[4], kl[4], kr[4], k4[4];
+        { const F *t[8] = {bO, beta, fO, fb, nullptr, nullptr, nullptr, nullptr}; HB_TRY(launch_err_terms(ctx, 2, t, nullptr, B, k2)); }
+        { const F *t[8] = {bL, fL, fa, fb, beta, nullptr, nullptr, nullptr}; HB_TRY(launch_err_terms(ctx, 3, t, bS, B, kl)); }
+        { const F *t[8] = {bR, fR, fa, fb, beta, nullptr, nullptr, nullptr}; HB_TRY(launch_err_terms(ctx, 3, t, bS, B, kr)); }
+        { const F *t[8] = {bL, bR, beta, fL, fR, fb, fm, nullptr}; HB_TRY(launch_err_terms(ctx, 4, t, bS, B, k4)); }
+        if (!feq(fsub(fadd(fadd(k4[3], kl[2]), kr[2]), k2[1]), fmake(0))) o->checks[0] = 0;                 // "Error in gate consistency 1" (:840-843)
+        rnd = mimc_hash(k2[0], rnd); rnd = mimc_hash(k2[1], rnd);
+        rnd = mimc_hash(kl[0], rnd); rnd = mimc_hash(kl[1], rnd); rnd = mimc_hash(kl[2], rnd);
+        rnd = mimc_hash(kr[0], rnd); rnd = mimc_hash(kr[1], rnd); rnd = mimc_hash(kr[2], rnd);
+        R.push_back(rnd);
+        const F x1 = rnd, x2 = fmul(rnd, x1), x3 = fmul(rnd, x2), x4 = fmul(rnd, x3);
+        KO = fadd(KO, fadd(fmul(x1, k2[0]), fmul(x2, k2[1])));
+        KL = fadd(KL, fadd(fadd(fmul(x1, kl[0]), fmul(x2, kl[1])), fmul(x3, kl[2])));
+        KR = fadd(KR, fadd(fadd(fmul(x1, kr[0]), fmul(x2, kr[1])), fmul(x3, kr[2])));
+        KM = fadd(KM, fadd(fadd(fmul(x1, k4[0]), fmul(x2, k4[1])), fadd(fmul(x3, k4[2]), fmul(x4, k4[3]))));
+        HB_TRY(launch_axpy_i32(ctx, fa, bS, rnd, 0, B)); HB_TRY(launch_axpy(ctx, fL, bL, rnd, B)); HB_TRY(launch_axpy(ctx, fR, bR, rnd, B));      // (:862-869)
+        HB_TRY(launch_axpy(ctx, fO, bO, rnd, B)); HB_TRY(launch_axpy_i32(ctx, fm, bS, rnd, 1, B)); HB_TRY(launch_axpy(ctx, fb, beta, rnd, B));
+    }
+    HB_TRY(next(0, &bL, &bR, &bO, &bS));                                                 // reset_stream(tr) (:871)
+    memcpy(o->R, R.data(), n_chunks * sizeof(F));
+    F a[4]; { F cst = fmake(0); for (int i = 0; i < 4; i++) { if (i % 100 == 0) cst = fmake((uint64_t)random()); a[i] = fadd(cst, fmake((uint64_t)rand())); } }      // a = generate_randomness(4)
+    memcpy(o->a, a, sizeof a);
+    F sum = fadd(fadd(fmul(a[0], KL), fmul(a[1], KR)), fadd(fmul(a[2], KM), fmul(KO, a[3])));
+    int chk2 = 0;
+    HB_TRY(hobbit_gate_sumcheck(ctx, reinterpret_cast<hobbit_F *>(fa), reinterpret_cast<hobbit_F *>(fb), reinterpret_cast<hobbit_F *>(fL), reinterpret_cast<hobbit_F *>(fR),
+                                reinterpret_cast<hobbit_F *>(fO), reinterpret_cast<hobbit_F *>(fm), B, reinterpret_cast<hobbit_F *>(a), reinterpret_cast<hobbit_F *>(&rnd),
+                                reinterpret_cast<hobbit_F *>(&sum), o->poly, o->gr, o->fin6, &chk2));
+    o->checks[1] = chk2;
+    // Peval pass (:941-959): beta1 over the sumcheck challenges
+    HB_TRY(hobbit_eq_table(ctx, o->gr, logB, reinterpret_cast<hobbit_F *>(tmp)));
+    for (size_t c = 0; c < n_chunks; c++) {
+        HB_TRY(next(B, &bL, &bR, &bO, &bS));
+        HB_TRY(launch_dot_gen(ctx, tmp, bL, 1, nullptr, B, part, dres + 0 * n_chunks + c));
+        HB_TRY(launch_dot_gen(ctx, tmp, bR, 1, nullptr, B, part, dres + 1 * n_chunks + c));
+        HB_TRY(launch_dot_gen(ctx, tmp, bO, 1, nullptr, B, part, dres + 2 * n_chunks + c));
+        HB_TRY(launch_dot_i32(ctx, tmp, bS, 0, B, part, dres + 3 * n_chunks + c));
+        HB_TRY(launch_dot_i32(ctx, tmp, bS, 1, B, part, dres + 4 * n_chunks + c));
+        HB_TRY(launch_dot_gen(ctx, tmp, beta, 1, nullptr, B, part, dres + 5 * n_chunks + c));
+    }
+    HB_TRY(hobbit_memcpy_d2h(ctx, o->Peval, dres, 6 * n_chunks * sizeof(F)));
+    F b[6]; { F cst = fmake(0); for (int i = 0; i < 6; i++) { if (i % 100 == 0) cst = fmake((uint64_t)random()); b[i] = fadd(cst, fmake((uint64_t)rand())); } }      // b = generate_randomness(6)
+    memcpy(o->b, b, sizeof b);
+    std::vector<F> pe(n_chunks, fmake(0));
+    for (size_t j = 0; j < n_chunks; j++) for (int i = 0; i < 6; i++) pe[j] = fadd(pe[j], fmul(b[i], cF(o->Peval)[(size_t)i * n_chunks + j]));
+    HB_TRY(hobbit_memcpy_h2d(ctx, dR, R.data(), n_chunks * sizeof(F)));
+    HB_TRY(hobbit_memcpy_h2d(ctx, dR + n_chunks, pe.data(), n_chunks * sizeof(F)));
+    HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(dR), reinterpret_cast<hobbit_F *>(dR + n_chunks), n_chunks, reinterpret_cast<hobbit_F *>(&rnd), o->q2, o->r2, o->vr2, o->fin2));
+    {   // "Error in gate consistency 3" (:966-972); fin6 = add, beta, L, R, O, mul
+        const F *f6 = cF(o->fin6), *q2 = cF(o->q2);
+        F sm = fadd(fadd(fmul(f6[2], b[0]), fmul(f6[3], b[1])), fadd(fmul(f6[4], b[2]), fmul(b[3], f6[0])));
+        sm = fadd(sm, fadd(fmul(b[4], f6[5]), fmul(b[5], f6[1])));
+        o->checks[2] = feq(fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])), sm);
+    }
     return 0;
 }
 

@@ -2034,4 +2034,79 @@ int launch_spread_cols(hobbit_ctx *ctx, const uint32_t *d_cols, const F *d_vals,
     return 0;
 }
 
+// ============================================================================================
+// Streaming provers: product layers of the stream (src/witness_stream.cpp:2413-2510 read_mul_tree_layer / read_mul_tree_data),
+// partial evaluations (src/sumcheck.cpp:1327-1340, 949-959)
+// ============================================================================================
+// out[t] = prod_{j < seg} in[t*seg + j]
+__global__ void k_seg_prod(const F *__restrict__ in, uint32_t seg, size_t n_out, F *__restrict__ out) {
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= n_out) return;
+    const F *p = in + t * seg;
+    F a = ldF(p);
+    for (uint32_t j = 1; j < seg; j++) a = fmul(a, ldF(p + j));
+    stF(out + t, a);
+}
+int launch_seg_prod(hobbit_ctx *ctx, const F *in, uint32_t seg, size_t n_out, F *out) {
+    if (!n_out) return 0;
+    HB_LAUNCH(ctx, "k_seg_prod", k_seg_prod, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, in, seg, n_out, out);
+    return 0;
+}
+// a[j] = v[2j], b[j] = v[2j+1]
+__global__ void k_deinterleave(const F *__restrict__ v, size_t n, F *__restrict__ a, F *__restrict__ b) {
+    const size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    stF(a + j, ldF(v + 2 * j)); stF(b + j, ldF(v + 2 * j + 1));
+}
+int launch_deinterleave(hobbit_ctx *ctx, const F *v, size_t n, F *a, F *b) {
+    if (!n) return 0;
+    HB_LAUNCH(ctx, "k_deinterleave", k_deinterleave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, v, n, a, b);
+    return 0;
+}
+// sum_j a[j] * b[j*sb] (* c[j] when c != NULL)
+__global__ void __launch_bounds__(256) k_dot_gen(const F *__restrict__ a, const F *__restrict__ b, size_t sb, const F *__restrict__ c, size_t n, F *__restrict__ partials) {
+    F s[1] = {fmake(0)};
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+        F t = fmul(ldF(a + j), ldF(b + j * sb));
+        if (c) t = fmul(t, ldF(c + j));
+        s[0] = fadd(s[0], t);
+    }
+    block_reduce_store<1>(s, partials);
+}
+int launch_dot_gen(hobbit_ctx *ctx, const F *a, const F *b, size_t sb, const F *c, size_t n, F *part, F *out) {
+    int nb = grid_for(n, 256, 1024);
+    HB_LAUNCH(ctx, "k_dot_gen", k_dot_gen, dim3(nb), dim3(256), 0, a, b, sb, c, n, part);
+    HB_LAUNCH(ctx, "k_sc_reduce", k_sc_reduce<1>, dim3(1), dim3(256), 0, part, nb, out);
+    return 0;
+}
+// sum_j a[j] * F(sel[j])  (one_minus: 1 - F(sel[j]))
+__global__ void __launch_bounds__(256) k_dot_i32(const F *__restrict__ a, const int32_t *__restrict__ sel, int one_minus, size_t n, F *__restrict__ partials) {
+    F s[1] = {fmake(0)};
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+        F v = fmake((uint64_t)(int64_t)sel[j]);
+        if (one_minus) v = fsub(fmake(1), v);
+        s[0] = fadd(s[0], fmul(ldF(a + j), v));
+    }
+    block_reduce_store<1>(s, partials);
+}
+int launch_dot_i32(hobbit_ctx *ctx, const F *a, const int32_t *sel, int one_minus, size_t n, F *part, F *out) {
+    int nb = grid_for(n, 256, 1024);
+    HB_LAUNCH(ctx, "k_dot_i32", k_dot_i32, dim3(nb), dim3(256), 0, a, sel, one_minus, n, part);
+    HB_LAUNCH(ctx, "k_sc_reduce", k_sc_reduce<1>, dim3(1), dim3(256), 0, part, nb, out);
+    return 0;
+}
+// y[j] = F(sel[j]) or 1 - F(sel[j])
+__global__ void k_i32_to_F(const int32_t *__restrict__ sel, int one_minus, size_t n, F *__restrict__ y) {
+    const size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    F v = fmake((uint64_t)(int64_t)sel[j]);
+    if (one_minus) v = fsub(fmake(1), v);
+    stF(y + j, v);
+}
+int launch_i32_to_F(hobbit_ctx *ctx, const int32_t *sel, int one_minus, size_t n, F *y) {
+    if (!n) return 0;
+    HB_LAUNCH(ctx, "k_i32_to_F", k_i32_to_F, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sel, one_minus, n, y);
+    return 0;
+}
+
 }  // namespace hobbit

@@ -62,4 +62,9 @@ int launch_sumcheck3(hobbit_ctx *ctx, const F *v1, const F *v2, const F *v3, siz
 int launch_any_nonzero(hobbit_ctx *ctx, const F *v, size_t n, int *d_flag);
 int launch_gather_cols(hobbit_ctx *ctx, const F *T, size_t ld, uint32_t nrows, const uint32_t *d_cols, uint32_t ncols, F *G, size_t ldG);
 int launch_spread_cols(hobbit_ctx *ctx, const uint32_t *d_cols, const F *d_vals, uint32_t ncols, uint32_t nrows, size_t ld, F *out);
+int launch_seg_prod(hobbit_ctx *ctx, const F *in, uint32_t seg, size_t n_out, F *out);
+int launch_deinterleave(hobbit_ctx *ctx, const F *v, size_t n, F *a, F *b);
+int launch_dot_gen(hobbit_ctx *ctx, const F *a, const F *b, size_t sb, const F *c, size_t n, F *part, F *out);
+int launch_dot_i32(hobbit_ctx *ctx, const F *a, const int32_t *sel, int one_minus, size_t n, F *part, F *out);
+int launch_i32_to_F(hobbit_ctx *ctx, const int32_t *sel, int one_minus, size_t n, F *y);
 }  // namespace hobbit

@@ -349,6 +349,56 @@ int hobbit_fold_axpy_i32(hobbit_ctx *ctx, hobbit_F *d_fold, const int32_t *d_sel
 int hobbit_batch_prod(hobbit_ctx *ctx, hobbit_F *d_f1, hobbit_F *d_f2, hobbit_F *d_f3, const hobbit_F *d_b1, const hobbit_F *d_b2, const hobbit_F *d_b3, int batches,
                       size_t n, const hobbit_F *h_r_last, const hobbit_F *h_a, const hobbit_F *h_rem_beta, hobbit_F *h_Kf, hobbit_F *h_Kp, hobbit_F *h_rand);
 
+/* ---- streaming provers over a caller-supplied chunk source (BASELINE config 4: the MLP prover's math phases) ------------------- */
+/* The reference re-generates its streams on demand (read_stream / read_trace, src/witness_stream.cpp) instead of holding them;
+ * that machinery (and the Seval oracle behind it) stays with the host.  A source is called once per read, in stream order:
+ * it must make the next n elements available on the device and hand back pointers that stay valid until its next call; n == 0
+ * means reset_stream (src/witness_stream.cpp:228-234).  Its writes must be ordered after the work already queued on the
+ * context's stream (hobbit_memcpy_h2d does that).  Return non-zero to abort. */
+typedef int (*hobbit_chunk_source)(void *user, size_t n, const hobbit_F **d_chunk);
+typedef int (*hobbit_trace_source)(void *user, size_t n, const hobbit_F **d_L, const hobbit_F **d_R, const hobbit_F **d_O, const int32_t **d_S);
+/* read_mul_tree_layer (src/witness_stream.cpp:2413-2456; every stream but "wiring_consistency_check"): d_out[0..size) = products of
+ * 2^layer consecutive stream elements (reads of 2*size elements; 1 <= layer).  read_mul_tree_data (:2458-2510): level 0 = `size`
+ * products of 2^layer elements (reads of `size` elements), level i = products of 2^distance entries of level i-1; levels back to
+ * back in d_out (size, size >> distance, ...). */
+int hobbit_read_mul_tree_layer(hobbit_ctx *ctx, hobbit_chunk_source source, void *user, size_t size, int layer, hobbit_F *d_out);
+int hobbit_read_mul_tree_data(hobbit_ctx *ctx, hobbit_chunk_source source, void *user, size_t size, int layer, int distance, int batches, hobbit_F *d_out);
+/* generate_claims_opt (src/sumcheck.cpp:1014-1054): h_r (rlen F) is shared by the batches; h_claims: batches F */
+int hobbit_generate_claims_opt(hobbit_ctx *ctx, hobbit_chunk_source source, void *user, size_t fd_size, size_t B, const hobbit_F *h_r, int rlen, int batches, int layer_id,
+                               int distance, hobbit_F *h_claims);
+/* generate_3product_sumcheck_beta_stream_batch_optimized (src/sumcheck.cpp:1150-1393): one pass of batch_prod over the stream
+ * (error terms on the device, MiMC transcript on the host), batch_3product_sumcheck on the folded tables, the Partial_Evals pass,
+ * the closing 2-product sumcheck over the chunk challenges.  libc draws in the reference's order (a, b, the pad challenge).
+ * h_r: batches rows of rlen F.  All hobbit_stream3_out pointers are host buffers:
+ *   new_claims: batches F; new_r: batches rows at stride new_r_ld (row i: 1 + (log2 B - i*distance) + log2(size/2B) entries);
+ *   cpoly1 / r1 / vr1: batch_3product_sumcheck's transcript (log2 B rounds x 4 F; batches x 3 F);
+ *   qpoly2 / r2 / vr2 / fin2: the 2-product sumcheck (log2(size/2B) rounds);  R: the permuted chunk challenges (size/2B F, nullable);
+ *   checks[3]: K_partial == old_claims ("Error in sumcheck 0": the reference only prints), "Error in sumcheck 1", "Error in sumcheck 2". */
+typedef struct {
+    hobbit_F *new_claims, *new_r; int new_r_ld;
+    hobbit_F *cpoly1, *r1, *vr1, *qpoly2, *r2, *vr2, *fin2, *R; int *checks;
+} hobbit_stream3_out;
+int hobbit_sumcheck3_stream_batch(hobbit_ctx *ctx, hobbit_chunk_source source, void *user, size_t fd_size, size_t B, const hobbit_F *h_r, int rlen, int batches, int distance,
+                                  int layer_id, const hobbit_F *h_old_claims, int n_old, hobbit_stream3_out *out);
+/* prove_multiplication_tree_stream_shallow (src/sumcheck.cpp:1746-1915) for every stream but "wiring_consistency_check", WITHOUT
+ * commit_layers / open_layers (Elastic_PC commit / open of the "PC_layer" streams: the caller's business -- they run only when
+ * layers > distance and naive == 0).  output: the `vectors` products; cpoly .. layers: the in-memory tree's transcript, as
+ * hobbit_mul_tree; steps[0 .. *n_steps): the streaming sumchecks, last product layer first (buffers as hobbit_stream3_out, supplied by
+ * the caller, max_steps of them); claims0: generate_claims_opt's output on the batched path (nullable); stream_layers: `layers`. */
+typedef struct {
+    hobbit_F *output, *cpoly, *r, *vr, *fin, *final_r, *out_eval, *final_eval; int *layers;
+    hobbit_stream3_out *steps; int max_steps; int *n_steps; hobbit_F *claims0; int *stream_layers;
+} hobbit_mul_stream_out;
+int hobbit_mul_tree_stream_shallow(hobbit_ctx *ctx, hobbit_chunk_source source, void *user, size_t fd_size, size_t B, int vectors, size_t size, const hobbit_F *h_previous_r,
+                                   int distance, const hobbit_F *h_prev_x, int naive, hobbit_mul_stream_out *out);
+/* prove_gate_consistency (src/sumcheck.cpp:796-975): the chunk loop (compute{2,3,4}p_error_terms, transcript, six folds), the degree-4
+ * sumcheck over the folded tables, the Peval pass and the closing 2-product sumcheck.  The trace source is read n_chunks times, reset,
+ * and read n_chunks times again.  Host outputs: R (n_chunks F, R[0] = 1), a (4), poly (log2 B x 5 F), gr (log2 B), fin6 (the folded
+ * add, beta, L, R, O, mul), Peval (6 x n_chunks), b (6), q2 / r2 / vr2 / fin2 (log2 n_chunks rounds), checks[3] ("Error in gate
+ * consistency 1 / 2 / 3"; 1 = holds). */
+typedef struct { hobbit_F *R, *a, *poly, *gr, *fin6, *Peval, *b, *q2, *r2, *vr2, *fin2; int *checks; } hobbit_gate_stream_out;
+int hobbit_gate_consistency_stream(hobbit_ctx *ctx, hobbit_trace_source source, void *user, size_t n_chunks, size_t B, const hobbit_F *h_r, hobbit_gate_stream_out *out);
+
 /* ---- synthetic inputs on the device (bench / tests) ---------------------------------------- */
 /* splitmix64-derived full-range elements: element i = (sm(seed,2i+1) mod p, sm(seed,2i+2) mod p) */
 int hobbit_fill_splitmix(hobbit_ctx *ctx, hobbit_F *d_out, size_t n, uint64_t seed);

@@ -1044,3 +1044,110 @@ def test_host_mirror_test_elastic_pc(oracle):
     assert np.array_equal(I, want["I"]) and np.array_equal(reply, want["reply"])
     assert np.array_equal(q[:rounds], want["poly"]) and np.array_equal(r[:rounds], want["r"])
     assert ps.value == elastic_open_proof_size(want, N, B)
+
+
+# ---- streaming provers (BASELINE config 4's math phases) ---------------------------------------------------------------------
+def test_stream_product_layers_vs_golden(hb):
+    """read_mul_tree_layer / read_mul_tree_data on the reference's default stream against the REAL reference (tests/golden/streamdrv.npz)"""
+    g = gold("streamdrv"); src = hb.chunk_source(0)
+    for layer in (1, 2, 4):
+        assert np.array_equal(dg(hb.read_mul_tree_layer(src, 1 << 11, layer)), g["layer_%d" % layer])
+    for (layer, dist, bt) in ((0, 1, 1), (2, 1, 1), (1, 2, 2), (0, 3, 3)):
+        assert np.array_equal(dg(hb.read_mul_tree_data(src, 1 << 12, layer, dist, bt)), g["data_%d_%d_%d" % (layer, dist, bt)])
+
+
+@pytest.mark.parametrize("shape", golden_cases.STREAM_SHAPES)
+def test_stream_sumcheck3_vs_golden(hb, shape):
+    """generate_3product_sumcheck_beta_stream_batch_optimized against the REAL reference: the new claims and challenge rows are functions
+    of every message of the streaming pass, of batch_3product_sumcheck, of the Partial_Evals pass and of the closing 2-product sumcheck,
+    and of every libc draw in between"""
+    import ctypes
+    fd, B, layer_id, batches, dist = shape
+    g = gold("streamdrv"); key = "gsb_%d_%d_%d_%d_%d_" % shape
+    rr, oc = golden_cases.stream_batch_inputs(fd, B, layer_id, batches, dist)
+    ctypes.CDLL(None).srandom(5)
+    res = hb.sumcheck3_stream_batch(hb.chunk_source(0), fd, B, rr, batches, dist, layer_id, oc)
+    assert np.array_equal(res["new_claims"], g[key + "claims"])
+    for i, row in enumerate(res["new_r"]):
+        assert np.array_equal(row, g[key + "r%d" % i]), i
+    assert res["checks"].tolist()[1:] == [1, 1]
+
+
+@pytest.mark.parametrize("fd,B,layer_id,batches,dist", [(1 << 16, 1 << 10, 0, 1, 1), (1 << 17, 1 << 10, 1, 3, 2), (1 << 22, 1 << 16, 1, 2, 3)])
+def test_stream_sumcheck3_varying_stream_vs_oracle(hb, oracle, fd, B, layer_id, batches, dist):
+    """the same on a stream whose reads all differ (the reference's default stream repeats one chunk, which would hide a chunk-order
+    mistake): every transcript piece against the oracle"""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    rr, oc = golden_cases.stream_batch_inputs(fd, B, layer_id, batches, dist)
+    oracle.stream_config(1, 777)
+    try:
+        libc.srandom(8); want = oracle.sumcheck3_stream_batch(fd, B, rr, batches, dist, layer_id, oc, full=True)
+    finally:
+        oracle.stream_config(0, 0)
+    libc.srandom(8); got = hb.sumcheck3_stream_batch(hb.chunk_source(1, 777), fd, B, rr, batches, dist, layer_id, oc)
+    for k in ("new_claims", "cpoly1", "r1", "vr1", "qpoly2", "r2", "vr2", "fin2", "R", "checks"):
+        assert np.array_equal(got[k], want[k]), k
+    for a, b in zip(got["new_r"], want["new_r"]):
+        assert np.array_equal(a, b)
+
+
+def test_generate_claims_opt_vs_golden(hb):
+    g = gold("streamdrv")
+    assert np.array_equal(hb.generate_claims_opt(hb.chunk_source(0), 1 << 16, 1 << 10, splitmix_field(16, 70), 2, 1, 2), g["claims_opt"])
+
+
+@pytest.mark.parametrize("distance,naive,kind", [(5, True, 0), (5, True, 1), (2, False, 1), (1, True, 1)])
+def test_mul_tree_stream_shallow_vs_oracle(hb, oracle, distance, naive, kind):
+    """prove_multiplication_tree_stream_shallow (config 4's shape scaled down: 8 vectors, layers = 4 <= distance = 5; then the batched and
+    the naive paths): product-layer read, in-memory tree, and every streaming sumcheck, bit-exact against the oracle; on the default
+    stream the output also against the REAL reference.  Each step's K_partial equals the claim handed down by the previous layer."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    B, vectors, size = 1 << 10, 8, 1 << 12
+    pr = np.array([32, 0], np.uint64); px = splitmix_field(3, 9)
+    oracle.stream_config(kind, 4000)
+    try:
+        libc.srandom(11); want = oracle.mul_tree_stream_shallow(vectors * size, B, vectors, size, pr, distance, px, naive=naive)
+    finally:
+        oracle.stream_config(0, 0)
+    libc.srandom(11); got = hb.mul_tree_stream_shallow(hb.chunk_source(kind, 4000), vectors * size, B, vectors, size, pr, distance, px, naive=naive)
+    assert got["layers"] == want["layers"] and len(got["steps"]) == len(want["steps"]) > 0
+    assert np.array_equal(got["output"], want["output"])
+    if kind == 0 and distance == 5:
+        assert np.array_equal(got["output"], gold("streamdrv")["shallow_out"])
+    for k in ("final_r", "final_eval", "out_eval", "vr", "fin"):
+        assert np.array_equal(got["tree"][k], want["tree"][k]), k
+    for a, b in zip(got["steps"], want["steps"]):
+        assert a["checks"].tolist() == [1, 1, 1] and b["checks"].tolist() == [1, 1, 1]
+        for k in ("new_claims", "cpoly1", "r1", "vr1", "qpoly2", "r2", "vr2", "fin2", "R"):
+            assert np.array_equal(a[k], b[k]), k
+        for x, y in zip(a["new_r"], b["new_r"]):
+            assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("logB,nch", [(8, 8), (14, 4), (18, 4)])
+def test_gate_consistency_stream_vs_oracle(hb, oracle, logB, nch):
+    """prove_gate_consistency's chunk loop, degree-4 sumcheck, Peval pass and closing sumcheck over a synthetic consistent trace
+    (logB = 18, 4 chunks = config 4's transcript_stream shape): every message against the oracle; the three exit(-1) checks hold"""
+    import ctypes
+    from oracle.pyoracle import gate_standard_inputs
+    libc = ctypes.CDLL(None)
+    B = 1 << logB
+    if logB <= 14:
+        parts = [gate_standard_inputs(B, 100 + c) for c in range(nch)]
+    else:                                                   # (gate_standard_inputs multiplies in Python: too slow at 2^18; vectorised here)
+        parts = []
+        for c in range(nch):
+            g = np.random.default_rng(200 + c); z = np.zeros(B, np.uint64)
+            sel = g.integers(0, 2, B).astype(np.uint64); Lr = g.integers(0, 1 << 30, B).astype(np.uint64); Rr = g.integers(0, 1 << 30, B).astype(np.uint64)
+            prod = (Lr * Rr) % np.uint64(P)
+            parts.append((np.stack([Lr, z], 1), np.stack([Rr, z], 1), np.stack([np.where(sel == 1, Lr + Rr, prod), z], 1), np.stack([sel, z], 1)))
+    L, R, O = [np.concatenate([p[i] for p in parts]) for i in range(3)]
+    S = np.concatenate([p[3][:, 0] for p in parts]).astype(np.int32)
+    r = splitmix_field(logB, 3)
+    libc.srandom(21); want = oracle.gate_consistency_stream(L, R, O, S, B, r)
+    libc.srandom(21); got = hb.gate_consistency_stream(hb.trace_source(L, R, O, S, B), nch, B, r)
+    assert want["checks"].tolist() == [1, 1, 1] and got["checks"].tolist() == [1, 1, 1]
+    for k in ("R", "a", "poly", "gr", "fin6", "Peval", "b", "q2", "r2", "vr2", "fin2"):
+        assert np.array_equal(got[k], want[k]), k
