@@ -11,8 +11,10 @@
 
 using namespace hobbit;
 
-static inline const F *cF(const hobbit_F *p) { return reinterpret_cast<const F *>(p); }
-static inline F *mF(hobbit_F *p) { return reinterpret_cast<F *>(p); }
+// (HF = F with the C ABI's 8-byte alignment, hobbit_field.hpp: host buffers are dereferenced through it; device pointers pass through
+// to the launchers unchanged)
+static inline const HF *cF(const hobbit_F *p) { return reinterpret_cast<const HF *>(p); }
+static inline HF *mF(hobbit_F *p) { return reinterpret_cast<HF *>(p); }
 static_assert(sizeof(hobbit_F) == sizeof(F), "ABI field element must be 16 bytes");
 
 struct hobbit_commitment {
@@ -1136,7 +1138,7 @@ static int mul_tree_impl(hobbit_ctx *ctx, const hobbit_F *d_input, size_t vector
             HB_TRY(hobbit_eq_table(ctx, reinterpret_cast<hobbit_F *>(r.data()), rl, reinterpret_cast<hobbit_F *>(beta)));
             HB_TRY(hobbit_sumcheck3(ctx, reinterpret_cast<hobbit_F *>(in1 + lo[i]), reinterpret_cast<hobbit_F *>(in2 + lo[i]), reinterpret_cast<hobbit_F *>(beta), n,
                                     reinterpret_cast<hobbit_F *>(&previous_r), h_cpoly + qo, h_r + ro, h_vr + 3 * layers, h_fin + layers));
-            const F *q0 = cF(h_cpoly + qo);
+            const HF *q0 = cF(h_cpoly + qo);
             F claim = fadd(fadd(fadd(q0[0], q0[1]), fadd(q0[2], q0[3])), q0[3]);        // P.c_poly[0].eval(1) + eval(0)
             if (!feq(claim, sum)) printf("error %d\n", i);                              // the reference's own (non-fatal) check, :151,:203
             for (int t = 0; t < rl; t++) r[t] = cF(h_r + ro)[t];
@@ -1161,7 +1163,7 @@ struct hobbit_elastic_open {
     F *d_aggr, *d_T, *d_G, *d_reply, *d_encf; uint8_t *d_lvf; uint32_t *d_ucols; uint64_t *d_pick; int *d_nz;
 };
 // precompute_beta (src/utils.cpp:251-296) on the host for a handful of variables
-static void host_eq_table(const F *r, int k, std::vector<F> &out) {
+static void host_eq_table(const HF *r, int k, std::vector<F> &out) {
     out.assign((size_t)1 << k, fmake(0)); out[0] = fmake(1);
     for (int i = 0; i < k; i++) for (size_t j = ((size_t)1 << i); j-- > 0;) { F t = fmul(r[k - 1 - i], out[j]); out[2 * j + 1] = t; out[2 * j] = fsub(out[j], t); }
 }
@@ -1289,7 +1291,7 @@ int hobbit_elastic_open_finish(hobbit_ctx *ctx, hobbit_elastic_open *e, const ui
     HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(out3), reinterpret_cast<hobbit_F *>(bt), np2 * rows2, &p323, Q, Rr, o->vr, o->fin));          // P0 (:474)
     const hobbit_F *r0 = Rr; Q += 3 * R0; Rr += R0;
     HB_TRY(hobbit_prove_fft_matrix(ctx, reinterpret_cast<hobbit_F *>(sel), np2, trs, r0, Q, Rr, o->vr + 2, o->fin + 1));                                       // P2 (:480)
-    { const F *q2 = cF(Q); o->checks[0] = feq(fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])), cF(o->vr)[0]); }                                                   // src/sumcheck.cpp:3016-3019
+    { const HF *q2 = cF(Q); o->checks[0] = feq(fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])), cF(o->vr)[0]); }                                                   // src/sumcheck.cpp:3016-3019
     const hobbit_F *r2 = Rr; Q += 3 * logr; Rr += logr;
     // r_point: P2.randomness[0] (its logr sumcheck challenges, then r1 = P0.r[logr..]) from index log2(trs) on (:482-485)
     std::vector<F> rpt; rpt.push_back(cF(r2)[logt]);
@@ -1306,7 +1308,7 @@ int hobbit_elastic_open_finish(hobbit_ctx *ctx, hobbit_elastic_open *e, const ui
     HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(out1), reinterpret_cast<hobbit_F *>(b2), trs * cols, &p323, Q, Rr, o->vr + 4, o->fin + 2));     // P3 (:498)
     const hobbit_F *r3 = Rr; Q += 3 * (logt + logc); Rr += logt + logc;
     HB_TRY(hobbit_prove_fft_matrix(ctx, reinterpret_cast<hobbit_F *>(e->d_aggr), trs, half, r3, Q, Rr, o->vr + 6, o->fin + 3));                               // P5 (:503)
-    { const F *q5 = cF(Q); o->checks[1] = feq(fadd(fadd(q5[0], q5[1]), fadd(q5[2], q5[2])), cF(o->vr)[4]); }
+    { const HF *q5 = cF(Q); o->checks[1] = feq(fadd(fadd(q5[0], q5[1]), fadd(q5[2], q5[2])), cF(o->vr)[4]); }
     // r_x = P5.randomness[0]: its sumcheck challenges, then r1 = P3.r[logc .. logc + log2 trs) (src/sumcheck.cpp:3021-3023)
     std::vector<hobbit_F> rx((size_t)logc + (size_t)logt);
     memcpy(rx.data(), Rr, sizeof(hobbit_F) * (size_t)logc); memcpy(rx.data() + logc, r3 + logc, sizeof(hobbit_F) * (size_t)logt);
@@ -1324,7 +1326,7 @@ static int src_next(hobbit_ctx *ctx, const StreamSrc &s, size_t n, const F **d) 
 }
 static int src_reset(hobbit_ctx *ctx, const StreamSrc &s) { const F *d; return src_next(ctx, s, 0, &d); }   // reset_stream (src/witness_stream.cpp:228-234)
 // evaluate_vector (src/utils.cpp:789-802) on a handful of host values
-static F host_eval_vector(std::vector<F> v, const F *r, int k) {
+static F host_eval_vector(std::vector<F> v, const HF *r, int k) {
     for (int i = 0; i < k; i++) { size_t L = v.size() / 2; for (size_t j = 0; j < L; j++) v[j] = fadd(v[2 * j], fmul(r[i], fsub(v[2 * j + 1], v[2 * j]))); v.resize(L); }
     return v[0];
 }
@@ -1371,7 +1373,7 @@ struct StreamPlan {
     int batches, logB; size_t size, nch, tot, vtot;
     size_t sz[16], off[16], vlen[16], voff[16]; int n_init[16]; std::vector<F> rb[16];
 };
-static int stream_plan(hobbit_ctx *ctx, StreamPlan &P, size_t fd_size, size_t B, const F *h_r, int rlen, int rstride, int batches, int distance, int layer_id) {
+static int stream_plan(hobbit_ctx *ctx, StreamPlan &P, size_t fd_size, size_t B, const HF *h_r, int rlen, int rstride, int batches, int distance, int layer_id) {
     if (batches < 1 || batches > 16 || distance < 1 || layer_id < 0) return ctx->fail(HOBBIT_EINVAL, "streaming sumcheck: bad batches / distance / layer");
     P.batches = batches; P.size = fd_size >> layer_id; P.logB = ilog2_exact(B);
     if (P.logB < 1 || ilog2_exact(P.size) < 0 || P.size < 4 * B) return ctx->fail(HOBBIT_EINVAL, "streaming sumcheck: needs power-of-two sizes with size >= 4*BUFFER_SPACE");
@@ -1475,7 +1477,7 @@ int hobbit_sumcheck3_stream_batch(hobbit_ctx *ctx, hobbit_chunk_source source, v
     std::vector<size_t> lens(batches); for (int i = 0; i < batches; i++) lens[i] = P.sz[i];
     HB_TRY(hobbit_batch_3product_sumcheck(ctx, reinterpret_cast<hobbit_F *>(f1), reinterpret_cast<hobbit_F *>(f2), reinterpret_cast<hobbit_F *>(f3), lens.data(), batches,
                                           reinterpret_cast<hobbit_F *>(a.data()), o->cpoly1, o->r1, o->vr1));
-    { const F *q0 = cF(o->cpoly1); o->checks[1] = feq(fadd(fadd(fadd(q0[0], q0[1]), fadd(q0[2], q0[3])), q0[3]), Kf); }
+    { const HF *q0 = cF(o->cpoly1); o->checks[1] = feq(fadd(fadd(fadd(q0[0], q0[1]), fadd(q0[2], q0[3])), q0[3]), Kf); }
     // Partial_Evals pass (:1303-1340): beta[k] over P1's first log2(sizes[k]) challenges
     for (int k = 0; k < batches; k++) HB_TRY(hobbit_eq_table(ctx, o->r1, ilog2_exact(P.sz[k]), reinterpret_cast<hobbit_F *>(b3 + P.off[k])));
     for (size_t i = 0; i < P.nch; i++) {
@@ -1503,14 +1505,14 @@ int hobbit_sumcheck3_stream_batch(hobbit_ctx *ctx, hobbit_chunk_source source, v
     hobbit_F zero = {0, 0};                                                             // previous_r = the local `rand`, never updated: F(0) (:1207, 1351)
     HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(dR), reinterpret_cast<hobbit_F *>(dR + nR), nR, &zero, o->qpoly2, o->r2, o->vr2, o->fin2));
     {   // "Error in sumcheck 2" (:1356-1365)
-        F sum = fmake(0); const F *vr1 = cF(o->vr1), *q2 = cF(o->qpoly2);
+        F sum = fmake(0); const HF *vr1 = cF(o->vr1), *q2 = cF(o->qpoly2);
         for (int i = 0; i < batches; i++) { sum = fadd(sum, fmul(bb[2 * i], vr1[3 * i])); sum = fadd(sum, fmul(bb[2 * i + 1], vr1[3 * i + 1])); }
         o->checks[2] = feq(fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])), sum);
     }
     const int lR = ilog2_exact(nR);
     const F pad = fmake((uint64_t)random());                                            // (:1368)
     for (int i = 0; i < batches; i++) {
-        F *row = mF(o->new_r) + (size_t)i * o->new_r_ld; int n = 0;
+        HF *row = mF(o->new_r) + (size_t)i * o->new_r_ld; int n = 0;
         if (1 + P.n_init[i] + lR > o->new_r_ld) return ctx->fail(HOBBIT_EINVAL, "sumcheck3_stream_batch: new_r_ld too small");
         row[n++] = pad;
         for (int j = 0; j < P.n_init[i]; j++) row[n++] = cF(o->r1)[j];
@@ -1666,7 +1668,7 @@ int hobbit_gate_consistency_stream(hobbit_ctx *ctx, hobbit_trace_source source, 
     HB_TRY(hobbit_memcpy_h2d(ctx, dR + n_chunks, pe.data(), n_chunks * sizeof(F)));
     HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(dR), reinterpret_cast<hobbit_F *>(dR + n_chunks), n_chunks, reinterpret_cast<hobbit_F *>(&rnd), o->q2, o->r2, o->vr2, o->fin2));
     {   // "Error in gate consistency 3" (:966-972); fin6 = add, beta, L, R, O, mul
-        const F *f6 = cF(o->fin6), *q2 = cF(o->q2);
+        const HF *f6 = cF(o->fin6), *q2 = cF(o->q2);
         F sm = fadd(fadd(fmul(f6[2], b[0]), fmul(f6[3], b[1])), fadd(fmul(f6[4], b[2]), fmul(b[3], f6[0])));
         sm = fadd(sm, fadd(fmul(b[4], f6[5]), fmul(b[5], f6[1])));
         o->checks[2] = feq(fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])), sm);
@@ -1786,7 +1788,7 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     HB_TRY(launch_vecmat(ctx, BIG, rows2, cols, d_b1, d_ev));
     hobbit_F p17 = {021, 0};
     HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(d_s), reinterpret_cast<hobbit_F *>(d_ev), cols, &p17, Q, Rr, o->vr + 2, o->fin + 1));
-    const hobbit_F *r_p2 = Rr; const F *q2 = cF(Q);
+    const hobbit_F *r_p2 = Rr; const HF *q2 = cF(Q);
     { F c2 = fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])); o->checks[0] = feq(c2, cF(o->vr)[1]); }       // "Error recursion 1" (:323-326)
     Q += 3 * logc; Rr += logc;
     tr.mark("evals, P2");
@@ -1819,7 +1821,7 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     HB_TRY(launch_eq_pair_axpy(ctx, cF(rcat.data()), cF(r_p3), R3, a, d_bb, d_b));      // d_b = beta(r) + a * beta(P3.r), d_bb: scratch
     hobbit_F p312 = {312, 0};
     HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(d_b), reinterpret_cast<hobbit_F *>(BIG), big, &p312, Q, Rr, o->vr + 6, o->fin + 3));
-    const hobbit_F *r_p4 = Rr; const F *q4 = cF(Q);
+    const hobbit_F *r_p4 = Rr; const HF *q4 = cF(Q);
     { F c4 = fadd(fadd(q4[0], q4[1]), fadd(q4[2], q4[2])); F want = fadd(fmul(a, cF(o->vr)[4]), cF(o->vr)[3]); o->checks[1] = feq(c4, want); }
     Q += 3 * R3; Rr += R3;
     tr.mark("betas, P4");
@@ -1828,7 +1830,7 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     HB_TRY(hobbit_eval_vector(ctx, reinterpret_cast<hobbit_F *>(Mp), (size_t)trs * cols, r_p4, reinterpret_cast<hobbit_F *>(&y1)));
     o->scalars[4] = *reinterpret_cast<hobbit_F *>(&y1);
     HB_TRY(hobbit_prove_fft_matrix(ctx, reinterpret_cast<hobbit_F *>(d_aggr), (size_t)trs, cols / 2, r_p4, Q, Rr, o->vr + 8, o->fin + 4));
-    { const F *q5 = cF(Q); F c5 = fadd(fadd(q5[0], q5[1]), fadd(q5[2], q5[2])); o->checks[2] = feq(c5, y1); }
+    { const HF *q5 = cF(Q); F c5 = fadd(fadd(q5[0], q5[1]), fadd(q5[2], q5[2])); o->checks[2] = feq(c5, y1); }
     tr.mark("y1, P5");   // src/sumcheck.cpp:3016-3019
     if (!full) return 0;
     // shockwave_prove(C_c, P4.r minus its last entry) (src/PC_utils.cpp:368) -- in the reference it runs before P5; P5 draws nothing

@@ -27,6 +27,9 @@ static constexpr uint64_t P61 = 2305843009213693951ULL;
 struct __attribute__((aligned(16))) F {
     uint64_t re, im;
 };
+// Host view of the same element: the C ABI's hobbit_F (and the reference's virgo::fieldElement) is 8-byte aligned, so every access
+// through a HOST pointer that came in over the boundary goes through this typedef (unaligned 16-byte moves instead of movaps/movdqa).
+typedef F HF __attribute__((aligned(8)));
 
 HB_HD F fmake(uint64_t re, uint64_t im = 0) { F r; r.re = re; r.im = im; return r; }
 HB_HD bool fis0(const F &a) { return (a.re | a.im) == 0; }

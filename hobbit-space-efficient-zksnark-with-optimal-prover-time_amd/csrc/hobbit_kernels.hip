@@ -1088,7 +1088,7 @@ __global__ void k_eq_final_axpy(const F *__restrict__ o1, const F *__restrict__ 
         stF(out + 2 * j + 1, fadd(t1, fmul(a, t2)));
     }
 }
-int launch_eq_table(hobbit_ctx *ctx, const F *h_r, int k, F *d_out) {
+int launch_eq_table(hobbit_ctx *ctx, const HF *h_r, int k, F *d_out) {
     // head in one workgroup, then ping-pong between d_out (final) and workspace so that the last step lands in d_out
     size_t n = (size_t)1 << k;
     F *tmp = nullptr;
@@ -1111,7 +1111,7 @@ int launch_eq_table(hobbit_ctx *ctx, const F *h_r, int k, F *d_out) {
     return 0;
 }
 // d_out[0..2^k) = eq(r1) + a * eq(r2); d_half: scratch of 2^k elements (the two half-size tables)
-int launch_eq_pair_axpy(hobbit_ctx *ctx, const F *h_r1, const F *h_r2, int k, F a, F *d_half, F *d_out) {
+int launch_eq_pair_axpy(hobbit_ctx *ctx, const HF *h_r1, const HF *h_r2, int k, F a, F *d_half, F *d_out) {
     if (k < 1) return ctx->fail(HOBBIT_EINVAL, "eq_pair_axpy: k must be >= 1");
     const size_t m = (size_t)1 << (k - 1);
     HB_TRY(launch_eq_table(ctx, h_r1 + 1, k - 1, d_half));             // levels 0..k-2 use r[k-1] .. r[1]; the last level uses r[0]
@@ -1136,7 +1136,7 @@ __global__ void k_aggregate_arg(const F *__restrict__ poly, size_t M, int K, Agg
         stF(aggr + j, acc);
     }
 }
-int launch_aggregate(hobbit_ctx *ctx, const F *poly, size_t M, int K, const F *h_beta, F *aggr) {
+int launch_aggregate(hobbit_ctx *ctx, const F *poly, size_t M, int K, const HF *h_beta, F *aggr) {
     if (K <= 64) {
         AggCoef cf;
         for (int i = 0; i < 64; i++) cf.b[i] = i < K ? h_beta[i] : fmake(0);
@@ -1233,7 +1233,7 @@ __global__ void __launch_bounds__(256) k_phi_head(F *__restrict__ g, int n, int 
     }
     for (uint32_t j = threadIdx.x; j < (1u << h); j += 256) stF(g + j, ldF(&s[j]));
 }
-int launch_phi_head(hobbit_ctx *ctx, F *g, int n, int h, const F *h_rx, F scale, const F *pm) {
+int launch_phi_head(hobbit_ctx *ctx, F *g, int n, int h, const HF *h_rx, F scale, const F *pm) {
     if (h < 1 || h > 11 || h >= n) return ctx->fail(HOBBIT_EINVAL, "phi_head: 1 <= h <= min(11, n - 1)");
     EqHead rx;
     for (int i = 1; i <= 12; i++) rx.b[i - 1] = i <= h ? h_rx[n - i] : fmake(0);
@@ -1482,7 +1482,7 @@ __global__ void __launch_bounds__(256) k_sc_reduce_post(const F *__restrict__ pa
 
 // host tail of the 2-product sumcheck: tables a,b of size sz (not yet folded with `rnd` when
 // pending_fold), continuing at round `round` exactly as src/sumcheck.cpp:2401-2452
-static void sc2_host_tail(std::vector<F> &a, std::vector<F> &b, F &rnd, bool pending_fold, int round, int rounds, F *h_qpoly, F *h_r) {
+static void sc2_host_tail(std::vector<F> &a, std::vector<F> &b, F &rnd, bool pending_fold, int round, int rounds, HF *h_qpoly, HF *h_r) {
     size_t sz = a.size();
     auto fold = [&](std::vector<F> &v) { for (size_t j = 0; j < sz / 2; j++) v[j] = fadd(v[2 * j], fmul(rnd, fsub(v[2 * j + 1], v[2 * j]))); };
     if (pending_fold) { fold(a); fold(b); sz /= 2; }
@@ -1541,7 +1541,7 @@ __global__ void __launch_bounds__(256) k_err_terms(ErrArgs a, size_t n, F *__res
 }
 // runs one error-term reduction; h_K receives the NC sums (not accumulated)
 template <int KIND, int NC>
-static int run_err(hobbit_ctx *ctx, const char *name, const ErrArgs &a, size_t n, F *h_K) {
+static int run_err(hobbit_ctx *ctx, const char *name, const ErrArgs &a, size_t n, HF *h_K) {
     const int MAXB = 1024;
     F *ws; HB_TRY(ctx->workspace(((size_t)MAXB * NC + NC + 4) * sizeof(F), (void **)&ws));
     F *part = ws, *coef = ws + (size_t)MAXB * NC;
@@ -1554,7 +1554,7 @@ static int run_err(hobbit_ctx *ctx, const char *name, const ErrArgs &a, size_t n
     for (int q = 0; q < NC; q++) h_K[q] = pin[q];
     return 0;
 }
-int launch_err_terms(hobbit_ctx *ctx, int kind, const F *const *tables, const int32_t *gate, size_t n, F *h_K) {
+int launch_err_terms(hobbit_ctx *ctx, int kind, const F *const *tables, const int32_t *gate, size_t n, HF *h_K) {
     ErrArgs a; for (int i = 0; i < 8; i++) a.t[i] = tables[i]; a.gate = gate;
     if (!n) { int nc = kind == 2 ? 2 : kind == 4 ? 4 : 3; for (int q = 0; q < nc; q++) h_K[q] = fmake(0); return 0; }
     switch (kind) {
@@ -1663,7 +1663,7 @@ int launch_fill_F(hobbit_ctx *ctx, F *p, size_t stride, size_t n, F v) {
     return 0;
 }
 
-int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev_r, F *h_qpoly, F *h_r, F *h_vr, F *h_final) {
+int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev_r, HF *h_qpoly, HF *h_r, HF *h_vr, HF *h_final) {
     int rounds = 0; while (((size_t)1 << rounds) < n) rounds++;
     if (((size_t)1 << rounds) != n || n < 2) return ctx->fail(HOBBIT_EINVAL, "sumcheck2: n must be a power of two >= 2");
     const int MAXB = 1024;
@@ -1823,7 +1823,7 @@ static bool gate_round_host(const F *c, const F *a, F &rnd, F &sum, F *poly_out,
     return ok;
 }
 // inputs are preserved (the reference folds in place and afterwards only reads element 0 of each table: h_final)
-int launch_gate_sumcheck(hobbit_ctx *ctx, const F *const tabs[6], size_t n, const F *h_a, F *h_rand, F *h_sum, F *h_poly, F *h_r, F *h_final, int *h_check) {
+int launch_gate_sumcheck(hobbit_ctx *ctx, const F *const tabs[6], size_t n, const HF *h_a, HF *h_rand, HF *h_sum, HF *h_poly, HF *h_r, HF *h_final, int *h_check) {
     int rounds = 0; while (((size_t)1 << rounds) < n) rounds++;
     if (((size_t)1 << rounds) != n || n < 2) return ctx->fail(HOBBIT_EINVAL, "gate_sumcheck: n must be a power of two >= 2");
     const int MAXB = 512;
@@ -1940,7 +1940,7 @@ int launch_mul_layer(hobbit_ctx *ctx, const F *x, size_t n_out, F *in1, F *in2, 
 }
 
 // host rounds of the 3-product sumcheck on tables of size sz (src/sumcheck.cpp:1981-2037)
-static void sc3_host_tail(std::vector<F> &a, std::vector<F> &b, std::vector<F> &c3, F &rnd, int round, int rounds, F *h_cpoly, F *h_r) {
+static void sc3_host_tail(std::vector<F> &a, std::vector<F> &b, std::vector<F> &c3, F &rnd, int round, int rounds, HF *h_cpoly, HF *h_r) {
     size_t sz = a.size();
     for (int i = round; i < rounds; i++) {
         F pa = fmake(0), pb = fmake(0), pc = fmake(0), pd = fmake(0);
@@ -1958,7 +1958,7 @@ static void sc3_host_tail(std::vector<F> &a, std::vector<F> &b, std::vector<F> &
         sz /= 2;
     }
 }
-int launch_sumcheck3(hobbit_ctx *ctx, const F *v1, const F *v2, const F *v3, size_t n, F prev_r, F *h_cpoly, F *h_r, F *h_vr, F *h_final) {
+int launch_sumcheck3(hobbit_ctx *ctx, const F *v1, const F *v2, const F *v3, size_t n, F prev_r, HF *h_cpoly, HF *h_r, HF *h_vr, HF *h_final) {
     int rounds = 0; while (((size_t)1 << rounds) < n) rounds++;
     if (((size_t)1 << rounds) != n || n < 2) return ctx->fail(HOBBIT_EINVAL, "sumcheck3: n must be a power of two >= 2");
     const int MAXB = 1024;
