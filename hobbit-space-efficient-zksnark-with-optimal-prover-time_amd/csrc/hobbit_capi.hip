@@ -420,7 +420,10 @@ int hobbit_eval_vector(hobbit_ctx *ctx, const hobbit_F *d_v, size_t n, const hob
 }
 
 // ---- tensor code / commit ---------------------------------------------------------------------
-static int tensorcode_chunks(hobbit_ctx *ctx, const F *d_msg, size_t M, int K, int trs, int lin, F *d_out) {
+// d_dig (nullable; honoured on the large RS x expander path only, *dig_done says whether): the inner digests of the commitment's leaves,
+// K x cols x trs/2 x 32 B, written by the encode passes into the row-FFT scratch (workspace2), which is dead once the transpose has run
+static int tensorcode_chunks(hobbit_ctx *ctx, const F *d_msg, size_t M, int K, int trs, int lin, F *d_out, uint8_t **d_dig = nullptr) {
+    if (d_dig) *d_dig = nullptr;
     if (trs <= 0 || M % (size_t)trs) return ctx->fail(HOBBIT_EINVAL, "tensorcode: trs must divide M");
     size_t half = M / trs, cols = 2 * half, rows2 = 2 * (size_t)trs;
     int logc = ilog2_exact(cols), logr = ilog2_exact(rows2);
@@ -446,7 +449,18 @@ static int tensorcode_chunks(hobbit_ctx *ctx, const F *d_msg, size_t M, int K, i
     if ((size_t)K * trs * cols * sizeof(F) >= ((size_t)64 << 20)) {
         F *rm; HB_TRY(ctx->workspace2((size_t)K * trs * cols * sizeof(F), (void **)&rm));
         HB_TRY(fft_rows(ctx, d_msg, half, (uint32_t)half, rm, cols, 1, logc, false, (uint32_t)K, (uint32_t)trs, M, (size_t)trs * cols));
+        const char *es_env = getenv("HOBBIT_ENC_STRIDED"); const bool enc_strided = es_env && es_env[0] == '1';
+        if (lin && enc_strided && trs > 13 && ctx->code.n == trs && ((size_t)K * cols) % 64 == 0) {
+            // EXPERIMENT (off by default, measured slower: DESIGN.md 4): no transpose pass, the encode reads its message as a strided
+            // column of the row-major FFT output (8 adjacent columns on one XCD) and writes message + parity contiguously
+            return launch_encode_strided(ctx, rm, 0, (uint32_t)cols, (uint32_t)cols, (size_t)trs * cols, d_out, rows2, trs, (size_t)K * cols, 1, nullptr);
+        }
         HB_TRY(launch_transpose(ctx, rm, (size_t)trs * cols, (uint32_t)trs, (uint32_t)cols, d_out, cols * rows2, rows2, (uint32_t)K));
+        const char *dg_env = getenv("HOBBIT_ENC_DIGESTS");
+        if (lin && d_dig && trs > 13 && trs % 4 == 0 && ctx->code.n == trs && dg_env && dg_env[0] == '1') {     // EXPERIMENT, off by default (measured slower: DESIGN.md 4)
+            *d_dig = reinterpret_cast<uint8_t *>(rm);                   // K*M digests of 32 B = the scratch's K*trs*cols elements of 16 B
+            return launch_encode_strided(ctx, d_out, rows2, 1, 0, 0, d_out, rows2, trs, (size_t)K * cols, 0, *d_dig);
+        }
     } else
         HB_TRY(fft_rows(ctx, d_msg, half, (uint32_t)half, d_out, 1, rows2, logc, false, (uint32_t)K, (uint32_t)trs, M, cols * rows2));
     if (lin) {     // columns: expander code, in place on contiguous codewords (src/PC_utils.cpp:110-121)
@@ -481,9 +495,13 @@ int hobbit_commit_standard(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, in
     } else if (hipMalloc((void **)&c->d_tensor, tbytes) != hipSuccess || hipMalloc((void **)&c->d_levels, 64 * M) != hipSuccess) {
         hobbit_commitment_free(c); return ctx->fail(HOBBIT_ENOMEM, "commit_standard: tensor allocation failed");
     }
-    int r = tensorcode_chunks(ctx, cF(d_poly), M, K, trs, linear_time, c->d_tensor);
+    uint8_t *dig = nullptr;
+    int r = tensorcode_chunks(ctx, cF(d_poly), M, K, trs, linear_time, c->d_tensor, &dig);
     // leaf chain over the K chunks (src/Our_PC.cpp:155-167), then the tree (src/Our_PC.cpp:169)
-    if (!r) r = launch_leaf_chain(ctx, c->d_tensor, cols * rows2, K, (uint32_t)cols, (uint32_t)(trs / 2), c->d_levels);
+    if (!r && dig) r = launch_leaf_chain_dig(ctx, dig, M * 32, K, (uint32_t)cols, (uint32_t)(trs / 2), c->d_levels);
+    // rows >= the codeword length are zero in every chunk of an RS x expander tensor (RS x RS fills all 2*trs rows)
+    else if (!r) r = launch_leaf_chain(ctx, c->d_tensor, cols * rows2, K, (uint32_t)cols, (uint32_t)(trs / 2), c->d_levels,
+                                       linear_time && ctx->code.n == trs ? (uint32_t)ctx->code.len : (uint32_t)rows2);
     if (!r) r = launch_merkle_levels(ctx, c->d_levels, M, 1);
     if (r) { hobbit_commitment_free(c); return r; }
     *out = c;

@@ -529,6 +529,7 @@ int launch_transpose_tw(hobbit_ctx *ctx, const F *in, size_t gs, uint32_t R, F *
 //     S_lo = sum w * lo32(a),  S_hi = sum w * hi32(a)        (for a = re and a = im)
 // i.e. 4 v_mad_u64_u32 + 4 carry adds per edge and ONE Mersenne fold per output -- exact integer
 // arithmetic, so the result is the same canonical element the reference's per-edge mod-p loop gives.
+__device__ __forceinline__ void store8w(void *p, const uint32_t h[8]);
 struct Acc96 { uint64_t lo; uint32_t hi; };
 // a += w * x (32x32 -> 64 product into a 96-bit sum): one v_mad_u64_u32 whose carry-out feeds one
 // v_addc (hipcc does not use the instruction's own carry output, hence the two-line asm).
@@ -555,23 +556,38 @@ __device__ __forceinline__ F shfl_xor_F(const F &a, int m) {
 // CU) and pass B = everything else (46 KB window, 3 per CU) so that one workgroup's global
 // load/store overlaps another's gather loop.
 struct EncPass { uint32_t base, ld_lo, ld_hi, s_lo, s_hi, st_lo, st_hi, direct_out; };
+struct EncSrc { uint32_t stride, cols, remap; size_t gs; };      // stride <= 1: contiguous messages at ld_src
+// digest output of a pass: groups [g_lo, g_hi) of 4 consecutive codeword entries (all inside the pass's LDS window after its last step;
+// entries >= len are zero), written to out[(block * per_col + g) * 32]; groups [g_hi, g_fill) are entirely zero: the constant H(0^64)
+struct EncDig { uint8_t *out; uint32_t g_lo, g_hi, g_fill, per_col; uint32_t zero[8]; };
 
-template <bool SMALLW>
+// DIG: the workgroup also hashes the 4-row groups of the part of the codeword it holds in LDS -- inner digests H(t[4j..4j+3][col])
+// of the commitment's leaves (src/merkle_tree.cpp:70-75) -- into dig[(column * groups_per_col + j) * 32].  The encode's waves wait on
+// LDS gathers and barriers for most of their cycles, the hash is pure VALU work: done here it fills issue slots that are idle anyway,
+// and the leaf chain afterwards reads 32-byte digests instead of re-reading the 64 bytes of tensor behind each of them.
+template <bool SMALLW, bool DIG>
 __global__ void __launch_bounds__(1024)
 k_encode(const F *__restrict__ src, size_t ld_src, F *__restrict__ dst, size_t ld_dst, uint32_t len, EncPass ps,
          const EncStep *__restrict__ steps, const uint32_t *__restrict__ slice_ptr,
          const uint32_t *__restrict__ slice_width, const uint32_t *__restrict__ slice_out, const uint2 *__restrict__ e32,
-         const uint32_t *__restrict__ eidx, const F *__restrict__ ew) {
+         const uint32_t *__restrict__ eidx, const F *__restrict__ ew, EncSrc es, EncDig dg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     F *cw = reinterpret_cast<F *>(lds_raw) - ps.base;          // cw[i] addresses codeword index i
-    const F *in = src + (size_t)blockIdx.x * ld_src;
-    F *out = dst + (size_t)blockIdx.x * ld_dst;
+    // Strided source (es.stride > 1): the message is column `c` of a row-major matrix (the row FFT's output), element i at
+    // in[i * stride]; a 128-byte line then holds the same row of 8 adjacent columns, so the block -> column map keeps 8 adjacent
+    // columns on blocks b, b+8, ..., b+56 -- dealt to ONE XCD back to back (MI355X_MICROARCH.md, workgroup dispatch) -- and the
+    // other seven find the line in that XCD's L2.  A speed choice only: any placement gives the same result.
+    uint32_t b = blockIdx.x;
+    if (es.stride > 1 && es.remap) { const uint32_t x = b & 7, q = b >> 3; b = ((q >> 3) << 6) + (x << 3) + (q & 7); }
+    const F *in = es.stride > 1 ? src + (size_t)(b / es.cols) * es.gs + (b % es.cols) : src + (size_t)b * ld_src;
+    const size_t istr = es.stride > 1 ? es.stride : 1;
+    F *out = dst + (size_t)b * ld_dst;
     // window load: eight global loads per thread in flight before the first LDS store (one at a time cost a full memory round
     // trip per element: 7 400 of pass A's 27 000 cycles per column, measured with s_memtime stamps)
     for (uint32_t b0 = ps.ld_lo; b0 < ps.ld_hi; b0 += 8 * blockDim.x) {
         F v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const uint32_t i = b0 + u * blockDim.x + threadIdx.x; if (i < ps.ld_hi) v[u] = ldF(in + i); }
+        for (int u = 0; u < 8; u++) { const uint32_t i = b0 + u * blockDim.x + threadIdx.x; if (i < ps.ld_hi) v[u] = ldF(in + (size_t)i * istr); }
 #pragma unroll
         for (int u = 0; u < 8; u++) { const uint32_t i = b0 + u * blockDim.x + threadIdx.x; if (i < ps.ld_hi) stF(&cw[i], v[u]); }
     }
@@ -661,17 +677,39 @@ k_encode(const F *__restrict__ src, size_t ld_src, F *__restrict__ dst, size_t l
         }
         __syncthreads();
     }
+    if (DIG) {
+        uint8_t *dout = dg.out + (size_t)b * dg.per_col * 32;
+        for (uint32_t g = dg.g_lo + threadIdx.x; g < dg.g_hi; g += blockDim.x) {
+            uint32_t m[16], h[8];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t i = 4 * g + q;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (i < len) v = *reinterpret_cast<const uint4 *>(&cw[i]);
+                m[4 * q] = v.x; m[4 * q + 1] = v.y; m[4 * q + 2] = v.z; m[4 * q + 3] = v.w;
+            }
+            blake3_compress64(m, h);
+            store8w(dout + 32 * (size_t)g, h);
+        }
+        for (uint32_t g = dg.g_hi + threadIdx.x; g < dg.g_fill; g += blockDim.x) store8w(dout + 32 * (size_t)g, dg.zero);
+    }
     for (uint32_t i = ps.st_lo + threadIdx.x; i < ps.st_hi; i += blockDim.x) stF(out + i, i < len ? ldF(&cw[i]) : fmake(0));
 }
 
+template <bool SMALLW, bool DIG>
+static int launch_encode_pass(hobbit_ctx *ctx, const char *name, const F *src, size_t ld_src, F *dst, size_t ld_dst, size_t batch, EncPass ps,
+                              uint32_t lds_elems, uint32_t block, EncSrc es, EncDig dg) {
+    DeviceCode &c = ctx->code;
+    hipFuncSetAttribute((const void *)k_encode<SMALLW, DIG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    HB_LAUNCH(ctx, name, (k_encode<SMALLW, DIG>), dim3((unsigned)batch), dim3(block), (size_t)lds_elems * 16, src, ld_src, dst, ld_dst, (uint32_t)c.len, ps,
+              c.d_steps, c.d_slice_ptr, c.d_slice_width, c.d_slice_out, c.d_edges32, c.d_eidx, c.d_ew, es, dg);
+    return 0;
+}
 template <bool SMALLW>
 static int launch_encode_pass(hobbit_ctx *ctx, const char *name, const F *src, size_t ld_src, F *dst, size_t ld_dst, size_t batch, EncPass ps,
-                              uint32_t lds_elems, uint32_t block) {
-    DeviceCode &c = ctx->code;
-    hipFuncSetAttribute((const void *)k_encode<SMALLW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    HB_LAUNCH(ctx, name, k_encode<SMALLW>, dim3((unsigned)batch), dim3(block), (size_t)lds_elems * 16, src, ld_src, dst, ld_dst, (uint32_t)c.len, ps,
-              c.d_steps, c.d_slice_ptr, c.d_slice_width, c.d_slice_out, c.d_edges32, c.d_eidx, c.d_ew);
-    return 0;
+                              uint32_t lds_elems, uint32_t block, EncSrc es = EncSrc{1, 0, 0, 0}, const EncDig *dg = nullptr) {
+    if (dg && dg->out) return launch_encode_pass<SMALLW, true>(ctx, name, src, ld_src, dst, ld_dst, batch, ps, lds_elems, block, es, *dg);
+    return launch_encode_pass<SMALLW, false>(ctx, name, src, ld_src, dst, ld_dst, batch, ps, lds_elems, block, es, EncDig{});
 }
 static uint32_t block_for(const DeviceCode &c, uint32_t s_lo, uint32_t s_hi, uint32_t max_waves) {
     uint32_t widest = 1;
@@ -680,17 +718,35 @@ static uint32_t block_for(const DeviceCode &c, uint32_t s_lo, uint32_t s_hi, uin
 }
 
 int launch_encode(hobbit_ctx *ctx, const F *src, size_t ld_src, F *dst, size_t ld_dst, long long n, size_t batch, int write_msg) {
+    return launch_encode_strided(ctx, src, ld_src, 1, 0, 0, dst, ld_dst, n, batch, write_msg, nullptr);
+}
+// src_stride > 1: message b is column (b % src_cols) of row-major matrix (b / src_cols) (matrices src_gs apart, element stride
+// src_stride); the message is then always written to dst as well (it is not there yet).
+// d_dig != NULL (n a multiple of 4): the inner digests of the 2n/4 four-row groups of every codeword are written to
+// d_dig[(b * (n/2) + j) * 32] by the passes that hold those rows in LDS (see k_encode<.., DIG>).
+int launch_encode_strided(hobbit_ctx *ctx, const F *src, size_t ld_src, uint32_t src_stride, uint32_t src_cols, size_t src_gs, F *dst, size_t ld_dst, long long n,
+                          size_t batch, int write_msg, uint8_t *d_dig) {
     DeviceCode &c = ctx->code;
     if (c.n != n) return ctx->fail(HOBBIT_ESTATE, "encode: graphs for this n are not finalized (hobbit_graph_finalize)");
     if (batch == 0) return 0;
     if ((size_t)c.len * 16 > 160 * 1024) return ctx->fail(HOBBIT_EINVAL, "encode: codeword does not fit in 160 KB of LDS (n <= 4096 supported)");
     const uint32_t nn = (uint32_t)n, nsteps = (uint32_t)c.steps.size();
+    EncSrc es{src_stride, src_cols, (uint32_t)(src_stride > 1 && batch % 64 == 0 ? 1 : 0), src_gs};
+    if (src_stride > 1) { write_msg = 1; if (!src_cols || batch % src_cols) return ctx->fail(HOBBIT_EINVAL, "encode: strided source needs batch to be a multiple of the matrix width"); }
     const bool split = nsteps >= 2 && (size_t)c.len * 16 > 80 * 1024;     // cannot co-schedule two workgroups per CU otherwise
+    if (d_dig && nn % 4) return ctx->fail(HOBBIT_EINVAL, "encode: digests need n to be a multiple of 4");
+    EncDig dgA{d_dig, 0, 0, 0, nn / 2, {0}}, dgB = dgA;
+    if (d_dig) {
+        uint32_t z[16] = {0}; blake3_compress64(z, dgA.zero); memcpy(dgB.zero, dgA.zero, sizeof dgA.zero);
+        const uint32_t g_len = ((uint32_t)c.len + 3) / 4;                  // groups with at least one non-zero entry
+        if (!split) { dgA.g_lo = 0; dgA.g_hi = g_len; dgA.g_fill = nn / 2; }
+        else { dgA.g_lo = 0; dgA.g_hi = nn / 4; dgA.g_fill = nn / 4; dgB.g_lo = nn / 4; dgB.g_hi = g_len; dgB.g_fill = nn / 2; }
+    }
     if (!split) {
         EncPass ps = {0, 0, nn, 0, nsteps, write_msg ? 0u : nn, 2 * nn, 0};
         uint32_t block = block_for(c, 0, nsteps, 16);
-        return c.small_weights ? launch_encode_pass<true>(ctx, "k_encode", src, ld_src, dst, ld_dst, batch, ps, (uint32_t)c.len, block)
-                               : launch_encode_pass<false>(ctx, "k_encode_fullw", src, ld_src, dst, ld_dst, batch, ps, (uint32_t)c.len, block);
+        return c.small_weights ? launch_encode_pass<true>(ctx, "k_encode", src, ld_src, dst, ld_dst, batch, ps, (uint32_t)c.len, block, es, &dgA)
+                               : launch_encode_pass<false>(ctx, "k_encode_fullw", src, ld_src, dst, ld_dst, batch, ps, (uint32_t)c.len, block, es, &dgA);
     }
     // pass A: x_1 = C_0 x_0, outputs straight to the column in global memory
     const uint32_t r0 = c.steps[0].out_len;
@@ -698,11 +754,11 @@ int launch_encode(hobbit_ctx *ctx, const F *src, size_t ld_src, F *dst, size_t l
     // pass B: the remaining steps on the window [n, len)
     EncPass pb = {nn, nn, nn + r0, 1, nsteps, nn + r0, 2 * nn, 0};
     if (c.small_weights) {
-        HB_TRY(launch_encode_pass<true>(ctx, "k_encode_A", src, ld_src, dst, ld_dst, batch, pa, nn, block_for(c, 0, 1, 16)));
-        return launch_encode_pass<true>(ctx, "k_encode_B", dst, ld_dst, dst, ld_dst, batch, pb, (uint32_t)c.len - nn, block_for(c, 1, nsteps, 8));
+        HB_TRY(launch_encode_pass<true>(ctx, "k_encode_A", src, ld_src, dst, ld_dst, batch, pa, nn, block_for(c, 0, 1, 16), es, &dgA));
+        return launch_encode_pass<true>(ctx, "k_encode_B", dst, ld_dst, dst, ld_dst, batch, pb, (uint32_t)c.len - nn, block_for(c, 1, nsteps, 8), EncSrc{1, 0, 0, 0}, &dgB);
     }
-    HB_TRY(launch_encode_pass<false>(ctx, "k_encode_fullw_A", src, ld_src, dst, ld_dst, batch, pa, nn, block_for(c, 0, 1, 8)));
-    return launch_encode_pass<false>(ctx, "k_encode_fullw_B", dst, ld_dst, dst, ld_dst, batch, pb, (uint32_t)c.len - nn, block_for(c, 1, nsteps, 8));
+    HB_TRY(launch_encode_pass<false>(ctx, "k_encode_fullw_A", src, ld_src, dst, ld_dst, batch, pa, nn, block_for(c, 0, 1, 8), es, &dgA));
+    return launch_encode_pass<false>(ctx, "k_encode_fullw_B", dst, ld_dst, dst, ld_dst, batch, pb, (uint32_t)c.len - nn, block_for(c, 1, nsteps, 8), EncSrc{1, 0, 0, 0}, &dgB);
 }
 
 // ============================================================================================
@@ -787,15 +843,26 @@ __global__ void __launch_bounds__(1024) k_merkle_top(const uint8_t *__restrict__
 // ([chunk][col][2 trs]), so the 4 field elements of leaf (j, col) are 64 contiguous bytes.  One
 // thread owns one leaf and keeps its Merkle-Damgard state in registers across the chunk loop:
 // the tensor is read exactly once and the leaf array is written exactly once.
+// Rows at or beyond the codeword length are zero in every chunk (the expander code fills 1.72 n of the 2 n rows), so for the groups
+// j >= zero_from the inner digest is the constant H(0^64) (passed in as zdig): one compression per chunk instead of two for those
+// leaves (14 % of them at n = 4096).  A wavefront covers 64 consecutive j of one column, so the branch is wave-uniform but for one wave
+// per column.
+struct ZeroDig { uint32_t w[8]; };
 template <int NL>
 __global__ void __launch_bounds__(256)
-k_leaf_chain(const F *__restrict__ tensor, size_t chunk_stride, int K, uint32_t cols, uint32_t half_trs, uint8_t *__restrict__ leaves) {
+k_leaf_chain(const F *__restrict__ tensor, size_t chunk_stride, int K, uint32_t cols, uint32_t half_trs, uint8_t *__restrict__ leaves, uint32_t zero_from, ZeroDig zdig) {
     // NL leaves per thread (independent hash chains interleaved for instruction-level parallelism)
     const size_t total = (size_t)cols * half_trs, per = (total + NL - 1) / NL;
-    for (size_t g0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g0 < per; g0 += (size_t)gridDim.x * blockDim.x) {
+    // Blocks are dealt round-robin over the 8 XCDs, and with 8 blocks per column the all-zero groups of EVERY column would land on one
+    // XCD (b % 8 == 7): that XCD would idle while the other seven set the kernel's time (measured: skipping 6 % of the compressions
+    // bought 0.5 %).  Rotating the block index inside each run of 8 by the run's number spreads the cheap blocks evenly.
+    size_t bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & ~(size_t)7) | ((bid + (bid >> 3)) & 7);
+    for (size_t g0 = bid * (size_t)blockDim.x + threadIdx.x; g0 < per; g0 += (size_t)gridDim.x * blockDim.x) {
         uint32_t st[NL][8];
         const F *p[NL];
         size_t g[NL];
+        bool zero[NL];
 #pragma unroll
         for (int l = 0; l < NL; l++) {
             g[l] = g0 + (size_t)l * per;
@@ -803,13 +870,17 @@ k_leaf_chain(const F *__restrict__ tensor, size_t chunk_stride, int K, uint32_t 
 #pragma unroll
             for (int q = 0; q < 8; q++) st[l][q] = 0;
             p[l] = tensor + gg * 4;                                   // (c * 2trs + 4j) with gg = c*half_trs + j
+            zero[l] = (uint32_t)(gg % half_trs) >= zero_from;
         }
         for (int i = 0; i < K; i++) {
             uint32_t m[NL][16], h[NL][8];
 #pragma unroll
-            for (int l = 0; l < NL; l++) load16w(p[l] + (size_t)i * chunk_stride, m[l]);
+            for (int l = 0; l < NL; l++) {
+                if (zero[l]) {
 #pragma unroll
-            for (int l = 0; l < NL; l++) blake3_compress64(m[l], h[l]);
+                    for (int q = 0; q < 8; q++) h[l][q] = zdig.w[q];
+                } else { load16w(p[l] + (size_t)i * chunk_stride, m[l]); blake3_compress64(m[l], h[l]); }
+            }
 #pragma unroll
             for (int l = 0; l < NL; l++) {
 #pragma unroll
@@ -1024,11 +1095,42 @@ int launch_merkle_levels(hobbit_ctx *ctx, uint8_t *levels, size_t n, int quirk) 
     }
     return 0;
 }
-int launch_leaf_chain(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, int K, uint32_t cols, uint32_t half_trs, uint8_t *leaves) {
+// The same chain from inner digests already computed by the encode passes (k_encode<.., DIG>): dig[(i*cols*half_trs + c*half_trs + j)*32].
+// One compression per leaf and chunk instead of two, 32 bytes read instead of 64.
+__global__ void __launch_bounds__(256)
+k_leaf_chain_dig(const uint8_t *__restrict__ dig, size_t chunk_stride_bytes, int K, uint32_t cols, uint32_t half_trs, uint8_t *__restrict__ leaves) {
+    const size_t total = (size_t)cols * half_trs;
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        uint32_t st[8], m[16];
+#pragma unroll
+        for (int q = 0; q < 8; q++) st[q] = 0;
+        const uint8_t *p = dig + 32 * g;
+        uint32_t nx[8];
+        load8w(p, nx);
+        for (int i = 0; i < K; i++) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) { m[q] = nx[q]; m[8 + q] = st[q]; }
+            if (i + 1 < K) load8w(p + (size_t)(i + 1) * chunk_stride_bytes, nx);      // next chunk's digest in flight during the compression
+            blake3_compress64(m, st);
+        }
+        const uint32_t c = (uint32_t)(g / half_trs), j = (uint32_t)(g % half_trs);
+        store8w(leaves + 32 * ((size_t)j * cols + c), st);
+    }
+}
+int launch_leaf_chain_dig(hobbit_ctx *ctx, const uint8_t *dig, size_t chunk_stride_bytes, int K, uint32_t cols, uint32_t half_trs, uint8_t *leaves) {
+    size_t total = (size_t)cols * half_trs;
+    HB_LAUNCH(ctx, "k_leaf_chain_dig", k_leaf_chain_dig, dim3(grid_for(total, 256, 1 << 20)), dim3(256), 0, dig, chunk_stride_bytes, K, cols, half_trs, leaves);
+    return 0;
+}
+// zero_rows_from: first row index that is zero in EVERY chunk (the expander codeword length; 2*half_trs = none)
+int launch_leaf_chain(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, int K, uint32_t cols, uint32_t half_trs, uint8_t *leaves, uint32_t zero_rows_from) {
     size_t total = (size_t)cols * half_trs;
     constexpr int NL = 1;   // 2 interleaved chains measured no faster: the kernel sits at the VALU issue limit (profiles/r01_microbench.txt)
+    ZeroDig zd; { uint32_t z[16] = {0}; blake3_compress64(z, zd.w); }
+    const char *e = getenv("HOBBIT_LEAF_ZERO_SKIP");
+    const uint32_t zero_from = (e && e[0] == '0') ? 0xFFFFFFFFu : (e && e[0] == 'X') ? 0u /* timing experiment only: wrong digests */ : (zero_rows_from + 3) / 4;
     HB_LAUNCH(ctx, "k_leaf_chain", k_leaf_chain<NL>, dim3(grid_for((total + NL - 1) / NL, 256, 1 << 20)), dim3(256), 0, tensor, chunk_stride, K, cols,
-              half_trs, leaves);
+              half_trs, leaves, zero_from, zd);
     return 0;
 }
 int launch_merkle_paths(hobbit_ctx *ctx, const uint8_t *levels, size_t n, const uint64_t *d_pos, size_t nq, int depth, uint8_t *d_paths) {
