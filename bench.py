@@ -1,17 +1,18 @@
 #!/usr/bin/env python3
-"""bench.py -- Our_PC commit on MI355X (north-star size 2^28), one JSON line on rank 0.
+"""bench.py -- Our_PC commit + open on MI355X (north-star size 2^28), one JSON line on rank 0.
 
-A "step" is one Our_PC commit_standard (reference src/Our_PC.cpp:146-171, the commit phase of
-test_PC(2^28, 4, 32)): RS row FFTs, expander column encode, BLAKE3 Merkle-Damgard leaf chain over
-the K chunks and the Merkle tree -- all on the GPU through the C ABI (libhobbit_hip.so), with the
-polynomial already resident in HBM when the timed region starts.
+A "step" (default --phase commit+open) is one Our_PC commit_standard (reference src/Our_PC.cpp:146-171: RS row FFTs, expander column
+encode, BLAKE3 Merkle-Damgard leaf chain over the K chunks, Merkle tree) followed by the whole prover side of open_standard
+(src/Our_PC.cpp:604-661 + recursive_prover_Spielman, src/PC_utils.cpp:271-385, with both shockwave_prove / WHIR proofs) of
+test_PC(2^28, 4, 32) -- all on the GPU through the C ABI (libhobbit_hip.so), with the polynomial already resident in HBM when the
+timed region starts.  --phase commit times the commit alone.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--logn 28] [--chunks 32]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--logn 28] [--chunks 32] [--mode replicas|sharded]
 
-N > 1: launched by torch.distributed.run, one rank per GPU.  The path shards over independent
-polynomials this round (each rank commits its own 2^logn polynomial; no data-path collective;
-"scaling": "weak"); the chunk-sharded single commitment with the digest exchange is DESIGN.md's
-next multi-GPU step.
+N > 1: launched by torch.distributed.run, one rank per GPU.  Default mode for N > 1 is `sharded`: ONE commitment and ONE opening
+of the same 2^logn polynomial, chunks sharded over the ranks (parallel.py: one digest exchange, one all-gather of subtree roots, one
+all-gather of partial aggregates) -- the north-star's 1/2/4/8 curve, "scaling": "strong".  --mode replicas commits and opens an
+independent polynomial per rank (no data-path collective, "scaling": "weak").
 """
 import argparse
 import json
@@ -41,6 +42,13 @@ def commit_op_counts(N, K, edges):
     return mul, add, comp
 
 
+# which resource binds each bulk kernel: "valu" kernels report frac_valu (issue cycles the instruction stream needs at the
+# sustained clock / measured time) as the primary fraction; the HBM fraction the contract asks for stays in `frac`
+KERNEL_BOUND = {"k_leaf_chain": "valu", "k_fft4096": "valu", "k_encode_A": "valu", "k_encode_B": "valu", "k_encode": "valu", "k_transpose": "hbm",
+                "k_inner_digests": "valu", "k_chain_digests": "valu", "k_aggregate": "hbm"}
+SUSTAINED_GHZ, PEAK_GHZ = 1.78, 2.4       # profiles/r01_microbench.txt: clock held under the VALU-heavy kernels; the chip's peak clock
+TRAFFIC_PROFILE = "r02_hbm_traffic_commit_2e28.json"     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (scripts/hbm_traffic.py)
+
 ROOFLINE_NOTES = {
     "k_leaf_chain": "VALU-issue bound, not HBM bound: BLAKE3 compress = 2023 SIMD-cycles per wave-compression with v_alignbit/v_add3 at half rate "
                     "(profiles/r01_microbench.txt); 2^29+2^23 compressions = 9.4 ms at the 1.78 GHz the chip holds = the measured time",
@@ -52,16 +60,18 @@ ROOFLINE_NOTES = {
 
 
 def measured_traffic(kernel, logn, K):
-    """HBM bytes per launch from the rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this same command (profiles/, gfx950-corrected);
-    only valid for the default 2^28 / K=32 workload."""
+    """HBM bytes per launch of `kernel`.  PMC counters cannot be collected inside a timed run (rocprofv3 --pmc is its own pass and
+    serialises kernels), so this REPLAYS the committed FETCH_SIZE/WRITE_SIZE passes of this same command (profiles/, gfx950-corrected
+    by scripts/hbm_traffic.py); only valid for the default 2^28 / K=32 workload.  Returns (bytes or None, provenance string)."""
     if logn != 28 or K != 32:
-        return None
-    path = os.path.join(ROOT, "profiles", "r01_e_hbm_traffic_commit_2e28.json")
+        return None, "not collected for this workload"
+    path = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
     try:
         with open(path) as f:
-            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+            d = json.load(f)
+        return d["kernels"][kernel]["hbm_bytes_per_launch"], "replayed from profiles/%s (separate rocprofv3 --pmc passes; code at %s)" % (TRAFFIC_PROFILE, d.get("commit", "?"))
     except Exception:
-        return None
+        return None, "profiles/%s not present" % TRAFFIC_PROFILE
 
 
 def open_core_op_counts(N, K, edges):
@@ -119,7 +129,12 @@ def open_op_counts(N, K, edges, full=True):
     return mul, add
 
 
-def algorithmic_bytes(N, K, world=1, sharded=False):
+def nonzero_group_fraction(trs, code_len):
+    """share of the 4-row leaf groups with a non-zero row: rows >= the codeword length are zero in every chunk"""
+    return min(1.0, ((code_len + 3) // 4) / (trs / 2.0)) if trs >= 4 else 1.0
+
+
+def algorithmic_bytes(N, K, world=1, sharded=False, nz=1.0):
     """HBM-compulsory bytes per launch of each commit kernel (DESIGN.md 'Kernels'): what the
     algorithm must move given that the tensor is retained, not what the kernel happens to move."""
     M = N // K
@@ -132,7 +147,7 @@ def algorithmic_bytes(N, K, world=1, sharded=False):
         "k_encode": f * (32 * N + 32 * N),              # single-pass encode: read message half, write parity half
         "k_encode_A": f * (32 * N + 32 * N * r0),       # read message half, write x_1 = C_0 x_0
         "k_encode_B": f * (32 * N * r0 + 32 * N * (1 - r0)),   # read x_1, write the rest of the parity half
-        "k_leaf_chain": 64 * N + 32 * M,                # read the whole tensor once, write the leaves once
+        "k_leaf_chain": 64 * N * nz + 32 * M,           # read the non-zero rows of the tensor once (rows past the codeword length are zero), write the leaves once
         "k_inner_digests": f * (64 * N + 32 * N),       # read the local tensor shard, write its 32-byte digests
         "k_chain_digests": (32 * M * K + 64 * M) * (1.0 / world if sharded else 1.0),
     }
@@ -145,9 +160,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--logn", type=int, default=28)
     ap.add_argument("--chunks", type=int, default=32)
-    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
-                    help="N>1: replicas = one independent polynomial per GPU (weak); sharded = ONE commitment, chunks sharded over the GPUs "
-                         "with the digest exchange + subtree-root all-gather of parallel.py (strong)")
+    ap.add_argument("--mode", choices=["replicas", "sharded"], default=None,
+                    help="default: sharded when --gpus > 1 (ONE commitment + opening, chunks sharded over the GPUs with the digest exchange + "
+                         "subtree-root all-gather of parallel.py: strong scaling, the north-star curve), replicas on one GPU; "
+                         "replicas = one independent polynomial per GPU (weak)")
     ap.add_argument("--phase", choices=["commit", "commit+open", "commit+opencore"], default="commit+open",
                     help="commit+open adds the whole prover side of open_standard (recursive_prover_Spielman with both shockwave_prove/WHIR proofs); "
                          "commit+opencore stops before the two shockwave_prove calls")
@@ -155,6 +171,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-logn", type=int, default=24, help="size of the CPU-baseline sample (2^24: about 17 s of single-thread reference time)")
     args = ap.parse_args()
+    if args.mode is None:
+        args.mode = "sharded" if args.gpus > 1 else "replicas"
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -178,7 +196,7 @@ def main():
     # small `generate_randomness` values), one distinct polynomial per rank
     d_poly = hb.fill_splitmix(N, 1000 + rank)
     hb.rng_reset()
-    hb.expander_init_store(trs)           # graphs drawn on the host with libc, reference order
+    code_len = hb.expander_init_store(trs)   # graphs drawn on the host with libc, reference order; returns the codeword length
     edges = sum(int(L) * int(d) for (L, R, d, nbr, w) in hb._graph_levels.values())
     mul, add, comp = commit_op_counts(N, K, edges)
 
@@ -278,7 +296,8 @@ def main():
                     assert open_last["res"][sp]["wchecks"].tolist() == [1, 1], "open: WHIR round / final checks failed in " + sp
         ops = (mul + add + omul + oadd) * (1 if sharded else world)
         value = ops / (wall_max / args.steps)
-        ab = algorithmic_bytes(N, K, world, sharded)
+        nz = nonzero_group_fraction(trs, code_len)
+        ab = algorithmic_bytes(N, K, world, sharded, nz)
         cand = {k: v for k, v in prof.items() if ab.get(k)} or {"k_leaf_chain": (1.0, 1)}
         dom = max(cand, key=lambda k: cand[k][0])
         dom_ms = cand[dom][0] / cand[dom][1]
@@ -297,14 +316,16 @@ def main():
                        "Our_PC commit_standard (test_PC(2^%d,4,%d) commit phase): trs=%d, cols=4096, tensor retained in HBM; open phase not in the timed region" % (args.logn, K, trs),
                        "N": N, "K": K, "trs": trs, "mode": args.mode, "polynomials_per_gpu": (1.0 / world) if sharded else 1},
             "prover_s": wall_max / args.steps, "step_ms_rank0": step_ms, "hip_event_ms_per_step": ev_ms / args.steps,
+            "step_ms_median": float(np.median(step_ms)), "step_ms_mean": float(np.mean(step_ms)),
+            "step_ms_outliers": [x for x in step_ms if x > 1.25 * float(np.median(step_ms))],
             "f_mul_per_s": mul * (1 if sharded else world) / (wall_max / args.steps),
             "blake3_compressions_per_s": comp * (1 if sharded else world) / (wall_max / args.steps),
             "op_counts": {"f_mul": mul, "f_add": add, "blake3_compress": comp, "expander_edges": edges, "open_f_mul": omul, "open_f_add": oadd},
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items())},
             "kernels_ms_extra_profiled_step": {k: v[0] for k, v in sorted(prof_full.items())},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(dom, args.logn, K), "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": dom_ms,
-                         "note": ROOFLINE_NOTES.get(dom, "")},
+            "roofline": {"bound": KERNEL_BOUND.get(dom, "hbm"), "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(dom, args.logn, K)[0], "traffic_source": measured_traffic(dom, args.logn, K)[1],
+                         "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": dom_ms, "note": ROOFLINE_NOTES.get(dom, "")},
             "root": root,
         }
         if dom == "k_leaf_chain" and not sharded:
@@ -312,10 +333,13 @@ def main():
             # cycles + message/finalisation moves; profiles/r01_microbench.txt), 64 compressions per wave, 1024 SIMDs: the clock at which
             # the chip would have to issue without a single bubble to finish in the measured time -- compare with the 1.78 GHz it
             # sustains under this load (2.4 GHz peak)
-            wave_comp = (2.0 * K * (N // K)) / 64.0          # 2 compressions per leaf and chunk
+            wave_comp = ((1.0 + nz) * K * (N // K)) / 64.0   # per leaf and chunk: the chain compression, plus the inner one unless the group is all zero
             cyc = wave_comp * 2023.0 / 1024.0
             out["roofline"]["binding"] = {"resource": "VALU issue", "simd_cycles_per_launch": cyc,
-                                          "implied_issue_clock_ghz": cyc / (dom_ms * 1e-3) / 1e9, "sustained_clock_ghz": 1.78, "peak_clock_ghz": 2.4}
+                                          "implied_issue_clock_ghz": cyc / (dom_ms * 1e-3) / 1e9, "sustained_clock_ghz": SUSTAINED_GHZ, "peak_clock_ghz": PEAK_GHZ}
+            # primary fraction for a VALU-bound kernel: issue cycles the instruction stream needs / cycles available at the sustained clock
+            out["roofline"]["frac_valu"] = cyc / (dom_ms * 1e-3 * SUSTAINED_GHZ * 1e9)
+            out["roofline"]["frac_valu_of_peak_clock"] = cyc / (dom_ms * 1e-3 * PEAK_GHZ * 1e9)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_logn, K)
             if do_open:

@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "hobbit_commit_standard", "hobbit_commitment_free", "hobbit_commitment_num_leaves", "hobbit_commitment_levels_dev",
     "hobbit_commitment_tensor_dev", "hobbit_commitment_levels", "hobbit_commitment_root", "hobbit_commitment_tensor_row",
     "hobbit_commitment_gather", "hobbit_commitment_path", "hobbit_commitment_paths",
-    "hobbit_elastic_begin", "hobbit_elastic_push", "hobbit_elastic_finish", "hobbit_elastic_free",
+    "hobbit_elastic_begin", "hobbit_elastic_push", "hobbit_elastic_push_inner", "hobbit_elastic_finish", "hobbit_elastic_free",
     "hobbit_elastic_open_begin", "hobbit_elastic_open_aggregate_push", "hobbit_elastic_open_aggregate_finish", "hobbit_elastic_open_reply_push",
     "hobbit_elastic_open_finish", "hobbit_elastic_open_free", "hobbit_generate_randomness",
     "hobbit_read_mul_tree_layer", "hobbit_read_mul_tree_data", "hobbit_generate_claims_opt", "hobbit_sumcheck3_stream_batch", "hobbit_mul_tree_stream_shallow",
@@ -98,7 +98,7 @@ def load_library(path=LIB_PATH):
         "hobbit_compute4p_error_terms": [V, V, V, V, V, V, V, V, V, S, V], "hobbit_fold_axpy": [V, V, V, V, S],
         "hobbit_fold_axpy_i32": [V, V, V, V, I, S], "hobbit_batch_prod": [V, V, V, V, V, V, V, I, S, V, V, V, V, V, V],
         "hobbit_elastic_begin": [V, S, I, I, I, V], "hobbit_elastic_push": [V, V, V], "hobbit_elastic_finish": [V, V, V],
-        "hobbit_elastic_free": [V],
+        "hobbit_elastic_free": [V], "hobbit_elastic_push_inner": [V, V, V, V],
         "hobbit_elastic_open_begin": [V, S, S, I, V, I, V], "hobbit_elastic_open_aggregate_push": [V, V, V], "hobbit_elastic_open_aggregate_finish": [V, V],
         "hobbit_elastic_open_reply_push": [V, V, V], "hobbit_elastic_open_finish": [V, V, V, V], "hobbit_elastic_open_free": [V],
         "hobbit_generate_randomness": [S, V],

@@ -595,6 +595,18 @@ int hobbit_elastic_push(hobbit_ctx *ctx, hobbit_elastic *e, const hobbit_F *d_ch
     e->count++;
     return 0;
 }
+// Multi-GPU form of the push: the 4th chunk of a group writes the group's inner digests (4B x 32 B, the reference's leaf order) to
+// d_digests instead of chaining them into the running leaves; the owner of each leaf range chains what it receives (hobbit_chain_digests).
+int hobbit_elastic_push_inner(hobbit_ctx *ctx, hobbit_elastic *e, const hobbit_F *d_chunk, uint8_t *d_digests) {
+    const int slot = (int)(e->count % 4);
+    HB_TRY(tensorcode_chunks(ctx, cF(d_chunk), e->B, 1, e->trs, e->lin, e->t[slot]));
+    if (slot == 3) {
+        if (!d_digests) return ctx->fail(HOBBIT_EINVAL, "elastic_push_inner: the 4th chunk of a group needs a digest buffer");
+        HB_TRY(launch_elastic_inner(ctx, e->t[0], e->t[1], e->t[2], e->t[3], e->rows2, e->cols, e->shift, d_digests));
+    }
+    e->count++;
+    return 0;
+}
 int hobbit_elastic_finish(hobbit_ctx *ctx, hobbit_elastic *e, uint8_t *d_levels) {
     HB_TRY(launch_elastic_finish(ctx, e->state, e->rows2, e->cols, d_levels));
     return launch_merkle_levels(ctx, d_levels, 4 * e->B, 1);                    // :277-283

@@ -971,6 +971,34 @@ k_elastic_leaf(const F *__restrict__ t0, const F *__restrict__ t1, const F *__re
         store8w(state + 32 * g, h);
     }
 }
+// Multi-GPU streaming commit ("Elastic: groups of 4 consecutive chunks"): only the INNER digest H(c0, c1, c2, t3) of every
+// position of one 4-chunk group, written in the reference's leaf order (p = j*cols + k) so that a rank's leaf range is one byte range
+__global__ void __launch_bounds__(256)
+k_elastic_inner(const F *__restrict__ t0, const F *__restrict__ t1, const F *__restrict__ t2, const F *__restrict__ t3, uint32_t rows2, uint32_t cols,
+                int shift, uint8_t *__restrict__ out) {
+    const size_t T = (size_t)rows2 * cols;
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < T; g += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t k = (uint32_t)(g / rows2), j = (uint32_t)(g % rows2);
+        size_t gs = g; bool zero = false;
+        if (shift) {
+            if (k + 1 < cols) gs = g + rows2;
+            else if (j + 1 < rows2) gs = (size_t)j + 1;
+            else zero = true;
+        }
+        const F a = zero ? fmake(0) : ldF(t0 + gs), b = zero ? fmake(0) : ldF(t1 + gs), c = ldF(t2 + g), d = ldF(t3 + g);
+        uint32_t m[16], h[8];
+        m[0] = (uint32_t)a.re; m[1] = (uint32_t)(a.re >> 32); m[2] = (uint32_t)a.im; m[3] = (uint32_t)(a.im >> 32);
+        m[4] = (uint32_t)b.re; m[5] = (uint32_t)(b.re >> 32); m[6] = (uint32_t)b.im; m[7] = (uint32_t)(b.im >> 32);
+        m[8] = (uint32_t)c.re; m[9] = (uint32_t)(c.re >> 32); m[10] = (uint32_t)c.im; m[11] = (uint32_t)(c.im >> 32);
+        m[12] = (uint32_t)d.re; m[13] = (uint32_t)(d.re >> 32); m[14] = (uint32_t)d.im; m[15] = (uint32_t)(d.im >> 32);
+        blake3_compress64(m, h);
+        store8w(out + 32 * ((size_t)j * cols + k), h);
+    }
+}
+int launch_elastic_inner(hobbit_ctx *ctx, const F *t0, const F *t1, const F *t2, const F *t3, uint32_t rows2, uint32_t cols, int shift, uint8_t *out) {
+    HB_LAUNCH(ctx, "k_elastic_inner", k_elastic_inner, dim3(grid_for((size_t)rows2 * cols, 256, 1 << 16)), dim3(256), 0, t0, t1, t2, t3, rows2, cols, shift, out);
+    return 0;
+}
 __global__ void k_elastic_finish(const uint8_t *__restrict__ state, uint32_t rows2, uint32_t cols, uint8_t *__restrict__ leaves) {
     const size_t T = (size_t)rows2 * cols;
     for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < T; g += (size_t)gridDim.x * blockDim.x) {
@@ -992,8 +1020,26 @@ int launch_elastic_finish(hobbit_ctx *ctx, const uint8_t *state, uint32_t rows2,
 __global__ void __launch_bounds__(256)
 k_col_digest(const F *__restrict__ enc, size_t W, int k, int quirk, uint8_t *__restrict__ out) {
     for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < W; c += (size_t)gridDim.x * blockDim.x) {
-        uint32_t node[16][8];
         const int leaves = k / 4;
+        if (quirk) {
+            // create_tree_blake's parent is H(left | left) (src/merkle_tree.cpp:275-280): the root is leaf 0 re-hashed log2(leaves)
+            // times -- rows 0..3 of the column are all that reaches it.  1 + log2(leaves) compressions instead of 2*leaves - 1, in registers.
+            uint32_t m[16], h[8];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const F v = ldF(enc + (size_t)e * W + c);
+                m[4 * e] = (uint32_t)v.re; m[4 * e + 1] = (uint32_t)(v.re >> 32); m[4 * e + 2] = (uint32_t)v.im; m[4 * e + 3] = (uint32_t)(v.im >> 32);
+            }
+            blake3_compress64(m, h);
+            for (int n = leaves; n > 1; n >>= 1) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) { m[q] = h[q]; m[8 + q] = h[q]; }
+                blake3_compress64(m, h);
+            }
+            store8w(out + 32 * c, h);
+            continue;
+        }
+        uint32_t node[16][8];
         for (int l = 0; l < leaves; l++) {
             uint32_t m[16];
 #pragma unroll

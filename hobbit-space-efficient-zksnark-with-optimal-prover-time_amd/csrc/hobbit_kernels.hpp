@@ -12,6 +12,7 @@ int launch_fft4096(hobbit_ctx *ctx, const F *src, size_t src_ld, size_t src_es, 
                    size_t src_gs, size_t dst_gs);
 int launch_fft_combine(hobbit_ctx *ctx, int logr, const F *Y, F *dst, size_t dst_ld, const F *tw, uint32_t rows);
 int launch_elastic_leaf(hobbit_ctx *ctx, const F *t0, const F *t1, const F *t2, const F *t3, uint32_t rows2, uint32_t cols, int shift, uint8_t *state);
+int launch_elastic_inner(hobbit_ctx *ctx, const F *t0, const F *t1, const F *t2, const F *t3, uint32_t rows2, uint32_t cols, int shift, uint8_t *out);
 int launch_elastic_finish(hobbit_ctx *ctx, const uint8_t *state, uint32_t rows2, uint32_t cols, uint8_t *leaves);
 int launch_transpose(hobbit_ctx *ctx, const F *in, size_t in_gs, uint32_t rows, uint32_t cols, F *out, size_t out_gs, size_t ld_out, uint32_t groups);
 int launch_encode(hobbit_ctx *ctx, const F *src, size_t ld_src, F *dst, size_t ld_dst, long long n, size_t batch, int write_msg);

@@ -41,44 +41,72 @@ class ShardPlan:
 def sharded_commit(ops, dist, plan, rank, local_chunks):
     """local_chunks: this rank's chunk messages in `ops`' native form.  Returns a dict with this
     rank's leaf range, its subtree levels (flat: m_local leaves ... subtree root), the top levels
-    (flat: G subtree roots ... root) and the root."""
+    (flat: G subtree roots ... root) and the root.
+
+    The exchange is posted chunk by chunk: as soon as local chunk li's tensor code and inner digests exist, its leaf ranges go out to
+    their owners (and the matching receives are posted) while the next chunk is being encoded; everything is received straight into
+    the [K, m_local, 32] buffer the chain kernel reads -- no staging copy of the 8 GiB / G of digests."""
     import torch
     G = plan.world
     own = plan.chunks_of(rank)
-    # 1. local tensor codes + inner digests: uint8 tensor [n_own, M, 32] on ops.device
-    digests = ops.inner_digests(local_chunks, plan)
-    assert tuple(digests.shape) == (len(own), plan.M, 32)
-    # 2. the one exchange
     lo, hi = plan.leaf_range(rank)
-    recv = {h: torch.empty((len(plan.chunks_of(h)), plan.m_local, 32), dtype=torch.uint8, device=digests.device) for h in range(G) if h != rank}
-    reqs = []
-    for h in range(G):
-        if h == rank:
-            continue
-        l2, h2 = plan.leaf_range(h)
-        reqs.append(dist.P2POp(dist.isend, digests[:, l2:h2].contiguous(), h))
-        reqs.append(dist.P2POp(dist.irecv, recv[h], h))
-    if reqs:
-        for r in dist.batch_isend_irecv(reqs):
-            r.wait()
+    mine = ops.empty_digests(plan.K, plan.m_local)             # uint8 [K, m_local, 32] on ops.device, global chunk order
+    works, keep = [], []
+    for li, i in enumerate(own):
+        d = ops.inner_digests_one(local_chunks, li, plan)      # uint8 [M, 32], complete (the library's stream has been drained)
+        keep.append(d)                                         # alive until the sends have completed
+        mine[i].copy_(d[lo:hi])
+        reqs = []
+        for h in range(G):
+            if h == rank:
+                continue
+            l2, h2 = plan.leaf_range(h)
+            reqs.append(dist.P2POp(dist.isend, d[l2:h2], h))
+            reqs.append(dist.P2POp(dist.irecv, mine[plan.chunks_of(h)[li]], h))      # every rank owns the same number of chunks
+        if reqs:
+            works += dist.batch_isend_irecv(reqs)              # asynchronous: overlaps the next chunk's tensor code
+    for w in works:
+        w.wait()
     ops.after_collective()        # RCCL: wait() only orders torch's stream; the library has its own
-    # assemble the K digests of my leaf range in global chunk order
-    parts = []
-    for i in range(plan.K):
-        owner, li = plan.owner(i)
-        parts.append(digests[li, lo:hi] if owner == rank else recv[owner][li])
-    mine = torch.stack(parts).contiguous()                     # [K, m_local, 32]
-    # 3. chain + subtree
+    del keep
+    # chain + subtree
     subtree = ops.chain_and_tree(mine, plan)                   # flat uint8 [2*m_local-1, 32]
-    # 4. all-gather of subtree roots, top of the tree everywhere
+    # all-gather of subtree roots, top of the tree everywhere
     my_root = subtree[-1:].contiguous()
     roots = [torch.empty_like(my_root) for _ in range(G)]
     if G > 1:
         dist.all_gather(roots, my_root)
+        ops.after_collective()
     else:
         roots = [my_root]
     top = ops.tree_top(torch.cat(roots).cpu().numpy())         # flat [2G-1, 32] (numpy, host)
     return dict(leaf_range=(lo, hi), subtree=subtree, top=top, root=top[-1])
+
+
+class ElasticPlan:
+    """Elastic_PC streaming commit sharded over GPUs: a leaf hashes 4 consecutive chunks together
+    (src/Elastic_PC.cpp:228-243), so the unit of work is a GROUP of 4 chunks; rank g encodes groups g, g+G, ... and owns the leaf range
+    [g*4B/G, (g+1)*4B/G) of the 4B running leaves.  Same exchange as the Our_PC commit: `sharded_commit(ops, dist, ElasticPlan(...), rank,
+    source)` with ops.inner_digests_one producing a group's 4B inner digests."""
+
+    def __init__(self, N, B, opt, world):
+        assert N % (4 * B) == 0, "N must be a whole number of 4-chunk groups"
+        self.N, self.B, self.opt, self.world = N, B, opt, world
+        self.lin, self.trs = (0, B >> 11) if opt == 1 else (1, B >> 14)
+        self.K = N // (4 * B)                                  # groups: the chain length of every leaf
+        assert self.K % world == 0, "world size must divide the number of 4-chunk groups"
+        self.M = 4 * B                                         # leaves
+        assert self.M % world == 0
+        self.m_local = self.M // world
+
+    def chunks_of(self, rank):
+        return list(range(rank, self.K, self.world))           # group indices
+
+    def owner(self, group):
+        return group % self.world, group // self.world
+
+    def leaf_range(self, rank):
+        return rank * self.m_local, (rank + 1) * self.m_local
 
 
 def sharded_open(ops, dist, plan, rank, commit_res, x, queries=5900):
@@ -110,6 +138,15 @@ def sharded_open(ops, dist, plan, rank, commit_res, x, queries=5900):
     # 3. the rest of the open, replicated
     res = ops.open_from_aggregate(aggr, plan, queries)
     cols = np.asarray(res["cols"], np.int64); rows = np.asarray(res["rows"], np.int64)
+    if G > 1:
+        # every rank must have drawn the same libc sequence inside the replicated open: a divergence (a library on one rank drawing
+        # from libc, a different call history) would silently answer different queries -- compare with rank 0's and fail loudly
+        q_mine = torch.from_numpy(np.stack([cols, rows])).to(ops.device)
+        q0 = q_mine.clone()
+        dist.broadcast(q0, 0)
+        ops.after_collective()
+        if not torch.equal(q0, q_mine):
+            raise RuntimeError("sharded_open: rank %d drew different queries than rank 0 (the libc generator streams diverged)" % rank)
     # 4. replies
     mine = ops.gather_local(rows, cols, plan)                                        # int64 tensor (queries, n_own, 2)
     rep = [torch.empty_like(mine) for _ in range(G)]
@@ -175,24 +212,37 @@ class HipOps:
         self.hb = hb
         self.device = torch_device
 
-    def inner_digests(self, local_chunks, plan):
-        """local_chunks: (device_ptr, n_own): n_own messages of M F each, contiguous, resident."""
+    def empty_digests(self, K, m_local):
         import torch
-        from ctypes import c_void_p
+        return torch.empty((K, m_local, 32), dtype=torch.uint8, device=self.device)
+
+    def inner_digests_one(self, local_chunks, li, plan):
+        """local_chunks: (device_ptr, n_own): n_own messages of M F each, contiguous, resident.  Tensor code of local chunk li into the
+        retained shard, its inner digests into a fresh torch buffer; returns once the library's stream has produced them (the
+        collective that follows runs on RCCL's stream, which only orders itself after torch's)."""
+        import torch
         ptr, n_own = local_chunks
         hb = self.hb
-        self._tensor = hb.alloc(16 * 4 * plan.M * n_own)       # retained: the commitment's tensor shard
-        hb._chk(hb.lib.hobbit_tensorcode_chunks(hb.ctx, ptr, plan.M, n_own, plan.trs, 1, self._tensor.ptr))
-        out = torch.empty((n_own, plan.M, 32), dtype=torch.uint8, device=self.device)
-        hb._chk(hb.lib.hobbit_inner_digests(hb.ctx, self._tensor.ptr, plan.M, n_own, plan.trs, out.data_ptr()))
+        if li == 0:
+            self._tensor = hb.alloc(16 * 4 * plan.M * n_own)   # retained: the commitment's tensor shard
+        t = self._tensor.ptr + 16 * 4 * plan.M * li
+        hb._chk(hb.lib.hobbit_tensorcode_chunks(hb.ctx, ptr + 16 * plan.M * li, plan.M, 1, plan.trs, 1, t))
+        out = torch.empty((plan.M, 32), dtype=torch.uint8, device=self.device)
+        hb._chk(hb.lib.hobbit_inner_digests(hb.ctx, t, plan.M, 1, plan.trs, out.data_ptr()))
         hb.sync()
         return out
+
+    def inner_digests(self, local_chunks, plan):
+        import torch
+        return torch.stack([self.inner_digests_one(local_chunks, li, plan) for li in range(local_chunks[1])])
 
     def chain_and_tree(self, mine, plan):
         import torch
         hb = self.hb
         m = plan.m_local
-        levels = torch.zeros((2 * m, 32), dtype=torch.uint8, device=self.device)
+        levels = torch.empty((2 * m, 32), dtype=torch.uint8, device=self.device)
+        torch.cuda.synchronize(self.device)                    # (allocation only; nothing of torch's is pending on `levels`)
+        hb._chk(hb.lib.hobbit_memset(hb.ctx, levels.data_ptr(), 0, 32 * m))     # the chain starts from zero leaves; zeroed on the LIBRARY's stream
         hb._chk(hb.lib.hobbit_chain_digests(hb.ctx, mine.data_ptr(), 32 * m, plan.K, m, levels.data_ptr()))
         hb._chk(hb.lib.hobbit_merkle_levels(hb.ctx, levels.data_ptr(), m, 1))
         hb.sync()
@@ -250,6 +300,32 @@ class HipOps:
         out = np.zeros((len(pos), depth, 32), np.uint8)
         hb._chk(hb.lib.hobbit_merkle_paths(hb.ctx, subtree.data_ptr(), plan.m_local, pos.ctypes.data, len(pos), out.ctypes.data))
         return torch.from_numpy(out).to(self.device)
+
+
+class ElasticHipOps(HipOps):
+    """Per-rank compute of the sharded streaming commit: a group's four chunks go through hobbit_elastic_push_inner.
+    `source(chunk_index)` returns the device pointer of that B-element chunk (valid until the next call)."""
+
+    def inner_digests_one(self, source, li, plan):
+        import ctypes
+        import torch
+        hb = self.hb
+        if li == 0:
+            e = ctypes.c_void_p()
+            hb._chk(hb.lib.hobbit_elastic_begin(hb.ctx, plan.B, plan.trs, plan.lin, 1, ctypes.byref(e)))
+            self._e = e
+        g = plan.chunks_of(self.rank)[li]
+        out = torch.empty((plan.M, 32), dtype=torch.uint8, device=self.device)
+        for q in range(4):
+            hb._chk(hb.lib.hobbit_elastic_push_inner(hb.ctx, self._e, source(4 * g + q), out.data_ptr()))
+        hb.sync()
+        if li == len(plan.chunks_of(self.rank)) - 1:
+            hb.lib.hobbit_elastic_free(self._e); self._e = None
+        return out
+
+    def __init__(self, hb, torch_device, rank):
+        super().__init__(hb, torch_device)
+        self.rank = rank
 
 
 def tree_top_host(lib, roots):

@@ -151,6 +151,10 @@ int hobbit_commitment_paths(hobbit_ctx *ctx, const hobbit_commitment *c, const u
 int hobbit_elastic_begin(hobbit_ctx *ctx, size_t B, int trs, int linear_time, int gcc_arg_order, hobbit_elastic **out);
 int hobbit_elastic_push(hobbit_ctx *ctx, hobbit_elastic *e, const hobbit_F *d_chunk);
 int hobbit_elastic_finish(hobbit_ctx *ctx, hobbit_elastic *e, uint8_t *d_levels);
+/* multi-GPU form (groups of 4 consecutive chunks per GPU): as hobbit_elastic_push, but the 4th chunk of a group writes
+ * the group's 4B inner digests H(c0, c1, c2, t3) (32 B each, the reference's leaf order) to d_digests instead of chaining them into
+ * the running leaves; the rank that owns a leaf range chains the digests of all groups (hobbit_chain_digests) and builds its subtree */
+int hobbit_elastic_push_inner(hobbit_ctx *ctx, hobbit_elastic *e, const hobbit_F *d_chunk, uint8_t *d_digests);
 void hobbit_elastic_free(hobbit_elastic *e);
 
 /* ---- inner PCS commitments of the opening (src/Virgo.cpp:104-178) ------------------------------ */

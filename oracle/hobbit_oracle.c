@@ -1577,6 +1577,41 @@ void orc_gate_consistency_stream(const oF *L, const oF *Rt, const oF *O, const i
     free(beta); free(fb); free(fL); free(fR); free(fO); free(fa); free(fm); free(b1); free(pe);
 }
 
+/* Multi-GPU streaming commit (test infra for tests/test_dist_gloo.py): the inner digests H(c0[p+1], c1[p+1], c2[p], t3[p]) of ONE group of
+ * 4 consecutive chunks, 4B x 32 B in leaf order, exactly what orc_elastic_commit chains -- chunk c of the stream under the stream model
+ * (kind 0: every chunk is read_stream_PC's default; kind 1: chunk c = splitmix_field(B, seed + c)). */
+void orc_elastic_group_digests(size_t B, int opt, size_t group, uint8_t *out) {
+    int lin, trs;
+    if (opt == 1) { lin = 0; trs = (int)(B >> 11); } else { lin = 1; trs = (int)(B >> 14); }
+    size_t T = 4 * B;
+    oF *buff = (oF *)malloc(sizeof(oF) * B), *t[4];
+    const uint64_t save = g_stream_count;
+    for (int q = 0; q < 4; q++) {
+        t[q] = (oF *)malloc(sizeof(oF) * T);
+        if (g_stream_kind == 0) orc_read_stream_pc(B, buff); else { g_stream_count = 4 * group + (size_t)q; stream_read(buff, B); }
+        orc_compute_tensorcode(buff, B, trs, lin, t[q]);
+    }
+    g_stream_count = save;
+    for (size_t p = 0; p < T; p++) {
+        oF z = fint(0);
+        oF x[4] = {p + 1 < T ? t[0][p + 1] : z, p + 1 < T ? t[1][p + 1] : z, t[2][p], t[3][p]};
+        blake3_64((const uint8_t *)x, out + 32 * p);
+    }
+    free(buff); for (int q = 0; q < 4; q++) free(t[q]);
+}
+/* the whole streaming commit under the stream model (kind 1: chunk c = splitmix_field(B, seed + c)); graphs must already be drawn for opt 2 */
+size_t orc_elastic_commit_model(size_t N, size_t B, int opt, uint8_t *levels_out) {
+    size_t T = 4 * B, groups = N / T;
+    uint8_t *dg = (uint8_t *)malloc(32 * T);
+    memset(levels_out, 0, 32 * T);
+    for (size_t g = 0; g < groups; g++) {
+        orc_elastic_group_digests(B, opt, g, dg);
+        for (size_t p = 0; p < T; p++) { uint8_t blk[64]; memcpy(blk, dg + 32 * p, 32); memcpy(blk + 32, levels_out + 32 * p, 32); blake3_64(blk, levels_out + 32 * p); }
+    }
+    free(dg);
+    return create_tree(levels_out, T);
+}
+
 /* test_PC(N, 4, K) inputs (src/Our_PC.cpp:757-813) + timed commit_standard */
 double orc_time_commit_standard(size_t N, int K) {
     srandom(1);

@@ -21,13 +21,15 @@ class OracleOps:
     def __init__(self, orc, lib):
         self.orc, self.lib = orc, lib
 
-    def inner_digests(self, local_chunks, plan):
-        out = np.zeros((len(local_chunks), plan.M, 32), np.uint8)
-        for li, msg in enumerate(local_chunks):
-            t = self.orc.compute_tensorcode(msg, plan.trs, 1)            # (2trs, cols, 2) row-major
-            for j in range(plan.trs // 2):
-                blk = np.ascontiguousarray(t[4 * j:4 * j + 4].transpose(1, 0, 2)).view(np.uint8).reshape(plan.cols, 64)
-                out[li, j * plan.cols:(j + 1) * plan.cols] = self.orc.blake3_64(blk)
+    def empty_digests(self, K, m_local):
+        return torch.empty((K, m_local, 32), dtype=torch.uint8)
+
+    def inner_digests_one(self, local_chunks, li, plan):
+        out = np.zeros((plan.M, 32), np.uint8)
+        t = self.orc.compute_tensorcode(local_chunks[li], plan.trs, 1)    # (2trs, cols, 2) row-major
+        for j in range(plan.trs // 2):
+            blk = np.ascontiguousarray(t[4 * j:4 * j + 4].transpose(1, 0, 2)).view(np.uint8).reshape(plan.cols, 64)
+            out[j * plan.cols:(j + 1) * plan.cols] = self.orc.blake3_64(blk)
         return torch.from_numpy(out)
 
     def chain_and_tree(self, mine, plan):
@@ -74,6 +76,40 @@ class OracleOps:
     def subtree_paths(self, subtree, local_pos, plan):
         lv = subtree.numpy()
         return torch.from_numpy(np.stack([self.orc.open_tree_blake(lv, plan.m_local, int(p), 0, 0) for p in local_pos]))
+
+
+class OracleElasticOps(OracleOps):
+    """CPU stand-in for ElasticHipOps: a group's inner digests from the oracle (stream model set by the worker)"""
+
+    def __init__(self, orc, lib, rank):
+        super().__init__(orc, lib); self.rank = rank
+
+    def inner_digests_one(self, source, li, plan):
+        import ctypes
+        g = plan.chunks_of(self.rank)[li]
+        out = np.zeros((plan.M, 32), np.uint8)
+        self.orc.lib.orc_elastic_group_digests(ctypes.c_size_t(plan.B), ctypes.c_int(plan.opt), ctypes.c_size_t(g), out.ctypes.data_as(ctypes.c_void_p))
+        return torch.from_numpy(out)
+
+
+def _elastic_worker(rank, world, port, N, B, opt, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle
+    from __graft_entry__ import load_package
+    mod = load_package()
+    orc = pyoracle.Oracle()
+    plan = mod.parallel.ElasticPlan(N, B, opt, world)
+    orc.rng_reset()
+    if opt == 2:
+        orc.expander_init_store(plan.trs)
+    orc.stream_config(1, 9000)                       # chunk c = splitmix_field(B, 9000 + c): every group differs
+    ops = OracleElasticOps(orc, mod.load_library(), rank)
+    res = mod.parallel.sharded_commit(ops, dist, plan, rank, None)
+    q.put((rank, res["subtree"].numpy(), res["top"], res["root"], None))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def _worker(rank, world, port, N, K, q, do_open=False):
@@ -187,6 +223,50 @@ def test_sharded_open_matches_single_process(oracle):
         assert np.array_equal(o["sp_c_wq"], want["sp_c"]["wq"]) and np.array_equal(o["sp_f_q1"], want["sp_f"]["q1"])
         for qi in (0, 7, 150, queries - 1):
             assert np.array_equal(o["paths"][qi], oracle.open_tree_blake(lv, M, int(want["I"][qi, 0]), int(want["I"][qi, 1]), 2 * M // trs)), (g[0], qi)
+
+
+@pytest.mark.parametrize("opt", [1, 2])
+def test_sharded_elastic_commit_matches_single_process(oracle, opt):
+    """config 5's split at world 2: groups of 4 consecutive chunks per rank, one exchange of inner digests, per-rank chain + subtree, one
+    all-gather of subtree roots -- the assembled tree equals the single-process streaming commit on the same (varying) stream"""
+    import ctypes
+    from __graft_entry__ import load_package, build_hip
+    build_hip()
+    mod = load_package()
+    world, N, B = 2, 1 << 19, 1 << 14                 # 8 groups of 4 chunks
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_elastic_worker, args=(r, world, port, N, B, opt, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = []
+    import queue as _q
+    import time as _t
+    deadline = _t.time() + 240
+    while len(got) < world:
+        try:
+            got.append(q.get(timeout=2))
+        except _q.Empty:
+            assert all(p.exitcode in (None, 0) for p in procs), "a rank died: exit codes %s" % [p.exitcode for p in procs]
+            assert _t.time() < deadline, "timeout waiting for ranks"
+    got.sort(key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    plan = mod.parallel.ElasticPlan(N, B, opt, world)
+    oracle.rng_reset()
+    if opt == 2:
+        oracle.expander_init_store(plan.trs)
+    oracle.stream_config(1, 9000)
+    try:
+        want = np.zeros((8 * B, 32), np.uint8)
+        oracle.lib.orc_elastic_commit_model.restype = ctypes.c_size_t
+        cnt = oracle.lib.orc_elastic_commit_model(ctypes.c_size_t(N), ctypes.c_size_t(B), ctypes.c_int(opt), want.ctypes.data_as(ctypes.c_void_p))
+    finally:
+        oracle.stream_config(0, 0)
+    levels = mod.parallel.assemble_levels(plan, [g[1] for g in got], got[0][2])
+    T = 4 * B
+    assert np.array_equal(levels[:T - 1], want[:T - 1]) and np.array_equal(levels[T:], want[T:cnt])     # leaf 4B-1 is undefined in the reference
 
 
 def test_shard_plan():

@@ -1151,3 +1151,37 @@ def test_gate_consistency_stream_vs_oracle(hb, oracle, logB, nch):
     assert want["checks"].tolist() == [1, 1, 1] and got["checks"].tolist() == [1, 1, 1]
     for k in ("R", "a", "poly", "gr", "fin6", "Peval", "b", "q2", "r2", "vr2", "fin2"):
         assert np.array_equal(got[k], want[k]), k
+
+
+@pytest.mark.parametrize("opt", [1, 2])
+def test_sharded_elastic_commit_hip_ops_world1(hb, oracle, opt):
+    """Per-rank GPU operations of the sharded streaming commit (groups of 4 consecutive chunks; hobbit_elastic_push_inner,
+    chain of the group digests, subtree) at world size 1 on a stream whose chunks all differ, against the oracle's streaming commit on the
+    same stream; the collective pattern is covered by tests/test_dist_gloo.py at world 2."""
+    import ctypes
+    import torch
+    from __graft_entry__ import load_package
+    mod = load_package()
+    N, B = 1 << 19, 1 << 14
+    plan = mod.parallel.ElasticPlan(N, B, opt, 1)
+    oracle.rng_reset()
+    if opt == 2:
+        oracle.expander_init_store(plan.trs)
+        hb.upload_graphs(plan.trs, graphs_from(oracle, plan.trs)) if plan.trs > 13 else hb.expander_init_store(plan.trs)
+    oracle.stream_config(1, 9000)
+    try:
+        want = np.zeros((8 * B, 32), np.uint8)
+        oracle.lib.orc_elastic_commit_model.restype = ctypes.c_size_t
+        cnt = oracle.lib.orc_elastic_commit_model(ctypes.c_size_t(N), ctypes.c_size_t(B), ctypes.c_int(opt), want.ctypes.data_as(ctypes.c_void_p))
+    finally:
+        oracle.stream_config(0, 0)
+    live = []
+
+    def source(c):
+        buf = hb.to_device(splitmix_field(B, 9000 + c)); live.append(buf); del live[:-2]
+        return buf.ptr
+    ops = mod.parallel.ElasticHipOps(hb, torch.device("cuda", 0), 0)
+    res = mod.parallel.sharded_commit(ops, None, plan, 0, source)
+    levels = mod.parallel.assemble_levels(plan, [res["subtree"].cpu().numpy()], res["top"])
+    T = 4 * B
+    assert np.array_equal(levels[:T - 1], want[:T - 1]) and np.array_equal(levels[T:], want[T:cnt])
