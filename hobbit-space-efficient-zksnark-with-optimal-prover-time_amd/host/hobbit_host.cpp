@@ -593,6 +593,184 @@ void test_Elastic_PC_commit(size_t N, int option) {                 // commit ph
     printf("\n");
 }
 
+// ---- remaining reference-named entry points of the path ------------------------------------------------------
+shockwave_data *C_f = nullptr, *C_c = nullptr;                     // src/PC_utils.cpp:6-7
+F *scratch[2][100];                                                // src/linear_code_encode.cpp:3
+bool __encode_initialized = false;                                 // src/linear_code_encode.cpp:4
+double routine_time = 0.0, sc_vt = 0.0;                            // src/sumcheck.cpp:27,29
+
+mul_tree_proof prove_multiplication_tree_new(vector<vector<F>> &input, F previous_r, vector<F> prev_x, double &vt, double &ps) {   // src/sumcheck.cpp:35-257
+    size_t vectors = input.size(), size = input[0].size();
+    for (auto &v : input) if (v.size() != size) { printf("Error in mul tree sumcheck, no equal size vectors\n"); exit(-1); }
+    int depth = (int)log2((double)size);
+    if (((size_t)1 << depth) != size) { depth++; size = (size_t)1 << depth; for (auto &v : input) v.resize(size, F(1)); }          // (:48-54)
+    if (vectors != ((size_t)1 << (int)log2((double)vectors))) {                                                                        // (:56-64)
+        size_t nv = (size_t)1 << ((int)log2((double)vectors) + 1);
+        for (size_t i = vectors; i < nv; i++) input.push_back(vector<F>(size, F(0)));
+        vectors = nv;
+    }
+    vector<F> flat(vectors * size);
+    for (size_t j = 0; j < vectors; j++) memcpy((void *)(flat.data() + j * size), input[j].data(), size * sizeof(F));
+    DevBuf d(flat.data(), flat.size() * sizeof(F));
+    const int lt = (int)log2((double)(vectors * size)); size_t nr = 0; for (int i = 0; i < lt; i++) nr += (size_t)i;
+    vector<F> q(4 * (nr + 1)), r(nr + 1), vr(3 * (size_t)depth), fin(depth), final_r(lt), out(vectors); F oe, fe; int layers = 0;
+    HCHK(hobbit_mul_tree(hobbit_host_ctx(), (const hobbit_F *)d.p, vectors, size, hF(&previous_r), prev_x.empty() ? nullptr : hF(prev_x.data()), hF(q.data()), hF(r.data()),
+                         hF(vr.data()), hF(fin.data()), hF(final_r.data()), hF(&oe), hF(&fe), &layers));
+    mul_tree_proof P; P.size = size; P.initial_randomness = previous_r; P.out_eval = oe; P.final_eval = fe; P.final_r = final_r;
+    size_t qo = 0, ro = 0; int rl = vectors == 1 ? 1 : (int)log2((double)vectors);
+    for (int l = 0; l < layers; l++) {
+        struct proof p;
+        for (int i = 0; i < rl; i++) p.c_poly.push_back(cubic_poly(q[qo + 4 * i], q[qo + 4 * i + 1], q[qo + 4 * i + 2], q[qo + 4 * i + 3]));
+        p.randomness.push_back(vector<F>(r.begin() + ro, r.begin() + ro + rl)); p.vr = {vr[3 * l], vr[3 * l + 1], vr[3 * l + 2]}; p.final_rand = fin[l];
+        P.proofs.push_back(p); qo += 4 * (size_t)rl; ro += (size_t)rl; rl++;
+        ps += (p.c_poly.size() * 5 + 3) * sizeof(F) / 1024.0;
+    }
+    for (int i = 0; i < depth; i++) P.individual_randomness.push_back(final_r[i]);                                                     // (:221-229)
+    for (int i = depth; i < lt; i++) P.global_randomness.push_back(final_r[i]);
+    P.output.resize(vectors);                                                                                                           // products per vector
+    for (size_t j = 0; j < vectors; j++) { F m = F(1); for (size_t i = 0; i < size; i++) m = m * input[j][i]; P.output[j] = m; }
+    (void)vt;
+    return P;
+}
+struct proof batch_3product_sumcheck(vector<vector<F>> &arr1, vector<vector<F>> &arr2, vector<vector<F>> &arr3, vector<F> a, double &vt, double &ps) {   // src/sumcheck.cpp:275-372
+    const int batches = (int)a.size();
+    vector<size_t> lens(batches); size_t tot = 0, L = 0;
+    for (int j = 0; j < batches; j++) { lens[j] = arr1[j].size(); tot += lens[j]; L = lens[j] > L ? lens[j] : L; }
+    vector<F> t1(tot), t2(tot), t3(tot); size_t o = 0;
+    for (int j = 0; j < batches; j++) { memcpy((void *)(t1.data() + o), arr1[j].data(), lens[j] * sizeof(F)); memcpy((void *)(t2.data() + o), arr2[j].data(), lens[j] * sizeof(F));
+                                        memcpy((void *)(t3.data() + o), arr3[j].data(), lens[j] * sizeof(F)); o += lens[j]; }
+    DevBuf d1(t1.data(), tot * sizeof(F)), d2(t2.data(), tot * sizeof(F)), d3(t3.data(), tot * sizeof(F));
+    const int rounds = (int)log2((double)L);
+    vector<F> q(4 * (size_t)rounds), r(rounds), vr(3 * (size_t)batches);
+    HCHK(hobbit_batch_3product_sumcheck(hobbit_host_ctx(), (const hobbit_F *)d1.p, (const hobbit_F *)d2.p, (const hobbit_F *)d3.p, lens.data(), batches, hF(a.data()),
+                                        hF(q.data()), hF(r.data()), hF(vr.data())));
+    struct proof P;
+    for (int i = 0; i < rounds; i++) P.c_poly.push_back(cubic_poly(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]));
+    P.randomness.push_back(r); P.vr = vr;
+    ps += rounds * 4 * sizeof(F) / 1024.0 + (P.vr.size() - P.vr.size() / 3) * sizeof(F) / 1024.0; (void)vt;
+    // the reference folds its inputs in place; callers rely on element 0 afterwards (= vr)
+    for (int j = 0; j < batches; j++) { arr1[j][0] = vr[3 * j]; arr2[j][0] = vr[3 * j + 1]; arr3[j][0] = vr[3 * j + 2]; }
+    return P;
+}
+void _compute_tensorcode(F *message, F **tensor, int size) {                                                   // src/PC_utils.cpp:9-64
+    vector<F> m(message, message + size); vector<vector<F>> t;
+    compute_tensorcode(m, t);
+    for (size_t i = 0; i < t.size(); i++) memcpy((void *)tensor[i], t[i].data(), t[i].size() * sizeof(F));
+}
+shockwave_data::~shockwave_data() {
+    if (k > 0) { for (int i = 0; i < k; i++) { delete[] encoded_matrix[i]; delete[] matrix[i]; } delete[] encoded_matrix; delete[] matrix; }
+    for (void *p : {d_matrix, d_enc, d_levels}) if (p && g_ctx) hobbit_free(g_ctx, p);
+}
+shockwave_data *shockwave_commit(vector<F> &poly, int k) {                                                     // src/Virgo.cpp:120-157
+    shockwave_data *d = new shockwave_data; d->k = k; d->N = (int)poly.size();
+    const size_t N = poly.size(), w = N / k, W = 2 * w;
+    HCHK(hobbit_malloc(hobbit_host_ctx(), N * sizeof(F), &d->d_matrix)); HCHK(hobbit_malloc(g_ctx, 2 * N * sizeof(F), &d->d_enc)); HCHK(hobbit_malloc(g_ctx, 64 * W, &d->d_levels));
+    HCHK(hobbit_memcpy_h2d(g_ctx, d->d_matrix, poly.data(), N * sizeof(F)));
+    HCHK(hobbit_shockwave_commit(g_ctx, (const hobbit_F *)d->d_matrix, N, k, (hobbit_F *)d->d_enc, (uint8_t *)d->d_levels));
+    d->matrix = new F *[k]; d->encoded_matrix = new F *[k];
+    for (int i = 0; i < k; i++) {
+        d->matrix[i] = new F[w]; d->encoded_matrix[i] = new F[W];
+        memcpy((void *)d->matrix[i], poly.data() + (size_t)i * w, w * sizeof(F));
+        HCHK(hobbit_memcpy_d2h(g_ctx, d->encoded_matrix[i], (const char *)d->d_enc + (size_t)i * W * sizeof(F), W * sizeof(F)));
+    }
+    const int levels = (int)log2((double)W) + 1; d->MT.resize(levels); size_t off = 0;
+    for (int l = 0, sz = (int)W; l < levels; l++, sz /= 2) { d->MT[l].resize(sz); HCHK(hobbit_memcpy_d2h(g_ctx, d->MT[l].data(), (const char *)d->d_levels + 32 * off, 32 * (size_t)sz)); off += sz; }
+    return d;
+}
+static hobbit_host_shockwave_transcript g_sw;
+hobbit_host_shockwave_transcript &hobbit_host_last_shockwave() { return g_sw; }
+void shockwave_prove(shockwave_data *data, vector<F> x, double &vt, double &ps) {                              // src/Virgo.cpp:435-517
+    SpBuffers b(g_sw, (size_t)data->N, data->k);
+    HCHK(hobbit_shockwave_prove(hobbit_host_ctx(), (const hobbit_F *)data->d_matrix, (const hobbit_F *)data->d_enc, (const uint8_t *)data->d_levels, (size_t)data->N, data->k,
+                                hF(x.data()), (int)x.size(), &b.o));
+    if (g_sw.iters && !(g_sw.wchecks[0] && g_sw.wchecks[1])) { printf("Error in final verification step\n"); exit(-1); }               // src/Virgo.cpp:562-565, 648-651
+    shockwave_ps(g_sw, (size_t)data->N, data->k, ps); (void)vt;
+    delete data;                                                                                                                      // (:515)
+}
+// the streaming multiplication-tree prover over read_stream: the stream is re-generated on the host exactly as the reference does, every
+// read is uploaded and handed to the library as a chunk source
+struct HostStream { stream_descriptor fd; vector<F> buf; DevBuf *dev = nullptr; size_t cap = 0; };
+static int host_stream_source(void *user, size_t n, const hobbit_F **out) {
+    HostStream *hs = (HostStream *)user;
+    if (n == 0) { hs->fd.pos = 0; hs->fd.idx = 0; hs->fd.stage = 0; hs->fd.offset = 0; hs->fd.finished = false; return 0; }          // reset_stream (src/witness_stream.cpp:228-234)
+    auto t0 = std::chrono::steady_clock::now();
+    if (hs->buf.size() < n) hs->buf.resize(n);
+    read_stream(hs->fd, hs->buf, (int)n);
+    if (hs->cap < n) { delete hs->dev; hs->dev = new DevBuf(n * sizeof(F)); hs->cap = n; }
+    if (hobbit_memcpy_h2d(g_ctx, hs->dev->p, hs->buf.data(), n * sizeof(F)) != 0) return 1;
+    routine_time += std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::steady_clock::now() - t0).count();       // "streaming time" (src/sumcheck.cpp:1185-1188)
+    *out = (const hobbit_F *)hs->dev->p;
+    return 0;
+}
+struct S3Buffers {   // host buffers behind one hobbit_stream3_out
+    vector<F> nc, nr, c1, r1, vr1, q2, r2, vr2, fin2, R; int checks[3] = {0, 0, 0}; hobbit_stream3_out o;
+    S3Buffers(size_t fd_size, size_t B, int batches, int layer_id) {
+        const size_t size = fd_size >> layer_id; const int logB = (int)log2((double)B), lR = (int)log2((double)(size / (2 * B))); const int ld = 1 + logB + lR;
+        nc.assign(batches, F(0)); nr.assign((size_t)batches * ld, F(0)); c1.assign(4 * (size_t)logB, F(0)); r1.assign(logB, F(0)); vr1.assign(3 * (size_t)batches, F(0));
+        q2.assign(3 * (size_t)lR, F(0)); r2.assign(lR, F(0)); vr2.assign(2, F(0)); fin2.assign(1, F(0)); R.assign(size / (2 * B), F(0));
+        o = hobbit_stream3_out{hF(nc.data()), hF(nr.data()), ld, hF(c1.data()), hF(r1.data()), hF(vr1.data()), hF(q2.data()), hF(r2.data()), hF(vr2.data()), hF(fin2.data()), hF(R.data()), checks};
+    }
+};
+static void s3_check(const S3Buffers &b, double &ps, int batches, int rounds1, int rounds2) {
+    if (!b.checks[1]) { printf("Error in sumcheck 1\n"); exit(-1); }                                            // src/sumcheck.cpp:1280-1283
+    if (!b.checks[2]) { printf("Error in sumcheck 2\n"); exit(-1); }                                            // (:1362-1365)
+    ps += (1 + batches) * sizeof(F) / 1024.0;                                                                   // (:1214)
+    ps += rounds1 * 4 * sizeof(F) / 1024.0 + 2 * batches * sizeof(F) / 1024.0;                                  // batch_3product_sumcheck
+    ps += rounds2 * 3 * sizeof(F) / 1024.0 + 2 * sizeof(F) / 1024.0;                                            // the closing 2-product sumcheck
+}
+void generate_3product_sumcheck_beta_stream_batch_optimized(stream_descriptor fd, vector<vector<F>> r, int batches, int distance, int layer_id, vector<F> old_claims,
+                                                            vector<F> &new_claims, vector<vector<F>> &new_r, double &vt, double &ps) {   // src/sumcheck.cpp:1150-1393
+    HostStream hs; hs.fd = fd;
+    size_t rlen = 0; for (auto &v : r) rlen = v.size() > rlen ? v.size() : rlen;
+    vector<F> rr((size_t)batches * rlen, F(0));
+    for (int i = 0; i < batches; i++) memcpy((void *)(rr.data() + (size_t)i * rlen), r[i].data(), r[i].size() * sizeof(F));
+    S3Buffers b(fd.size, BUFFER_SPACE, batches, layer_id);
+    HCHK(hobbit_sumcheck3_stream_batch(hobbit_host_ctx(), host_stream_source, &hs, fd.size, BUFFER_SPACE, hF(rr.data()), (int)rlen, batches, distance, layer_id,
+                                       hF(old_claims.data()), (int)old_claims.size(), &b.o));
+    delete hs.dev;
+    for (size_t i = 0; i < old_claims.size(); i++) if (!b.checks[0]) { printf("Error in sumcheck 0 %d\n", (int)i); break; }   // the reference prints and continues (:1246-1251)
+    const int logB = (int)log2((double)BUFFER_SPACE), lR = (int)log2((double)((fd.size >> layer_id) / (2 * BUFFER_SPACE)));
+    s3_check(b, ps, batches, logB, lR); (void)vt;
+    new_claims = b.nc; new_r.resize(batches);
+    for (int i = 0; i < batches; i++) new_r[i].assign(b.nr.begin() + (size_t)i * b.o.new_r_ld, b.nr.begin() + (size_t)i * b.o.new_r_ld + 1 + (logB - i * distance) + lR);
+}
+vector<F> prove_multiplication_tree_stream_shallow(stream_descriptor fd, int vectors, int size, F previous_r, int distance, vector<F> prev_x, bool naive, double &vt, double &ps) {   // src/sumcheck.cpp:1746-1915
+    const size_t total = (size_t)size * vectors, B = BUFFER_SPACE;
+    int layers = total > 2 * B ? (int)log2((double)(total / (2 * B))) : 0;
+    if (layers % distance != 0 && layers > distance) layers = distance + layers - (layers % distance);
+    if (total > 2 * B && !naive && layers > distance && layers / distance - 1 > 0) {
+        // commit_layers / open_layers (src/sumcheck.cpp:983-1011) commit to and open "PC_layer" streams with Elastic_PC; that wiring is not built
+        printf("Error: prove_multiplication_tree_stream_shallow with committed layers (layers %d > distance %d, naive == false) is not built; call it with naive = true\n", layers, distance);
+        exit(-1);
+    }
+    HostStream hs; hs.fd = fd;
+    const size_t n1 = total > 2 * B ? fd.size >> layers : total; const size_t sz = n1 / vectors;
+    const int lt = (int)log2((double)n1), depth = (int)log2((double)sz); size_t nr = 0; for (int i = 0; i < lt; i++) nr += (size_t)i;
+    vector<F> out(vectors), q(4 * (nr + 1)), r(nr + 1), vr(3 * (size_t)depth + 3), fin(depth + 1), final_r(lt); F oe, fe; int tl = 0, nst = 0, sl = 0;
+    vector<S3Buffers *> bufs; vector<hobbit_stream3_out> steps;
+    if (total > 2 * B) {
+        if (layers <= distance || naive) for (int i = layers - 1; i >= 0; i--) bufs.push_back(new S3Buffers(fd.size, B, 1, i));
+        else for (int i = distance - 1; i >= 0; i--) bufs.push_back(new S3Buffers(fd.size, B, layers / distance, i));
+        for (auto *b : bufs) steps.push_back(b->o);
+    }
+    vector<F> claims0(16);
+    hobbit_mul_stream_out mo{hF(out.data()), hF(q.data()), hF(r.data()), hF(vr.data()), hF(fin.data()), hF(final_r.data()), hF(&oe), hF(&fe), &tl,
+                             steps.data(), (int)steps.size(), &nst, hF(claims0.data()), &sl};
+    HCHK(hobbit_mul_tree_stream_shallow(hobbit_host_ctx(), host_stream_source, &hs, fd.size, B, vectors, (size_t)size, hF(&previous_r), distance,
+                                        prev_x.empty() ? nullptr : hF(prev_x.data()), naive ? 1 : 0, &mo));
+    delete hs.dev;
+    const int logB = (int)log2((double)B);
+    for (int i = 0; i < nst; i++) {
+        printf("OK %d\n", nst - 1 - i);                                                                           // (:1857)
+        if (!bufs[i]->checks[0]) printf("Error in sumcheck 0 0\n");
+        const int batches = (int)bufs[i]->nc.size();
+        s3_check(*bufs[i], ps, batches, logB, (int)bufs[i]->r2.size());
+    }
+    for (auto *b : bufs) delete b;
+    (void)vt;
+    return out;
+}
+
 // ---- driver (src/Our_PC.cpp:757-826, option 4, commit phase) ---------------------------------------
 void test_PC(size_t N, int option, int K) {
     if (option != 4) { printf("Error: only option 4 (RS x expander Our_PC) is built on the device path\n"); exit(-1); }
@@ -690,6 +868,54 @@ int hobbit_host_elastic_open(size_t N, size_t B, uint8_t *root_out, uint32_t *co
     checks[0] = t.checks[0]; checks[1] = t.checks[1]; checks[2] = t.sp_f.wchecks[0] & t.sp_f.wchecks[1];
     *ps_out = ps;
     return t.rounds;
+}
+// one call through each of the remaining reference-named wrappers; results for the test to compare with the oracle
+int hobbit_host_mirror_check(const uint64_t *tree_in /* 4 x 64 F */, const uint64_t *b3 /* 3 tables: 256 | 64 F each */, const uint64_t *b3a /* 2 F */, uint64_t *out /* >= 64 F */,
+                             uint8_t *roots /* 2 x 32 B */, double *ps_out) {
+    double vt = 0, ps = 0; F *o = (F *)out; int n = 0;
+    {   // prove_multiplication_tree_new
+        vector<vector<F>> in(4, vector<F>(64)); for (int j = 0; j < 4; j++) memcpy((void *)in[j].data(), tree_in + 2 * 64 * j, 64 * sizeof(F));
+        srandom(77);
+        mul_tree_proof P = prove_multiplication_tree_new(in, F(17, 5), vector<F>(), vt, ps);
+        o[n++] = P.out_eval; o[n++] = P.final_eval; for (auto &v : P.output) o[n++] = v; o[n++] = P.final_r[0]; o[n++] = P.final_r.back(); o[n++] = F((long long)P.proofs.size());
+    }
+    {   // batch_3product_sumcheck
+        vector<vector<F>> A(2), Bv(2), C(2); size_t lens[2] = {256, 64}, off = 0;
+        for (int j = 0; j < 2; j++) { A[j].assign((const F *)b3 + off, (const F *)b3 + off + lens[j]); Bv[j].assign((const F *)b3 + 320 + off, (const F *)b3 + 320 + off + lens[j]);
+                                      C[j].assign((const F *)b3 + 640 + off, (const F *)b3 + 640 + off + lens[j]); off += lens[j]; }
+        vector<F> a((const F *)b3a, (const F *)b3a + 2);
+        struct proof P = batch_3product_sumcheck(A, Bv, C, a, vt, ps);
+        o[n++] = P.c_poly[0].a; o[n++] = P.c_poly.back().d; o[n++] = P.randomness[0].back(); for (auto &v : P.vr) o[n++] = v;
+    }
+    {   // _compute_tensorcode (RS x RS, trs = 4) and shockwave_commit / shockwave_prove, globals C_f / C_c
+        vector<F> msg((const F *)tree_in, (const F *)tree_in + 256);
+        linear_time = false; tensor_row_size = 4; BUFFER_SPACE = 256;
+        vector<vector<F>> rows(8, vector<F>(128)); vector<F *> ptr(8); for (int i = 0; i < 8; i++) ptr[i] = rows[i].data();
+        _compute_tensorcode(msg.data(), ptr.data(), 256);
+        o[n++] = rows[0][0]; o[n++] = rows[7][127]; o[n++] = rows[3][64];
+        vector<F> big(1 << 13); for (size_t i = 0; i < big.size(); i++) big[i] = ((const F *)tree_in)[i % 256] * F((long long)(i / 256 + 1));
+        C_f = shockwave_commit(big, 32);
+        memcpy(roots, C_f->MT.back()[0].arr, 32); o[n++] = C_f->encoded_matrix[31][511]; o[n++] = C_f->matrix[5][7];
+        C_c = shockwave_commit(msg, 8); memcpy(roots + 32, C_c->MT.back()[0].arr, 32); delete C_c; C_c = nullptr;
+        vector<F> x((const F *)b3a, (const F *)b3a + 2); x.resize(13, F(3)); for (int i = 2; i < 13; i++) x[i] = ((const F *)b3)[i];
+        srandom(78);
+        shockwave_prove(C_f, x, vt, ps); C_f = nullptr;
+        hobbit_host_shockwave_transcript &t = hobbit_host_last_shockwave();
+        o[n++] = t.q1[0]; o[n++] = t.fin1; o[n++] = t.fin2; o[n++] = F((long long)t.iters); o[n++] = F((long long)(t.wchecks[0] + 2 * t.wchecks[1]));
+    }
+    *ps_out = ps;
+    return n;
+}
+// prove_multiplication_tree_stream_shallow through the mirror on the default stream (returns the number of products)
+int hobbit_host_mul_tree_stream(size_t B, int vectors, size_t size, int distance, const uint64_t *prev_x, int nx, uint64_t *out, double *ps_out) {
+    BUFFER_SPACE = B;
+    stream_descriptor fd; fd.name = "test"; fd.size = size * (size_t)vectors;
+    double vt = 0, ps = 0;
+    vector<F> px((const F *)prev_x, (const F *)prev_x + nx);
+    srandom(11);
+    vector<F> o = prove_multiplication_tree_stream_shallow(fd, vectors, (int)size, F(32), distance, px, true, vt, ps);
+    memcpy(out, o.data(), o.size() * sizeof(F)); *ps_out = ps;
+    return (int)o.size();
 }
 void hobbit_host_close(void) { hobbit_host_shutdown(); }
 }

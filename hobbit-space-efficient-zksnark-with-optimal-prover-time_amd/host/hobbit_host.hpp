@@ -146,6 +146,47 @@ void phiGInit(vector<F> &phi_g, const vector<F>::const_iterator &rx, const F &sc
 vector<F> prepare_matrix(vector<vector<F>> M, vector<F> r);
 vector<vector<F>> transpose(vector<vector<F>> M);
 
+/* src/sumcheck.h:8-20 */
+struct mul_tree_proof {
+    F initial_randomness;
+    size_t size = 0;
+    F in1, in2;
+    F out_eval;
+    vector<struct proof> proofs;
+    vector<F> output;
+    vector<F> final_r;
+    vector<F> global_randomness, individual_randomness;
+    vector<F> partial_eval;
+    F final_eval;
+};
+/* src/sumcheck.h:92, src/sumcheck.cpp:275 (defined there without a header declaration) */
+mul_tree_proof prove_multiplication_tree_new(vector<vector<F>> &input, F previous_r, vector<F> prev_x, double &vt, double &ps);
+struct proof batch_3product_sumcheck(vector<vector<F>> &arr1, vector<vector<F>> &arr2, vector<vector<F>> &arr3, vector<F> a, double &vt, double &ps);
+/* src/PC_utils.h:9 : tensor = 2*tensor_row_size row pointers of 2*size/tensor_row_size F each */
+void _compute_tensorcode(F *message, F **tensor, int size);
+/* src/Virgo.h:27-47, 95 ; src/Virgo.cpp:120, 435.  The encoded matrix and the column tree stay on the device (d_*); matrix /
+ * encoded_matrix are materialised on the host as the reference has them (k rows). */
+struct shockwave_data {
+    int k = 0;
+    int N = 0;
+    F **encoded_matrix = nullptr, **matrix = nullptr;
+    vector<vector<_hash>> MT;
+    void *d_matrix = nullptr, *d_enc = nullptr, *d_levels = nullptr;      /* not in the reference: device residents of the same data */
+    ~shockwave_data();
+};
+shockwave_data *shockwave_commit(vector<F> &poly, int k);
+void shockwave_prove(shockwave_data *data, vector<F> x, double &vt, double &ps);
+struct hobbit_host_shockwave_transcript;
+hobbit_host_shockwave_transcript &hobbit_host_last_shockwave();           /* the messages of the last shockwave_prove (the reference returns none) */
+/* src/PC_utils.cpp:6-7 ; src/linear_code_encode.cpp:3-4 ; src/sumcheck.cpp:27,29 : globals of the reference ABI.  C_f / C_c are set by
+ * this mirror's shockwave users as the reference's _aggregate / aggregate do; scratch / __encode_initialized exist for source
+ * compatibility only (the device encode has no host scratch); routine_time accumulates the time spent re-generating streams, sc_vt is
+ * never written on the prover side. */
+extern shockwave_data *C_f, *C_c;
+extern F *scratch[2][100];
+extern bool __encode_initialized;
+extern double routine_time, sc_vt;
+
 /* src/witness_stream.h:5-16 (the fields the PCS reads), src/Elastic_PC.hpp:12-16 */
 struct stream_descriptor {
     int idx = 0, offset = 0, stage = 0;
@@ -171,6 +212,10 @@ struct hobbit_host_elastic_transcript {
 };
 hobbit_host_elastic_transcript &hobbit_host_last_elastic_open();
 void test_Elastic_PC_commit(size_t N, int option);              /* commit phase of test_Elastic_PC (src/Elastic_PC.cpp:736-771) */
+/* src/sumcheck.h:84, src/sumcheck.cpp:1150 : the streaming multiplication-tree prover over read_stream (default stream only) */
+vector<F> prove_multiplication_tree_stream_shallow(stream_descriptor fd, int vectors, int size, F previous_r, int distance, vector<F> prev_x, bool naive, double &vt, double &ps);
+void generate_3product_sumcheck_beta_stream_batch_optimized(stream_descriptor fd, vector<vector<F>> r, int batches, int distance, int layer_id, vector<F> old_claims,
+                                                            vector<F> &new_claims, vector<vector<F>> &new_r, double &vt, double &ps);
 
 /* Not in the reference: the 16 GiB `_tensor` of a 2^28 commit stays on the device.
  * commit_standard leaves `_tensor[i]` empty unless HOBBIT_MATERIALIZE_TENSOR=1 (or the tensor is

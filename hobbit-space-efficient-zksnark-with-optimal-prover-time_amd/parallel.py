@@ -223,8 +223,9 @@ class HipOps:
         import torch
         ptr, n_own = local_chunks
         hb = self.hb
-        if li == 0:
-            self._tensor = hb.alloc(16 * 4 * plan.M * n_own)   # retained: the commitment's tensor shard
+        if li == 0 and (getattr(self, "_tensor", None) is None or self._tensor.ptr is None or self._tensor.nbytes != 16 * 4 * plan.M * n_own):
+            self._tensor = hb.alloc(16 * 4 * plan.M * n_own)   # retained: the commitment's tensor shard (re-used by the next commit of the same shape:
+                                                               # allocating and freeing 16 GiB / G per commit stalls the device queue for seconds now and then)
         t = self._tensor.ptr + 16 * 4 * plan.M * li
         hb._chk(hb.lib.hobbit_tensorcode_chunks(hb.ctx, ptr + 16 * plan.M * li, plan.M, 1, plan.trs, 1, t))
         out = torch.empty((plan.M, 32), dtype=torch.uint8, device=self.device)

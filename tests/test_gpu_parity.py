@@ -1185,3 +1185,45 @@ def test_sharded_elastic_commit_hip_ops_world1(hb, oracle, opt):
     levels = mod.parallel.assemble_levels(plan, [res["subtree"].cpu().numpy()], res["top"])
     T = 4 * B
     assert np.array_equal(levels[:T - 1], want[:T - 1]) and np.array_equal(levels[T:], want[T:cnt])
+
+
+def test_host_mirror_remaining_wrappers(oracle):
+    """The reference-named C++ entry points SURVEY.md 8(b) lists beyond the drivers -- prove_multiplication_tree_new, batch_3product_sumcheck,
+    _compute_tensorcode(F*, F**, int), shockwave_commit / shockwave_prove with the globals C_f / C_c, and the streaming
+    prove_multiplication_tree_stream_shallow over read_stream -- each called once through libhobbit_host.so and compared with the oracle."""
+    import ctypes
+    from __graft_entry__ import PKG, build_host
+    build_host()
+    lib = ctypes.CDLL(os.path.join(PKG, "libhobbit_host.so"))
+    libc = ctypes.CDLL(None)
+    P_ = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    tree = splitmix_field(256, 1201); b3 = splitmix_field(960, 1202); b3a = splitmix_field(2, 1203)
+    out = np.zeros((64, 2), np.uint64); roots = np.zeros((2, 32), np.uint8); ps = ctypes.c_double()
+    lib.hobbit_host_mirror_check.argtypes = [ctypes.c_void_p] * 6
+    n = lib.hobbit_host_mirror_check(P_(tree), P_(b3), P_(b3a), P_(out), P_(roots), ctypes.byref(ps))
+    want = []
+    libc.srandom(77); mt = oracle.mul_tree(tree.reshape(4, 64, 2), np.array([17, 5], np.uint64), None)
+    want += [mt["out_eval"], mt["final_eval"]] + [oracle.field_prod(tree.reshape(4, 64, 2)[j]) for j in range(4)] + [mt["final_r"][0], mt["final_r"][7], np.array([int(mt["layers"][0]), 0], np.uint64)]
+    lens = [256, 64]
+    t = [np.concatenate([b3[320 * k:320 * k + 256], b3[320 * k + 256:320 * k + 320]]) for k in range(3)]
+    bs = oracle.batch_3product_sumcheck(t[0], t[1], t[2], lens, b3a)
+    want += [bs["poly"][0][0], bs["poly"][-1][3], bs["r"][-1]] + list(bs["vr"].reshape(-1, 2))
+    tc = oracle.compute_tensorcode(tree, 4, 0)
+    want += [tc[0][0], tc[7][127], tc[3][64]]
+    big = np.concatenate([oracle.f_mul(tree, np.tile(np.array([[i + 1, 0]], np.uint64), (256, 1))) for i in range(32)])
+    enc, lv = oracle.shockwave_commit(big, 32)
+    want += [enc[31][511], big[5 * 256 + 7]]
+    _, lv8 = oracle.shockwave_commit(tree, 8)
+    x = np.concatenate([b3a, b3[2:13]])
+    libc.srandom(78); sp = oracle.shockwave_prove(big, enc, 32, x, lv)
+    want += [sp["q1"][0][0], sp["fin1"], sp["fin2"], np.array([int(sp["iters"][0]), 0], np.uint64), np.array([int(sp["wchecks"][0]) + 2 * int(sp["wchecks"][1]), 0], np.uint64)]
+    want = np.stack([np.asarray(w, np.uint64).reshape(2) for w in want])
+    assert n == want.shape[0]
+    assert np.array_equal(out[:n], want), np.nonzero((out[:n] != want).any(axis=1))
+    assert np.array_equal(roots[0], lv[-1]) and np.array_equal(roots[1], lv8[-1])
+    # streaming multiplication tree through the mirror on the default stream: config 4's shape scaled down; output vs the REAL reference
+    o2 = np.zeros((8, 2), np.uint64); px = splitmix_field(3, 9)
+    lib.hobbit_host_mul_tree_stream.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    m = lib.hobbit_host_mul_tree_stream(1 << 10, 8, 1 << 12, 5, P_(px), 3, P_(o2), ctypes.byref(ps))
+    lib.hobbit_host_close()
+    assert m == 8 and np.array_equal(o2, gold("streamdrv")["shallow_out"]) and ps.value > 0
