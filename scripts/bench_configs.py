@@ -1,8 +1,12 @@
 """Timings of the other BASELINE.json configs on one MI355X (the north-star line is bench.py):
   C2  2-product sumcheck over 2^24 elements           (scripts/bench_sumcheck.py has the per-kernel view)
   C3  Our_PC commit of 2^26 coefficients (K = 32)
+  C4  the MLP prover's math phases at MLP_test.sh's shape (B = 2^18, circuit 2^20: src/main.cpp:862-887) on synthetic resident streams:
+      Elastic commit of the 4 * 2^20 witness (RS x RS), prove_multiplication_tree_stream_shallow(8 vectors x 2^20, distance 5),
+      prove_gate_consistency over 2^20 gates, Elastic open.  The witness generator (Seval + witness_stream.cpp) is out of scope: what is
+      timed is everything the prover computes once a chunk is in HBM (the reference spends 2.4-2.8 s of its 14 s there).
   C5  Elastic_PC streaming commit of 2^30 coefficients, B = 2^20, opt 1 and 2, on ONE GPU (chunks generated on the device side once:
-      the reference's default stream repeats the same chunk, src/witness_stream.cpp:2405-2411)
+      the reference's default stream repeats the same chunk, src/witness_stream.cpp:2405-2411), and the option-1 open (N = 2^26 too)
 Prints one JSON object."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -34,11 +38,53 @@ def c3():
 out["C3_commit_2e26_ms"] = 1e3 * timed(c3, reps=5)
 del d
 
+# C4: math phases of the MLP prover (reference on one Xeon core: commit 5.08 s, mul-tree 5.53 s, gate 0.80 s, open 2.84 s)
+import ctypes
+B4 = 1 << 18; circ = 1 << 20
+chunk_w = hb.to_device(hb.read_stream_PC(B4))
+out["C4_commit_witness_4x2e20_s"] = timed(lambda: hb.elastic_commit(4 * circ, B4, 1, chunk=chunk_w), reps=3)
+lv_host, lv_dev = hb.elastic_commit(4 * circ, B4, 1, chunk=chunk_w, keep_levels=True)
+src4 = hb.chunk_source(0)
+pr32 = np.array([32, 0], np.uint64); px3 = splitmix_field(3, 9)
+def c4_mul():
+    r = hb.mul_tree_stream_shallow(src4, 8 * circ, B4, 8, circ, pr32, 5, px3, naive=False)
+    assert all(st["checks"].tolist() == [1, 1, 1] for st in r["steps"]) and len(r["steps"]) == 4
+out["C4_mul_tree_stream_8x2e20_s"] = timed(c4_mul, reps=3)
+g = np.random.default_rng(1); z = np.zeros(circ, np.uint64)
+sel = g.integers(0, 2, circ).astype(np.uint64); Lr = g.integers(0, 1 << 30, circ).astype(np.uint64); Rr = g.integers(0, 1 << 30, circ).astype(np.uint64)
+P61 = np.uint64((1 << 61) - 1)
+O = np.stack([np.where(sel == 1, Lr + Rr, (Lr * Rr) % P61), z], 1)
+tsrc = hb.trace_source(np.stack([Lr, z], 1), np.stack([Rr, z], 1), O, sel.astype(np.int32), B4)
+rg = splitmix_field(20, 3)
+def c4_gate():
+    r = hb.gate_consistency_stream(tsrc, circ // B4, B4, rg)
+    assert r["checks"].tolist() == [1, 1, 1]
+out["C4_gate_consistency_2e20_s"] = timed(c4_gate, reps=3)
+chunk_r = hb.to_device(hb.read_stream(B4)); x4 = splitmix_field(22, 4)
+def c4_open():
+    r = hb.elastic_open(4 * circ, B4, x4, 700, commit_levels=lv_dev, chunk=chunk_r)
+    assert r["checks"].tolist() == [1, 1]
+out["C4_open_witness_s"] = timed(c4_open, reps=3)
+out["C4_math_phases_total_s"] = sum(out[k] for k in ("C4_commit_witness_4x2e20_s", "C4_mul_tree_stream_8x2e20_s", "C4_gate_consistency_2e20_s", "C4_open_witness_s"))
+out["C4_reference_one_core_s"] = {"commit": 5.08, "mul_tree": 5.53, "gate": 0.80, "open": 2.84, "note": "SURVEY.md 6; includes 2.4-2.8 s of stream generation"}
+del chunk_w, lv_dev, chunk_r
+
 # C5 (one GPU)
 chunk = hb.to_device(hb.read_stream_PC(1 << 20))          # the host-side stream generator is not part of the path
 for opt in (1, 2):
     hb.rng_reset()
     t = timed(lambda: hb.elastic_commit(1 << 30, 1 << 20, opt, chunk=chunk), reps=2, warm=1)
     out["C5_elastic_commit_2e30_B2e20_opt%d_s" % opt] = t
+# C5 open (option 1): N = 2^26 and 2^30 with B = 2^20 (1024 chunks x 2 passes at 2^30)
+chunk_r = hb.to_device(hb.read_stream(1 << 20))
+for logN in (26, 30):
+    N5 = 1 << logN
+    lvh, lvd = hb.elastic_commit(N5, 1 << 20, 1, chunk=chunk, keep_levels=True)
+    x5 = splitmix_field(logN, 6)
+    def c5_open():
+        r = hb.elastic_open(N5, 1 << 20, x5, 700, commit_levels=lvd, chunk=chunk_r)
+        assert r["checks"].tolist() == [1, 1]
+    out["C5_elastic_open_2e%d_B2e20_opt1_s" % logN] = timed(c5_open, reps=2, warm=1)
+    del lvd
 print(json.dumps(out))
 hb.close()
