@@ -695,13 +695,20 @@ def test_open_standard_vs_oracle(hb, oracle, N, K):
     oracle.rng_reset(); poly = oracle.generate_randomness(N); oracle.expander_init_store(trs)
     x = oracle.generate_randomness(N.bit_length() - 1)
     queries = 5900
-    libc.srandom(777); want = oracle.open_standard(poly, K, trs, x, queries)
+    small = N <= (1 << 20)                                      # replies and paths too where the oracle's commit takes a second or two
+    lv, T = oracle.commit_standard(poly, K, trs, 1, want_tensor=True) if small else (None, None)
+    libc.srandom(777); want = oracle.open_standard(poly, K, trs, x, queries, tensor=T)
     hb.upload_graphs(trs, graphs_from(oracle, trs))
     c = hb.commit_standard(poly, K, trs, 1)
-    libc.srandom(777); got = hb.open_standard(poly, c, x, queries, want_paths=False)
+    libc.srandom(777); got = hb.open_standard(poly, c, x, queries, want_paths=small)
     assert want["checks"].tolist() == [1, 1, 1] and got["checks"].tolist() == [1, 1, 1]
     for k in ("I", "scalars", "poly", "r", "vr", "fin", "roots"):
         assert np.array_equal(got[k], want[k]), k
+    if small:
+        assert np.array_equal(got["reply"], want["reply"])
+        M = N // K
+        for q in range(0, queries, 97):
+            assert np.array_equal(got["paths"][q], oracle.open_tree_blake(lv, M, int(got["I"][q, 0]), int(got["I"][q, 1]), 4096)), q
     for sp in ("sp_c", "sp_f"):
         has_whir = int(want[sp]["iters"][0]) > 0                 # none for a width of 256 (C_f at 2^18): src/Virgo.cpp:479-483
         assert want[sp]["wchecks"].tolist() == ([1, 1] if has_whir else [0, 0]), sp
