@@ -472,6 +472,7 @@ void init_commitment(bool mod) {                                    // src/Elast
     tensor_row_size = (int)(BUFFER_SPACE / (1ULL << 11));
     if (tensor_row_size == 0) tensor_row_size = 16;
 }
+static int pc_layer_chunk(stream_descriptor &raw, int layer, size_t B, void *d_out);
 void commit(stream_descriptor fd, _hash &comm, vector<vector<_hash>> &MT_hashes) {   // src/Elastic_PC.cpp:174-285
     (void)comm;
     if (fd.size / BUFFER_SPACE < 4) printf("Decrease buffer size %d\n", (int)(fd.size / BUFFER_SPACE));
@@ -480,8 +481,15 @@ void commit(stream_descriptor fd, _hash &comm, vector<vector<_hash>> &MT_hashes)
     vector<F> buff(BUFFER_SPACE);
     DevBuf d(BUFFER_SPACE * sizeof(F));
     for (size_t i = 0; i < fd.size / BUFFER_SPACE; i++) {
-        read_stream_PC(fd, buff.data(), (int)BUFFER_SPACE);
-        HCHK(hobbit_memcpy_h2d(g_ctx, d.p, buff.data(), BUFFER_SPACE * sizeof(F)));
+        if (fd.name == "PC_layer") {
+            // read_stream_PC's PC_layer branch (src/witness_stream.cpp:2357-2364): read_mul_tree_layer on the descriptor itself, whose
+            // name read_stream does not know -> the product layer fd.layer of the DEFAULT stream; the products are taken on the device
+            stream_descriptor raw = fd; raw.name = "test";
+            if (pc_layer_chunk(raw, (int)fd.layer, BUFFER_SPACE, d.p) != 0) { printf("Error: PC_layer chunk\n"); exit(-1); }
+        } else {
+            read_stream_PC(fd, buff.data(), (int)BUFFER_SPACE);
+            HCHK(hobbit_memcpy_h2d(g_ctx, d.p, buff.data(), BUFFER_SPACE * sizeof(F)));
+        }
         HCHK(hobbit_elastic_push(g_ctx, e, (const hobbit_F *)d.p));
     }
     size_t T = 4 * BUFFER_SPACE;
@@ -702,6 +710,33 @@ static int host_stream_source(void *user, size_t n, const hobbit_F **out) {
     *out = (const hobbit_F *)hs->dev->p;
     return 0;
 }
+static int pc_layer_chunk(stream_descriptor &raw, int layer, size_t B, void *d_out) {
+    HostStream hs; hs.fd = raw;
+    int rc = hobbit_read_mul_tree_layer(hobbit_host_ctx(), host_stream_source, &hs, B, layer, (hobbit_F *)d_out);
+    if (rc == 0) rc = hobbit_sync(g_ctx);               // the source's upload buffer dies with hs
+    delete hs.dev;
+    return rc;
+}
+// src/sumcheck.cpp:983-1003
+void commit_layers(stream_descriptor fd, vector<stream_descriptor> &fd_com, vector<vector<vector<_hash>>> &MT_hashes, int batches, int layer_id, int distance) {
+    printf("%lld,%d\n", (long long)fd.size, (int)(1ULL << layer_id));
+    const size_t size = fd.size / (1ULL << layer_id);
+    if (batches - 1 <= 0) return;
+    fd_com.resize(batches - 1); MT_hashes.resize(batches - 1);
+    for (int i = 0; i < batches - 1; i++) {
+        fd_com[i] = stream_descriptor(); fd_com[i].name = "PC_layer"; fd_com[i].size = size / (1ULL << (distance * i)); fd_com[i].layer = layer_id + i * distance;
+        _hash comm;
+        init_commitment(false);
+        printf("Committing to: %d\n", (int)fd_com[i].size);
+        if (fd_com[i].size > BUFFER_SPACE) commit(fd_com[i], comm, MT_hashes[i]);
+    }
+}
+// src/sumcheck.cpp:1005-1011.  Elastic_PC::open reads its two passes through read_stream, which serves a "PC_layer" descriptor from its
+// default branch -- the raw default stream, not the product layer the commitment was computed over (the reference as it is).
+void open_layers(vector<stream_descriptor> &fd_com, vector<vector<vector<_hash>>> &MT_hashes, double &vt, double &ps) {
+    for (size_t i = 0; i < fd_com.size(); i++)
+        if (fd_com[i].size > BUFFER_SPACE) open(fd_com[i], generate_randomness((int)log2((double)fd_com[i].size)), MT_hashes[i], vt, ps);
+}
 struct S3Buffers {   // host buffers behind one hobbit_stream3_out
     vector<F> nc, nr, c1, r1, vr1, q2, r2, vr2, fin2, R; int checks[3] = {0, 0, 0}; hobbit_stream3_out o;
     S3Buffers(size_t fd_size, size_t B, int batches, int layer_id) {
@@ -738,11 +773,8 @@ vector<F> prove_multiplication_tree_stream_shallow(stream_descriptor fd, int vec
     const size_t total = (size_t)size * vectors, B = BUFFER_SPACE;
     int layers = total > 2 * B ? (int)log2((double)(total / (2 * B))) : 0;
     if (layers % distance != 0 && layers > distance) layers = distance + layers - (layers % distance);
-    if (total > 2 * B && !naive && layers > distance && layers / distance - 1 > 0) {
-        // commit_layers / open_layers (src/sumcheck.cpp:983-1011) commit to and open "PC_layer" streams with Elastic_PC; that wiring is not built
-        printf("Error: prove_multiplication_tree_stream_shallow with committed layers (layers %d > distance %d, naive == false) is not built; call it with naive = true\n", layers, distance);
-        exit(-1);
-    }
+    vector<stream_descriptor> fd_com; vector<vector<vector<_hash>>> MT_layers;
+    if (total > 2 * B && !naive) commit_layers(fd, fd_com, MT_layers, layers / distance, distance - 1, distance);        // (:1791-1795)
     HostStream hs; hs.fd = fd;
     const size_t n1 = total > 2 * B ? fd.size >> layers : total; const size_t sz = n1 / vectors;
     const int lt = (int)log2((double)n1), depth = (int)log2((double)sz); size_t nr = 0; for (int i = 0; i < lt; i++) nr += (size_t)i;
@@ -767,7 +799,7 @@ vector<F> prove_multiplication_tree_stream_shallow(stream_descriptor fd, int vec
         s3_check(*bufs[i], ps, batches, logB, (int)bufs[i]->r2.size());
     }
     for (auto *b : bufs) delete b;
-    (void)vt;
+    if (total > 2 * B && !naive) open_layers(fd_com, MT_layers, vt, ps);                                                      // (:1910-1912)
     return out;
 }
 
@@ -907,13 +939,22 @@ int hobbit_host_mirror_check(const uint64_t *tree_in /* 4 x 64 F */, const uint6
     return n;
 }
 // prove_multiplication_tree_stream_shallow through the mirror on the default stream (returns the number of products)
-int hobbit_host_mul_tree_stream(size_t B, int vectors, size_t size, int distance, const uint64_t *prev_x, int nx, uint64_t *out, double *ps_out) {
+// commit_layers through the mirror: roots of the layer commitments (zero where a layer fits one buffer)
+int hobbit_host_commit_layers(size_t fd_size, size_t B, int batches, int layer_id, int distance, uint8_t *roots) {
+    BUFFER_SPACE = B;
+    stream_descriptor fd; fd.name = "test"; fd.size = fd_size;
+    vector<stream_descriptor> fc; vector<vector<vector<_hash>>> MT;
+    commit_layers(fd, fc, MT, batches, layer_id, distance);
+    for (size_t i = 0; i < fc.size(); i++) { if (!MT[i].empty()) memcpy(roots + 32 * i, MT[i].back()[0].arr, 32); else memset(roots + 32 * i, 0, 32); }
+    return (int)fc.size();
+}
+int hobbit_host_mul_tree_stream(size_t B, int vectors, size_t size, int distance, const uint64_t *prev_x, int nx, uint64_t *out, double *ps_out, int naive) {
     BUFFER_SPACE = B;
     stream_descriptor fd; fd.name = "test"; fd.size = size * (size_t)vectors;
     double vt = 0, ps = 0;
     vector<F> px((const F *)prev_x, (const F *)prev_x + nx);
     srandom(11);
-    vector<F> o = prove_multiplication_tree_stream_shallow(fd, vectors, (int)size, F(32), distance, px, true, vt, ps);
+    vector<F> o = prove_multiplication_tree_stream_shallow(fd, vectors, (int)size, F(32), distance, px, naive != 0, vt, ps);
     memcpy(out, o.data(), o.size() * sizeof(F)); *ps_out = ps;
     return (int)o.size();
 }

@@ -214,6 +214,9 @@ hobbit_host_elastic_transcript &hobbit_host_last_elastic_open();
 void test_Elastic_PC_commit(size_t N, int option);              /* commit phase of test_Elastic_PC (src/Elastic_PC.cpp:736-771) */
 /* src/sumcheck.h:84, src/sumcheck.cpp:1150 : the streaming multiplication-tree prover over read_stream (default stream only) */
 vector<F> prove_multiplication_tree_stream_shallow(stream_descriptor fd, int vectors, int size, F previous_r, int distance, vector<F> prev_x, bool naive, double &vt, double &ps);
+/* src/sumcheck.cpp:983-1011: Elastic_PC commitments to / openings of the "PC_layer" streams of the batched path */
+void commit_layers(stream_descriptor fd, vector<stream_descriptor> &fd_com, vector<vector<vector<_hash>>> &MT_hashes, int batches, int layer_id, int distance);
+void open_layers(vector<stream_descriptor> &fd_com, vector<vector<vector<_hash>>> &MT_hashes, double &vt, double &ps);
 void generate_3product_sumcheck_beta_stream_batch_optimized(stream_descriptor fd, vector<vector<F>> r, int batches, int distance, int layer_id, vector<F> old_claims,
                                                             vector<F> &new_claims, vector<vector<F>> &new_r, double &vt, double &ps);
 

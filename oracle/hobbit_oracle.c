@@ -1577,6 +1577,29 @@ void orc_gate_consistency_stream(const oF *L, const oF *Rt, const oF *O, const i
     free(beta); free(fb); free(fL); free(fR); free(fO); free(fa); free(fm); free(b1); free(pe);
 }
 
+/* Elastic_PC commit (RS x RS) of a "PC_layer" stream (commit_layers, src/sumcheck.cpp:983-1003): read_stream_PC's PC_layer branch
+ * (src/witness_stream.cpp:2357-2364) hands read_mul_tree_layer the descriptor itself, whose name no branch of read_stream knows -- so
+ * every chunk is the product layer `layer` of the DEFAULT stream (not of the stream the tree is about: the reference as it is). */
+size_t orc_elastic_commit_pc_layer(size_t N, size_t B, int layer, uint8_t *levels_out) {
+    const int trs = (int)(B >> 11);
+    size_t T = 4 * B;
+    oF *buff = (oF *)malloc(sizeof(oF) * B), *tensor = (oF *)malloc(sizeof(oF) * T);
+    oF *ci[3]; for (int i = 0; i < 3; i++) ci[i] = (oF *)malloc(sizeof(oF) * T);
+    memset(levels_out, 0, 32 * T);
+    for (size_t i = 0; i < N / B; i++) {
+        stream_reset(); read_mul_tree_layer(buff, B, layer);
+        orc_compute_tensorcode(buff, B, trs, 0, tensor);
+        if (i % 4 != 3) memcpy(ci[i % 4], tensor, sizeof(oF) * T);
+        else for (size_t p = 0; p < T; p++) {
+            oF z = fint(0);
+            oF xx[4] = {p + 1 < T ? ci[0][p + 1] : z, p + 1 < T ? ci[1][p + 1] : z, ci[2][p], tensor[p]};
+            hash_md(xx, levels_out + 32 * p, levels_out + 32 * p);
+        }
+    }
+    free(buff); free(tensor); for (int i = 0; i < 3; i++) free(ci[i]);
+    return create_tree(levels_out, T);
+}
+
 /* Multi-GPU streaming commit (test infra for tests/test_dist_gloo.py): the inner digests H(c0[p+1], c1[p+1], c2[p], t3[p]) of ONE group of
  * 4 consecutive chunks, 4B x 32 B in leaf order, exactly what orc_elastic_commit chains -- chunk c of the stream under the stream model
  * (kind 0: every chunk is read_stream_PC's default; kind 1: chunk c = splitmix_field(B, seed + c)). */

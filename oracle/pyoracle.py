@@ -529,6 +529,22 @@ class Oracle(_Base):
 
 
 
+    def commit_layers(self, fd_size, B, batches, layer_id, distance):
+        """commit_layers (src/sumcheck.cpp:983-1003): roots of the Elastic commitments to the PC_layer streams; returns (sizes, layers, roots)"""
+        size = fd_size >> layer_id
+        sizes, layers, roots = [], [], []
+        for i in range(max(batches - 1, 0)):
+            sz = size >> (distance * i); ly = layer_id + i * distance
+            sizes.append(sz); layers.append(ly)
+            if sz > B:
+                lv = np.zeros((8 * B, 32), np.uint8)
+                f = self.lib.orc_elastic_commit_pc_layer; f.restype = c_sz
+                cnt = f(c_sz(sz), c_sz(B), ctypes.c_int(ly), _p(lv))
+                roots.append(lv[cnt - 1].copy())
+            else:
+                roots.append(np.zeros(32, np.uint8))
+        return np.array(sizes, np.uint64), np.array(layers, np.uint64), np.stack(roots) if roots else np.zeros((0, 32), np.uint8)
+
     def generate_claims_opt(self, fd_size, B, r, batches, layer_id, distance):
         r = F(r).reshape(-1, 2); c = np.zeros((batches, 2), np.uint64)
         self.lib.orc_generate_claims_opt(c_sz(fd_size), c_sz(B), _p(r), ctypes.c_int(batches), ctypes.c_int(layer_id), ctypes.c_int(distance), _p(c))
@@ -812,6 +828,12 @@ class Ref(_Base):
         r = F(r).reshape(-1, 2); c = np.zeros((batches, 2), np.uint64)
         self.lib.ref_generate_claims_opt(c_sz(fd_size), c_sz(B), _p(r), ctypes.c_int(r.shape[0]), ctypes.c_int(batches), ctypes.c_int(layer_id), ctypes.c_int(distance), _p(c))
         return c
+
+    def commit_layers(self, fd_size, B, batches, layer_id, distance):
+        n = max(batches - 1, 0)
+        roots = np.zeros((n, 32), np.uint8); sizes = np.zeros(n, np.uint64); layers = np.zeros(n, np.uint64)
+        self.lib.ref_commit_layers(c_sz(fd_size), c_sz(B), ctypes.c_int(batches), ctypes.c_int(layer_id), ctypes.c_int(distance), _p(roots), _p(sizes), _p(layers))
+        return sizes, layers, roots
 
     def sumcheck3_stream_batch(self, fd_size, B, r, batches, distance, layer_id, old_claims, full=False):
         r = F(r); rlen = r.shape[1]; oc = F(old_claims).reshape(-1, 2)

@@ -54,6 +54,8 @@ void generate_3product_sumcheck_beta_stream_batch_optimized(stream_descriptor fd
                                                             vector<F> &new_claims, vector<vector<F>> &new_r, double &vt, double &ps);      // src/sumcheck.cpp:1150
 void generate_claims_opt(stream_descriptor fd, vector<F> r, vector<F> &claims, int batches, int layer_id, int distance);                      // src/sumcheck.cpp:1014
 
+void commit_layers(stream_descriptor fd, vector<stream_descriptor> &fd_com, vector<vector<vector<_hash>>> &MT_hashes, int batches, int layer_id, int distance);   // src/sumcheck.cpp:983
+
 static_assert(sizeof(F) == 16, "fieldElement must be 16 bytes");
 static_assert(sizeof(_hash) == 32, "_hash must be 32 bytes");
 
@@ -489,6 +491,20 @@ int ref_mul_tree_stream_shallow(size_t fd_size, size_t B, int vectors, size_t si
     vector<F> o = prove_multiplication_tree_stream_shallow(fd, vectors, (int)size, ldF(previous_r), distance, vecF(prev_x, nx), true, vt, ps);
     memcpy(out, o.data(), 16 * o.size());
     return (int)o.size();
+}
+
+// commit_layers (src/sumcheck.cpp:983-1003): Elastic_PC commitments (RS x RS) to the "PC_layer" streams of the batched multiplication-tree
+// prover; roots_out: (batches - 1) x 32 B (zero where the reference skips a layer that fits one buffer), sizes_out / layers_out likewise
+int ref_commit_layers(size_t fd_size, size_t B, int batches, int layer_id, int distance, uint8_t *roots_out, uint64_t *sizes_out, uint64_t *layers_out) {
+    BUFFER_SPACE = B;
+    stream_descriptor fd; fd.name = "test"; fd.size = fd_size; fd.pos = 0;
+    vector<stream_descriptor> fc; vector<vector<vector<_hash>>> MT;
+    commit_layers(fd, fc, MT, batches, layer_id, distance);
+    for (size_t i = 0; i < fc.size(); i++) {
+        sizes_out[i] = fc[i].size; layers_out[i] = fc[i].layer;
+        if (!MT[i].empty()) memcpy(roots_out + 32 * i, MT[i].back()[0].arr, 32); else memset(roots_out + 32 * i, 0, 32);
+    }
+    return (int)fc.size();
 }
 
 // whole-driver timing hook for bench.py's cpu_baseline ("reference" kind): commit only.

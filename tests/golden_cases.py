@@ -313,6 +313,9 @@ def case_streamdrv(lib):
         for i, row in enumerate(res["new_r"]):
             out[key + "r%d" % i] = row
     out["claims_opt"] = lib.generate_claims_opt(1 << 16, 1 << 10, splitmix_field(16, 70), 2, 1, 2)
+    # commit_layers (src/sumcheck.cpp:983-1003) of the batched path: vectors*size = 2^20, B = 2^13, distance 2 -> layers 6, batches 3
+    sz, ly, roots = lib.commit_layers(1 << 20, 1 << 13, 3, 1, 2)
+    out["cl_sizes"] = sz; out["cl_layers"] = ly; out["cl_roots"] = roots
     libc.srandom(11)
     o = lib.mul_tree_stream_shallow(1 << 15, 1 << 10, 8, 1 << 12, np.array([32, 0], np.uint64), 5, splitmix_field(3, 9))
     out["shallow_out"] = o["output"] if isinstance(o, dict) else o

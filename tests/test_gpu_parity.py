@@ -1230,7 +1230,19 @@ def test_host_mirror_remaining_wrappers(oracle):
     assert np.array_equal(roots[0], lv[-1]) and np.array_equal(roots[1], lv8[-1])
     # streaming multiplication tree through the mirror on the default stream: config 4's shape scaled down; output vs the REAL reference
     o2 = np.zeros((8, 2), np.uint64); px = splitmix_field(3, 9)
-    lib.hobbit_host_mul_tree_stream.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
-    m = lib.hobbit_host_mul_tree_stream(1 << 10, 8, 1 << 12, 5, P_(px), 3, P_(o2), ctypes.byref(ps))
-    lib.hobbit_host_close()
+    lib.hobbit_host_mul_tree_stream.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    m = lib.hobbit_host_mul_tree_stream(1 << 10, 8, 1 << 12, 5, P_(px), 3, P_(o2), ctypes.byref(ps), 1)
     assert m == 8 and np.array_equal(o2, gold("streamdrv")["shallow_out"]) and ps.value > 0
+    # commit_layers (src/sumcheck.cpp:983-1003): Elastic commitments to the PC_layer streams, roots against the REAL reference
+    g = gold("streamdrv"); roots = np.zeros((2, 32), np.uint8)
+    lib.hobbit_host_commit_layers.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    assert lib.hobbit_host_commit_layers(1 << 20, 1 << 13, 3, 1, 2, P_(roots)) == 2
+    assert np.array_equal(roots, g["cl_roots"])
+    # the batched path end to end through the mirror (layers 6 > distance 2, naive = false): commit_layers, the in-memory tree,
+    # generate_claims_opt, two batched streaming sumchecks, open_layers (two Elastic opens); every exit(-1) check of the way holds
+    # (the mirror would exit), the products equal the oracle's
+    o3 = np.zeros((8, 2), np.uint64)
+    m = lib.hobbit_host_mul_tree_stream(1 << 13, 8, 1 << 17, 2, P_(px), 3, P_(o3), ctypes.byref(ps), 0)
+    lib.hobbit_host_close()
+    libc.srandom(11); want3 = oracle.mul_tree_stream_shallow(1 << 20, 1 << 13, 8, 1 << 17, np.array([32, 0], np.uint64), 2, px, naive=False)
+    assert m == 8 and np.array_equal(o3, want3["output"]) and all(st["checks"].tolist() == [1, 1, 1] for st in want3["steps"])
