@@ -492,8 +492,15 @@ int hobbit_commit_standard(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, in
     if (ctx->spare_tensor && ctx->spare_tensor_bytes == tbytes && ctx->spare_levels_bytes == 64 * M) {
         c->d_tensor = (F *)ctx->spare_tensor; c->d_levels = (uint8_t *)ctx->spare_levels;
         ctx->spare_tensor = nullptr; ctx->spare_levels = nullptr;
-    } else if (hipMalloc((void **)&c->d_tensor, tbytes) != hipSuccess || hipMalloc((void **)&c->d_levels, 64 * M) != hipSuccess) {
-        hobbit_commitment_free(c); return ctx->fail(HOBBIT_ENOMEM, "commit_standard: tensor allocation failed");
+    } else {
+        if (ctx->spare_tensor) {          // a parked commitment of another shape: release it BEFORE allocating (it can be 16.5 GiB)
+            HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            hipFree(ctx->spare_tensor); hipFree(ctx->spare_levels);
+            ctx->spare_tensor = nullptr; ctx->spare_levels = nullptr; ctx->spare_tensor_bytes = ctx->spare_levels_bytes = 0;
+        }
+        if (hipMalloc((void **)&c->d_tensor, tbytes) != hipSuccess || hipMalloc((void **)&c->d_levels, 64 * M) != hipSuccess) {
+            hobbit_commitment_free(c); return ctx->fail(HOBBIT_ENOMEM, "commit_standard: tensor allocation failed");
+        }
     }
     uint8_t *dig = nullptr;
     int r = tensorcode_chunks(ctx, cF(d_poly), M, K, trs, linear_time, c->d_tensor, &dig);
@@ -584,7 +591,7 @@ int hobbit_elastic_begin(hobbit_ctx *ctx, size_t B, int trs, int linear_time, in
     for (int i = 0; i < 4 && ok; i++) ok = hipMalloc((void **)&e->t[i], 4 * B * sizeof(F)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->state, 4 * B * 32) == hipSuccess;
     if (!ok) { hobbit_elastic_free(e); return ctx->fail(HOBBIT_ENOMEM, "elastic_begin: allocation failed"); }
-    HB_CHECK(ctx, hipMemsetAsync(e->state, 0, 4 * B * 32, ctx->stream));       // buff_hash starts at zero (:186-193)
+    HB_TRY(launch_zero(ctx, e->state, 4 * B * 32));       // buff_hash starts at zero (:186-193)
     *out = e;
     return 0;
 }
@@ -641,7 +648,7 @@ int hobbit_change_form(hobbit_ctx *ctx, hobbit_F *d_poly, int logn) {
     F *cur = mF(d_poly), *nxt = tmp;
     int l = 0;
     for (; l < logn && (n >> l) > 4096; l++) { HB_TRY(launch_change_form_level(ctx, cur, nxt, n, n >> l)); std::swap(cur, nxt); }   // block size > 4096: one pass per level
-    if (cur != mF(d_poly)) HB_CHECK(ctx, hipMemcpyAsync(d_poly, cur, n * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    if (cur != mF(d_poly)) HB_TRY(launch_copy(ctx, d_poly, cur, n * sizeof(F)));
     if (l < logn) HB_TRY(launch_change_form_tail(ctx, mF(d_poly), n, (uint32_t)(n >> l)));                                           // the rest inside LDS
     return 0;
 }
@@ -651,7 +658,7 @@ int hobbit_whir_commit(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, hobbit
     const size_t L = 2 * N;
     F *pc; HB_TRY(ctx->workspace4(2 * L * sizeof(F), (void **)&pc));      // (the open arena, workspace3, may hold d_poly)
     F *enc = pc + L;
-    HB_CHECK(ctx, hipMemcpyAsync(pc, d_poly, N * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    HB_TRY(launch_copy(ctx, pc, d_poly, N * sizeof(F)));
     HB_TRY(hobbit_change_form(ctx, reinterpret_cast<hobbit_F *>(pc), logn));
     HB_TRY(rs_rows(ctx, pc, N, 1, enc));                                        // resize(2N, 0) + _fft (:165-166)
     // buff[j*16 + kk] = poly_com[j + kk * L/16] (:168-173): a (16 x L/16) -> (L/16 x 16) transpose
@@ -664,15 +671,15 @@ int hobbit_whir_commit(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, hobbit
 // which the next query round reads.
 static int whir_fri_layer(hobbit_ctx *ctx, const F *d_poly, size_t cur, size_t fsz, F *fp, F *keep, uint8_t *d_root) {
     F *buf = keep; uint8_t *lv = reinterpret_cast<uint8_t *>(buf + fsz);
-    HB_CHECK(ctx, hipMemsetAsync(fp, 0, fsz * sizeof(F), ctx->stream));
-    HB_CHECK(ctx, hipMemcpyAsync(fp, d_poly, cur * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    HB_TRY(launch_zero(ctx, fp, fsz * sizeof(F)));
+    HB_TRY(launch_copy(ctx, fp, d_poly, cur * sizeof(F)));
     HB_TRY(hobbit_change_form(ctx, reinterpret_cast<hobbit_F *>(fp), ilog2_exact(cur)));
     const int lg = ilog2_exact(fsz);
     if (lg <= 12) HB_TRY(fft_rows(ctx, fp, fsz, (uint32_t)fsz, fp, fsz, 1, lg, false, 1, 1, 0, 0));
     else HB_TRY(fft_long(ctx, fp, fsz, fsz, fp, lg, false, 1));
     HB_TRY(launch_transpose_ld(ctx, fp, 0, fsz / 16, 16, (uint32_t)(fsz / 16), buf, 0, 16, 1));
     HB_TRY(hobbit_mt_commit_blake(ctx, reinterpret_cast<hobbit_F *>(buf), fsz, lv));
-    HB_CHECK(ctx, hipMemcpyAsync(d_root, lv + 32 * (2 * (fsz / 4) - 2), 32, hipMemcpyDeviceToDevice, ctx->stream));
+    HB_TRY(launch_copy(ctx, d_root, lv + 32 * (2 * (fsz / 4) - 2), 32));
     return 0;
 }
 // compute_zetas (src/Virgo.cpp:220-236), host side, libc draws in the reference's order
@@ -709,7 +716,7 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
     // pinned staging: one slot per iteration, laid out exactly like its device twin (z | pows | indices), then the read-back area
     uint8_t *pinb; HB_TRY(ctx->pinned((WHIR_DIN * 6 + WHIR_DRES) * sizeof(F), (void **)&pinb));
     F *pin_in = reinterpret_cast<F *>(pinb), *pin_res = pin_in + WHIR_DIN * 6;
-    HB_CHECK(ctx, hipMemcpyAsync(poly, d_poly, N * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    HB_TRY(launch_copy(ctx, poly, d_poly, N * sizeof(F)));
     HB_TRY(hobbit_eq_table(ctx, h_x, logN, reinterpret_cast<hobbit_F *>(beta)));
     HB_TRY(launch_dot(ctx, beta, poly, N, part, dres));                          // eval = <beta, poly> (:535-538)
     int iter = 0, repeats = 100, nq = 0; size_t remaining = 0;
@@ -771,8 +778,8 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
     }
     // final verification step (:641-651): sum = <final_poly, final_beta>
     HB_TRY(launch_dot(ctx, beta, poly, remaining, part, res_fin));
-    HB_CHECK(ctx, hipMemcpyAsync(res_fin + 4, poly, remaining * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
-    HB_CHECK(ctx, hipMemcpyAsync(res_fin + 4 + remaining, beta, remaining * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    HB_TRY(launch_copy(ctx, res_fin + 4, poly, remaining * sizeof(F)));
+    HB_TRY(launch_copy(ctx, res_fin + 4 + remaining, beta, remaining * sizeof(F)));
     {   // closing draws (:652-655) and the last query round (:656), leaving the libc stream where the reference leaves it
         const int lr = ilog2_exact(remaining);
         F cst = fmake(0); for (int i = 0; i < lr; i++) { if (i % 100 == 0) cst = fmake((uint64_t)random()); (void)rand(); }
@@ -844,7 +851,7 @@ int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobb
     }
     std::vector<uint64_t> I(240); std::vector<F> one(240, fmake(1));
     for (int i = 0; i < 240; i++) { I[i] = (uint64_t)(rand() % (long)W); if (o->I) o->I[i] = (uint32_t)I[i]; }      // (:463-467)
-    HB_CHECK(ctx, hipMemsetAsync(b1v, 0, W * sizeof(F), ctx->stream));
+    HB_TRY(launch_zero(ctx, b1v, W * sizeof(F)));
     HB_CHECK(ctx, hipMemcpyAsync(ones, one.data(), 240 * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
     HB_CHECK(ctx, hipMemcpyAsync(didx, I.data(), 240 * 8, hipMemcpyHostToDevice, ctx->stream));
     HB_TRY(launch_scatter(ctx, didx, ones, 240, b1v));
@@ -939,7 +946,7 @@ int hobbit_phi_g(hobbit_ctx *ctx, const hobbit_F *h_rx, int n, const hobbit_F *h
     const size_t N = (size_t)1 << n;
     const F *pm; HB_TRY(get_twiddles(ctx, n, is_ifft != 0, &pm));      // phi_mul[k] = rou^k, k < N/2 (all that is indexed)
     F *g = mF(d_out);
-    HB_CHECK(ctx, hipMemsetAsync(g, 0, N * sizeof(F), ctx->stream));
+    HB_TRY(launch_zero(ctx, g, N * sizeof(F)));
     const int last = is_ifft ? n : n - 1;
     int first = 1;
     if (!is_ifft && last >= 2) {                                       // the first levels in one workgroup: a level per launch is latency only up there
@@ -954,7 +961,7 @@ int hobbit_phi_g(hobbit_ctx *ctx, const hobbit_F *h_rx, int n, const hobbit_F *h
 // arr[c] = multilinear evaluation over the ROW index of column c at r (prepare_matrix(transpose(M), r))
 int hobbit_prepare_matrix_cols(hobbit_ctx *ctx, const hobbit_F *d_M, size_t rows, size_t cols, const hobbit_F *h_r, int k, hobbit_F *d_out) {
     if (ilog2_exact(rows) < 0 || k > ilog2_exact(rows)) return ctx->fail(HOBBIT_EINVAL, "prepare_matrix_cols: rows must be a power of two, k <= log2 rows");
-    if (k == 0) { HB_CHECK(ctx, hipMemcpyAsync(d_out, d_M, cols * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream)); return 0; }
+    if (k == 0) { HB_TRY(launch_copy(ctx, d_out, d_M, cols * sizeof(F))); return 0; }
     F *ws; HB_TRY(ctx->workspace2((rows / 2 + rows / 4 + 1) * cols * sizeof(F), (void **)&ws));
     F *a = ws, *b = ws + (rows / 2) * cols;
     const F *src = cF(d_M); F *dst = a; size_t r = rows;
@@ -963,7 +970,7 @@ int hobbit_prepare_matrix_cols(hobbit_ctx *ctx, const hobbit_F *d_M, size_t rows
         HB_TRY(launch_fold_rows(ctx, src, o, r / 2, cols, cF(h_r)[t]));
         src = o; dst = dst == a ? b : a; r /= 2;
     }
-    if (src != cF(d_out)) HB_CHECK(ctx, hipMemcpyAsync(d_out, src, cols * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));   // row 0 (src/utils.cpp:771-773)
+    if (src != cF(d_out)) HB_TRY(launch_copy(ctx, d_out, src, cols * sizeof(F)));   // row 0 (src/utils.cpp:771-773)
     return 0;
 }
 int hobbit_prove_linear_code(hobbit_ctx *ctx, const hobbit_F *d_codeword, size_t size, long long n, const hobbit_F *h_r1, hobbit_F *h_qpoly,
@@ -982,8 +989,8 @@ int hobbit_prove_fft(hobbit_ctx *ctx, const hobbit_F *d_m, size_t s, const hobbi
     if (k < 1) return ctx->fail(HOBBIT_EINVAL, "prove_fft: size must be a power of two");
     F *tmp; HB_TRY(ctx->workspace2(2 * S * sizeof(F), (void **)&tmp));
     F *mm = tmp, *FG = tmp + S;
-    HB_CHECK(ctx, hipMemsetAsync(mm + s, 0, s * sizeof(F), ctx->stream));                       // m.resize(2*m.size(), 0)
-    HB_CHECK(ctx, hipMemcpyAsync(mm, d_m, s * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    HB_TRY(launch_zero(ctx, mm + s, s * sizeof(F)));                       // m.resize(2*m.size(), 0)
+    HB_TRY(launch_copy(ctx, mm, d_m, s * sizeof(F)));
     hobbit_F one = {1, 0};
     HB_TRY(hobbit_phi_g(ctx, h_r, k, &one, 0, (hobbit_F *)FG));
     return hobbit_sumcheck2(ctx, (const hobbit_F *)FG, (const hobbit_F *)mm, S, h_r + (k - 1), h_qpoly, h_rr, h_vr, h_final);
@@ -995,13 +1002,13 @@ int hobbit_prove_fft_matrix(hobbit_ctx *ctx, const hobbit_F *d_M, size_t rows, s
     // arr = prepare_matrix(transpose(M padded), r1): column evaluations, upper half zero; Fg1 = phiG(r2)
     F *tmp; HB_TRY(ctx->workspace(2 * C2 * sizeof(F), (void **)&tmp));
     F *arr = tmp, *Fg = tmp + C2;
-    HB_CHECK(ctx, hipMemsetAsync(arr + cols, 0, cols * sizeof(F), ctx->stream));
+    HB_TRY(launch_zero(ctx, arr + cols, cols * sizeof(F)));
     HB_TRY(hobbit_prepare_matrix_cols(ctx, d_M, rows, cols, h_r + k2, k1, (hobbit_F *)arr));
     hobbit_F one = {1, 0};
     HB_TRY(hobbit_phi_g(ctx, h_r, k2, &one, 0, (hobbit_F *)Fg));
     // sumcheck2 uses ctx->workspace itself: move the two tables to workspace2 first
     F *t2; HB_TRY(ctx->workspace2(2 * C2 * sizeof(F), (void **)&t2));
-    HB_CHECK(ctx, hipMemcpyAsync(t2, tmp, 2 * C2 * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    HB_TRY(launch_copy(ctx, t2, tmp, 2 * C2 * sizeof(F)));
     return hobbit_sumcheck2(ctx, (const hobbit_F *)(t2 + C2), (const hobbit_F *)t2, C2, h_r + (k1 + k2 - 1), h_qpoly, h_rr, h_vr, h_final);
 }
 
@@ -1077,9 +1084,9 @@ int hobbit_batch_3product_sumcheck(hobbit_ctx *ctx, const hobbit_F *d_t1, const 
     // ping-pong copies of the three concatenated tables (inputs are preserved), partials, per-table coefficients
     F *ws; HB_TRY(ctx->workspace2((6 * tot + 4 * 1024 + 4 * (size_t)batches + 16) * sizeof(F), (void **)&ws));
     F *A = ws, *B = ws + 3 * tot, *part = B + 3 * tot, *coef = part + 4 * 1024;
-    HB_CHECK(ctx, hipMemcpyAsync(A, d_t1, tot * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
-    HB_CHECK(ctx, hipMemcpyAsync(A + tot, d_t2, tot * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
-    HB_CHECK(ctx, hipMemcpyAsync(A + 2 * tot, d_t3, tot * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    HB_TRY(launch_copy(ctx, A, d_t1, tot * sizeof(F)));
+    HB_TRY(launch_copy(ctx, A + tot, d_t2, tot * sizeof(F)));
+    HB_TRY(launch_copy(ctx, A + 2 * tot, d_t3, tot * sizeof(F)));
     std::vector<size_t> off(batches), len(batches); std::vector<char> set(batches, 0);
     std::vector<F> sc(3 * (size_t)batches);                          // host copies of tables that are down to one element
     { size_t o = 0; for (int j = 0; j < batches; j++) { off[j] = o; len[j] = h_lens[j]; o += h_lens[j]; } }
@@ -1231,8 +1238,8 @@ int hobbit_elastic_open_begin(hobbit_ctx *ctx, size_t N, size_t B, int trs, cons
               hipMalloc((void **)&e->d_ucols, nc * 4) == hipSuccess && hipMalloc((void **)&e->d_pick, (size_t)queries * 8) == hipSuccess &&
               hipMalloc((void **)&e->d_nz, e->K * sizeof(int)) == hipSuccess;
     if (!ok) { hobbit_elastic_open_free(e); return ctx->fail(HOBBIT_ENOMEM, "elastic_open_begin: allocation failed"); }
-    HB_CHECK(ctx, hipMemsetAsync(e->d_aggr, 0, B * sizeof(F), ctx->stream));
-    HB_CHECK(ctx, hipMemsetAsync(e->d_nz, 0, e->K * sizeof(int), ctx->stream));
+    HB_TRY(launch_zero(ctx, e->d_aggr, B * sizeof(F)));
+    HB_TRY(launch_zero(ctx, e->d_nz, e->K * sizeof(int)));
     HB_CHECK(ctx, hipMemcpyAsync(e->d_ucols, e->ucols.data(), nc * 4, hipMemcpyHostToDevice, ctx->stream));
     HB_CHECK(ctx, hipMemcpyAsync(e->d_pick, pick.data(), (size_t)queries * 8, hipMemcpyHostToDevice, ctx->stream));
     HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));                                                        // `pick` is a local
@@ -1293,7 +1300,7 @@ int hobbit_elastic_open_finish(hobbit_ctx *ctx, hobbit_elastic_open *e, const ui
     F *arena; HB_TRY(ctx->workspace3((2 * B + np2 * trs + 2 * np2 * rows2 + 2 * B + 4096 + 64) * sizeof(F), (void **)&arena));
     F *out1 = arena, *sel = out1 + 2 * B, *out3 = sel + np2 * trs, *bt = out3 + np2 * rows2, *b2 = bt + np2 * rows2, *stage = b2 + 2 * B;
     HB_TRY(fft_rows(ctx, e->d_aggr, half, (uint32_t)half, out1, cols, 1, logc, false, 1, (uint32_t)trs, 0, 0));                  // out_1 (:406-420)
-    HB_CHECK(ctx, hipMemsetAsync(sel, 0, (np2 * trs + 2 * np2 * rows2 + 2 * B) * sizeof(F), ctx->stream));                         // sel | out3 | bt | b2
+    HB_TRY(launch_zero(ctx, sel, (np2 * trs + 2 * np2 * rows2 + 2 * B) * sizeof(F)));                         // sel | out3 | bt | b2
     HB_TRY(launch_gather_cols(ctx, out1, cols, (uint32_t)trs, e->d_ucols, (uint32_t)nc, sel, trs));                                // selected_collumns (:422-431)
     HB_TRY(fft_rows(ctx, sel, trs, (uint32_t)trs, out3, rows2, 1, logr, false, 1, (uint32_t)nc, 0, 0));                            // out_3 (:436-452)
     std::vector<F> rq(nq);
@@ -1460,7 +1467,7 @@ int hobbit_sumcheck3_stream_batch(hobbit_ctx *ctx, hobbit_chunk_source source, v
       *dres = part + 1024, *dR = dres + npe + 16;
     F *V[16]; for (int i = 0; i < batches; i++) V[i] = Vb + P.voff[i];
     for (int i = 0; i < batches; i++) HB_TRY(hobbit_eq_table(ctx, h_r + (size_t)i * rlen, P.n_init[i], reinterpret_cast<hobbit_F *>(b3 + P.off[i])));   // buff3 = beta(initial_r) (:1171)
-    HB_CHECK(ctx, hipMemcpyAsync(f3, b3, P.tot * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));                                                       // fold_buff3 = buff3
+    HB_TRY(launch_copy(ctx, f3, b3, P.tot * sizeof(F)));                                                       // fold_buff3 = buff3
     HB_TRY(src_reset(ctx, src));
     HB_TRY(dev_read_mul_tree_data(ctx, src, V, P.vlen, batches, 4 * B, layer_id, distance));                                                              // (:1187)
     std::vector<F> Kp(batches), a(batches);
@@ -1631,12 +1638,12 @@ int hobbit_gate_consistency_stream(hobbit_ctx *ctx, hobbit_trace_source source, 
     F *base; HB_TRY(ctx->workspace4((8 * B + 1024 + 6 * n_chunks + 2 * n_chunks + 64) * sizeof(F), (void **)&base));
     F *beta = base, *fb = beta + B, *fL = fb + B, *fR = fL + B, *fO = fR + B, *fa = fO + B, *fm = fa + B, *tmp = fm + B, *part = tmp + B, *dres = part + 1024, *dR = dres + 6 * n_chunks + 16;
     HB_TRY(hobbit_eq_table(ctx, h_r, logB, reinterpret_cast<hobbit_F *>(beta)));
-    HB_CHECK(ctx, hipMemcpyAsync(fb, beta, B * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    HB_TRY(launch_copy(ctx, fb, beta, B * sizeof(F)));
     HB_TRY(next(0, &bL, &bR, &bO, &bS));
     HB_TRY(next(B, &bL, &bR, &bO, &bS));
-    HB_CHECK(ctx, hipMemcpyAsync(fL, bL, B * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
-    HB_CHECK(ctx, hipMemcpyAsync(fR, bR, B * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
-    HB_CHECK(ctx, hipMemcpyAsync(fO, bO, B * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    HB_TRY(launch_copy(ctx, fL, bL, B * sizeof(F)));
+    HB_TRY(launch_copy(ctx, fR, bR, B * sizeof(F)));
+    HB_TRY(launch_copy(ctx, fO, bO, B * sizeof(F)));
     HB_TRY(launch_i32_to_F(ctx, bS, 0, B, fa)); HB_TRY(launch_i32_to_F(ctx, bS, 1, B, fm));
     // Kf_O, Kf_L, Kf_R, Kf_M (:818-826)
     HB_TRY(launch_dot_gen(ctx, beta, fO, 1, nullptr, B, part, dres));
@@ -1764,7 +1771,7 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     F *Mp = BIG, *C = BIG + (size_t)trs * cols;
     tr.mark("beta + arena");
     if (c) HB_TRY(hobbit_aggregate(ctx, d_poly, N, reinterpret_cast<const hobbit_F *>(beta.data()), K, reinterpret_cast<hobbit_F *>(d_aggr)));   // _aggregate axpy (:258-272)
-    else HB_CHECK(ctx, hipMemcpyAsync(d_aggr, d_poly, M * sizeof(F), hipMemcpyDeviceToDevice, ctx->stream));
+    else HB_TRY(launch_copy(ctx, d_aggr, d_poly, M * sizeof(F)));
     // compute_tensorcode(aggr) (:277): M' = row FFTs (row-major), codeword-major copy, expander encode, parity half back to row-major C
     tr.mark("beta, arena, aggregate");
     HB_TRY(fft_rows(ctx, d_aggr, cols / 2, (uint32_t)(cols / 2), Mp, cols, 1, logc, false, 1, (uint32_t)trs, 0, 0));
@@ -1829,7 +1836,7 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
         for (int q = 0; q < queries; q++) { last[Iv[q]] = pw; pw = fmul(pw, s2); }
         std::vector<uint64_t> idx; std::vector<F> val;
         for (auto &kv : last) { idx.push_back(kv.first); val.push_back(kv.second); }
-        HB_CHECK(ctx, hipMemsetAsync(d_b, 0, big * sizeof(F), ctx->stream));
+        HB_TRY(launch_zero(ctx, d_b, big * sizeof(F)));
         // staged through the pinned buffer into the arena tail (no hipMalloc / hipFree on the hot path)
         F *tmpv = d_b1 + rows2; uint64_t *tmpi = reinterpret_cast<uint64_t *>(tmpv + queries + 1);
         uint8_t *pin; HB_TRY(ctx->pinned((size_t)queries * (sizeof(F) + 8) + 64, (void **)&pin));   // sized by the query count, not by the distinct positions

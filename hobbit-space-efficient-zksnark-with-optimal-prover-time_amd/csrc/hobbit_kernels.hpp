@@ -71,4 +71,6 @@ int launch_deinterleave(hobbit_ctx *ctx, const F *v, size_t n, F *a, F *b);
 int launch_dot_gen(hobbit_ctx *ctx, const F *a, const F *b, size_t sb, const F *c, size_t n, F *part, F *out);
 int launch_dot_i32(hobbit_ctx *ctx, const F *a, const int32_t *sel, int one_minus, size_t n, F *part, F *out);
 int launch_i32_to_F(hobbit_ctx *ctx, const int32_t *sel, int one_minus, size_t n, F *y);
+int launch_zero(hobbit_ctx *ctx, void *p, size_t bytes);
+int launch_copy(hobbit_ctx *ctx, void *d, const void *s, size_t bytes);
 }  // namespace hobbit
