@@ -24,6 +24,36 @@ struct hobbit_commitment {
     size_t tensor_bytes, levels_bytes;
 };
 
+// Scope of one library call for the staging arena (hobbit_ctx.hpp): the outermost scope resets the arena on entry and, in finish(),
+// synchronises the stream and hands the staged results to the caller's buffers; nested calls share the arena and defer to it.
+struct StageScope {
+    hobbit_ctx *ctx; bool top;
+    explicit StageScope(hobbit_ctx *c) : ctx(c), top(c->stage_depth++ == 0) { if (top) { ctx->stage_off = 0; ctx->deferred.clear(); } }
+    ~StageScope() { ctx->stage_depth--; if (top) ctx->deferred.clear(); }
+    int finish() {
+        if (!top) return 0;
+        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        for (auto &d : ctx->deferred) memcpy(d.dst, d.src, d.bytes);
+        ctx->deferred.clear();
+        return 0;
+    }
+};
+static int h2d_staged(hobbit_ctx *ctx, void *d, const void *h, size_t bytes) {
+    if (!bytes) return 0;
+    void *p = ctx->stage_depth > 0 ? ctx->stage_alloc(bytes) : nullptr;
+    if (!p) { HB_CHECK(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream)); return 0; }     // pageable fallback (synchronous in effect)
+    memcpy(p, h, bytes);
+    HB_CHECK(ctx, hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+static int d2h_staged(hobbit_ctx *ctx, void *h, const void *d, size_t bytes) {
+    if (!bytes) return 0;
+    void *p = ctx->stage_depth > 0 ? ctx->stage_alloc(bytes) : nullptr;
+    if (!p) { HB_CHECK(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream)); return 0; }
+    HB_CHECK(ctx, hipMemcpyAsync(p, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->deferred.push_back({h, p, bytes});
+    return 0;
+}
 static int ilog2_exact(size_t n) { int l = 0; while (((size_t)1 << l) < n) l++; return ((size_t)1 << l) == n ? l : -1; }
 
 static int get_twiddles(hobbit_ctx *ctx, int logn, bool inverse, const F **out) {
@@ -197,6 +227,7 @@ void hobbit_ctx_destroy(hobbit_ctx *ctx) {
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->ws2) hipFree(ctx->ws2);
     if (ctx->pin) hipHostFree(ctx->pin);
+    if (ctx->stage) hipHostFree(ctx->stage);
     if (ctx->mbox) hipHostFree((void *)ctx->mbox);
     if (ctx->d_ticket) hipFree(ctx->d_ticket);
     for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
@@ -382,14 +413,14 @@ static int paths_common(hobbit_ctx *ctx, const uint8_t *d_levels, size_t n, cons
     if (depth < 0) return ctx->fail(HOBBIT_EINVAL, "merkle_path: n must be a power of two");
     for (size_t q = 0; q < nq; q++) if (h_pos[q] >= n) return ctx->fail(HOBBIT_EINVAL, "merkle_path: position out of range");   // src/merkle_tree.cpp:310-313
     if (depth == 0 || nq == 0) return 0;
+    StageScope sc(ctx);
     uint8_t *buf; size_t pbytes = nq * 8, obytes = nq * depth * 32;
-    HB_TRY(ctx->workspace(pbytes + obytes + 64, (void **)&buf));
+    HB_TRY(ctx->workspace(pbytes + obytes + 64, (void **)&buf));     // (the staged read-back is queued right behind the kernel: later users of the workspace come after it)
     uint8_t *d_paths = buf; uint64_t *d_pos = reinterpret_cast<uint64_t *>(buf + ((obytes + 15) / 16) * 16);
-    HB_CHECK(ctx, hipMemcpyAsync(d_pos, h_pos, pbytes, hipMemcpyHostToDevice, ctx->stream));
+    HB_TRY(h2d_staged(ctx, d_pos, h_pos, pbytes));
     HB_TRY(launch_merkle_paths(ctx, d_levels, n, d_pos, nq, depth, d_paths));
-    HB_CHECK(ctx, hipMemcpyAsync(h_paths, d_paths, obytes, hipMemcpyDeviceToHost, ctx->stream));
-    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    HB_TRY(d2h_staged(ctx, h_paths, d_paths, obytes));
+    return sc.finish();
 }
 int hobbit_merkle_path(hobbit_ctx *ctx, const uint8_t *d_levels, size_t n, size_t pos, uint8_t *h_path) {
     uint64_t p = pos; return paths_common(ctx, d_levels, n, &p, 1, h_path);
@@ -541,13 +572,15 @@ int hobbit_commitment_tensor_row(hobbit_ctx *ctx, const hobbit_commitment *c, in
 int hobbit_commitment_gather(hobbit_ctx *ctx, const hobbit_commitment *c, const uint32_t *h_rows, const uint32_t *h_cols, size_t nq, hobbit_F *h_reply) {
     for (size_t q = 0; q < nq; q++) if (h_rows[q] >= c->rows2 || h_cols[q] >= c->cols) return ctx->fail(HOBBIT_EINVAL, "gather: query out of range");
     if (!nq) return 0;
+    StageScope sc(ctx);
     uint8_t *buf; size_t rb = ((nq * c->K * sizeof(F) + 15) / 16) * 16;
     HB_TRY(ctx->workspace(rb + 8 * nq + 64, (void **)&buf));
     F *d_reply = reinterpret_cast<F *>(buf); uint32_t *d_rows = reinterpret_cast<uint32_t *>(buf + rb), *d_cols = d_rows + nq;
-    HB_CHECK(ctx, hipMemcpyAsync(d_rows, h_rows, 4 * nq, hipMemcpyHostToDevice, ctx->stream));
-    HB_CHECK(ctx, hipMemcpyAsync(d_cols, h_cols, 4 * nq, hipMemcpyHostToDevice, ctx->stream));
+    HB_TRY(h2d_staged(ctx, d_rows, h_rows, 4 * nq));
+    HB_TRY(h2d_staged(ctx, d_cols, h_cols, 4 * nq));
     HB_TRY(launch_gather(ctx, c->d_tensor, (size_t)c->cols * c->rows2, c->rows2, c->K, d_rows, d_cols, nq, d_reply));
-    return hobbit_memcpy_d2h(ctx, h_reply, d_reply, nq * c->K * sizeof(F));
+    HB_TRY(d2h_staged(ctx, h_reply, d_reply, nq * c->K * sizeof(F)));
+    return sc.finish();
 }
 // the same gather on a raw tensor shard (codeword-major, `nchunks` chunks of 4M F): the multi-GPU open's replies
 int hobbit_tensor_gather(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M, int nchunks, int trs, const uint32_t *h_rows, const uint32_t *h_cols, size_t nq, hobbit_F *h_reply) {
@@ -558,8 +591,9 @@ int hobbit_tensor_gather(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M, in
     uint8_t *buf; size_t rb = ((nq * nchunks * sizeof(F) + 15) / 16) * 16;
     HB_TRY(ctx->workspace(rb + 8 * nq + 64, (void **)&buf));
     F *d_reply = reinterpret_cast<F *>(buf); uint32_t *d_rows = reinterpret_cast<uint32_t *>(buf + rb), *d_cols = d_rows + nq;
-    HB_CHECK(ctx, hipMemcpyAsync(d_rows, h_rows, 4 * nq, hipMemcpyHostToDevice, ctx->stream));
-    HB_CHECK(ctx, hipMemcpyAsync(d_cols, h_cols, 4 * nq, hipMemcpyHostToDevice, ctx->stream));
+    StageScope sc(ctx);
+    HB_TRY(h2d_staged(ctx, d_rows, h_rows, 4 * nq));
+    HB_TRY(h2d_staged(ctx, d_cols, h_cols, 4 * nq));
     HB_TRY(launch_gather(ctx, cF(d_tensor), cols * rows2, (uint32_t)rows2, nchunks, d_rows, d_cols, nq, d_reply));
     return hobbit_memcpy_d2h(ctx, h_reply, d_reply, nq * nchunks * sizeof(F));
 }
@@ -705,6 +739,7 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
     const int k = 4, logN = ilog2_exact(N);
     if (logN < 9 || logN > 24 || !o) return ctx->fail(HOBBIT_EINVAL, "whir_prove: N must be a power of two in [2^9, 2^24]");
     hobbit_F *h_qpoly = o->qpoly, *h_a = o->a, *h_scal = o->scal; uint8_t *h_fri_roots = o->fri_roots; int *h_checks = o->checks;
+    StageScope sc(ctx);
     const size_t curmax = N >> k, sz_front = 4 * N, sz_E = 100 * curmax;
     F *base; HB_TRY(ctx->workspace4((sz_front + whir_scratch_elems(N)) * sizeof(F), (void **)&base));
     F *poly = base + sz_front, *beta = poly + N, *E0 = beta + N, *E1 = E0 + sz_E, *fp = E1 + sz_E, *keepA = fp + N, *keepB = keepA + 2 * N, *part = keepB + N + 64,
@@ -796,8 +831,8 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
     }
     // the one read-back
     HB_CHECK(ctx, hipMemcpyAsync(pin_res, dres, WHIR_DRES * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
-    if (o->qreply && q_tot) HB_CHECK(ctx, hipMemcpyAsync(o->qreply, d_rep, q_tot * 16 * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
-    if (o->qpaths && path_off) HB_CHECK(ctx, hipMemcpyAsync(o->qpaths, d_paths, path_off, hipMemcpyDeviceToHost, ctx->stream));
+    if (o->qreply && q_tot) HB_TRY(d2h_staged(ctx, o->qreply, d_rep, q_tot * 16 * sizeof(F)));
+    if (o->qpaths && path_off) HB_TRY(d2h_staged(ctx, o->qpaths, d_paths, path_off));
     HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     // replay: round checks ("Error in %d", :562-565), eval updates (:566, :631), final check (:648-651)
     F eval = pin_res[0];
@@ -818,7 +853,7 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
     mF(h_scal)[0] = eval; mF(h_scal)[1] = sum;
     if (o->final_pb) memcpy(o->final_pb, pin_res + 904, 2 * remaining * sizeof(F));
     if (o->iters) *o->iters = iter;
-    return 0;
+    return sc.finish();
 }
 // shockwave_prove (src/Virgo.cpp:435-517), prover side
 // workspace4 elements of one shockwave_prove: [0, nested) belongs to the nested whir_commit / whir_prove calls, its own vectors follow
@@ -831,6 +866,7 @@ int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobb
     const int lk = ilog2_exact((size_t)k);
     if (lk < 0 || k > 64 || N % (size_t)k || xlen < lk || !o) return ctx->fail(HOBBIT_EINVAL, "shockwave_prove: bad k / N / x");
     const size_t w = N / k, W = 2 * w;
+    StageScope sc(ctx);
     std::vector<F> beta1((size_t)k); beta1[0] = fmake(1);
     for (int i = 0; i < lk; i++) for (size_t j = ((size_t)1 << i); j-- > 0;) { F t = fmul(cF(h_x)[xlen - lk + (lk - 1 - i)], beta1[j]); beta1[2 * j + 1] = t; beta1[2 * j] = fsub(beta1[j], t); }
     // workspace4 layout: [0, nested) belongs to the nested whir_commit / whir_prove calls (they carve from the start and never ask
@@ -841,29 +877,29 @@ int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobb
     F *wcom = ones + 256 + 256; uint8_t *wlv = reinterpret_cast<uint8_t *>(wcom + 2 * w); F *d_rep = wcom + 4 * w;
     uint8_t *d_pth = reinterpret_cast<uint8_t *>(d_rep + 240 * (size_t)k);
     // (host vectors handed to asynchronous copies live to the end of this function, which ends synchronised)
-    HB_CHECK(ctx, hipMemcpyAsync(dbeta, beta1.data(), (size_t)k * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+    HB_TRY(h2d_staged(ctx, dbeta, beta1.data(), (size_t)k * sizeof(F)));
     HB_TRY(launch_vecmat(ctx, cF(d_matrix), (size_t)k, w, dbeta, aggr));        // aggr = beta1^T matrix (:444-456)
     HB_TRY(launch_vecmat(ctx, cF(d_enc), (size_t)k, W, dbeta, at));
     const bool committed = w > 256;
     if (committed) {                                                         // whir_commit(aggr, C) (:458-461)
         HB_TRY(hobbit_whir_commit(ctx, reinterpret_cast<hobbit_F *>(aggr), w, reinterpret_cast<hobbit_F *>(wcom), wlv));
-        if (o->whir_root) HB_CHECK(ctx, hipMemcpyAsync(o->whir_root, wlv + 32 * (w - 2), 32, hipMemcpyDeviceToHost, ctx->stream));
+        if (o->whir_root) HB_TRY(d2h_staged(ctx, o->whir_root, wlv + 32 * (w - 2), 32));
     }
     std::vector<uint64_t> I(240); std::vector<F> one(240, fmake(1));
     for (int i = 0; i < 240; i++) { I[i] = (uint64_t)(rand() % (long)W); if (o->I) o->I[i] = (uint32_t)I[i]; }      // (:463-467)
     HB_TRY(launch_zero(ctx, b1v, W * sizeof(F)));
-    HB_CHECK(ctx, hipMemcpyAsync(ones, one.data(), 240 * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
-    HB_CHECK(ctx, hipMemcpyAsync(didx, I.data(), 240 * 8, hipMemcpyHostToDevice, ctx->stream));
+    HB_TRY(h2d_staged(ctx, ones, one.data(), 240 * sizeof(F)));
+    HB_TRY(h2d_staged(ctx, didx, I.data(), 240 * 8));
     HB_TRY(launch_scatter(ctx, didx, ones, 240, b1v));
     if (o->reply) {                                                          // reply[i][j] = encoded_matrix[j][I[i]] (:468-472)
         HB_TRY(launch_gather_strided(ctx, cF(d_enc), didx, 240, (uint32_t)k, 1, W, d_rep));
-        HB_CHECK(ctx, hipMemcpyAsync(o->reply, d_rep, 240 * (size_t)k * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+        HB_TRY(d2h_staged(ctx, o->reply, d_rep, 240 * (size_t)k * sizeof(F)));
     }
     if (o->paths && d_levels) {                                              // open_tree_blake(data->MT, {I[i],0}, 0) (:503)
         const int depth = ilog2_exact(W);
         if (depth > 32) return ctx->fail(HOBBIT_EINVAL, "shockwave_prove: tree too deep for the path buffer");
         HB_TRY(launch_merkle_paths(ctx, d_levels, W, didx, 240, depth, d_pth));
-        HB_CHECK(ctx, hipMemcpyAsync(o->paths, d_pth, 240 * (size_t)depth * 32, hipMemcpyDeviceToHost, ctx->stream));
+        HB_TRY(d2h_staged(ctx, o->paths, d_pth, 240 * (size_t)depth * 32));
     }
     hobbit_F p33 = {33, 0};
     HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(at), reinterpret_cast<hobbit_F *>(b1v), W, &p33, o->q1, o->r1, o->vr1, o->fin1));         // (:477)
@@ -877,7 +913,7 @@ int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobb
     }
     if (o->iters) *o->iters = iters;
     HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    return sc.finish();
 }
 
 // ---- multi-GPU commit building blocks -------------------------------------------
@@ -1746,6 +1782,7 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     std::vector<F> beta((size_t)K); beta[0] = fmake(1);
     if (c) for (int i = 0; i < logK; i++) for (size_t j = ((size_t)1 << i); j-- > 0;) { F t = fmul(cF(h_x)[logK - 1 - i], beta[j]); beta[2 * j + 1] = t; beta[2 * j] = fsub(beta[j], t); }
     { F rv0 = fmake((uint64_t)random()); rv0 = fadd(rv0, fmake((uint64_t)rand())); memcpy(&o->scalars[0], &rv0, sizeof(F)); }   // generate_randomness(1)
+    StageScope sc(ctx);
     // device arena
     F *arena = nullptr;
     // + the two inner shockwave commitments kept for the later shockwave_prove: encoded matrices (2M and 2*trs*cols F) and their trees
@@ -1793,28 +1830,44 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
         HB_TRY(hobbit_shockwave_commit(ctx, reinterpret_cast<hobbit_F *>(C), nc_el, 32, reinterpret_cast<hobbit_F *>(encc), lvc));
         if (o->roots) {
             // (asynchronous: complete at the next of the many synchronisation points below)
-            HB_CHECK(ctx, hipMemcpyAsync(o->roots, lvf + 32 * (2 * (2 * M / 32) - 2), 32, hipMemcpyDeviceToHost, ctx->stream));
-            HB_CHECK(ctx, hipMemcpyAsync(o->roots + 32, lvc + 32 * (2 * (2 * nc_el / 32) - 2), 32, hipMemcpyDeviceToHost, ctx->stream));
+            HB_TRY(d2h_staged(ctx, o->roots, lvf + 32 * (2 * (2 * M / 32) - 2), 32));
+            HB_TRY(d2h_staged(ctx, o->roots + 32, lvc + 32 * (2 * (2 * nc_el / 32) - 2), 32));
         }
     }
     tr.mark("shockwave_commit C_f, C_c");
-    // queries (:633-641), replies (:291-305) and Merkle paths (:645-647)
+    // Every libc draw of this function, in the reference's order -- queries (:633-641), s (src/PC_utils.cpp:293), r1 (prove_linear_code's
+    // generate_randomness, src/sumcheck.cpp:3225), s2 (:331), a (:342) -- none depends on device data, and nothing between them draws.
+    // Taken here, while the GPU still works through the aggregate's tensor code and inner commitments queued above, together with
+    // the host tables derived from them (powers of s, powers of s2 at the queried positions): the GPU never waits for the host later.
     std::vector<uint32_t> qc(queries), qr(queries); std::vector<uint64_t> Iv(queries);
     for (int q = 0; q < queries; q++) { qc[q] = (uint32_t)(rand() % (long)cols); qr[q] = (uint32_t)(rand() % (long)rows2); Iv[q] = qc[q] + cols * (uint64_t)qr[q]; }
-    if (o->cols) memcpy(o->cols, qc.data(), 4 * (size_t)queries);
-    if (o->rows) memcpy(o->rows, qr.data(), 4 * (size_t)queries);
-    if (c && o->reply) HB_TRY(hobbit_commitment_gather(ctx, c, qr.data(), qc.data(), (size_t)queries, o->reply));
-    if (c && o->paths) HB_TRY(hobbit_commitment_paths(ctx, c, qc.data(), qr.data(), (size_t)queries, o->paths));
-    tr.mark("queries+gather+paths");
-    // recursive_prover_Spielman: s powers (:293-297), aggr_c = [M' | C] . s (:298-309)
     std::vector<F> sv(cols);
     sv[0] = fmake((uint64_t)random()); o->scalars[1] = *reinterpret_cast<hobbit_F *>(&sv[0]);
-    for (size_t i = 1; i < cols; i++) sv[i] = fmul(sv[i - 1], sv[0]);
-    HB_CHECK(ctx, hipMemcpyAsync(d_s, sv.data(), cols * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
-    HB_TRY(launch_matvec_rows(ctx, BIG, rows2, cols, d_s, d_ac));
-    // P1 = prove_linear_code(aggr_c, trs) with r1 = generate_randomness(log2 2trs) (:310; src/sumcheck.cpp:3223-3235)
     std::vector<F> r1(R1);
     { F cst = fmake(0); for (int i = 0; i < R1; i++) { if (i % 100 == 0) cst = fmake((uint64_t)random()); r1[i] = fadd(cst, fmake((uint64_t)rand())); } }
+    const F s2 = fmake((uint64_t)random()); o->scalars[2] = *reinterpret_cast<const hobbit_F *>(&s2);
+    const F a = fmake((uint64_t)random()); o->scalars[3] = *reinterpret_cast<const hobbit_F *>(&a);
+    if (o->cols) memcpy(o->cols, qc.data(), 4 * (size_t)queries);
+    if (o->rows) memcpy(o->rows, qr.data(), 4 * (size_t)queries);
+    if (c && o->reply) HB_TRY(hobbit_commitment_gather(ctx, c, qr.data(), qc.data(), (size_t)queries, o->reply));     // replies (:291-305)
+    if (c && o->paths) HB_TRY(hobbit_commitment_paths(ctx, c, qc.data(), qr.data(), (size_t)queries, o->paths));      // Merkle paths (:645-647)
+    for (size_t i = 1; i < cols; i++) sv[i] = fmul(sv[i - 1], sv[0]);                                                   // s powers (:293-297)
+    HB_TRY(h2d_staged(ctx, d_s, sv.data(), cols * sizeof(F)));
+    {   // buff2: s2 powers at the queried positions, last write wins (:331-336)
+        std::map<uint64_t, F> last; F pw = s2;
+        for (int q = 0; q < queries; q++) { last[Iv[q]] = pw; pw = fmul(pw, s2); }
+        std::vector<uint64_t> idx; std::vector<F> val;
+        for (auto &kv : last) { idx.push_back(kv.first); val.push_back(kv.second); }
+        HB_TRY(launch_zero(ctx, d_b, big * sizeof(F)));
+        F *tmpv = d_b1 + rows2; uint64_t *tmpi = reinterpret_cast<uint64_t *>(tmpv + queries + 1);      // arena tail
+        HB_TRY(h2d_staged(ctx, tmpv, val.data(), val.size() * sizeof(F)));
+        HB_TRY(h2d_staged(ctx, tmpi, idx.data(), idx.size() * 8));
+        HB_TRY(launch_scatter(ctx, tmpi, tmpv, idx.size(), d_b));
+    }
+    tr.mark("queries+gather+paths, host tables");
+    // recursive_prover_Spielman: aggr_c = [M' | C] . s (:298-309)
+    HB_TRY(launch_matvec_rows(ctx, BIG, rows2, cols, d_s, d_ac));
+    // P1 = prove_linear_code(aggr_c, trs) with r1 = generate_randomness(log2 2trs) (:310; src/sumcheck.cpp:3223-3235)
     hobbit_F *Q = o->qpoly, *Rr = o->r;
     HB_TRY(hobbit_prove_linear_code(ctx, reinterpret_cast<hobbit_F *>(d_ac), rows2, trs, reinterpret_cast<hobbit_F *>(r1.data()), Q, Rr, o->vr, o->fin));
     const hobbit_F *r_p1 = Rr; const hobbit_F *q_p1 = Q; (void)q_p1;
@@ -1829,30 +1882,13 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     { F c2 = fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])); o->checks[0] = feq(c2, cF(o->vr)[1]); }       // "Error recursion 1" (:323-326)
     Q += 3 * logc; Rr += logc;
     tr.mark("evals, P2");
-    // buff2: s2 powers at the queried positions, last write wins (:331-336); P3 (:339)
-    const F s2 = fmake((uint64_t)random()); o->scalars[2] = *reinterpret_cast<const hobbit_F *>(&s2);
-    {
-        std::map<uint64_t, F> last; F pw = s2;
-        for (int q = 0; q < queries; q++) { last[Iv[q]] = pw; pw = fmul(pw, s2); }
-        std::vector<uint64_t> idx; std::vector<F> val;
-        for (auto &kv : last) { idx.push_back(kv.first); val.push_back(kv.second); }
-        HB_TRY(launch_zero(ctx, d_b, big * sizeof(F)));
-        // staged through the pinned buffer into the arena tail (no hipMalloc / hipFree on the hot path)
-        F *tmpv = d_b1 + rows2; uint64_t *tmpi = reinterpret_cast<uint64_t *>(tmpv + queries + 1);
-        uint8_t *pin; HB_TRY(ctx->pinned((size_t)queries * (sizeof(F) + 8) + 64, (void **)&pin));   // sized by the query count, not by the distinct positions
-        memcpy(pin, val.data(), val.size() * sizeof(F)); memcpy(pin + val.size() * sizeof(F), idx.data(), idx.size() * 8);
-        HB_CHECK(ctx, hipMemcpyAsync(tmpv, pin, val.size() * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
-        HB_CHECK(ctx, hipMemcpyAsync(tmpi, pin + val.size() * sizeof(F), idx.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-        int rc = launch_scatter(ctx, tmpi, tmpv, idx.size(), d_b);
-        if (rc) return rc;                                     // (the staging buffer is next written by _whir_prove, many synchronisations later)
-    }
+    // P3 (:339) against buff2 (built above)
     hobbit_F p121 = {121, 0};
     HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(BIG), reinterpret_cast<hobbit_F *>(d_b), big, &p121, Q, Rr, o->vr + 4, o->fin + 2));
     const hobbit_F *r_p3 = Rr;
     Q += 3 * R3; Rr += R3;
     tr.mark("buff2, P3");
     // a, beta(P2.r | P1.r) + a * beta(P3.r) (:342-349); P4 against [M' | C] (:362); "Error recursion 2" (:364-367)
-    const F a = fmake((uint64_t)random()); o->scalars[3] = *reinterpret_cast<const hobbit_F *>(&a);
     std::vector<hobbit_F> rcat(R3);
     memcpy(rcat.data(), r_p2, sizeof(hobbit_F) * logc); memcpy(rcat.data() + logc, r_p1, sizeof(hobbit_F) * R1);
     HB_TRY(launch_eq_pair_axpy(ctx, cF(rcat.data()), cF(r_p3), R3, a, d_bb, d_b));      // d_b = beta(r) + a * beta(P3.r), d_bb: scratch
@@ -1869,7 +1905,7 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     HB_TRY(hobbit_prove_fft_matrix(ctx, reinterpret_cast<hobbit_F *>(d_aggr), (size_t)trs, cols / 2, r_p4, Q, Rr, o->vr + 8, o->fin + 4));
     { const HF *q5 = cF(Q); F c5 = fadd(fadd(q5[0], q5[1]), fadd(q5[2], q5[2])); o->checks[2] = feq(c5, y1); }
     tr.mark("y1, P5");   // src/sumcheck.cpp:3016-3019
-    if (!full) return 0;
+    if (!full) return sc.finish();
     // shockwave_prove(C_c, P4.r minus its last entry) (src/PC_utils.cpp:368) -- in the reference it runs before P5; P5 draws nothing
     // from libc, so running it here leaves every draw where the reference has it
     HB_TRY(hobbit_shockwave_prove(ctx, reinterpret_cast<hobbit_F *>(C), reinterpret_cast<hobbit_F *>(encc), lvc, nc_el, 32, r_p4, R3 - 1, o->sp_c));
@@ -1880,7 +1916,7 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     HB_TRY(hobbit_shockwave_prove(ctx, reinterpret_cast<hobbit_F *>(d_aggr), reinterpret_cast<hobbit_F *>(encf), lvf, M, 32, x5.data(), (int)x5.size() - 1, o->sp_f));
     tr.mark("shockwave_prove C_f");
     if (tr.on) fprintf(stderr, "[hobbit open] scratch at exit:  ws %zu ws2 %zu ws3 %zu ws4 %zu pin %zu\n", ctx->ws_bytes, ctx->ws2_bytes, ctx->ws3_bytes, ctx->ws4_bytes, ctx->pin_bytes);
-    return 0;
+    return sc.finish();
 }
 int hobbit_open_core(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const hobbit_F *h_x, int queries, hobbit_open_out *o) {
     if (!c) return ctx->fail(HOBBIT_EINVAL, "open_core: null commitment");

@@ -101,6 +101,19 @@ struct hobbit_ctx {
         }
         *p = pin; return 0;
     }
+    // Pinned staging arena of the open path.  hipMemcpyAsync to or from PAGEABLE host memory is not asynchronous on this runtime: a
+    // device-to-host copy into a caller's buffer first waits for everything queued on the stream (rocprofv3: 100-170 us of GPU idle time
+    // after every such copy, 2 ms per open).  So host inputs are copied here and uploaded from here, results land here and reach the
+    // caller's buffers (`deferred`) after the closing synchronisation of the outermost library call (`stage_depth`).
+    uint8_t *stage = nullptr; size_t stage_cap = 0, stage_off = 0; int stage_depth = 0;
+    struct Deferred { void *dst; const void *src; size_t bytes; };
+    std::vector<Deferred> deferred;
+    void *stage_alloc(size_t bytes) {
+        if (!stage) { if (hipHostMalloc((void **)&stage, (size_t)24 << 20) != hipSuccess) { stage = nullptr; return nullptr; } stage_cap = (size_t)24 << 20; }
+        const size_t a = (stage_off + 63) & ~(size_t)63;
+        if (a + bytes > stage_cap) return nullptr;
+        stage_off = a + bytes; return stage + a;
+    }
     // pinned, device-visible buffer for small per-launch constant tables (read in place by kernels)
     void *pinc = nullptr; size_t pinc_bytes = 0;
     int pinned_const(size_t bytes, void **p) {
