@@ -82,7 +82,7 @@ inline F root_of_unity(int logn) { F r = fmake(2147483648ULL, 103332177126900268
 
 // MiMC transcript hash (src/mimc.cpp:95-107; constants Common[i] = F(i), src/mimc.cpp:11-19):
 // 161 rounds t <- (h + k + c_{i-1})^3 (round 0: t = x + k), result h + k.  Strictly sequential.
-HB_HD F mimc_hash(const F &x, const F &k) {
+HB_HD F mimc_hash_plain(const F &x, const F &k) {
     F h = fmake(0), t;
     for (int i = 0; i < 161; i++) {
         t = i == 0 ? fadd(x, k) : fadd(fadd(h, k), fmake((uint64_t)(i - 1)));
@@ -90,5 +90,35 @@ HB_HD F mimc_hash(const F &x, const F &k) {
     }
     return fadd(h, k);
 }
+#if !defined(__HIP_DEVICE_COMPILE__)
+// The host runs ~520 of these per open, one after the other, each on the critical path of a sumcheck round (the GPU waits for the
+// challenge).  Same function with lazy reductions: values ride as any residue below 2^62 + 8, the square uses
+// (a + b)(a - b) + 2ab i (two products instead of three), folds replace the conditional subtractions, and the result is made
+// canonical once at the end.  Exact integer arithmetic mod p throughout, so the output equals mimc_hash_plain's bit for bit
+// (tests/test_abi.py checks 20 000 inputs incl. the edge set against the oracle).
+static inline uint64_t lz_fold(uint64_t s) { return (s & P61) + (s >> 61); }                       // any u64 -> < 2^61 + 8, same residue
+static inline uint64_t lz_red(u128 x) {                                                             // x < 2^128 -> < 2^62 + 2^6, same residue
+    const uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+    return (lo & P61) + (((hi << 3) | (lo >> 61)) & P61) + (hi >> 58);
+}
+inline F mimc_hash(const F &x, const F &k) {
+    uint64_t hr = 0, hi_ = 0;                                                                      // h, lazy
+    const uint64_t kr = k.re, ki = k.im;
+    for (int i = 0; i < 161; i++) {
+        // t = h + k + c, folded below 2^61 + 8
+        const uint64_t a = lz_fold(i == 0 ? x.re + kr : hr + kr + (uint64_t)(i - 1)), b = lz_fold(i == 0 ? x.im + ki : hi_ + ki);
+        // t^2 = (a + b)(a - b) + 2ab i ; a - b taken as a + 2p - b > 0 (b < 2p)
+        const uint64_t sr = lz_red((u128)(a + b) * (a + 2 * P61 - b)), si = lz_red(((u128)a * b) << 1);     // < 2^62 + 2^6
+        // t^3 = t^2 t, Karatsuba; C = 4p 2^62 >= bd keeps the real part non-negative (ac + C < 2^127)
+        const u128 ac = (u128)sr * a, bd = (u128)si * b, all = (u128)(sr + si) * (a + b);
+        hr = lz_red(ac + ((((u128)P61) << 64)) - bd);
+        hi_ = lz_red(all - ac - bd);
+    }
+    const uint64_t r = lz_fold(lz_fold(hr + kr)), m = lz_fold(lz_fold(hi_ + ki));                  // <= p + small
+    return fmake(r >= P61 ? r - P61 : r, m >= P61 ? m - P61 : m);
+}
+#else
+HB_HD F mimc_hash(const F &x, const F &k) { return mimc_hash_plain(x, k); }
+#endif
 
 }  // namespace hobbit

@@ -57,3 +57,20 @@ def test_host_helpers_match_oracle(mod, oracle):
         r = np.zeros(2, np.uint64)
         lib.hobbit_mimc(a[i].ctypes.data_as(ctypes.c_void_p), b[i].ctypes.data_as(ctypes.c_void_p), r.ctypes.data_as(ctypes.c_void_p))
         assert np.array_equal(r, want[i])
+
+
+def test_host_mimc_lazy_reduction_matches_oracle(mod, oracle):
+    """hobbit_mimc runs with lazy reductions (csrc/hobbit_field.hpp): every combination of the edge values and 20 000 full-range inputs
+    against the oracle's plain restatement, which is pinned by the reference's own outputs (tests/golden/mimc.npz)"""
+    import itertools
+    from oracle.pyoracle import splitmix_field, P
+    lib = mod.load_library()
+    edge = [0, 1, 2, P - 1, P - 2, 1 << 60]
+    xs = np.array([[a, b] for a, b in itertools.product(edge, edge)], np.uint64)
+    X = np.concatenate([np.repeat(xs, len(xs), axis=0), splitmix_field(20000, 31)])
+    K = np.concatenate([np.tile(xs, (len(xs), 1)), splitmix_field(20000, 32)])
+    want = oracle.mimc(X, K)
+    got = np.zeros_like(X)
+    for i in range(X.shape[0]):
+        lib.hobbit_mimc(X[i].ctypes.data_as(ctypes.c_void_p), K[i].ctypes.data_as(ctypes.c_void_p), got[i].ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(got, want)
