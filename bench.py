@@ -325,6 +325,8 @@ def main():
             "op_counts": {"f_mul": mul, "f_add": add, "blake3_compress": comp, "expander_edges": edges, "open_f_mul": omul, "open_f_add": oadd},
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items())},
             "kernels_ms_extra_profiled_step": {k: v[0] for k, v in sorted(prof_full.items())},
+            "launches_extra_profiled_step": {"total": int(sum(v[1] for v in prof_full.values())),
+                                             "open": int(sum(v[1] for k, v in prof_full.items() if not (k.startswith("k_leaf_chain") or k in ("k_fft4096", "k_transpose", "k_encode_A", "k_encode_B", "k_encode", "k_merkle_level", "k_merkle_top"))))},
             "roofline": {"bound": KERNEL_BOUND.get(dom, "hbm"), "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(dom, args.logn, K)[0], "traffic_source": measured_traffic(dom, args.logn, K)[1],
                          "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": dom_ms, "note": ROOFLINE_NOTES.get(dom, "")},

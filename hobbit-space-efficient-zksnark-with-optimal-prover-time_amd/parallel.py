@@ -135,7 +135,15 @@ def sharded_open(ops, dist, plan, rank, commit_res, x, queries=5900):
     else:
         parts = [partial]
     aggr = ops.sum_vectors(parts)
-    # 3. the rest of the open, replicated
+    # 3. the rest of the open, replicated.  Its challenges and queries are libc draws, so every rank must hold the same generator state:
+    #    rank 0 draws one value, everybody seeds with it (whatever a rank's runtime, RCCL or loader drew from libc before is forgotten)
+    if G > 1:
+        import ctypes
+        libc = ctypes.CDLL(None); libc.random.restype = ctypes.c_long
+        seed = torch.tensor([libc.random() if rank == 0 else 0], dtype=torch.int64, device=ops.device)
+        dist.broadcast(seed, 0)
+        ops.after_collective()
+        libc.srandom(ctypes.c_uint(int(seed.item()) & 0xFFFFFFFF))
     res = ops.open_from_aggregate(aggr, plan, queries)
     cols = np.asarray(res["cols"], np.int64); rows = np.asarray(res["rows"], np.int64)
     if G > 1:

@@ -213,7 +213,9 @@ def test_sharded_open_matches_single_process(oracle):
     oracle.rng_reset(); poly = oracle.generate_randomness(N); oracle.expander_init_store(trs)
     lv, T = oracle.commit_standard(poly, K, trs, 1, want_tensor=True)
     x = oracle.generate_randomness(N.bit_length() - 1)
-    ctypes.CDLL(None).srandom(2024)
+    libc = ctypes.CDLL(None); libc.random.restype = ctypes.c_long
+    libc.srandom(2024)
+    libc.srandom(ctypes.c_uint(libc.random() & 0xFFFFFFFF))            # sharded_open re-seeds every rank with one value drawn by rank 0
     want = oracle.open_standard(poly, K, trs, x, queries, tensor=T)
     M = N // K
     for g in got:
