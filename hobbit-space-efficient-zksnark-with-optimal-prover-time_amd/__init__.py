@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "hobbit_elastic_open_begin", "hobbit_elastic_open_aggregate_push", "hobbit_elastic_open_aggregate_finish", "hobbit_elastic_open_reply_push",
     "hobbit_elastic_open_finish", "hobbit_elastic_open_free", "hobbit_generate_randomness",
     "hobbit_read_mul_tree_layer", "hobbit_read_mul_tree_data", "hobbit_generate_claims_opt", "hobbit_sumcheck3_stream_batch", "hobbit_mul_tree_stream_shallow",
-    "hobbit_gate_consistency_stream",
+    "hobbit_gate_consistency_stream", "hobbit_set_lookups", "hobbit_gate_consistency_lookups_stream",
     "hobbit_tensorcode_chunks", "hobbit_inner_digests", "hobbit_chain_digests", "hobbit_blake3_64_host",
     "hobbit_parity_matrix", "hobbit_phi_g", "hobbit_prepare_matrix_cols", "hobbit_prove_linear_code", "hobbit_prove_fft",
     "hobbit_prove_fft_matrix",
@@ -105,6 +105,7 @@ def load_library(path=LIB_PATH):
         "hobbit_read_mul_tree_layer": [V, V, V, S, I, V], "hobbit_read_mul_tree_data": [V, V, V, S, I, I, I, V],
         "hobbit_generate_claims_opt": [V, V, V, S, S, V, I, I, I, I, V], "hobbit_sumcheck3_stream_batch": [V, V, V, S, S, V, I, I, I, I, V, I, V],
         "hobbit_mul_tree_stream_shallow": [V, V, V, S, S, I, S, V, I, V, I, V], "hobbit_gate_consistency_stream": [V, V, V, S, S, V, V],
+        "hobbit_set_lookups": [V, I, V], "hobbit_gate_consistency_lookups_stream": [V, V, V, S, S, V, V],
         "hobbit_tensorcode_chunks": [V, V, S, I, I, I, V], "hobbit_inner_digests": [V, V, S, I, I, V],
         "hobbit_chain_digests": [V, V, S, I, S, V], "hobbit_blake3_64_host": [V, V, S],
     }
@@ -880,6 +881,35 @@ class Hobbit:
             _fields_ = [(n, c_vp) for n in names]
         go = GO(*[out[k].ctypes.data for k in names])
         self._chk(self.lib.hobbit_gate_consistency_stream(self.ctx, ctypes.cast(tsrc, c_vp), None, n_chunks, B, _hp(r), ctypes.byref(go)))
+        return out
+
+    def set_lookups(self, lookup_rand):
+        """the reference's has_lookups / lookup_rand globals (src/main.cpp:67,70); None switches the lookup gate maps off"""
+        if lookup_rand is None:
+            self._chk(self.lib.hobbit_set_lookups(self.ctx, 0, None))
+        else:
+            lr = Fh(lookup_rand).reshape(-1, 2)[:2].copy()
+            self._chk(self.lib.hobbit_set_lookups(self.ctx, 1, _hp(lr)))
+
+    def gate_consistency_lookups_stream(self, tsrc, n_chunks, B, r, lookup_rand):
+        """prove_gate_consistency_lookups (src/sumcheck.cpp:503-795) over a trace source; sets has_lookups for the call and clears it after
+        (lookup_rand None: leaves the flag as it is -- the library refuses to run with it unset)"""
+        r = Fh(r).reshape(-1, 2); logB = B.bit_length() - 1; lR = n_chunks.bit_length() - 1
+        out = dict(R=np.zeros((n_chunks, 2), np.uint64), a=np.zeros((5, 2), np.uint64), poly=np.zeros((logB, 5, 2), np.uint64), gr=np.zeros((logB, 2), np.uint64),
+                   fin9=np.zeros((9, 2), np.uint64), Peval=np.zeros((8, n_chunks, 2), np.uint64), b=np.zeros((8, 2), np.uint64), q2=np.zeros((lR, 3, 2), np.uint64),
+                   r2=np.zeros((lR, 2), np.uint64), vr2=np.zeros((2, 2), np.uint64), fin2=np.zeros(2, np.uint64), checks=np.zeros(5, np.int32))
+        names = ("R", "a", "poly", "gr", "fin9", "Peval", "b", "q2", "r2", "vr2", "fin2", "checks")
+
+        class GO(ctypes.Structure):
+            _fields_ = [(n, c_vp) for n in names]
+        go = GO(*[out[k].ctypes.data for k in names])
+        if lookup_rand is not None:
+            self.set_lookups(lookup_rand)
+        try:
+            self._chk(self.lib.hobbit_gate_consistency_lookups_stream(self.ctx, ctypes.cast(tsrc, c_vp), None, n_chunks, B, _hp(r), ctypes.byref(go)))
+        finally:
+            if lookup_rand is not None:
+                self.set_lookups(None)
         return out
 
     def elastic_commit(self, N, B, opt, gcc_arg_order=1, chunk=None, keep_levels=False):

@@ -1749,6 +1749,120 @@ int hobbit_gate_consistency_stream(hobbit_ctx *ctx, hobbit_trace_source source, 
     return 0;
 }
 
+// has_lookups / lookup_rand (src/main.cpp:67,70,888,910): switches compute{3,4}p_error_terms to their lookup gate maps
+int hobbit_set_lookups(hobbit_ctx *ctx, int on, const hobbit_F *h_lookup_rand) {
+    if (on && !h_lookup_rand) return ctx->fail(HOBBIT_EINVAL, "set_lookups: lookup_rand[0..1] needed");
+    ctx->has_lookups = on != 0;
+    if (on) { ctx->lookup_rand[0] = cF(h_lookup_rand)[0]; ctx->lookup_rand[1] = cF(h_lookup_rand)[1]; }
+    return 0;
+}
+// prove_gate_consistency_lookups (src/sumcheck.cpp:503-795) over a caller-supplied trace source; selectors 0 add, 1 mul, 2 lookup
+int hobbit_gate_consistency_lookups_stream(hobbit_ctx *ctx, hobbit_trace_source source, void *user, size_t n_chunks, size_t B, const hobbit_F *h_r, hobbit_gate_lkp_stream_out *o) {
+    const int logB = ilog2_exact(B), lR = ilog2_exact(n_chunks);
+    if (!o || !source || logB < 1 || lR < 1) return ctx->fail(HOBBIT_EINVAL, "gate_consistency_lookups_stream: BUFFER_SPACE and the chunk count must be powers of two, chunks >= 2");
+    if (!ctx->has_lookups) return ctx->fail(HOBBIT_EINVAL, "gate_consistency_lookups_stream: has_lookups is not set (hobbit_set_lookups)");
+    auto next = [&](size_t n, const F **L, const F **R, const F **O, const int32_t **S) -> int {
+        const hobbit_F *l = nullptr, *r = nullptr, *oo = nullptr; const int32_t *s = nullptr;
+        if (source(user, n, &l, &r, &oo, &s) != 0 || (n && (!l || !r || !oo || !s))) return ctx->fail(HOBBIT_EINVAL, "trace source failed");
+        *L = cF(l); *R = cF(r); *O = cF(oo); *S = s; return 0;
+    };
+    enum { AL, AR, TL, TR, TO, LK, LO, MU, BE };
+    const F *bL, *bR, *bO; const int32_t *bS;
+    const size_t nres = 8 * n_chunks + 16;
+    F *base; HB_TRY(ctx->workspace4((13 * B + 1024 + nres + 2 * n_chunks + 64) * sizeof(F), (void **)&base));
+    F *t[9]; for (int q = 0; q < 9; q++) t[q] = base + (size_t)q * B;
+    F *beta = base + 9 * B, *blo = beta + B, *tmp = blo + B, *si = tmp + B, *part = si + B, *dres = part + 1024, *dR = dres + nres;
+    int32_t *s2 = reinterpret_cast<int32_t *>(si), *s3 = s2 + B;                          // 2 B int32 <= B F
+    const F one = fmake(1);
+    HB_TRY(hobbit_eq_table(ctx, h_r, logB, reinterpret_cast<hobbit_F *>(beta)));
+    HB_TRY(launch_copy(ctx, t[BE], beta, B * sizeof(F)));
+    HB_TRY(next(0, &bL, &bR, &bO, &bS));
+    HB_TRY(next(B, &bL, &bR, &bO, &bS));
+    HB_TRY(launch_copy(ctx, t[TL], bL, B * sizeof(F)));
+    HB_TRY(launch_copy(ctx, t[TR], bR, B * sizeof(F)));
+    HB_TRY(launch_copy(ctx, t[TO], bO, B * sizeof(F)));
+    // the selector tables of chunk 0 (:519-537) = one selector fold with rand = 1 over zeroed tables
+    HB_TRY(launch_zero(ctx, t[AL], B * sizeof(F))); HB_TRY(launch_zero(ctx, t[AR], B * sizeof(F))); HB_TRY(launch_zero(ctx, t[LK], B * sizeof(F))); HB_TRY(launch_zero(ctx, t[MU], B * sizeof(F)));
+    HB_TRY(launch_lkp_sel_fold(ctx, bS, one, t[AL], t[AR], t[LK], t[MU], B));
+    HB_TRY(launch_lkp_prepare(ctx, bS, bL, bR, bO, nullptr, nullptr, t[LO], B));
+    // Kf_O, Kf_L, Kf_R, Kf_lkp, Kf_M (:541-548)
+    HB_TRY(launch_dot_gen(ctx, beta, t[TO], 1, nullptr, B, part, dres));
+    HB_TRY(launch_dot_gen(ctx, beta, t[TL], 1, t[AL], B, part, dres + 1));
+    HB_TRY(launch_dot_gen(ctx, beta, t[TR], 1, t[AR], B, part, dres + 2));
+    HB_TRY(launch_dot_gen(ctx, beta, t[LO], 1, t[LK], B, part, dres + 3));
+    HB_TRY(launch_f_binop(ctx, 2, t[TR], t[TL], tmp, B));
+    HB_TRY(launch_dot_gen(ctx, beta, tmp, 1, t[MU], B, part, dres + 4));
+    F K0[5]; HB_TRY(hobbit_memcpy_d2h(ctx, K0, dres, 5 * sizeof(F)));
+    F KO = K0[0], KL = K0[1], KR = K0[2], KK = K0[3], KM = K0[4], rnd = fmake(0);
+    o->checks[0] = feq(fsub(fsub(fadd(fadd(KM, KL), KR), KK), KO), fmake(0)) ? 1 : 0;   // (:549-552: the reference exits)
+    o->checks[3] = 1;
+    std::vector<F> R; R.push_back(fmake(1));
+    for (size_t c = 1; c < n_chunks; c++) {
+        HB_TRY(next(B, &bL, &bR, &bO, &bS));
+        HB_TRY(launch_lkp_prepare(ctx, bS, bL, bR, bO, s2, s3, blo, B));
+        F k2[4], kl[4], kr[4], kk[4], k4[4];
+        { const F *tt[8] = {bO, beta, t[TO], t[BE], nullptr, nullptr, nullptr, nullptr}; HB_TRY(launch_err_terms(ctx, 2, tt, nullptr, B, k2)); }
+        { const F *tt[8] = {bL, t[TL], t[AL], t[BE], beta, nullptr, nullptr, nullptr}; HB_TRY(launch_err_terms(ctx, 3, tt, bS, B, kl)); }
+        { const F *tt[8] = {bR, t[TR], t[AR], t[BE], beta, nullptr, nullptr, nullptr}; HB_TRY(launch_err_terms(ctx, 3, tt, s2, B, kr)); }
+        { const F *tt[8] = {blo, t[LO], t[LK], t[BE], beta, nullptr, nullptr, nullptr}; HB_TRY(launch_err_terms(ctx, 3, tt, s3, B, kk)); }
+        { const F *tt[8] = {bL, bR, beta, t[TL], t[TR], t[BE], t[MU], nullptr}; HB_TRY(launch_err_terms(ctx, 4, tt, bS, B, k4)); }     // gate = [s == 1]: 2 and the reference's 4 agree
+        if (!feq(fsub(fsub(fadd(fadd(k4[3], kl[2]), kr[2]), kk[2]), k2[1]), fmake(0))) o->checks[0] = 0;                                  // "Error in gate consistency 1" (:588-591)
+        rnd = mimc_hash(k2[0], rnd); rnd = mimc_hash(k2[1], rnd);                                                                          // lookup and mul terms are NOT hashed (:593-600)
+        rnd = mimc_hash(kl[0], rnd); rnd = mimc_hash(kl[1], rnd); rnd = mimc_hash(kl[2], rnd);
+        rnd = mimc_hash(kr[0], rnd); rnd = mimc_hash(kr[1], rnd); rnd = mimc_hash(kr[2], rnd);
+        R.push_back(rnd);
+        const F x1 = rnd, x2 = fmul(rnd, x1), x3 = fmul(rnd, x2), x4 = fmul(rnd, x3);
+        KO = fadd(KO, fadd(fmul(x1, k2[0]), fmul(x2, k2[1])));
+        KK = fadd(KK, fadd(fadd(fmul(x1, kk[0]), fmul(x2, kk[1])), fmul(x3, kk[2])));
+        KL = fadd(KL, fadd(fadd(fmul(x1, kl[0]), fmul(x2, kl[1])), fmul(x3, kl[2])));
+        KR = fadd(KR, fadd(fadd(fmul(x1, kr[0]), fmul(x2, kr[1])), fmul(x3, kr[2])));
+        KM = fadd(KM, fadd(fadd(fmul(x1, k4[0]), fmul(x2, k4[1])), fadd(fmul(x3, k4[2]), fmul(x4, k4[3]))));
+        HB_TRY(launch_lkp_sel_fold(ctx, bS, rnd, t[AL], t[AR], t[LK], t[MU], B));                                                           // (:611-630)
+        HB_TRY(launch_axpy(ctx, t[TL], bL, rnd, B)); HB_TRY(launch_axpy(ctx, t[TR], bR, rnd, B)); HB_TRY(launch_axpy(ctx, t[TO], bO, rnd, B));
+        HB_TRY(launch_axpy(ctx, t[LO], blo, rnd, B)); HB_TRY(launch_axpy(ctx, t[BE], beta, rnd, B));
+        // the reference's per-chunk self-check  sum fold_beta fold_mul fold_R fold_L == Kf_M  (:632-641)
+        HB_TRY(launch_f_binop(ctx, 2, t[TR], t[TL], tmp, B));
+        HB_TRY(launch_dot_gen(ctx, t[BE], tmp, 1, t[MU], B, part, dres));
+        F sM; HB_TRY(hobbit_memcpy_d2h(ctx, &sM, dres, sizeof(F)));
+        if (!feq(sM, KM)) o->checks[3] = 0;
+    }
+    HB_TRY(next(0, &bL, &bR, &bO, &bS));                                                 // reset_stream(tr) (:643)
+    memcpy(o->R, R.data(), n_chunks * sizeof(F));
+    F a[5]; { F cst = fmake(0); for (int i = 0; i < 5; i++) { if (i % 100 == 0) cst = fmake((uint64_t)random()); a[i] = fadd(cst, fmake((uint64_t)rand())); } }      // a = generate_randomness(5)
+    memcpy(o->a, a, sizeof a);
+    { HB_TRY(launch_dot_gen(ctx, t[BE], t[LO], 1, t[LK], B, part, dres)); F sK; HB_TRY(hobbit_memcpy_d2h(ctx, &sK, dres, sizeof(F))); o->checks[4] = feq(sK, KK) ? 1 : 0; }   // (:646-652)
+    F sum = fadd(fadd(fadd(fmul(a[0], KL), fmul(a[1], KR)), fadd(fmul(a[2], KM), fmul(KO, a[3]))), fmul(KK, a[4]));
+    int chk2 = 0;
+    HB_TRY(launch_gate_lkp_sumcheck(ctx, t, B, a, &rnd, &sum, mF(o->poly), mF(o->gr), mF(o->fin9), &chk2));
+    o->checks[1] = chk2;
+    // Peval pass (:736-764): beta1 over the sumcheck challenges; the selector columns as field tables through the same selector fold
+    HB_TRY(hobbit_eq_table(ctx, o->gr, logB, reinterpret_cast<hobbit_F *>(tmp)));
+    for (size_t c = 0; c < n_chunks; c++) {
+        HB_TRY(next(B, &bL, &bR, &bO, &bS));
+        HB_TRY(launch_zero(ctx, t[AL], B * sizeof(F))); HB_TRY(launch_zero(ctx, t[AR], B * sizeof(F))); HB_TRY(launch_zero(ctx, t[LK], B * sizeof(F))); HB_TRY(launch_zero(ctx, t[MU], B * sizeof(F)));
+        HB_TRY(launch_lkp_sel_fold(ctx, bS, one, t[AL], t[AR], t[LK], t[MU], B));
+        HB_TRY(launch_lkp_prepare(ctx, bS, bL, bR, bO, nullptr, nullptr, blo, B));
+        const F *cols[8] = {bL, bR, bO, t[AL], t[AR], t[MU], t[LK], blo};
+        for (int q = 0; q < 8; q++) HB_TRY(launch_dot_gen(ctx, tmp, cols[q], 1, nullptr, B, part, dres + (size_t)q * n_chunks + c));
+    }
+    HB_TRY(hobbit_memcpy_d2h(ctx, o->Peval, dres, 8 * n_chunks * sizeof(F)));
+    F b[8]; { F cst = fmake(0); for (int i = 0; i < 8; i++) { if (i % 100 == 0) cst = fmake((uint64_t)random()); b[i] = fadd(cst, fmake((uint64_t)rand())); } }      // b = generate_randomness(8)
+    memcpy(o->b, b, sizeof b);
+    std::vector<F> pe(n_chunks, fmake(0));
+    for (size_t j = 0; j < n_chunks; j++) for (int i = 0; i < 8; i++) pe[j] = fadd(pe[j], fmul(b[i], cF(o->Peval)[(size_t)i * n_chunks + j]));
+    HB_TRY(hobbit_memcpy_h2d(ctx, dR, R.data(), n_chunks * sizeof(F)));
+    HB_TRY(hobbit_memcpy_h2d(ctx, dR + n_chunks, pe.data(), n_chunks * sizeof(F)));
+    HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(dR), reinterpret_cast<hobbit_F *>(dR + n_chunks), n_chunks, reinterpret_cast<hobbit_F *>(&rnd), o->q2, o->r2, o->vr2, o->fin2));
+    {   // "Error in gate consistency 3" (:783-789)
+        const HF *f9 = cF(o->fin9), *q2 = cF(o->q2);
+        F sm = fadd(fadd(fmul(f9[TL], b[0]), fmul(f9[TR], b[1])), fmul(f9[TO], b[2]));
+        sm = fadd(sm, fmul(b[3], f9[AL])); sm = fadd(sm, fmul(b[4], f9[AR])); sm = fadd(sm, fmul(b[5], f9[MU]));
+        sm = fadd(sm, fmul(b[6], f9[LK])); sm = fadd(sm, fmul(b[7], f9[LO]));
+        o->checks[2] = feq(fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])), sm);
+    }
+    return 0;
+}
+
 // ---- Our_PC open without the inner shockwave/WHIR PCS -------------------------------------------
 // open_standard (src/Our_PC.cpp:604-661) + recursive_prover_Spielman (src/PC_utils.cpp:271-385) minus
 // shockwave_commit / shockwave_prove.  Host: libc draws in the reference's order, the transcript,

@@ -79,6 +79,8 @@ struct hobbit_ctx {
     // graphs
     std::map<std::pair<int, int>, hobbit::HostGraph> graphs;   // (dep, kind)
     hobbit::DeviceCode code;
+    // the reference's globals has_lookups / lookup_rand[0..1] (src/main.cpp:67,70), set through hobbit_set_lookups
+    bool has_lookups = false; hobbit::F lookup_rand[2];
     // scratch
     void *ws = nullptr; size_t ws_bytes = 0;
     // second scratch: the row-major FFT output of a tensor code before its transpose

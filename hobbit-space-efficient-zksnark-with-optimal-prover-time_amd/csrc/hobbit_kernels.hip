@@ -1649,7 +1649,10 @@ static void sc2_host_tail(std::vector<F> &a, std::vector<F> &b, F &rnd, bool pen
 // ---- streaming-sumcheck error terms (src/sumcheck.cpp:374-432, 1093-1136): fused multi-output dot products --
 // KIND 2: compute2p (b1,b2,f1,f2) -> K1,K2;  KIND 3: compute3p (b1,gate,f1,f2,f3,beta) -> K1..K3;
 // KIND 4: compute4p (b1,b2,b3,gate,f1..f4) -> K1..K4;  KIND 13: one batch of batch_prod (b1,b2,b3,f1,f2,f3) -> K1,K2,K3
-struct ErrArgs { const F *t[8]; const int32_t *gate; };
+struct ErrArgs { const F *t[8]; const int32_t *gate; int lk; F lr0, lr1; };
+// compute3p_error_terms' selector -> gate map when has_lookups is set (src/sumcheck.cpp:413-427): 0 and 4 -> 1, 2 -> lookup_rand[0], 3 -> lookup_rand[1],
+// everything else (1, and the -1 the caller parks addition gates at) -> 0
+__device__ __forceinline__ F lk_gate3(int s, const F &lr0, const F &lr1) { return (s == 0 || s == 4) ? fmake(1) : s == 2 ? lr0 : s == 3 ? lr1 : fmake(0); }
 template <int KIND, int NC>
 __global__ void __launch_bounds__(256) k_err_terms(ErrArgs a, size_t n, F *__restrict__ partials) {
     F K[NC];
@@ -1662,7 +1665,7 @@ __global__ void __launch_bounds__(256) k_err_terms(ErrArgs a, size_t n, F *__res
             K[1] = fadd(K[1], fmul(b1, b2));
         } else if (KIND == 3) {
             const F b1 = ldF(a.t[0] + i), f1 = ldF(a.t[1] + i), f2 = ldF(a.t[2] + i), f3 = ldF(a.t[3] + i), be = ldF(a.t[4] + i);
-            const F gate = fmake((uint64_t)(int64_t)a.gate[i]);
+            const F gate = a.lk ? lk_gate3(a.gate[i], a.lr0, a.lr1) : fmake((uint64_t)(int64_t)a.gate[i]);
             const F t1 = fadd(fmul(b1, f2), fmul(gate, f1)), t2 = fmul(b1, gate);
             K[0] = fadd(K[0], fadd(fmul(f3, t1), fmul(fmul(be, f1), f2)));
             K[1] = fadd(K[1], fadd(fmul(be, t1), fmul(f3, t2)));
@@ -1670,7 +1673,7 @@ __global__ void __launch_bounds__(256) k_err_terms(ErrArgs a, size_t n, F *__res
         } else if (KIND == 4) {
             const F b1 = ldF(a.t[0] + i), b2 = ldF(a.t[1] + i), b3 = ldF(a.t[2] + i), f1 = ldF(a.t[3] + i), f2 = ldF(a.t[4] + i), f3 = ldF(a.t[5] + i),
                     f4 = ldF(a.t[6] + i);
-            const F gate = fsub(fmake(1), fmake((uint64_t)(int64_t)a.gate[i]));
+            const F gate = a.lk ? fmake(a.gate[i] == 1 ? 1 : 0) : fsub(fmake(1), fmake((uint64_t)(int64_t)a.gate[i]));      // (:388-394)
             const F t1 = fadd(fmul(f1, b2), fmul(f2, b1)), t2 = fadd(fmul(f3, gate), fmul(f4, b3));
             const F t3 = fmul(b1, b2), t4 = fmul(gate, b3), t5 = fmul(f1, f2), t6 = fmul(f3, f4);
             K[0] = fadd(K[0], fadd(fmul(t1, t6), fmul(t2, t5)));
@@ -1703,7 +1706,7 @@ static int run_err(hobbit_ctx *ctx, const char *name, const ErrArgs &a, size_t n
     return 0;
 }
 int launch_err_terms(hobbit_ctx *ctx, int kind, const F *const *tables, const int32_t *gate, size_t n, HF *h_K) {
-    ErrArgs a; for (int i = 0; i < 8; i++) a.t[i] = tables[i]; a.gate = gate;
+    ErrArgs a; for (int i = 0; i < 8; i++) a.t[i] = tables[i]; a.gate = gate; a.lk = ctx->has_lookups ? 1 : 0; a.lr0 = ctx->lookup_rand[0]; a.lr1 = ctx->lookup_rand[1];
     if (!n) { int nc = kind == 2 ? 2 : kind == 4 ? 4 : 3; for (int q = 0; q < nc; q++) h_K[q] = fmake(0); return 0; }
     switch (kind) {
         case 2: return run_err<2, 2>(ctx, "k_err2p", a, n, h_K);
@@ -1724,6 +1727,41 @@ __global__ void k_axpy_i32(F *__restrict__ y, const int32_t *__restrict__ sel, F
 int launch_axpy_i32(hobbit_ctx *ctx, F *y, const int32_t *sel, F a, int one_minus, size_t n) {
     if (!n) return 0;
     HB_LAUNCH(ctx, "k_axpy_i32", k_axpy_i32, dim3(grid_for(n, 256)), dim3(256), 0, y, sel, a, one_minus, n);
+    return 0;
+}
+
+// ---- prove_gate_consistency_lookups (src/sumcheck.cpp:503-795) device pieces ---------------------------------------
+// One chunk's selector rewrites (:568-585) and lookup output column: s2 = selectors for the R call (2 -> 3), s3 = for the lookup call
+// (0 -> -1, 2 -> 4), blo = lookup_rand[0] L + lookup_rand[1] R - O on lookup rows, 0 elsewhere.
+__global__ void k_lkp_prepare(const int32_t *__restrict__ S, const F *__restrict__ L, const F *__restrict__ R, const F *__restrict__ O, F lr0, F lr1,
+                              int32_t *__restrict__ s2, int32_t *__restrict__ s3, F *__restrict__ blo, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int s = S[i];
+        const bool lk = s != 0 && s != 1;
+        if (s2) s2[i] = s == 2 ? 3 : s;
+        if (s3) s3[i] = s == 0 ? -1 : s == 2 ? 4 : s;
+        stF(blo + i, lk ? fsub(fadd(fmul(lr0, ldF(L + i)), fmul(lr1, ldF(R + i))), ldF(O + i)) : fmake(0));
+    }
+}
+// the four selector-derived folds (:510-536 with rnd = 1 on zeroed tables, :614-625): add_L += rnd {1, 0, lr0}[s], add_R += rnd {1, 0, lr1}[s],
+// lkp += rnd [s is a lookup], mul += rnd [s == 1]
+__global__ void k_lkp_sel_fold(const int32_t *__restrict__ S, F rnd, F lr0, F lr1, F *__restrict__ aL, F *__restrict__ aR, F *__restrict__ lkp, F *__restrict__ mul, size_t n) {
+    const F rl0 = fmul(rnd, lr0), rl1 = fmul(rnd, lr1);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int s = S[i];
+        if (s == 1) stF(mul + i, fadd(ldF(mul + i), rnd));
+        else if (s == 0) { stF(aL + i, fadd(ldF(aL + i), rnd)); stF(aR + i, fadd(ldF(aR + i), rnd)); }
+        else { stF(lkp + i, fadd(ldF(lkp + i), rnd)); stF(aL + i, fadd(ldF(aL + i), rl0)); stF(aR + i, fadd(ldF(aR + i), rl1)); }
+    }
+}
+int launch_lkp_prepare(hobbit_ctx *ctx, const int32_t *S, const F *L, const F *R, const F *O, int32_t *s2, int32_t *s3, F *blo, size_t n) {
+    if (!n) return 0;
+    HB_LAUNCH(ctx, "k_lkp_prepare", k_lkp_prepare, dim3(grid_for(n, 256)), dim3(256), 0, S, L, R, O, ctx->lookup_rand[0], ctx->lookup_rand[1], s2, s3, blo, n);
+    return 0;
+}
+int launch_lkp_sel_fold(hobbit_ctx *ctx, const int32_t *S, F rnd, F *aL, F *aR, F *lkp, F *mul, size_t n) {
+    if (!n) return 0;
+    HB_LAUNCH(ctx, "k_lkp_sel_fold", k_lkp_sel_fold, dim3(grid_for(n, 256)), dim3(256), 0, S, rnd, ctx->lookup_rand[0], ctx->lookup_rand[1], aL, aR, lkp, mul, n);
     return 0;
 }
 
@@ -1903,126 +1941,180 @@ int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev
 // c[4..8]  quartic mul * beta * L * R              (cubic * linear, :99-101)
 // c[9..11] quadratic beta * O
 // The host combines them with a2, a3 (:899-903), hashes (mimc_hash(coefficient, rand): coefficient is the input) and folds.
-struct GateTabs { const F *s[6]; F *d[6]; };
-HB_HD void gate_acc(F (&c)[12], const F (&b)[6], const F (&e)[6], const F &a0, const F &a1) {
-    F d[6];
-#pragma unroll
-    for (int q = 0; q < 6; q++) d[q] = fsub(e[q], b[q]);
-    F l3a = fadd(fmul(a0, d[2]), fmul(a1, d[3])), l3b = fadd(fmul(a0, b[2]), fmul(a1, b[3]));
-    F qa = fmul(d[0], d[1]), qb = fadd(fmul(d[0], b[1]), fmul(b[0], d[1])), qc = fmul(b[0], b[1]);
-    c[0] = fadd(c[0], fmul(qa, l3a));
-    c[1] = fadd(c[1], fadd(fmul(qa, l3b), fmul(qb, l3a)));
-    c[2] = fadd(c[2], fadd(fmul(qb, l3b), fmul(qc, l3a)));
-    c[3] = fadd(c[3], fmul(qc, l3b));
-    F ma = fmul(d[5], d[1]), mb = fadd(fmul(d[5], b[1]), fmul(b[5], d[1])), mc = fmul(b[5], b[1]);
-    F ka = fmul(ma, d[2]), kb = fadd(fmul(ma, b[2]), fmul(mb, d[2])), kc = fadd(fmul(mb, b[2]), fmul(mc, d[2])), kd = fmul(mc, b[2]);
-    c[4] = fadd(c[4], fmul(ka, d[3]));
-    c[5] = fadd(c[5], fadd(fmul(ka, b[3]), fmul(kb, d[3])));
-    c[6] = fadd(c[6], fadd(fmul(kb, b[3]), fmul(kc, d[3])));
-    c[7] = fadd(c[7], fadd(fmul(kc, b[3]), fmul(kd, d[3])));
-    c[8] = fadd(c[8], fmul(kd, b[3]));
-    c[9] = fadd(c[9], fmul(d[1], d[4]));
-    c[10] = fadd(c[10], fadd(fmul(d[1], b[4]), fmul(b[1], d[4])));
-    c[11] = fadd(c[11], fmul(b[1], b[4]));
+template <int NT> struct GateTabsT { const F *s[NT]; F *d[NT]; };
+HB_HD void cubic_acc(F *c, const F &b0, const F &d0, const F &b1, const F &d1, const F &b2, const F &d2) {     // (l1*l2)*l3
+    F qa = fmul(d0, d1), qb = fadd(fmul(d0, b1), fmul(b0, d1)), qc = fmul(b0, b1);
+    c[0] = fadd(c[0], fmul(qa, d2));
+    c[1] = fadd(c[1], fadd(fmul(qa, b2), fmul(qb, d2)));
+    c[2] = fadd(c[2], fadd(fmul(qb, b2), fmul(qc, d2)));
+    c[3] = fadd(c[3], fmul(qc, b2));
 }
-// round 0: polynomial only
-__global__ void __launch_bounds__(256) k_gate_poly(GateTabs t, size_t L, F a0, F a1, F *__restrict__ partials) {
-    F c[12];
+HB_HD void quartic_acc(F *c, const F &bm, const F &dm, const F &bb, const F &db, const F &bl, const F &dl, const F &br, const F &dr) {   // ((mul*beta)*L)*R
+    F ma = fmul(dm, db), mb = fadd(fmul(dm, bb), fmul(bm, db)), mc = fmul(bm, bb);
+    F ka = fmul(ma, dl), kb = fadd(fmul(ma, bl), fmul(mb, dl)), kc = fadd(fmul(mb, bl), fmul(mc, dl)), kd = fmul(mc, bl);
+    c[0] = fadd(c[0], fmul(ka, dr));
+    c[1] = fadd(c[1], fadd(fmul(ka, br), fmul(kb, dr)));
+    c[2] = fadd(c[2], fadd(fmul(kb, br), fmul(kc, dr)));
+    c[3] = fadd(c[3], fadd(fmul(kc, br), fmul(kd, dr)));
+    c[4] = fadd(c[4], fmul(kd, br));
+}
+HB_HD void quad_acc(F *c, const F &b0, const F &d0, const F &b1, const F &d1) {
+    c[0] = fadd(c[0], fmul(d0, d1));
+    c[1] = fadd(c[1], fadd(fmul(d0, b1), fmul(b0, d1)));
+    c[2] = fadd(c[2], fmul(b0, b1));
+}
+// prove_gate_consistency / _standard: tables add, beta, L, R, O, mul; twelve sums
+struct GateStd {
+    static constexpr int NT = 6, NS = 12, NA = 4;
+    static HB_HD void acc(F (&c)[12], const F (&b)[6], const F (&e)[6], const F &a0, const F &a1) {
+        F d[6];
 #pragma unroll
-    for (int q = 0; q < 12; q++) c[q] = fmake(0);
-    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < L; j += (size_t)gridDim.x * blockDim.x) {
-        F b[6], e[6];
-#pragma unroll
-        for (int q = 0; q < 6; q++) { b[q] = ldF(t.s[q] + 2 * j); e[q] = ldF(t.s[q] + 2 * j + 1); }
-        gate_acc(c, b, e, a0, a1);
+        for (int q = 0; q < 6; q++) d[q] = fsub(e[q], b[q]);
+        const F l3a = fadd(fmul(a0, d[2]), fmul(a1, d[3])), l3b = fadd(fmul(a0, b[2]), fmul(a1, b[3]));
+        cubic_acc(c, b[0], d[0], b[1], d[1], l3b, l3a);
+        quartic_acc(c + 4, b[5], d[5], b[1], d[1], b[2], d[2], b[3], d[3]);
+        quad_acc(c + 9, b[1], d[1], b[4], d[4]);
     }
-    block_reduce_store<12>(c, partials);
+    // combine the twelve sums into the quartic (a..e)  (:899-903)
+    static void combine(const F *c, const HF *a, F *p) {
+        p[0] = fmul(a[2], c[4]);
+        p[1] = fadd(fmul(a[2], c[5]), c[0]);
+        p[2] = fadd(fadd(fmul(a[2], c[6]), c[1]), fmul(a[3], c[9]));
+        p[3] = fadd(fadd(fmul(a[2], c[7]), c[2]), fmul(a[3], c[10]));
+        p[4] = fadd(fadd(fmul(a[2], c[8]), c[3]), fmul(a[3], c[11]));
+    }
+};
+// prove_gate_consistency_lookups (src/sumcheck.cpp:654-729): tables add_L, add_R, L, R, O, lkp, lkp_O, mul, beta; twenty sums:
+// c[0..3] add_L*beta*L, c[4..7] add_R*beta*R, c[8..11] lkp*beta*lkp_O (cubics), c[12..16] mul*beta*L*R (quartic), c[17..19] beta*O
+struct GateLkp {
+    static constexpr int NT = 9, NS = 20, NA = 5;
+    static HB_HD void acc(F (&c)[20], const F (&b)[9], const F (&e)[9], const F &, const F &) {
+        F d[9];
+#pragma unroll
+        for (int q = 0; q < 9; q++) d[q] = fsub(e[q], b[q]);
+        cubic_acc(c, b[0], d[0], b[8], d[8], b[2], d[2]);
+        cubic_acc(c + 4, b[1], d[1], b[8], d[8], b[3], d[3]);
+        cubic_acc(c + 8, b[5], d[5], b[8], d[8], b[6], d[6]);
+        quartic_acc(c + 12, b[7], d[7], b[8], d[8], b[2], d[2], b[3], d[3]);
+        quad_acc(c + 17, b[8], d[8], b[4], d[4]);
+    }
+    static void combine(const F *c, const HF *a, F *p) {                       // (:689-704)
+        F C[4];
+        for (int k = 0; k < 4; k++) C[k] = fadd(fadd(fmul(a[0], c[k]), fmul(a[1], c[4 + k])), fmul(a[4], c[8 + k]));
+        p[0] = fmul(a[2], c[12]);
+        p[1] = fadd(fmul(a[2], c[13]), C[0]);
+        p[2] = fadd(fadd(fmul(a[2], c[14]), C[1]), fmul(a[3], c[17]));
+        p[3] = fadd(fadd(fmul(a[2], c[15]), C[2]), fmul(a[3], c[18]));
+        p[4] = fadd(fadd(fmul(a[2], c[16]), C[3]), fmul(a[3], c[19]));
+    }
+};
+// round 0: polynomial only
+template <class G>
+__global__ void __launch_bounds__(256) k_gate_poly(GateTabsT<G::NT> t, size_t L, F a0, F a1, F *__restrict__ partials) {
+    F c[G::NS];
+#pragma unroll
+    for (int q = 0; q < G::NS; q++) c[q] = fmake(0);
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < L; j += (size_t)gridDim.x * blockDim.x) {
+        F b[G::NT], e[G::NT];
+#pragma unroll
+        for (int q = 0; q < G::NT; q++) { b[q] = ldF(t.s[q] + 2 * j); e[q] = ldF(t.s[q] + 2 * j + 1); }
+        G::acc(c, b, e, a0, a1);
+    }
+    block_reduce_store<G::NS>(c, partials);
 }
 // rounds >= 1: fold the previous tables (4 -> 2 elements per thread and table) and accumulate this round's sums
-__global__ void __launch_bounds__(256) k_gate_fold_poly(GateTabs t, size_t L, F r, F a0, F a1, F *__restrict__ partials) {
-    F c[12];
+template <class G>
+__global__ void __launch_bounds__(256) k_gate_fold_poly(GateTabsT<G::NT> t, size_t L, F r, F a0, F a1, F *__restrict__ partials) {
+    F c[G::NS];
 #pragma unroll
-    for (int q = 0; q < 12; q++) c[q] = fmake(0);
+    for (int q = 0; q < G::NS; q++) c[q] = fmake(0);
     for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < L; j += (size_t)gridDim.x * blockDim.x) {
-        F b[6], e[6];
+        F b[G::NT], e[G::NT];
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
+        for (int q = 0; q < G::NT; q++) {
             F x0 = ldF(t.s[q] + 4 * j), x1 = ldF(t.s[q] + 4 * j + 1), x2 = ldF(t.s[q] + 4 * j + 2), x3 = ldF(t.s[q] + 4 * j + 3);
             b[q] = fadd(x0, fmul(r, fsub(x1, x0))); e[q] = fadd(x2, fmul(r, fsub(x3, x2)));
             stF(t.d[q] + 2 * j, b[q]); stF(t.d[q] + 2 * j + 1, e[q]);
         }
-        gate_acc(c, b, e, a0, a1);
+        G::acc(c, b, e, a0, a1);
     }
-    block_reduce_store<12>(c, partials);
+    block_reduce_store<G::NS>(c, partials);
 }
-// one transcript step: combine the twelve sums into the quartic (a..e), hash, check against the running sum, evaluate
-static bool gate_round_host(const F *c, const F *a, F &rnd, F &sum, F *poly_out, F *r_out) {
+// one transcript step: combine the sums into the quartic (a..e), hash, check against the running sum, evaluate
+template <class G>
+static bool gate_round_host(const F *c, const HF *a, F &rnd, F &sum, HF *poly_out, HF *r_out) {
     F p[5];
-    p[0] = fmul(a[2], c[4]);
-    p[1] = fadd(fmul(a[2], c[5]), c[0]);
-    p[2] = fadd(fadd(fmul(a[2], c[6]), c[1]), fmul(a[3], c[9]));
-    p[3] = fadd(fadd(fmul(a[2], c[7]), c[2]), fmul(a[3], c[10]));
-    p[4] = fadd(fadd(fmul(a[2], c[8]), c[3]), fmul(a[3], c[11]));
+    G::combine(c, a, p);
     for (int q = 0; q < 5; q++) { rnd = mimc_hash(p[q], rnd); poly_out[q] = p[q]; }
     F s01 = fadd(fadd(fadd(p[0], p[1]), fadd(p[2], p[3])), fadd(p[4], p[4]));
-    bool ok = feq(s01, sum);                                              // "Error in gate consistency 2" (:909-912)
+    bool ok = feq(s01, sum);                                              // "Error in gate consistency 2" (:909-912, :710-713)
     sum = fadd(fmul(fadd(fmul(fadd(fmul(fadd(fmul(p[0], rnd), p[1]), rnd), p[2]), rnd), p[3]), rnd), p[4]);
     *r_out = rnd;
     return ok;
 }
 // inputs are preserved (the reference folds in place and afterwards only reads element 0 of each table: h_final)
-int launch_gate_sumcheck(hobbit_ctx *ctx, const F *const tabs[6], size_t n, const HF *h_a, HF *h_rand, HF *h_sum, HF *h_poly, HF *h_r, HF *h_final, int *h_check) {
+template <class G>
+static int gate_sumcheck_impl(hobbit_ctx *ctx, const F *const *tabs, size_t n, const HF *h_a, HF *h_rand, HF *h_sum, HF *h_poly, HF *h_r, HF *h_final, int *h_check) {
+    constexpr int NT = G::NT, NS = G::NS;
     int rounds = 0; while (((size_t)1 << rounds) < n) rounds++;
     if (((size_t)1 << rounds) != n || n < 2) return ctx->fail(HOBBIT_EINVAL, "gate_sumcheck: n must be a power of two >= 2");
     const int MAXB = 512;
     F rnd = *h_rand, sum = *h_sum; bool ok = true;
-    std::vector<F> host[6];
+    const F a0 = h_a[0], a1 = h_a[1];
+    std::vector<F> host[NT];
     size_t cur = n; int i = 0; bool pending = false;
     if (n > SC_TAIL) {
         size_t szA = n / 2, szB = n / 4;
-        F *ws; HB_TRY(ctx->workspace((6 * (szA + szB) + (size_t)MAXB * 12 + 16) * sizeof(F), (void **)&ws));
-        F *A = ws, *B = A + 6 * szA, *part = B + 6 * szB, *coef = part + (size_t)MAXB * 12;
-        F *pin; HB_TRY(ctx->pinned(12 * sizeof(F), (void **)&pin));
-        GateTabs t;
-        for (int q = 0; q < 6; q++) { t.s[q] = tabs[q]; t.d[q] = A + (size_t)q * szA; }
+        F *ws; HB_TRY(ctx->workspace((NT * (szA + szB) + (size_t)MAXB * NS + NS + 4) * sizeof(F), (void **)&ws));
+        F *A = ws, *B = A + NT * szA, *part = B + NT * szB, *coef = part + (size_t)MAXB * NS;
+        F *pin; HB_TRY(ctx->pinned(NS * sizeof(F), (void **)&pin));
+        GateTabsT<NT> t;
+        for (int q = 0; q < NT; q++) { t.s[q] = tabs[q]; t.d[q] = A + (size_t)q * szA; }
         bool toA = true;
         for (;; i++) {
             size_t L = n >> (i + 1);
             int nb = grid_for(L, 256, MAXB);
-            if (i == 0) HB_LAUNCH(ctx, "k_gate_poly", k_gate_poly, dim3(nb), dim3(256), 0, t, L, h_a[0], h_a[1], part);
+            if (i == 0) HB_LAUNCH(ctx, "k_gate_poly", (k_gate_poly<G>), dim3(nb), dim3(256), 0, t, L, a0, a1, part);
             else {
-                HB_LAUNCH(ctx, "k_gate_fold_poly", k_gate_fold_poly, dim3(nb), dim3(256), 0, t, L, rnd, h_a[0], h_a[1], part);
+                HB_LAUNCH(ctx, "k_gate_fold_poly", (k_gate_fold_poly<G>), dim3(nb), dim3(256), 0, t, L, rnd, a0, a1, part);
                 cur = 2 * L; toA = !toA;
-                for (int q = 0; q < 6; q++) { t.s[q] = t.d[q]; t.d[q] = toA ? A + (size_t)q * szA : B + (size_t)q * szB; }
+                for (int q = 0; q < NT; q++) { t.s[q] = t.d[q]; t.d[q] = toA ? A + (size_t)q * szA : B + (size_t)q * szB; }
             }
-            HB_LAUNCH(ctx, "k_sc_reduce12", k_sc_reduce<12>, dim3(1), dim3(256), 0, part, nb, coef);
-            HB_CHECK(ctx, hipMemcpyAsync(pin, coef, 12 * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+            HB_LAUNCH(ctx, "k_sc_reduce12", k_sc_reduce<NS>, dim3(1), dim3(256), 0, part, nb, coef);
+            HB_CHECK(ctx, hipMemcpyAsync(pin, coef, NS * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
             HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-            ok &= gate_round_host(pin, h_a, rnd, sum, h_poly + 5 * i, h_r + i);
+            ok &= gate_round_host<G>(pin, h_a, rnd, sum, h_poly + 5 * i, h_r + i);
             if (cur <= 2 * SC_TAIL || i == rounds - 1) break;
         }
-        for (int q = 0; q < 6; q++) { host[q].resize(cur); HB_CHECK(ctx, hipMemcpyAsync(host[q].data(), t.s[q], cur * sizeof(F), hipMemcpyDeviceToHost, ctx->stream)); }
+        for (int q = 0; q < NT; q++) { host[q].resize(cur); HB_CHECK(ctx, hipMemcpyAsync(host[q].data(), t.s[q], cur * sizeof(F), hipMemcpyDeviceToHost, ctx->stream)); }
         HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         pending = true; i++;
     } else {
-        for (int q = 0; q < 6; q++) { host[q].resize(n); HB_CHECK(ctx, hipMemcpyAsync(host[q].data(), tabs[q], n * sizeof(F), hipMemcpyDeviceToHost, ctx->stream)); }
+        for (int q = 0; q < NT; q++) { host[q].resize(n); HB_CHECK(ctx, hipMemcpyAsync(host[q].data(), tabs[q], n * sizeof(F), hipMemcpyDeviceToHost, ctx->stream)); }
         HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     }
-    auto fold = [&]() { for (int q = 0; q < 6; q++) for (size_t j = 0; j < cur / 2; j++) host[q][j] = fadd(host[q][2 * j], fmul(rnd, fsub(host[q][2 * j + 1], host[q][2 * j]))); cur /= 2; };
+    auto fold = [&]() { for (int q = 0; q < NT; q++) for (size_t j = 0; j < cur / 2; j++) host[q][j] = fadd(host[q][2 * j], fmul(rnd, fsub(host[q][2 * j + 1], host[q][2 * j]))); cur /= 2; };
     if (pending) fold();
     for (; i < rounds; i++) {
-        F c[12]; for (int q = 0; q < 12; q++) c[q] = fmake(0);
+        F c[NS]; for (int q = 0; q < NS; q++) c[q] = fmake(0);
         for (size_t j = 0; j < cur / 2; j++) {
-            F b[6], e[6];
-            for (int q = 0; q < 6; q++) { b[q] = host[q][2 * j]; e[q] = host[q][2 * j + 1]; }
-            gate_acc(c, b, e, h_a[0], h_a[1]);
+            F b[NT], e[NT];
+            for (int q = 0; q < NT; q++) { b[q] = host[q][2 * j]; e[q] = host[q][2 * j + 1]; }
+            G::acc(c, b, e, a0, a1);
         }
-        ok &= gate_round_host(c, h_a, rnd, sum, h_poly + 5 * i, h_r + i);
+        ok &= gate_round_host<G>(c, h_a, rnd, sum, h_poly + 5 * i, h_r + i);
         fold();
     }
-    for (int q = 0; q < 6; q++) h_final[q] = host[q][0];
+    for (int q = 0; q < NT; q++) h_final[q] = host[q][0];
     *h_rand = rnd; *h_sum = sum; *h_check = ok ? 1 : 0;
     return 0;
+}
+int launch_gate_sumcheck(hobbit_ctx *ctx, const F *const tabs[6], size_t n, const HF *h_a, HF *h_rand, HF *h_sum, HF *h_poly, HF *h_r, HF *h_final, int *h_check) {
+    return gate_sumcheck_impl<GateStd>(ctx, tabs, n, h_a, h_rand, h_sum, h_poly, h_r, h_final, h_check);
+}
+// tabs: add_L, add_R, L, R, O, lkp, lkp_O, mul, beta; h_a: 5 coefficients; h_final: the nine folded values in that order
+int launch_gate_lkp_sumcheck(hobbit_ctx *ctx, const F *const tabs[9], size_t n, const HF *h_a, HF *h_rand, HF *h_sum, HF *h_poly, HF *h_r, HF *h_final, int *h_check) {
+    return gate_sumcheck_impl<GateLkp>(ctx, tabs, n, h_a, h_rand, h_sum, h_poly, h_r, h_final, h_check);
 }
 
 // 3-product: polynomial of the current tables and fold with the PRE-round challenge in one pass

@@ -403,6 +403,19 @@ int hobbit_mul_tree_stream_shallow(hobbit_ctx *ctx, hobbit_chunk_source source, 
 typedef struct { hobbit_F *R, *a, *poly, *gr, *fin6, *Peval, *b, *q2, *r2, *vr2, *fin2; int *checks; } hobbit_gate_stream_out;
 int hobbit_gate_consistency_stream(hobbit_ctx *ctx, hobbit_trace_source source, void *user, size_t n_chunks, size_t B, const hobbit_F *h_r, hobbit_gate_stream_out *out);
 
+/* The reference's globals has_lookups / lookup_rand (src/main.cpp:67,70; set at :888,:910 for circuits with lookup gates): while on,
+ * hobbit_compute3p_error_terms maps selectors 0 and 4 -> 1, 2 -> lookup_rand[0], 3 -> lookup_rand[1], anything else -> 0, and
+ * hobbit_compute4p_error_terms uses [selector == 1] (src/sumcheck.cpp:388-394, 413-427).  h_lookup_rand: 2 elements (ignored when on == 0). */
+int hobbit_set_lookups(hobbit_ctx *ctx, int on, const hobbit_F *h_lookup_rand);
+/* prove_gate_consistency_lookups (src/sumcheck.cpp:503-795), the gate-consistency prover of circuits with lookup gates (main.cpp:915);
+ * needs hobbit_set_lookups(ctx, 1, lookup_rand) first.  Trace selectors: 0 addition, 1 multiplication, 2 lookup (read_trace,
+ * src/witness_stream.cpp:1724-1746).  Same stream protocol as hobbit_gate_consistency_stream.  Host outputs: R (n_chunks, R[0] = 1), a (5),
+ * poly (log2 B x 5), gr (log2 B), fin9 (the folded add_L, add_R, L, R, O, lkp, lkp_O, mul, beta), Peval (8 x n_chunks), b (8),
+ * q2 / r2 / vr2 / fin2, checks[5]: "Error in gate consistency 1 / 2 / 3", the per-chunk Kf_M self-check (:635), the Kf_lkp one (:650). */
+typedef struct { hobbit_F *R, *a, *poly, *gr, *fin9, *Peval, *b, *q2, *r2, *vr2, *fin2; int *checks; } hobbit_gate_lkp_stream_out;
+int hobbit_gate_consistency_lookups_stream(hobbit_ctx *ctx, hobbit_trace_source source, void *user, size_t n_chunks, size_t B, const hobbit_F *h_r,
+                                           hobbit_gate_lkp_stream_out *out);
+
 /* ---- synthetic inputs on the device (bench / tests) ---------------------------------------- */
 /* splitmix64-derived full-range elements: element i = (sm(seed,2i+1) mod p, sm(seed,2i+2) mod p) */
 int hobbit_fill_splitmix(hobbit_ctx *ctx, hobbit_F *d_out, size_t n, uint64_t seed);

@@ -955,6 +955,10 @@ int orc_mul_tree(const oF *input, size_t vectors, size_t size, const oF *previou
 /* sumchecks): src/sumcheck.cpp:374-432 (compute{2,3,4}p_error_terms, has_lookups == false),      */
 /* 1093-1136 (batch_prod), 862-869 (fold += rand * chunk)                                         */
 /* ------------------------------------------------------------------------------------------ */
+/* has_lookups / lookup_rand[0..1] (src/main.cpp:67,70): the gate maps of compute{3,4}p_error_terms when set (:388-394, :413-427) */
+static int g_has_lookups = 0; static oF g_lookup_rand[2];
+void orc_set_lookups(int on, const oF *lr) { g_has_lookups = on; if (on) { g_lookup_rand[0] = lr[0]; g_lookup_rand[1] = lr[1]; } }
+static oF lk_gate3(int s, const oF *lr) { return s == 0 ? fint(1) : s == 2 ? lr[0] : s == 3 ? lr[1] : s == 4 ? fint(1) : fint(0); }
 void orc_err2p(const oF *b1, const oF *b2, const oF *f1, const oF *f2, size_t n, oF *K) {
     for (size_t i = 0; i < n; i++) {
         K[0] = f_add(K[0], f_add(f_mul(b1[i], f2[i]), f_mul(b2[i], f1[i])));
@@ -963,7 +967,7 @@ void orc_err2p(const oF *b1, const oF *b2, const oF *f1, const oF *f2, size_t n,
 }
 void orc_err3p(const oF *b1, const int32_t *b2, const oF *f1, const oF *f2, const oF *f3, const oF *beta, size_t n, oF *K) {
     for (size_t j = 0; j < n; j++) {
-        oF gate = fint((uint64_t)(int64_t)b2[j]);                 /* F(buff2[j]), selectors are 0/1 */
+        oF gate = g_has_lookups ? lk_gate3(b2[j], g_lookup_rand) : fint((uint64_t)(int64_t)b2[j]);      /* F(buff2[j]), selectors are 0/1 without lookups */
         oF t1 = f_add(f_mul(b1[j], f2[j]), f_mul(gate, f1[j]));
         oF t2 = f_mul(b1[j], gate);
         K[0] = f_add(K[0], f_add(f_mul(f3[j], t1), f_mul(f_mul(beta[j], f1[j]), f2[j])));
@@ -973,7 +977,7 @@ void orc_err3p(const oF *b1, const int32_t *b2, const oF *f1, const oF *f2, cons
 }
 void orc_err4p(const oF *b1, const oF *b2, const oF *b3, const int32_t *b4, const oF *f1, const oF *f2, const oF *f3, const oF *f4, size_t n, oF *K) {
     for (size_t i = 0; i < n; i++) {
-        oF gate = f_sub(fint(1), fint((uint64_t)(int64_t)b4[i]));
+        oF gate = g_has_lookups ? fint(b4[i] == 1 ? 1 : 0) : f_sub(fint(1), fint((uint64_t)(int64_t)b4[i]));
         oF t1 = f_add(f_mul(f1[i], b2[i]), f_mul(f2[i], b1[i]));
         oF t2 = f_add(f_mul(f3[i], gate), f_mul(f4[i], b3[i]));
         oF t3 = f_mul(b1[i], b2[i]), t4 = f_mul(gate, b3[i]), t5 = f_mul(f1[i], f2[i]), t6 = f_mul(f3[i], f4[i]);
@@ -1575,6 +1579,182 @@ void orc_gate_consistency_stream(const oF *L, const oF *Rt, const oF *O, const i
       sm = f_add(sm, f_add(f_mul(b_out[4], fin6[5]), f_mul(b_out[5], fin6[1])));
       oF c = f_add(f_add(q2[0], q2[1]), f_add(q2[2], q2[2])); checks[2] = (c.re == sm.re && c.im == sm.im); }
     free(beta); free(fb); free(fL); free(fR); free(fO); free(fa); free(fm); free(b1); free(pe);
+}
+
+/* prove_gate_consistency_lookups (src/sumcheck.cpp:503-795), the variant main.cpp:915 runs for circuits with lookup gates (has_lookups set),
+ * over a caller-supplied trace as orc_gate_consistency_stream: selectors S in {0 addition, 1 multiplication, 2 lookup}; lr = lookup_rand[0..1].
+ * The selector rewrites the reference does between its compute3p_error_terms calls (2 -> 3 -> 4, 0 -> -1 -> 0, :568-585) are restated
+ * literally, with compute{3,4}p_error_terms's has_lookups gate maps (:388-394, :413-427).  Only K1_O .. K3_R enter the per-chunk transcript
+ * (:596-603): the lookup and multiplication terms do not.  Unpinned as a whole for the same reason (read_trace is the witness generator's).
+ * Outputs: R, a (5), poly (logB x 5), gr, fin9 (folded add_L, add_R, L, R, O, lkp, lkp_O, mul, beta: the order of :716-726),
+ * Peval (8 x n_chunks), b (8), q2/r2/vr2/fin2.  checks: [0] "Error in gate consistency 1" per chunk incl. the initial one (:549),
+ * [1] "... 2" per round, [2] "... 3", [3] the per-chunk Kf_M self-check (:635-641), [4] the Kf_lkp self-check (:646-652). */
+static void err3p_lk(const oF *b1, const int32_t *sel, const oF *f1, const oF *f2, const oF *f3, const oF *beta, size_t n, const oF *lr, oF *K) {
+    for (size_t j = 0; j < n; j++) {
+        oF gate = lk_gate3(sel[j], lr);
+        oF t1 = f_add(f_mul(b1[j], f2[j]), f_mul(gate, f1[j])), t2 = f_mul(b1[j], gate);
+        K[0] = f_add(K[0], f_add(f_mul(f3[j], t1), f_mul(f_mul(beta[j], f1[j]), f2[j])));
+        K[1] = f_add(K[1], f_add(f_mul(beta[j], t1), f_mul(f3[j], t2)));
+        K[2] = f_add(K[2], f_mul(t2, beta[j]));
+    }
+}
+static void err4p_lk(const oF *b1, const oF *b2, const oF *b3, const int32_t *sel, const oF *f1, const oF *f2, const oF *f3, const oF *f4, size_t n, oF *K) {
+    for (size_t i = 0; i < n; i++) {
+        oF gate = sel[i] == 1 ? fint(1) : fint(0);
+        oF t1 = f_add(f_mul(f1[i], b2[i]), f_mul(f2[i], b1[i])), t2 = f_add(f_mul(f3[i], gate), f_mul(f4[i], b3[i]));
+        oF t3 = f_mul(b1[i], b2[i]), t4 = f_mul(gate, b3[i]), t5 = f_mul(f1[i], f2[i]), t6 = f_mul(f3[i], f4[i]);
+        K[0] = f_add(K[0], f_add(f_mul(t1, t6), f_mul(t2, t5)));
+        K[1] = f_add(K[1], f_add(f_add(f_mul(t1, t2), f_mul(t3, t6)), f_mul(t4, t5)));
+        K[2] = f_add(K[2], f_add(f_mul(t1, t4), f_mul(t2, t3)));
+        K[3] = f_add(K[3], f_mul(t3, t4));
+    }
+}
+static void cubic_acc(oF *c, oF b0, oF d0, oF b1, oF d1, oF b2, oF d2) {      /* (l1*l2)*l3, src/polynomial.cpp:91-93,133-135 */
+    oF qa = f_mul(d0, d1), qb = f_add(f_mul(d0, b1), f_mul(b0, d1)), qc = f_mul(b0, b1);
+    c[0] = f_add(c[0], f_mul(qa, d2));
+    c[1] = f_add(c[1], f_add(f_mul(qa, b2), f_mul(qb, d2)));
+    c[2] = f_add(c[2], f_add(f_mul(qb, b2), f_mul(qc, d2)));
+    c[3] = f_add(c[3], f_mul(qc, b2));
+}
+void orc_gate_consistency_lookups_stream(const oF *L, const oF *Rt, const oF *O, const int32_t *S, size_t n_chunks, size_t B, const oF *r, const oF *lr, oF *R_out, oF *a_out,
+                                         oF *poly, oF *gr, oF *fin9, oF *Peval, oF *b_out, oF *q2, oF *r2, oF *vr2, oF *fin2, int *checks) {
+    const int logB = (int)log2((double)B);
+    enum { AL, AR, TL, TR, TO, LK, LO, MU, BE };
+    oF *t[9]; for (int q = 0; q < 9; q++) t[q] = (oF *)malloc(sizeof(oF) * B);
+    oF *beta = (oF *)malloc(sizeof(oF) * B), *blo = (oF *)malloc(sizeof(oF) * B);
+    int32_t *sel = (int32_t *)malloc(sizeof(int32_t) * B);
+    orc_precompute_beta(r, logB, beta); memcpy(t[BE], beta, sizeof(oF) * B);
+    memcpy(t[TL], L, sizeof(oF) * B); memcpy(t[TR], Rt, sizeof(oF) * B); memcpy(t[TO], O, sizeof(oF) * B);
+    for (size_t i = 0; i < B; i++) {
+        t[MU][i] = t[AL][i] = t[AR][i] = t[LK][i] = t[LO][i] = fint(0);
+        if (S[i] == 0) { t[AL][i] = fint(1); t[AR][i] = fint(1); }
+        else if (S[i] == 1) t[MU][i] = fint(1);
+        else { t[AL][i] = lr[0]; t[AR][i] = lr[1]; t[LO][i] = f_sub(f_add(f_mul(lr[0], t[TL][i]), f_mul(lr[1], t[TR][i])), t[TO][i]); t[LK][i] = fint(1); }
+    }
+    oF rnd = fint(0), KO = fint(0), KL = fint(0), KR = fint(0), KM = fint(0), KK = fint(0);
+    for (size_t i = 0; i < B; i++) {
+        KO = f_add(KO, f_mul(beta[i], t[TO][i]));
+        KL = f_add(KL, f_mul(f_mul(beta[i], t[TL][i]), t[AL][i]));
+        KR = f_add(KR, f_mul(f_mul(beta[i], t[TR][i]), t[AR][i]));
+        KK = f_add(KK, f_mul(f_mul(beta[i], t[LO][i]), t[LK][i]));
+        KM = f_add(KM, f_mul(f_mul(f_mul(beta[i], t[TR][i]), t[TL][i]), t[MU][i]));
+    }
+    checks[0] = fis0(f_sub(f_sub(f_add(f_add(KM, KL), KR), KK), KO)); checks[3] = 1;
+    R_out[0] = fint(1);
+    for (size_t c = 1; c < n_chunks; c++) {
+        const oF *bL = L + c * B, *bR = Rt + c * B, *bO = O + c * B;
+        memcpy(sel, S + c * B, sizeof(int32_t) * B);
+        oF K2[2] = {fint(0), fint(0)}, KLs[3] = {fint(0), fint(0), fint(0)}, KRs[3] = {fint(0), fint(0), fint(0)}, KKs[3] = {fint(0), fint(0), fint(0)},
+           K4[4] = {fint(0), fint(0), fint(0), fint(0)};
+        orc_err2p(bO, beta, t[TO], t[BE], B, K2);
+        err3p_lk(bL, sel, t[TL], t[AL], t[BE], beta, B, lr, KLs);
+        for (size_t j = 0; j < B; j++) if (sel[j] == 2) sel[j] = 3;
+        err3p_lk(bR, sel, t[TR], t[AR], t[BE], beta, B, lr, KRs);
+        for (size_t j = 0; j < B; j++) {
+            blo[j] = fint(0);
+            if (sel[j] == 0) sel[j] = -1;
+            if (sel[j] == 3) { sel[j] = 4; blo[j] = f_sub(f_add(f_mul(lr[0], bL[j]), f_mul(lr[1], bR[j])), bO[j]); }
+        }
+        err3p_lk(blo, sel, t[LO], t[LK], t[BE], beta, B, lr, KKs);
+        for (size_t j = 0; j < B; j++) if (sel[j] == -1) sel[j] = 0;
+        err4p_lk(bL, bR, beta, sel, t[TL], t[TR], t[BE], t[MU], B, K4);
+        { oF e = f_sub(f_sub(f_add(f_add(K4[3], KLs[2]), KRs[2]), KKs[2]), K2[1]); if (!fis0(e)) checks[0] = 0; }
+        rnd = mimc_hash(K2[0], rnd); rnd = mimc_hash(K2[1], rnd);
+        rnd = mimc_hash(KLs[0], rnd); rnd = mimc_hash(KLs[1], rnd); rnd = mimc_hash(KLs[2], rnd);
+        rnd = mimc_hash(KRs[0], rnd); rnd = mimc_hash(KRs[1], rnd); rnd = mimc_hash(KRs[2], rnd);
+        R_out[c] = rnd;
+        oF x1 = rnd, x2 = f_mul(rnd, x1), x3 = f_mul(rnd, x2), x4 = f_mul(rnd, x3);
+        KO = f_add(KO, f_add(f_mul(x1, K2[0]), f_mul(x2, K2[1])));
+        KK = f_add(KK, f_add(f_add(f_mul(x1, KKs[0]), f_mul(x2, KKs[1])), f_mul(x3, KKs[2])));
+        KL = f_add(KL, f_add(f_add(f_mul(x1, KLs[0]), f_mul(x2, KLs[1])), f_mul(x3, KLs[2])));
+        KR = f_add(KR, f_add(f_add(f_mul(x1, KRs[0]), f_mul(x2, KRs[1])), f_mul(x3, KRs[2])));
+        KM = f_add(KM, f_add(f_add(f_mul(x1, K4[0]), f_mul(x2, K4[1])), f_add(f_mul(x3, K4[2]), f_mul(x4, K4[3]))));
+        for (size_t j = 0; j < B; j++) {
+            if (sel[j] != 1) {
+                if (sel[j] == 0) { t[AL][j] = f_add(t[AL][j], rnd); t[AR][j] = f_add(t[AR][j], rnd); }
+                else { t[LK][j] = f_add(t[LK][j], rnd); t[AL][j] = f_add(t[AL][j], f_mul(rnd, lr[0])); t[AR][j] = f_add(t[AR][j], f_mul(rnd, lr[1])); }
+            } else t[MU][j] = f_add(t[MU][j], rnd);
+            t[TL][j] = f_add(t[TL][j], f_mul(rnd, bL[j])); t[TR][j] = f_add(t[TR][j], f_mul(rnd, bR[j])); t[TO][j] = f_add(t[TO][j], f_mul(rnd, bO[j]));
+            t[LO][j] = f_add(t[LO][j], f_mul(rnd, blo[j])); t[BE][j] = f_add(t[BE][j], f_mul(rnd, beta[j]));
+        }
+        oF s = fint(0);
+        for (size_t j = 0; j < B; j++) s = f_add(s, f_mul(f_mul(f_mul(t[BE][j], t[MU][j]), t[TR][j]), t[TL][j]));
+        if (!(s.re == KM.re && s.im == KM.im)) checks[3] = 0;
+    }
+    orc_generate_randomness(5, a_out);
+    { oF s = fint(0); for (size_t i = 0; i < B; i++) s = f_add(s, f_mul(f_mul(t[BE][i], t[LK][i]), t[LO][i])); checks[4] = (s.re == KK.re && s.im == KK.im); }
+    const oF *a = a_out;
+    oF sum = f_add(f_add(f_add(f_mul(a[0], KL), f_mul(a[1], KR)), f_add(f_mul(a[2], KM), f_mul(KO, a[3]))), f_mul(KK, a[4]));
+    checks[1] = 1;
+    for (int rd = 0, i = logB - 1; i >= 0; i--, rd++) {
+        size_t Lh = (size_t)1 << i;
+        oF c1[3][4], c4[5], c2[3];
+        for (int q = 0; q < 3; q++) for (int k = 0; k < 4; k++) c1[q][k] = fint(0);
+        for (int k = 0; k < 5; k++) c4[k] = fint(0);
+        for (int k = 0; k < 3; k++) c2[k] = fint(0);
+        for (size_t j = 0; j < Lh; j++) {
+            oF b[9], d[9];
+            for (int q = 0; q < 9; q++) { b[q] = t[q][2 * j]; d[q] = f_sub(t[q][2 * j + 1], b[q]); }
+            cubic_acc(c1[0], b[AL], d[AL], b[BE], d[BE], b[TL], d[TL]);
+            cubic_acc(c1[1], b[AR], d[AR], b[BE], d[BE], b[TR], d[TR]);
+            cubic_acc(c1[2], b[LK], d[LK], b[BE], d[BE], b[LO], d[LO]);
+            oF ma = f_mul(d[MU], d[BE]), mb = f_add(f_mul(d[MU], b[BE]), f_mul(b[MU], d[BE])), mc = f_mul(b[MU], b[BE]);
+            oF ka = f_mul(ma, d[TL]), kb = f_add(f_mul(ma, b[TL]), f_mul(mb, d[TL])), kc = f_add(f_mul(mb, b[TL]), f_mul(mc, d[TL])), kd = f_mul(mc, b[TL]);
+            c4[0] = f_add(c4[0], f_mul(ka, d[TR]));
+            c4[1] = f_add(c4[1], f_add(f_mul(ka, b[TR]), f_mul(kb, d[TR])));
+            c4[2] = f_add(c4[2], f_add(f_mul(kb, b[TR]), f_mul(kc, d[TR])));
+            c4[3] = f_add(c4[3], f_add(f_mul(kc, b[TR]), f_mul(kd, d[TR])));
+            c4[4] = f_add(c4[4], f_mul(kd, b[TR]));
+            c2[0] = f_add(c2[0], f_mul(d[BE], d[TO]));
+            c2[1] = f_add(c2[1], f_add(f_mul(d[BE], b[TO]), f_mul(b[BE], d[TO])));
+            c2[2] = f_add(c2[2], f_mul(b[BE], b[TO]));
+        }
+        oF C[4], p[5];
+        for (int k = 0; k < 4; k++) C[k] = f_add(f_add(f_mul(a[0], c1[0][k]), f_mul(a[1], c1[1][k])), f_mul(a[4], c1[2][k]));
+        p[0] = f_mul(a[2], c4[0]);
+        p[1] = f_add(f_mul(a[2], c4[1]), C[0]);
+        p[2] = f_add(f_add(f_mul(a[2], c4[2]), C[1]), f_mul(a[3], c2[0]));
+        p[3] = f_add(f_add(f_mul(a[2], c4[3]), C[2]), f_mul(a[3], c2[1]));
+        p[4] = f_add(f_add(f_mul(a[2], c4[4]), C[3]), f_mul(a[3], c2[2]));
+        for (int q = 0; q < 5; q++) { rnd = mimc_hash(p[q], rnd); poly[5 * rd + q] = p[q]; }
+        oF s01 = f_add(f_add(f_add(p[0], p[1]), f_add(p[2], p[3])), f_add(p[4], p[4]));
+        if (!(s01.re == sum.re && s01.im == sum.im)) checks[1] = 0;
+        sum = f_add(f_mul(f_add(f_mul(f_add(f_mul(f_add(f_mul(p[0], rnd), p[1]), rnd), p[2]), rnd), p[3]), rnd), p[4]);
+        gr[rd] = rnd;
+        for (size_t j = 0; j < Lh; j++) for (int q = 0; q < 9; q++) t[q][j] = f_add(t[q][2 * j], f_mul(rnd, f_sub(t[q][2 * j + 1], t[q][2 * j])));
+    }
+    for (int q = 0; q < 9; q++) fin9[q] = t[q][0];
+    /* Peval pass (:741-764) */
+    oF *b1 = (oF *)malloc(sizeof(oF) * B);
+    orc_precompute_beta(gr, logB, b1);
+    for (size_t i = 0; i < 8 * n_chunks; i++) Peval[i] = fint(0);
+    for (size_t c = 0; c < n_chunks; c++)
+        for (size_t j = 0; j < B; j++) {
+            const size_t g = c * B + j;
+            oF *P = Peval + c;
+            P[0 * n_chunks] = f_add(P[0 * n_chunks], f_mul(b1[j], L[g]));
+            P[1 * n_chunks] = f_add(P[1 * n_chunks], f_mul(b1[j], Rt[g]));
+            P[2 * n_chunks] = f_add(P[2 * n_chunks], f_mul(b1[j], O[g]));
+            if (S[g] == 0) { P[3 * n_chunks] = f_add(P[3 * n_chunks], b1[j]); P[4 * n_chunks] = f_add(P[4 * n_chunks], b1[j]); }
+            else if (S[g] == 1) P[5 * n_chunks] = f_add(P[5 * n_chunks], b1[j]);
+            else {
+                P[3 * n_chunks] = f_add(P[3 * n_chunks], f_mul(b1[j], lr[0])); P[4 * n_chunks] = f_add(P[4 * n_chunks], f_mul(b1[j], lr[1]));
+                P[6 * n_chunks] = f_add(P[6 * n_chunks], b1[j]);
+                P[7 * n_chunks] = f_add(P[7 * n_chunks], f_mul(b1[j], f_sub(f_add(f_mul(lr[0], L[g]), f_mul(lr[1], Rt[g])), O[g])));
+            }
+        }
+    orc_generate_randomness(8, b_out);
+    oF *pe = (oF *)calloc(n_chunks, sizeof(oF));
+    for (size_t j = 0; j < n_chunks; j++) for (int i = 0; i < 8; i++) pe[j] = f_add(pe[j], f_mul(b_out[i], Peval[(size_t)i * n_chunks + j]));
+    orc_sumcheck2(R_out, pe, n_chunks, &rnd, q2, r2, vr2, fin2);
+    {   /* (:783-789) */
+        oF sm = f_add(f_add(f_mul(fin9[TL], b_out[0]), f_mul(fin9[TR], b_out[1])), f_mul(fin9[TO], b_out[2]));
+        sm = f_add(sm, f_mul(b_out[3], fin9[AL])); sm = f_add(sm, f_mul(b_out[4], fin9[AR])); sm = f_add(sm, f_mul(b_out[5], fin9[MU]));
+        sm = f_add(sm, f_mul(b_out[6], fin9[LK])); sm = f_add(sm, f_mul(b_out[7], fin9[LO]));
+        oF c = f_add(f_add(q2[0], q2[1]), f_add(q2[2], q2[2])); checks[2] = (c.re == sm.re && c.im == sm.im);
+    }
+    for (int q = 0; q < 9; q++) free(t[q]);
+    free(beta); free(blo); free(sel); free(b1); free(pe);
 }
 
 /* Elastic_PC commit (RS x RS) of a "PC_layer" stream (commit_layers, src/sumcheck.cpp:983-1003): read_stream_PC's PC_layer branch

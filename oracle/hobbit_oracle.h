@@ -139,6 +139,11 @@ void orc_generate_claims_opt(size_t fd_size, size_t B, const oF *r, int batches,
 void orc_gate_consistency_stream(const oF *L, const oF *Rt, const oF *O, const int32_t *S, size_t n_chunks, size_t B, const oF *r, oF *R_out, oF *a_out, oF *poly, oF *gr,
                                  oF *fin6, oF *Peval, oF *b_out, oF *q2, oF *r2, oF *vr2, oF *fin2, int *checks);
 
+void orc_set_lookups(int on, const oF *lr);      /* has_lookups / lookup_rand[0..1] for orc_err3p / orc_err4p */
+/* prove_gate_consistency_lookups (src/sumcheck.cpp:503-795); lr = lookup_rand[0..1]; fin9 = add_L, add_R, L, R, O, lkp, lkp_O, mul, beta; checks[5] */
+void orc_gate_consistency_lookups_stream(const oF *L, const oF *Rt, const oF *O, const int32_t *S, size_t n_chunks, size_t B, const oF *r, const oF *lr, oF *R_out, oF *a_out,
+                                         oF *poly, oF *gr, oF *fin9, oF *Peval, oF *b_out, oF *q2, oF *r2, oF *vr2, oF *fin2, int *checks);
+
 size_t orc_elastic_commit_pc_layer(size_t N, size_t B, int layer, uint8_t *levels_out);
 void orc_elastic_group_digests(size_t B, int opt, size_t group, uint8_t *out);
 size_t orc_elastic_commit_model(size_t N, size_t B, int opt, uint8_t *levels_out);

@@ -295,6 +295,14 @@ class _Base:
         self.fn("err2p")(*[_p(x) for x in a], c_sz(a[0].shape[0]), _p(K))
         return K
 
+    def set_lookups(self, lookup_rand):
+        """has_lookups / lookup_rand[0..1] (src/main.cpp:67,70); None = off"""
+        if lookup_rand is None:
+            self.fn("set_lookups")(ctypes.c_int(0), None)
+        else:
+            lr = F(lookup_rand).reshape(-1, 2)[:2].copy()
+            self.fn("set_lookups")(ctypes.c_int(1), _p(lr))
+
     def err3p(self, b1, gate, f1, f2, f3, beta):
         g = np.ascontiguousarray(gate, np.int32)
         a = [F(x).reshape(-1, 2) for x in (b1, f1, f2, f3, beta)]
@@ -602,6 +610,17 @@ class Oracle(_Base):
         self.lib.orc_gate_consistency_stream(_p(L), _p(R), _p(O), _p(S), c_sz(nch), c_sz(B), _p(r), *[_p(out[k]) for k in ("R", "a", "poly", "gr", "fin6", "Peval", "b", "q2", "r2", "vr2", "fin2", "checks")])
         return out
 
+    def gate_consistency_lookups_stream(self, L, R, O, S, B, r, lookup_rand):
+        """prove_gate_consistency_lookups (src/sumcheck.cpp:503-795) over a caller-supplied trace; S in {0, 1, 2}; lookup_rand: 2 elements"""
+        L, R, O = [F(v).reshape(-1, 2) for v in (L, R, O)]; S = np.ascontiguousarray(S, np.int32); r = F(r).reshape(-1, 2); lr = F(lookup_rand).reshape(2, 2)
+        nch = L.shape[0] // B; logB = B.bit_length() - 1; lR = nch.bit_length() - 1
+        out = dict(R=np.zeros((nch, 2), np.uint64), a=np.zeros((5, 2), np.uint64), poly=np.zeros((logB, 5, 2), np.uint64), gr=np.zeros((logB, 2), np.uint64),
+                   fin9=np.zeros((9, 2), np.uint64), Peval=np.zeros((8, nch, 2), np.uint64), b=np.zeros((8, 2), np.uint64), q2=np.zeros((lR, 3, 2), np.uint64),
+                   r2=np.zeros((lR, 2), np.uint64), vr2=np.zeros((2, 2), np.uint64), fin2=np.zeros(2, np.uint64), checks=np.zeros(5, np.int32))
+        self.lib.orc_gate_consistency_lookups_stream(_p(L), _p(R), _p(O), _p(S), c_sz(nch), c_sz(B), _p(r), _p(lr),
+                                                     *[_p(out[k]) for k in ("R", "a", "poly", "gr", "fin9", "Peval", "b", "q2", "r2", "vr2", "fin2", "checks")])
+        return out
+
     class _WQ(ctypes.Structure):
         _fields_ = [(n, ctypes.c_void_p) for n in ("qidx", "qreply", "qpaths", "final_pb", "nq")]
 
@@ -745,6 +764,20 @@ def gate_standard_inputs(n, seed):
     O = np.stack([np.where(sel == 1, (Lr + Rr) % np.uint64(P), prod), z], 1)
     add = np.stack([sel, z], 1)
     return L, R, O, add
+
+
+def gate_lookup_inputs(n, seed):
+    """consistent gates for the lookup variant (src/sumcheck.cpp:503-795): selector 0 -> O = L + R, 1 -> O = L * R, 2 -> lookup gate (any O: the
+    lookup term cancels it identically).  Returns L, R, O (n x 2 uint64) and S (int32)."""
+    P = (1 << 61) - 1
+    rng = np.random.default_rng(seed)
+    S = rng.integers(0, 3, n).astype(np.int32)
+    Lr = rng.integers(0, 1 << 31, n).astype(np.uint64); Rr = rng.integers(0, 1 << 31, n).astype(np.uint64)
+    z = np.zeros(n, np.uint64)
+    prod = np.array([(int(a) * int(b)) % P for a, b in zip(Lr, Rr)], np.uint64)
+    anyO = rng.integers(0, P, n).astype(np.uint64)
+    O = np.stack([np.where(S == 0, (Lr + Rr) % np.uint64(P), np.where(S == 1, prod, anyO)), np.where(S == 2, rng.integers(0, P, n).astype(np.uint64), z)], 1)
+    return np.stack([Lr, z], 1), np.stack([Rr, z], 1), O, S
 
 
 def gate_standard_via(be, L, R, O, add, r):

@@ -67,6 +67,8 @@ static vector<F> vecF(const uint64_t *p, size_t n) { vector<F> v(n); if (n) memc
 static vector<vector<_hash>> g_MT;
 static vector<vector<vector<F>>> g_tensor;
 
+extern bool has_lookups;            // src/main.cpp:70
+extern vector<F> lookup_rand;       // src/main.cpp:67
 extern "C" {
 
 void ref_init(void) { init_hash(); }
@@ -364,7 +366,12 @@ int ref_mul_tree(const uint64_t *input, size_t vectors, size_t size, const uint6
     return (int)MP.proofs.size();
 }
 
-// ---- streaming-sumcheck error terms (src/sumcheck.cpp:374-432, has_lookups == false) and batch_prod (:1093-1136)
+// the reference's own globals has_lookups / lookup_rand (src/main.cpp:67,70): lookup gate maps of compute{3,4}p_error_terms
+void ref_set_lookups(int on, const uint64_t *lr) {
+    has_lookups = on != 0;
+    if (on) { lookup_rand.assign(4, F(0)); lookup_rand[0] = ldF(lr); lookup_rand[1] = ldF(lr + 2); }
+}
+// ---- streaming-sumcheck error terms (src/sumcheck.cpp:374-432) and batch_prod (:1093-1136)
 void ref_err2p(const uint64_t *b1, const uint64_t *b2, const uint64_t *f1, const uint64_t *f2, size_t n, uint64_t *K) {
     vector<F> B1 = vecF(b1, n), B2 = vecF(b2, n), F1 = vecF(f1, n), F2 = vecF(f2, n);
     F K1 = ldF(K), K2 = ldF(K + 2);

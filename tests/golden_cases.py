@@ -398,6 +398,23 @@ def case_streamfold(lib):
     return out
 
 
+def case_lkpfold(lib):
+    """compute{3,4}p_error_terms with has_lookups set (src/sumcheck.cpp:388-394, 413-427): the selector values
+    prove_gate_consistency_lookups feeds them over its three rewrites (-1 .. 4), lookup_rand from a fixed seed"""
+    n = 4096
+    t = [splitmix_field(n, 440 + i) for i in range(8)]
+    gate = ((np.arange(n) * 7 + 3) % 6 - 1).astype(np.int32)         # -1 .. 4
+    lib.set_lookups(splitmix_field(2, 449))
+    try:
+        out = dict(e3=lib.err3p(t[0], gate, t[1], t[2], t[3], t[4]), e4=lib.err4p(t[0], t[1], t[2], gate, t[3], t[4], t[5], t[6]))
+        for v in range(-1, 5):                                        # one selector value at a time: pins each branch of the map
+            out["e3_%d" % (v + 1)] = lib.err3p(t[0][:64], np.full(64, v, np.int32), t[1][:64], t[2][:64], t[3][:64], t[4][:64])
+            out["e4_%d" % (v + 1)] = lib.err4p(t[0][:64], t[1][:64], t[2][:64], np.full(64, v, np.int32), t[3][:64], t[4][:64], t[5][:64], t[6][:64])
+    finally:
+        lib.set_lookups(None)
+    return out
+
+
 def case_multree(lib):
     """batch_3product_sumcheck (src/sumcheck.cpp:275-372) and prove_multiplication_tree_new (:35-257)"""
     out = {}
@@ -448,4 +465,4 @@ def case_gate(lib):
 
 
 CASES = dict(streamdrv=case_streamdrv, elastic_open=case_elastic_open, field=case_field, mimc=case_mimc, blake=case_blake, merkle=case_merkle, graph_encode=case_graph_encode,
-             fft=case_fft, tensorcode=case_tensorcode, commit=case_commit, sumcheck=case_sumcheck, elastic=case_elastic, codeproofs=case_codeproofs, streamfold=case_streamfold, multree=case_multree, innerpcs=case_innerpcs, gate=case_gate)
+             fft=case_fft, tensorcode=case_tensorcode, commit=case_commit, sumcheck=case_sumcheck, elastic=case_elastic, codeproofs=case_codeproofs, streamfold=case_streamfold, lkpfold=case_lkpfold, multree=case_multree, innerpcs=case_innerpcs, gate=case_gate)

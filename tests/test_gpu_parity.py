@@ -804,6 +804,15 @@ def test_streamfold_vs_golden(hb):
         assert np.array_equal(got[k], g[k]), k
 
 
+def test_lkpfold_vs_golden(hb):
+    """compute{3,4}p_error_terms under has_lookups (hobbit_set_lookups), every selector value of the lookup prover, against the REAL reference"""
+    g = gold("lkpfold")
+    got = golden_cases.case_lkpfold(hb)
+    assert set(got) == set(g.files)
+    for k in g.files:
+        assert np.array_equal(got[k], g[k]), k
+
+
 def test_streamfold_large_vs_oracle(hb, oracle):
     n = 1 << 18                                     # B = 2^18, the MLP config's chunk size
     t = [splitmix_field(n, 600 + i) for i in range(8)]
@@ -1158,6 +1167,58 @@ def test_gate_consistency_stream_vs_oracle(hb, oracle, logB, nch):
     assert want["checks"].tolist() == [1, 1, 1] and got["checks"].tolist() == [1, 1, 1]
     for k in ("R", "a", "poly", "gr", "fin6", "Peval", "b", "q2", "r2", "vr2", "fin2"):
         assert np.array_equal(got[k], want[k]), k
+
+
+def lookup_trace(B, nch, seed):
+    """consistent trace with lookup rows (selectors 0 add, 1 mul, 2 lookup), vectorised; lookup outputs are full-range elements"""
+    parts = []
+    for c in range(nch):
+        g = np.random.default_rng(seed + c); z = np.zeros(B, np.uint64)
+        S = g.integers(0, 3, B).astype(np.int32); Lr = g.integers(0, 1 << 30, B).astype(np.uint64); Rr = g.integers(0, 1 << 30, B).astype(np.uint64)
+        prod = (Lr * Rr) % np.uint64(P)
+        Ore = np.where(S == 0, Lr + Rr, np.where(S == 1, prod, g.integers(0, P, B).astype(np.uint64)))
+        Oim = np.where(S == 2, g.integers(0, P, B).astype(np.uint64), z)
+        parts.append((np.stack([Lr, z], 1), np.stack([Rr, z], 1), np.stack([Ore, Oim], 1), S))
+    return [np.concatenate([p[i] for p in parts]) for i in range(4)]
+
+
+@pytest.mark.parametrize("logB,nch", [(8, 8), (14, 4), (18, 4)])
+def test_gate_consistency_lookups_stream_vs_oracle(hb, oracle, logB, nch):
+    """prove_gate_consistency_lookups (src/sumcheck.cpp:503-795): chunk loop with the lookup gate maps of compute{3,4}p_error_terms, the 9-table
+    degree-4 sumcheck, the 8-column Peval pass and the closing sumcheck, every message against the oracle; all five reference self-checks hold.
+    The oracle restates the reference's in-place selector rewrites literally, the device derives its selector columns once per chunk."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    B = 1 << logB
+    L, R, O, S = lookup_trace(B, nch, 700)
+    r = splitmix_field(logB, 3); lr = splitmix_field(2, 77)
+    libc.srandom(23); want = oracle.gate_consistency_lookups_stream(L, R, O, S, B, r, lr)
+    libc.srandom(23); got = hb.gate_consistency_lookups_stream(hb.trace_source(L, R, O, S, B), nch, B, r, lr)
+    assert want["checks"].tolist() == [1] * 5 and got["checks"].tolist() == [1] * 5
+    for k in ("R", "a", "poly", "gr", "fin9", "Peval", "b", "q2", "r2", "vr2", "fin2"):
+        assert np.array_equal(got[k], want[k]), k
+    # a broken addition gate must trip "Error in gate consistency 1" on both sides, with identical messages up to there
+    O2 = O.copy(); O2[2 * B + int(np.nonzero(S[2 * B:3 * B] == 0)[0][0]), 0] ^= np.uint64(1)
+    libc.srandom(23); w2 = oracle.gate_consistency_lookups_stream(L, R, O2, S, B, r, lr)
+    libc.srandom(23); g2 = hb.gate_consistency_lookups_stream(hb.trace_source(L, R, O2, S, B), nch, B, r, lr)
+    assert w2["checks"][0] == 0 and g2["checks"][0] == 0 and np.array_equal(g2["R"], w2["R"]) and np.array_equal(g2["poly"], w2["poly"])
+
+
+def test_lookups_flag_is_required_and_scoped(hb):
+    """hobbit_gate_consistency_lookups_stream refuses to run with has_lookups unset (the reference would silently use the plain gate maps);
+    the flag set by hobbit_set_lookups changes compute3p/4p only while it is on"""
+    n = 4096
+    t = [splitmix_field(n, 900 + i) for i in range(8)]
+    gate = (np.arange(n) % 5 - 1).astype(np.int32)                                           # -1 .. 3
+    plain = hb.err3p(t[0], gate, t[1], t[2], t[3], t[4])
+    hb.set_lookups(splitmix_field(2, 5))
+    lk = hb.err3p(t[0], gate, t[1], t[2], t[3], t[4])
+    hb.set_lookups(None)
+    assert not np.array_equal(plain, lk) and np.array_equal(plain, hb.err3p(t[0], gate, t[1], t[2], t[3], t[4]))
+    L, R, O, S = lookup_trace(256, 2, 1)
+    mod = __import__("__graft_entry__").load_package()
+    with pytest.raises(mod.HobbitError, match="has_lookups"):
+        hb.gate_consistency_lookups_stream(hb.trace_source(L, R, O, S, 256), 2, 256, splitmix_field(8, 3), None)
 
 
 @pytest.mark.parametrize("opt", [1, 2])

@@ -116,3 +116,22 @@ def test_gate_consistency_stream_selfchecks(oracle):
     assert np.array_equal(res["R"][0], np.array([1, 0], np.uint64))
     O2 = O.copy(); O2[3 * B + 5, 0] ^= np.uint64(1)
     assert oracle.gate_consistency_stream(L, R, O2, S, B, splitmix_field(8, 3))["checks"][0] == 0
+
+
+def test_gate_consistency_lookups_stream_selfchecks(oracle):
+    """prove_gate_consistency_lookups (src/sumcheck.cpp:503-795) on consistent synthetic gates with lookup rows: every reference self-check
+    (gate consistency 1/2/3, the per-chunk Kf_M recomputation, the Kf_lkp recomputation) must hold; a corrupted addition gate trips check 1,
+    a corrupted lookup row does not (its output cancels identically)."""
+    from oracle.pyoracle import gate_lookup_inputs
+    B, nch = 1 << 8, 8
+    parts = [gate_lookup_inputs(B, 300 + c) for c in range(nch)]
+    L, R, O, S = [np.concatenate([p[i] for p in parts]) for i in range(4)]
+    lr = splitmix_field(2, 77); r = splitmix_field(8, 3)
+    res = oracle.gate_consistency_lookups_stream(L, R, O, S, B, r, lr)
+    assert res["checks"].tolist() == [1, 1, 1, 1, 1]
+    assert np.array_equal(res["R"][0], np.array([1, 0], np.uint64))
+    ia = 3 * B + int(np.nonzero(S[3 * B:4 * B] == 0)[0][0]); il = 3 * B + int(np.nonzero(S[3 * B:4 * B] == 2)[0][0])
+    O2 = O.copy(); O2[ia, 0] ^= np.uint64(1)
+    assert oracle.gate_consistency_lookups_stream(L, R, O2, S, B, r, lr)["checks"][0] == 0
+    O3 = O.copy(); O3[il, 0] ^= np.uint64(1)
+    assert oracle.gate_consistency_lookups_stream(L, R, O3, S, B, r, lr)["checks"].tolist() == [1, 1, 1, 1, 1]
