@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "hobbit_elastic_open_begin", "hobbit_elastic_open_aggregate_push", "hobbit_elastic_open_aggregate_finish", "hobbit_elastic_open_reply_push",
     "hobbit_elastic_open_finish", "hobbit_elastic_open_free", "hobbit_generate_randomness",
     "hobbit_read_mul_tree_layer", "hobbit_read_mul_tree_data", "hobbit_generate_claims_opt", "hobbit_sumcheck3_stream_batch", "hobbit_mul_tree_stream_shallow",
-    "hobbit_gate_consistency_stream", "hobbit_set_lookups", "hobbit_gate_consistency_lookups_stream",
+    "hobbit_gate_consistency_stream", "hobbit_set_lookups", "hobbit_gate_consistency_lookups_stream", "hobbit_open_standard_rs",
     "hobbit_tensorcode_chunks", "hobbit_inner_digests", "hobbit_chain_digests", "hobbit_blake3_64_host",
     "hobbit_parity_matrix", "hobbit_phi_g", "hobbit_prepare_matrix_cols", "hobbit_prove_linear_code", "hobbit_prove_fft",
     "hobbit_prove_fft_matrix",
@@ -105,7 +105,7 @@ def load_library(path=LIB_PATH):
         "hobbit_read_mul_tree_layer": [V, V, V, S, I, V], "hobbit_read_mul_tree_data": [V, V, V, S, I, I, I, V],
         "hobbit_generate_claims_opt": [V, V, V, S, S, V, I, I, I, I, V], "hobbit_sumcheck3_stream_batch": [V, V, V, S, S, V, I, I, I, I, V, I, V],
         "hobbit_mul_tree_stream_shallow": [V, V, V, S, S, I, S, V, I, V, I, V], "hobbit_gate_consistency_stream": [V, V, V, S, S, V, V],
-        "hobbit_set_lookups": [V, I, V], "hobbit_gate_consistency_lookups_stream": [V, V, V, S, S, V, V],
+        "hobbit_set_lookups": [V, I, V], "hobbit_open_standard_rs": [V, V, S, V, V, I, V], "hobbit_gate_consistency_lookups_stream": [V, V, V, S, S, V, V],
         "hobbit_tensorcode_chunks": [V, V, S, I, I, I, V], "hobbit_inner_digests": [V, V, S, I, I, V],
         "hobbit_chain_digests": [V, V, S, I, S, V], "hobbit_blake3_64_host": [V, V, S],
     }
@@ -747,6 +747,37 @@ class Hobbit:
         res["poly"] = res["poly"][:rounds]; res["r"] = res["r"][:rounds]
         rl = int(res["reply_len"][0])
         res["reply"] = res["reply"].reshape(-1, 2)[:queries * rl].reshape(queries, rl, 2)
+        res["I"] = np.stack([res["cols"], res["rows"]], axis=1)
+        if sp:
+            res["sp_f"] = self._sp_trim(sp[0], B, 32)
+        return res
+
+    def open_standard_rs(self, poly, c, x, queries=790, want_paths=True, shockwave=True):
+        """Our_PC open_standard with linear_time == false (test_PC option 1, src/Our_PC.cpp:604-692), prover side.  poly: host array or
+        (DeviceBuffer/ptr, N); c: the Commitment from commit_standard(..., lin=0)."""
+        if isinstance(poly, tuple):
+            ptr, N = poly; ptr = ptr.ptr if isinstance(ptr, DeviceBuffer) else int(ptr); keep = None
+        else:
+            p = Fh(poly).reshape(-1, 2); N = p.shape[0]; keep = self.to_device(p); ptr = keep.ptr
+        x = Fh(x).reshape(-1, 2)
+        K, trs, B = c.K, c.trs, c.M
+        cols = 2 * B // trs; logc = cols.bit_length() - 1; logr = (2 * trs).bit_length() - 1; logt = logr - 1
+        maxr = (2048 * 2 * trs).bit_length() - 1 + logr + (logt + logc) + logc
+        depth = B.bit_length() - 1
+        res = dict(cols=np.zeros(queries, np.uint32), rows=np.zeros(queries, np.uint32), rv0=np.zeros(2, np.uint64), reply=np.zeros((queries, K, 2), np.uint64),
+                   reply_len=np.zeros(1, np.int32), paths=np.zeros((queries, depth, 32), np.uint8) if want_paths else None,
+                   cf_root=np.zeros(32, np.uint8), ncols=np.zeros(1, np.int32), poly=np.zeros((maxr, 3, 2), np.uint64), r=np.zeros((maxr, 2), np.uint64),
+                   vr=np.zeros((4, 2, 2), np.uint64), fin=np.zeros((4, 2), np.uint64), checks=np.zeros(2, np.int32), rx=np.zeros((logc + logt, 2), np.uint64))
+        names = ("cols", "rows", "rv0", "reply", "reply_len", "paths", "cf_root", "ncols", "poly", "r", "vr", "fin", "checks", "rx")
+
+        class Out(ctypes.Structure):
+            _fields_ = [(n, c_vp) for n in names + ("sp_f",)]
+        sp = self._sp_buffers(B, 32) if shockwave else None
+        o = Out(*([(res[k].ctypes.data if res[k] is not None else None) for k in names] + [ctypes.addressof(sp[1]) if sp else None]))
+        self._chk(self.lib.hobbit_open_standard_rs(self.ctx, c_vp(ptr), c_sz(N), c.h, _hp(x), c_int(queries), ctypes.byref(o)))
+        nc = int(res["ncols"][0]); np2 = 1 << max(nc - 1, 0).bit_length()
+        rounds = (np2 * 2 * trs).bit_length() - 1 + logr + (logt + logc) + logc
+        res["poly"] = res["poly"][:rounds]; res["r"] = res["r"][:rounds]
         res["I"] = np.stack([res["cols"], res["rows"]], axis=1)
         if sp:
             res["sp_f"] = self._sp_trim(sp[0], B, 32)

@@ -458,10 +458,17 @@ static int tensorcode_chunks(hobbit_ctx *ctx, const F *d_msg, size_t M, int K, i
     if (trs <= 0 || M % (size_t)trs) return ctx->fail(HOBBIT_EINVAL, "tensorcode: trs must divide M");
     size_t half = M / trs, cols = 2 * half, rows2 = 2 * (size_t)trs;
     int logc = ilog2_exact(cols), logr = ilog2_exact(rows2);
-    if (logc < 1 || logc > 15) return ctx->fail(HOBBIT_EINVAL, "tensorcode: row length 2M/trs must be a power of two <= 32768");
+    if (logc < 1 || logc > 24) return ctx->fail(HOBBIT_EINVAL, "tensorcode: row length 2M/trs must be a power of two <= 2^24");
     if (logr < 1) return ctx->fail(HOBBIT_EINVAL, "tensorcode: trs must be a power of two");
     // rows: RS encode = zero-padded FFT (src/PC_utils.cpp:75-84,105-107)
-    if (logc > 12) {
+    if (logc > 15) {
+        // very long rows (test_PC option 1 at 2^27 and beyond: tensor_row_size stays 128): one chunk at a time through the long transform
+        F *rm; HB_TRY(ctx->workspace3((size_t)trs * cols * sizeof(F), (void **)&rm));
+        for (int i = 0; i < K; i++) {
+            HB_TRY(fft_long(ctx, d_msg + (size_t)i * M, half, half, rm, logc, false, (uint32_t)trs));
+            HB_TRY(launch_transpose(ctx, rm, (size_t)trs * cols, (uint32_t)trs, (uint32_t)cols, d_out + (size_t)i * cols * rows2, cols * rows2, rows2, 1));
+        }
+    } else if (logc > 12) {
         // long rows (Elastic_PC opt 2: 32768): R strided FFT-4096 per row + twiddle/R-point combine, then transpose
         const int lr = logc - 12; const uint32_t R = 1u << lr; const size_t nrows = (size_t)K * trs;
         F *Y, *rm;
@@ -1240,6 +1247,72 @@ static void host_eq_table(const HF *r, int k, std::vector<F> &out) {
     out.assign((size_t)1 << k, fmake(0)); out[0] = fmake(1);
     for (int i = 0; i < k; i++) for (size_t j = ((size_t)1 << i); j-- > 0;) { F t = fmul(r[k - 1 - i], out[j]); out[2 * j + 1] = t; out[2 * j] = fsub(out[j], t); }
 }
+// ---- recursive_prover_RS (src/PC_utils.cpp:396-512): the aggregate (B elements, trs rows), its queries, C_f (encoded matrix + tree) -> P0, P2, P3, P5
+// and shockwave_prove(C_f, r_x).  Shared by Elastic_PC::open option 1 and Our_PC's open_standard with linear_time == false.
+static int rs_prover_dev(hobbit_ctx *ctx, const F *d_aggr, size_t B, size_t trs, const std::vector<uint32_t> &qc, const std::vector<uint32_t> &qr,
+                         const std::vector<uint32_t> &ucols, const uint32_t *d_ucols, const F *d_encf, const uint8_t *d_lvf, hobbit_elastic_open_out *o) {
+    const size_t half = B / trs, cols = 2 * half, rows2 = 2 * trs, nq = qc.size(), nc = ucols.size();
+    const int logc = ilog2_exact(cols), logr = ilog2_exact(rows2), logt = logr - 1;
+    if (logc < 1 || logc > 24 || logr < 2 || logr > 12) return ctx->fail(HOBBIT_EINVAL, "recursive_prover_RS: needs 2 <= 2*trs <= 4096 and a power-of-two row length");
+    size_t np2 = 1; while (np2 < nc) np2 <<= 1;
+    const int R0 = ilog2_exact(np2 * rows2);
+    F *arena; HB_TRY(ctx->workspace3((2 * B + np2 * trs + 2 * np2 * rows2 + 2 * B + 4096 + 64) * sizeof(F), (void **)&arena));
+    F *out1 = arena, *sel = out1 + 2 * B, *out3 = sel + np2 * trs, *bt = out3 + np2 * rows2, *b2 = bt + np2 * rows2, *stage = b2 + 2 * B;
+    if (logc <= 12) { HB_TRY(fft_rows(ctx, d_aggr, half, (uint32_t)half, out1, cols, 1, logc, false, 1, (uint32_t)trs, 0, 0)); }   // out_1 (:406-420)
+    else { HB_TRY(fft_long(ctx, d_aggr, half, half, out1, logc, false, (uint32_t)trs)); }
+    HB_TRY(launch_zero(ctx, sel, (np2 * trs + 2 * np2 * rows2 + 2 * B) * sizeof(F)));                         // sel | out3 | bt | b2
+    HB_TRY(launch_gather_cols(ctx, out1, cols, (uint32_t)trs, d_ucols, (uint32_t)nc, sel, trs));                                // selected_collumns (:422-431)
+    HB_TRY(fft_rows(ctx, sel, trs, (uint32_t)trs, out3, rows2, 1, logr, false, 1, (uint32_t)nc, 0, 0));                            // out_3 (:436-452)
+    std::vector<F> rq(nq);
+    { F cst = fmake(0); for (size_t i = 0; i < nq; i++) { if (i % 100 == 0) cst = fmake((uint64_t)random()); rq[i] = fadd(cst, fmake((uint64_t)rand())); } }   // r = generate_randomness(I.size()) (:459)
+    {   // beta (:461-470): the sorted column walk is paired with the UNSORTED query rows, duplicates accumulate
+        std::vector<uint32_t> cs(qc); std::sort(cs.begin(), cs.end());
+        std::map<uint64_t, F> acc; size_t counter = 0;
+        for (size_t i = 0; i < nq; i++) {
+            if (ucols[counter] != cs[i]) counter++;
+            const uint64_t at = counter * rows2 + qr[i];
+            auto it = acc.find(at);
+            if (it == acc.end()) acc[at] = rq[i]; else it->second = fadd(it->second, rq[i]);
+        }
+        uint8_t *pin; HB_TRY(ctx->pinned(std::max(nq * (sizeof(F) + 8) + 64, (size_t)2048 * sizeof(F)), (void **)&pin));
+        F *pv = reinterpret_cast<F *>(pin); uint64_t *pi = reinterpret_cast<uint64_t *>(pin + nq * sizeof(F));
+        size_t n = 0; for (auto &kv : acc) { pi[n] = kv.first; pv[n] = kv.second; n++; }
+        F *dv = stage; uint64_t *di = reinterpret_cast<uint64_t *>(stage + nq);
+        if (2 * nq > 4096) return ctx->fail(HOBBIT_EINVAL, "recursive_prover_RS: too many queries for the staging area");
+        HB_CHECK(ctx, hipMemcpyAsync(dv, pv, n * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+        HB_CHECK(ctx, hipMemcpyAsync(di, pi, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        HB_TRY(launch_scatter(ctx, di, dv, n, bt));
+    }
+    hobbit_F p323 = {323, 0};
+    hobbit_F *Q = o->qpoly, *Rr = o->r;
+    HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(out3), reinterpret_cast<hobbit_F *>(bt), np2 * rows2, &p323, Q, Rr, o->vr, o->fin));          // P0 (:474)
+    const hobbit_F *r0 = Rr; Q += 3 * R0; Rr += R0;
+    HB_TRY(hobbit_prove_fft_matrix(ctx, reinterpret_cast<hobbit_F *>(sel), np2, trs, r0, Q, Rr, o->vr + 2, o->fin + 1));                                       // P2 (:480)
+    { const HF *q2 = cF(Q); o->checks[0] = feq(fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])), cF(o->vr)[0]); }                                                   // src/sumcheck.cpp:3016-3019
+    const hobbit_F *r2 = Rr; Q += 3 * logr; Rr += logr;
+    // r_point: P2.randomness[0] (its logr sumcheck challenges, then r1 = P0.r[logr..]) from index log2(trs) on (:482-485)
+    std::vector<F> rpt; rpt.push_back(cF(r2)[logt]);
+    for (int i = logr; i < R0; i++) rpt.push_back(cF(r0)[i]);
+    std::vector<F> rb; host_eq_table(rpt.data(), (int)rpt.size(), rb);
+    {   // beta[collumns[i] + j*cols] = r[i] (:489-496)
+        uint8_t *pin; HB_TRY(ctx->pinned(2048 * sizeof(F), (void **)&pin));
+        if (nc > 2048) return ctx->fail(HOBBIT_EINVAL, "recursive_prover_RS: more than 2048 distinct columns");
+        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));                                    // (the staging buffer's previous contents have been consumed: sumcheck2 synchronised)
+        memcpy(pin, rb.data(), nc * sizeof(F));
+        HB_CHECK(ctx, hipMemcpyAsync(stage, pin, nc * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+        HB_TRY(launch_spread_cols(ctx, d_ucols, stage, (uint32_t)nc, (uint32_t)trs, cols, b2));
+    }
+    HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(out1), reinterpret_cast<hobbit_F *>(b2), trs * cols, &p323, Q, Rr, o->vr + 4, o->fin + 2));     // P3 (:498)
+    const hobbit_F *r3 = Rr; Q += 3 * (logt + logc); Rr += logt + logc;
+    HB_TRY(hobbit_prove_fft_matrix(ctx, reinterpret_cast<const hobbit_F *>(d_aggr), trs, half, r3, Q, Rr, o->vr + 6, o->fin + 3));                               // P5 (:503)
+    { const HF *q5 = cF(Q); o->checks[1] = feq(fadd(fadd(q5[0], q5[1]), fadd(q5[2], q5[2])), cF(o->vr)[4]); }
+    // r_x = P5.randomness[0]: its sumcheck challenges, then r1 = P3.r[logc .. logc + log2 trs) (src/sumcheck.cpp:3021-3023)
+    std::vector<hobbit_F> rx((size_t)logc + (size_t)logt);
+    memcpy(rx.data(), Rr, sizeof(hobbit_F) * (size_t)logc); memcpy(rx.data() + logc, r3 + logc, sizeof(hobbit_F) * (size_t)logt);
+    if (o->rx) memcpy(o->rx, rx.data(), sizeof(hobbit_F) * rx.size());
+    if (o->sp_f) HB_TRY(hobbit_shockwave_prove(ctx, reinterpret_cast<const hobbit_F *>(d_aggr), reinterpret_cast<const hobbit_F *>(d_encf), d_lvf, B, 32, rx.data(), (int)rx.size(), o->sp_f));   // (:507)
+    return 0;
+}
 void hobbit_elastic_open_free(hobbit_elastic_open *e) {
     if (!e) return;
     hipStreamSynchronize(e->ctx->stream);
@@ -1308,8 +1381,7 @@ int hobbit_elastic_open_reply_push(hobbit_ctx *ctx, hobbit_elastic_open *e, cons
 }
 int hobbit_elastic_open_finish(hobbit_ctx *ctx, hobbit_elastic_open *e, const uint8_t *d_commit_levels, hobbit_elastic_open_out *o) {
     if (!o || !e->committed || e->n_reply != e->K) return ctx->fail(HOBBIT_ESTATE, "elastic_open_finish: the aggregate and reply passes must be complete");
-    const size_t B = e->B, trs = (size_t)e->trs, cols = e->cols, rows2 = e->rows2, half = B / trs, nq = (size_t)e->queries, nc = e->ucols.size();
-    const int logc = 12, logr = ilog2_exact(rows2), logt = logr - 1;
+    const size_t B = e->B, trs = (size_t)e->trs, cols = e->cols, nq = (size_t)e->queries, nc = e->ucols.size();
     if (o->cols) memcpy(o->cols, e->qc.data(), 4 * nq);
     if (o->rows) memcpy(o->rows, e->qr.data(), 4 * nq);
     if (o->rv0) *mF(o->rv0) = e->rv0;
@@ -1330,64 +1402,43 @@ int hobbit_elastic_open_finish(hobbit_ctx *ctx, hobbit_elastic_open *e, const ui
         for (size_t q = 0; q < nq; q++) pos[q] = (uint64_t)(e->qr[q] / 4) * cols + e->qc[q];
         HB_TRY(paths_common(ctx, d_commit_levels, 4 * B, pos.data(), nq, o->paths));
     }
-    // ---- recursive_prover_RS (src/PC_utils.cpp:396-512) ----
-    size_t np2 = 1; while (np2 < nc) np2 <<= 1;
-    const int R0 = ilog2_exact(np2 * rows2);
-    F *arena; HB_TRY(ctx->workspace3((2 * B + np2 * trs + 2 * np2 * rows2 + 2 * B + 4096 + 64) * sizeof(F), (void **)&arena));
-    F *out1 = arena, *sel = out1 + 2 * B, *out3 = sel + np2 * trs, *bt = out3 + np2 * rows2, *b2 = bt + np2 * rows2, *stage = b2 + 2 * B;
-    HB_TRY(fft_rows(ctx, e->d_aggr, half, (uint32_t)half, out1, cols, 1, logc, false, 1, (uint32_t)trs, 0, 0));                  // out_1 (:406-420)
-    HB_TRY(launch_zero(ctx, sel, (np2 * trs + 2 * np2 * rows2 + 2 * B) * sizeof(F)));                         // sel | out3 | bt | b2
-    HB_TRY(launch_gather_cols(ctx, out1, cols, (uint32_t)trs, e->d_ucols, (uint32_t)nc, sel, trs));                                // selected_collumns (:422-431)
-    HB_TRY(fft_rows(ctx, sel, trs, (uint32_t)trs, out3, rows2, 1, logr, false, 1, (uint32_t)nc, 0, 0));                            // out_3 (:436-452)
-    std::vector<F> rq(nq);
-    { F cst = fmake(0); for (size_t i = 0; i < nq; i++) { if (i % 100 == 0) cst = fmake((uint64_t)random()); rq[i] = fadd(cst, fmake((uint64_t)rand())); } }   // r = generate_randomness(I.size()) (:459)
-    {   // beta (:461-470): the sorted column walk is paired with the UNSORTED query rows, duplicates accumulate
-        std::vector<uint32_t> cs(e->qc); std::sort(cs.begin(), cs.end());
-        std::map<uint64_t, F> acc; size_t counter = 0;
-        for (size_t i = 0; i < nq; i++) {
-            if (e->ucols[counter] != cs[i]) counter++;
-            const uint64_t at = counter * rows2 + e->qr[i];
-            auto it = acc.find(at);
-            if (it == acc.end()) acc[at] = rq[i]; else it->second = fadd(it->second, rq[i]);
-        }
-        uint8_t *pin; HB_TRY(ctx->pinned(std::max(nq * (sizeof(F) + 8) + 64, (size_t)2048 * sizeof(F)), (void **)&pin));
-        F *pv = reinterpret_cast<F *>(pin); uint64_t *pi = reinterpret_cast<uint64_t *>(pin + nq * sizeof(F));
-        size_t n = 0; for (auto &kv : acc) { pi[n] = kv.first; pv[n] = kv.second; n++; }
-        F *dv = stage; uint64_t *di = reinterpret_cast<uint64_t *>(stage + nq);
-        if (2 * nq > 4096) return ctx->fail(HOBBIT_EINVAL, "elastic_open: too many queries for the staging area");
-        HB_CHECK(ctx, hipMemcpyAsync(dv, pv, n * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
-        HB_CHECK(ctx, hipMemcpyAsync(di, pi, n * 8, hipMemcpyHostToDevice, ctx->stream));
-        HB_TRY(launch_scatter(ctx, di, dv, n, bt));
-    }
-    hobbit_F p323 = {323, 0};
-    hobbit_F *Q = o->qpoly, *Rr = o->r;
-    HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(out3), reinterpret_cast<hobbit_F *>(bt), np2 * rows2, &p323, Q, Rr, o->vr, o->fin));          // P0 (:474)
-    const hobbit_F *r0 = Rr; Q += 3 * R0; Rr += R0;
-    HB_TRY(hobbit_prove_fft_matrix(ctx, reinterpret_cast<hobbit_F *>(sel), np2, trs, r0, Q, Rr, o->vr + 2, o->fin + 1));                                       // P2 (:480)
-    { const HF *q2 = cF(Q); o->checks[0] = feq(fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])), cF(o->vr)[0]); }                                                   // src/sumcheck.cpp:3016-3019
-    const hobbit_F *r2 = Rr; Q += 3 * logr; Rr += logr;
-    // r_point: P2.randomness[0] (its logr sumcheck challenges, then r1 = P0.r[logr..]) from index log2(trs) on (:482-485)
-    std::vector<F> rpt; rpt.push_back(cF(r2)[logt]);
-    for (int i = logr; i < R0; i++) rpt.push_back(cF(r0)[i]);
-    std::vector<F> rb; host_eq_table(rpt.data(), (int)rpt.size(), rb);
-    {   // beta[collumns[i] + j*cols] = r[i] (:489-496)
-        uint8_t *pin; HB_TRY(ctx->pinned(2048 * sizeof(F), (void **)&pin));
-        if (nc > 2048) return ctx->fail(HOBBIT_EINVAL, "elastic_open: more than 2048 distinct columns");
-        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));                                    // (the staging buffer's previous contents have been consumed: sumcheck2 synchronised)
-        memcpy(pin, rb.data(), nc * sizeof(F));
-        HB_CHECK(ctx, hipMemcpyAsync(stage, pin, nc * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
-        HB_TRY(launch_spread_cols(ctx, e->d_ucols, stage, (uint32_t)nc, (uint32_t)trs, cols, b2));
-    }
-    HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(out1), reinterpret_cast<hobbit_F *>(b2), trs * cols, &p323, Q, Rr, o->vr + 4, o->fin + 2));     // P3 (:498)
-    const hobbit_F *r3 = Rr; Q += 3 * (logt + logc); Rr += logt + logc;
-    HB_TRY(hobbit_prove_fft_matrix(ctx, reinterpret_cast<hobbit_F *>(e->d_aggr), trs, half, r3, Q, Rr, o->vr + 6, o->fin + 3));                               // P5 (:503)
-    { const HF *q5 = cF(Q); o->checks[1] = feq(fadd(fadd(q5[0], q5[1]), fadd(q5[2], q5[2])), cF(o->vr)[4]); }
-    // r_x = P5.randomness[0]: its sumcheck challenges, then r1 = P3.r[logc .. logc + log2 trs) (src/sumcheck.cpp:3021-3023)
-    std::vector<hobbit_F> rx((size_t)logc + (size_t)logt);
-    memcpy(rx.data(), Rr, sizeof(hobbit_F) * (size_t)logc); memcpy(rx.data() + logc, r3 + logc, sizeof(hobbit_F) * (size_t)logt);
-    if (o->rx) memcpy(o->rx, rx.data(), sizeof(hobbit_F) * rx.size());
-    if (o->sp_f) HB_TRY(hobbit_shockwave_prove(ctx, reinterpret_cast<hobbit_F *>(e->d_aggr), reinterpret_cast<hobbit_F *>(e->d_encf), e->d_lvf, B, 32, rx.data(), (int)rx.size(), o->sp_f));   // (:507)
-    return 0;
+    return rs_prover_dev(ctx, e->d_aggr, B, trs, e->qc, e->qr, e->ucols, e->d_ucols, e->d_encf, e->d_lvf, o);
+}
+
+// ---- Our_PC open_standard with linear_time == false (test_PC option 1; the circuit polynomial of prove_circuit_standard): src/Our_PC.cpp:604-692 ----
+// r_v[0], _aggregate (aggregate + C_f, no C_c: :258-276), `queries` (790 in the reference) draws, replies out of the retained tensor, paths,
+// recursive_prover_RS.  Output layout: hobbit_elastic_open_out (reply: queries x K).
+int hobbit_open_standard_rs(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const hobbit_F *h_x, int queries, hobbit_elastic_open_out *o) {
+    if (!c || !o || !h_x || queries <= 0) return ctx->fail(HOBBIT_EINVAL, "open_standard_rs: bad arguments");
+    if (c->lin) return ctx->fail(HOBBIT_EINVAL, "open_standard_rs: the commitment is RS x expander (use hobbit_open_standard)");
+    const int K = c->K; const size_t B = c->M, trs = (size_t)c->trs, cols = c->cols, rows2 = c->rows2, nq = (size_t)queries;
+    const int logK = ilog2_exact((size_t)K);
+    if (N != c->N || logK < 0) return ctx->fail(HOBBIT_EINVAL, "open_standard_rs: polynomial / commitment mismatch");
+    std::vector<F> beta; host_eq_table(cF(h_x), logK, beta);                                                // precompute_beta(x1, beta) (:619-621)
+    const F rv0 = fadd(fmake((uint64_t)random()), fmake((uint64_t)rand()));                                 // r_v[0] = generate_randomness(1)[0] (:623)
+    F *d_aggr = nullptr, *d_encf = nullptr; uint8_t *d_lvf = nullptr; uint32_t *d_ucols = nullptr;
+    auto release = [&]() { hipStreamSynchronize(ctx->stream); for (void *p : {(void *)d_aggr, (void *)d_encf, (void *)d_lvf, (void *)d_ucols}) if (p) hipFree(p); };
+    if (hipMalloc((void **)&d_aggr, B * sizeof(F)) != hipSuccess || hipMalloc((void **)&d_encf, 2 * B * sizeof(F)) != hipSuccess ||
+        hipMalloc((void **)&d_lvf, 64 * (2 * B / 32)) != hipSuccess || hipMalloc((void **)&d_ucols, nq * 4) != hipSuccess) { release(); return ctx->fail(HOBBIT_ENOMEM, "open_standard_rs: allocation failed"); }
+    int rc = [&]() -> int {
+        HB_TRY(launch_aggregate(ctx, cF(d_poly), B, K, beta.data(), d_aggr));                               // _aggregate (:267-272)
+        HB_TRY(hobbit_shockwave_commit(ctx, reinterpret_cast<hobbit_F *>(d_aggr), B, 32, reinterpret_cast<hobbit_F *>(d_encf), d_lvf));   // C_f (:274-275)
+        std::vector<uint32_t> qc(nq), qr(nq);
+        for (size_t q = 0; q < nq; q++) { qc[q] = (uint32_t)(rand() % (long)cols); qr[q] = (uint32_t)(rand() % (long)rows2); }      // (:634-638)
+        std::vector<uint32_t> ucols(qc); std::sort(ucols.begin(), ucols.end()); ucols.erase(std::unique(ucols.begin(), ucols.end()), ucols.end());
+        HB_TRY(hobbit_memcpy_h2d(ctx, d_ucols, ucols.data(), ucols.size() * 4));
+        if (o->cols) memcpy(o->cols, qc.data(), 4 * nq);
+        if (o->rows) memcpy(o->rows, qr.data(), 4 * nq);
+        if (o->rv0) *mF(o->rv0) = rv0;
+        if (o->ncols) *o->ncols = (int)ucols.size();
+        if (o->cf_root) HB_TRY(hobbit_memcpy_d2h(ctx, o->cf_root, d_lvf + 32 * (2 * (2 * B / 32) - 2), 32));
+        if (o->reply) HB_TRY(hobbit_commitment_gather(ctx, c, qr.data(), qc.data(), nq, o->reply));         // _compute_aggregation_reply (:291-305)
+        if (o->reply_len) *o->reply_len = K;
+        if (o->paths) HB_TRY(hobbit_commitment_paths(ctx, c, qc.data(), qr.data(), nq, o->paths));          // open_tree_blake(Commitment_MT, I[i], 2B/trs) (:643-645)
+        return rs_prover_dev(ctx, d_aggr, B, trs, qc, qr, ucols, d_ucols, d_encf, d_lvf, o);                // (:651-653)
+    }();
+    release();
+    return rc;
 }
 
 // ---- streaming (space-efficient) provers over a caller-supplied chunk source -------------------------------------------------

@@ -292,12 +292,52 @@ static void shockwave_ps(const hobbit_host_shockwave_transcript &t, size_t N, in
 }
 // src/Our_PC.cpp:604-692.  The prover side runs on the device (hobbit_open_standard: libc draws in the reference's order);
 // the reference's verifier emulation is reduced to its proof-size accounting (ps); vt is the time that accounting took here.
+static hobbit_host_elastic_transcript g_eopen;
+hobbit_host_elastic_transcript &hobbit_host_last_elastic_open() { return g_eopen; }
+// open_standard's linear_time == false branch (src/Our_PC.cpp:609-611, 651-652: 790 queries, recursive_prover_RS); the messages land in
+// hobbit_host_last_elastic_open() (same transcript shape as Elastic_PC::open option 1, replies queries x K)
+static void open_standard_rs(vector<F> &poly, vector<F> &x, vector<vector<_hash>> &Commitment_MT, int K, double &vt, double &ps) {
+    const size_t N = poly.size(), M = N / K;
+    const int queries = 790; aggregation_queries = queries;
+    const int trs = g_commit_trs; const size_t cols = g_commit_cols;
+    const int logc = (int)log2((double)cols), logr = (int)log2((double)(2 * trs)), logt = logr - 1, depth = (int)log2((double)M);
+    if (!g_poly_dev || g_poly_n != N || getenv("HOBBIT_HOST_REUPLOAD")) {
+        if (g_poly_dev) hobbit_free(hobbit_host_ctx(), g_poly_dev);
+        HCHK(hobbit_malloc(hobbit_host_ctx(), N * sizeof(F), &g_poly_dev)); g_poly_n = N;
+        HCHK(hobbit_memcpy_h2d(g_ctx, g_poly_dev, poly.data(), N * sizeof(F)));
+    }
+    hobbit_host_elastic_transcript &t = g_eopen;
+    const int maxr = 11 + logr + logr + (logt + logc) + logc;
+    t.queries = queries; t.cols.assign(queries, 0); t.rows.assign(queries, 0); t.reply.assign((size_t)queries * K, F(0)); t.paths.assign((size_t)queries * depth * 32, 0);
+    t.qpoly.assign(3 * (size_t)maxr, F(0)); t.r.assign(maxr, F(0)); t.vr.assign(8, F(0)); t.fin.assign(4, F(0)); t.rx.assign(logc + logt, F(0));
+    SpBuffers bf(t.sp_f, M, 32);
+    hobbit_elastic_open_out o{t.cols.data(), t.rows.data(), hF(&t.rv0), hF(t.reply.data()), &t.reply_len, t.paths.data(), t.cf_root, &t.ncols,
+                              hF(t.qpoly.data()), hF(t.r.data()), hF(t.vr.data()), hF(t.fin.data()), t.checks, hF(t.rx.data()), &bf.o};
+    HCHK(hobbit_open_standard_rs(g_ctx, (const hobbit_F *)g_poly_dev, N, g_commit, hF(x.data()), queries, &o));
+    if (!t.checks[0] || !t.checks[1]) { printf("Error in fft\n"); exit(-1); }                                   // src/sumcheck.cpp:3016-3019
+    if (t.sp_f.iters && !(t.sp_f.wchecks[0] && t.sp_f.wchecks[1])) { printf("Error in final verification step\n"); exit(-1); }
+    printf(">>OK\n");
+    auto t0 = std::chrono::steady_clock::now();
+    size_t np2 = 1; while (np2 < (size_t)t.ncols) np2 <<= 1;
+    t.rounds = (int)log2((double)(np2 * 2 * trs)) + logr + (logt + logc) + logc;
+    ps += (double)((size_t)queries * K * sizeof(F)) / 1024.0;                                                   // (:648)
+    printf(">> %lf Kb\n", (double)((size_t)queries * K * sizeof(F)) / 1024.0);
+    sumcheck2_ps((int)log2((double)(np2 * 2 * trs)), ps); sumcheck2_ps(logr, ps); sumcheck2_ps(logt + logc, ps); sumcheck2_ps(logc, ps);   // P0, P2, P3, P5
+    shockwave_ps(t.sp_f, M, 32, ps);
+    double MT_ps = 0.0;
+    vector<size_t> pos(queries);
+    for (int i = 0; i < queries; i++) pos[i] = (size_t)(t.rows[i] / 4) * cols + t.cols[i];
+    path_ps(Commitment_MT.empty() ? M : Commitment_MT[0].size(), depth, pos, MT_ps);                            // (:676-679)
+    printf("Opening proofs : %lf\n", MT_ps);
+    ps += MT_ps;
+    vt += std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::steady_clock::now() - t0).count();
+}
 void open_standard(vector<F> &poly, vector<F> x, vector<vector<_hash>> &Commitment_MT, vector<vector<vector<F>>> &_tensor, int K, double &vt, double &ps) {
     (void)_tensor;
-    if (!linear_time) { printf("Error: open_standard is built for linear_time (RS x expander) only\n"); exit(-1); }
     if (!g_commit || g_commit_K != K) { printf("Error: open_standard without a matching commit_standard\n"); exit(-1); }
     const size_t N = poly.size(), M = N / K;
     BUFFER_SPACE = M;
+    if (!linear_time) { open_standard_rs(poly, x, Commitment_MT, K, vt, ps); return; }
     const int queries = 5900; aggregation_queries = queries;
     const int trs = g_commit_trs; const size_t cols = g_commit_cols;
     const int R1 = (int)log2((double)(2 * trs)), logc = (int)log2((double)cols), R3 = R1 + logc, depth = (int)log2((double)M);
@@ -505,8 +545,6 @@ void read_stream(stream_descriptor &fd, vector<F> &v, int size) {   // src/witne
         fd.name.find("wiring_consistency_check") == 0) { printf("Error: stream '%s' belongs to the witness generator (out of scope)\n", fd.name.c_str()); exit(-1); }
     for (int i = 0; i < size; i++) v[i] = F((i % 1024) + 1);
 }
-static hobbit_host_elastic_transcript g_eopen;
-hobbit_host_elastic_transcript &hobbit_host_last_elastic_open() { return g_eopen; }
 // src/Elastic_PC.cpp:625-726, !linear_time (RS x RS).  Prover side on the device (hobbit_elastic_open_*: libc draws in the reference's
 // order, the stream re-read twice through read_stream as the reference does); the verifier emulation is reduced to its ps accounting.
 void open(stream_descriptor fd, vector<F> x, vector<vector<_hash>> &Commitment_MT, double &vt, double &ps) {
@@ -805,13 +843,16 @@ vector<F> prove_multiplication_tree_stream_shallow(stream_descriptor fd, int vec
 
 // ---- driver (src/Our_PC.cpp:757-826, option 4, commit phase) ---------------------------------------
 void test_PC(size_t N, int option, int K) {
-    if (option != 4) { printf("Error: only option 4 (RS x expander Our_PC) is built on the device path\n"); exit(-1); }
+    if (option != 4 && option != 1) { printf("Error: options 2 and 3 are the Orion / Brakedown comparison baselines, not built on the device path\n"); exit(-1); }
     vector<F> poly = generate_randomness((int)N);
     _hash comm; vector<vector<_hash>> MT_hashes;
-    linear_time = true;
-    tensor_row_size = (int)(N / (K * 1ULL << (11)));
-    printf("%d\n", tensor_row_size);
-    expander_init_store(tensor_row_size);
+    if (option == 1) { linear_time = false; tensor_row_size = 128; }                     // (:764-766: RS x RS)
+    else {
+        linear_time = true;
+        tensor_row_size = (int)(N / (K * 1ULL << (11)));
+        printf("%d\n", tensor_row_size);
+        expander_init_store(tensor_row_size);
+    }
     vector<vector<vector<F>>> _tensor;
     auto start = std::chrono::steady_clock::now();
     commit_standard(poly, comm, MT_hashes, _tensor, K);
@@ -860,6 +901,27 @@ int hobbit_host_test_pc_open(size_t N, int K, unsigned seed, uint64_t *qpoly, ui
     memcpy(sp_roots, t.roots, 64); memcpy(sp_roots + 64, t.sp_c.whir_root, 32); memcpy(sp_roots + 96, t.sp_f.whir_root, 32);
     checks5[0] = t.checks[0]; checks5[1] = t.checks[1]; checks5[2] = t.checks[2]; checks5[3] = t.sp_c.wchecks[0] & t.sp_c.wchecks[1]; checks5[4] = t.sp_f.wchecks[0] & t.sp_f.wchecks[1];
     *ps_out = ps;
+    return t.rounds;
+}
+// test_PC(N, 1, K) through the mirror (linear_time == false, tensor_row_size = 128): root, then the opening's transcript pieces
+int hobbit_host_test_pc_rs_open(size_t N, int K, unsigned seed, uint8_t *root_out, uint64_t *qpoly, uint64_t *r, uint32_t *cols_rows, uint8_t *roots2 /* C_f, whir_f */, int *checks3, double *ps_out) {
+    srandom(1);
+    vector<F> poly = generate_randomness((int)N);
+    linear_time = false; tensor_row_size = 128;
+    _hash comm; vector<vector<_hash>> MT; vector<vector<vector<F>>> T;
+    commit_standard(poly, comm, MT, T, K);
+    memcpy(root_out, MT.back()[0].arr, 32);
+    vector<F> x = generate_randomness((int)log2((double)N));
+    srandom(seed);
+    double vt = 0, ps = 0;
+    open_standard(poly, x, MT, T, K, vt, ps);
+    hobbit_host_elastic_transcript &t = hobbit_host_last_elastic_open();
+    memcpy(qpoly, t.qpoly.data(), 48 * (size_t)t.rounds); memcpy(r, t.r.data(), 16 * (size_t)t.rounds);
+    for (int i = 0; i < t.queries; i++) { cols_rows[2 * i] = t.cols[i]; cols_rows[2 * i + 1] = t.rows[i]; }
+    memcpy(roots2, t.cf_root, 32); memcpy(roots2 + 32, t.sp_f.whir_root, 32);
+    checks3[0] = t.checks[0]; checks3[1] = t.checks[1]; checks3[2] = t.sp_f.iters ? (t.sp_f.wchecks[0] & t.sp_f.wchecks[1]) : 1;
+    *ps_out = ps;
+    linear_time = true;
     return t.rounds;
 }
 int hobbit_host_sumcheck2(const uint64_t *v1, const uint64_t *v2, size_t n, const uint64_t *prev, uint64_t *qpoly, uint64_t *r, uint64_t *vr, uint64_t *fin) {

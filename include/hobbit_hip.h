@@ -284,6 +284,14 @@ int hobbit_elastic_open_reply_push(hobbit_ctx *ctx, hobbit_elastic_open *e, cons
 int hobbit_elastic_open_finish(hobbit_ctx *ctx, hobbit_elastic_open *e, const uint8_t *d_commit_levels, hobbit_elastic_open_out *out);
 void hobbit_elastic_open_free(hobbit_elastic_open *e);
 
+/* Our_PC open_standard with linear_time == false (src/Our_PC.cpp:604-692; test_PC option 1 and the circuit polynomial of
+ * prove_circuit_standard, src/main.cpp:1043-1051,1082: RS x RS tensor, tensor_row_size = 128, 790 queries): r_v[0]; _aggregate (:258-276:
+ * the aggregate and C_f, no C_c); the query draws; replies from the retained tensor; Merkle paths; recursive_prover_RS
+ * (src/PC_utils.cpp:396-512) with shockwave_prove(C_f, r_x).  The commitment must come from hobbit_commit_standard(..., linear_time = 0).
+ * Output as hobbit_elastic_open_out with reply = queries x K, paths = queries x log2(N/K) x 32 B, the P3 rounds log2(2 N/K) and the
+ * P5 rounds / first part of rx log2(2 (N/K) / trs) long. */
+int hobbit_open_standard_rs(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const hobbit_F *h_x, int queries, hobbit_elastic_open_out *out);
+
 /* ---- sumchecks ----------------------------------------------------------------------------- */
 /* generate_2product_sumcheck_proof (src/sumcheck.cpp:2391-2460).  Inputs preserved.
  * h_qpoly: rounds x 3 F (a,b,c highest degree first); h_r: rounds F; h_vr: 2 F; h_final: 1 F. */

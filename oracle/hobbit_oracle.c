@@ -1253,29 +1253,13 @@ size_t orc_elastic_reply(size_t N, size_t B, const uint64_t *Iq, size_t nq, oF *
 }
 static int cmp_sz(const void *a, const void *b) { size_t x = *(const size_t *)a, y = *(const size_t *)b; return x < y ? -1 : x > y; }
 static size_t next_pow2(size_t l) { size_t p = 1; while (p < l) p <<= 1; return p; }
-/* qpoly / r_out / vr / fin hold P0, P2, P3, P5 back to back (rounds R0 = log2(np2 * 2trs), log2(2trs), log2(2B), 12); rx = P5.randomness.
- * checks[0]: P2's claimed sum == P0.vr[0]; checks[1]: P5's == P3.vr[0] (prove_fft_matrix's own exit(-1) tests, src/sumcheck.c:3016-3019).
- * commit_levels: the commitment tree (4B leaves) or NULL; paths: queries x log2(4B) hashes. */
-int orc_elastic_open_rs(size_t N, size_t B, const oF *x, int queries, const uint8_t *commit_levels, uint32_t *I_out, oF *rv0_out, oF *aggr_out, uint8_t *cf_root,
-                        oF *reply_out, uint8_t *paths_out, int *ncols_out, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks, oF *rx_out) {
-    const size_t trs = B >> 11, half = B / trs, cols = 2 * half, rows2 = 2 * trs, K = N / B;
-    const int logK = (int)log2((double)K), logc = (int)log2((double)cols), logr = (int)log2((double)rows2), logt = (int)log2((double)trs);
-    /* open (:625-655): beta over the chunk variables, r_v[0], the queries */
-    oF *beta = (oF *)malloc(sizeof(oF) * K);
-    orc_precompute_beta(x, logK, beta);
-    orc_generate_randomness(1, rv0_out);
-    uint64_t *Iq = (uint64_t *)malloc(sizeof(uint64_t) * 2 * (size_t)queries);
-    for (int q = 0; q < queries; q++) {
-        Iq[2 * q] = (uint64_t)(rand() % (long)cols); Iq[2 * q + 1] = (uint64_t)(rand() % (long)rows2);
-        I_out[2 * q] = (uint32_t)Iq[2 * q]; I_out[2 * q + 1] = (uint32_t)Iq[2 * q + 1];
-    }
-    orc_elastic_aggregate(N, B, beta, aggr_out, cf_root);
-    if (reply_out) orc_elastic_reply(N, B, Iq, (size_t)queries, reply_out);
-    if (commit_levels && paths_out) {                     /* open_tree_blake(Commitment_MT, I[i], 2B/trs) (:684-687) */
-        const int depth = (int)log2((double)(4 * B));
-        for (int q = 0; q < queries; q++) orc_open_tree_blake(commit_levels, 4 * B, Iq[2 * q], Iq[2 * q + 1], cols, paths_out + (size_t)q * depth * 32);
-    }
-    /* recursive_prover_RS (src/PC_utils.cpp:396-512) */
+/* recursive_prover_RS (src/PC_utils.cpp:396-512) on an aggregated vector of B elements seen as trs rows (globals tensor_row_size, C_f), for the
+ * queries Iq = (column, row) pairs.  qpoly / r_out / vr / fin hold P0, P2, P3, P5 back to back (rounds R0 = log2(np2 * 2trs), log2(2trs),
+ * log2(2B), log2(2B/trs)); rx = P5.randomness[0], the point shockwave_prove(C_f, .) is then run on by the caller.
+ * checks[0]: P2's claimed sum == P0.vr[0]; checks[1]: P5's == P3.vr[0] (prove_fft_matrix's own exit(-1) tests, src/sumcheck.cpp:3016-3019). */
+static int rs_prover(const oF *aggr, size_t B, size_t trs, const uint64_t *Iq, int queries, int *ncols_out, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks, oF *rx_out) {
+    const size_t half = B / trs, cols = 2 * half, rows2 = 2 * trs;
+    const int logc = (int)log2((double)cols), logr = (int)log2((double)rows2), logt = (int)log2((double)trs);
     size_t *cs = (size_t *)malloc(sizeof(size_t) * (size_t)queries);
     for (int q = 0; q < queries; q++) cs[q] = Iq[2 * q];
     qsort(cs, (size_t)queries, sizeof(size_t), cmp_sz);                       /* I_sorted's first entries / I_t (:128-142) */
@@ -1284,7 +1268,7 @@ int orc_elastic_open_rs(size_t N, size_t B, const oF *x, int queries, const uint
     const size_t np2 = next_pow2(nc);
     if (ncols_out) *ncols_out = (int)nc;
     oF *out1 = (oF *)calloc(trs * cols, sizeof(oF));                          /* rows of the aggregate, RS-encoded (:406-420) */
-    for (size_t i = 0; i < trs; i++) { memcpy(out1 + i * cols, aggr_out + i * half, sizeof(oF) * half); orc_fft_cached(out1 + i * cols, logc, 0); }
+    for (size_t i = 0; i < trs; i++) { memcpy(out1 + i * cols, aggr + i * half, sizeof(oF) * half); orc_fft_cached(out1 + i * cols, logc, 0); }
     oF *sel = (oF *)calloc(np2 * trs, sizeof(oF)), *out3 = (oF *)calloc(np2 * rows2, sizeof(oF));
     for (size_t i = 0; i < nc; i++) {                                         /* selected columns and their codewords (:422-452) */
         for (size_t j = 0; j < trs; j++) { sel[i * trs + j] = out1[j * cols + col[i]]; out3[i * rows2 + j] = sel[i * trs + j]; }
@@ -1322,13 +1306,72 @@ int orc_elastic_open_rs(size_t N, size_t B, const oF *x, int queries, const uint
     orc_sumcheck2(out1, b2, trs * cols, &p323, q3, r3, vr + 4, fin + 2);      /* P3 (:498) */
     qo += 3 * (size_t)(logt + logc); ro += (size_t)(logt + logc);
     oF *q5 = qpoly + qo, *r5 = r_out + ro;
-    orc_prove_fft_matrix(aggr_out, trs, half, r3, q5, r5, vr + 6, fin + 3);  /* P5 (:503) */
+    orc_prove_fft_matrix(aggr, trs, half, r3, q5, r5, vr + 6, fin + 3);      /* P5 (:503) */
     { oF c = f_add(f_add(q5[0], q5[1]), f_add(q5[2], q5[2])); checks[1] = (c.re == vr[4].re && c.im == vr[4].im); }
     /* r_x = P5.randomness[0] = its sumcheck challenges (logc) followed by r1 = P3.r[logc .. logc + log2 trs) (src/sumcheck.cpp:3021-3023) */
     memcpy(rx_out, r5, sizeof(oF) * (size_t)logc);
     memcpy(rx_out + logc, r3 + logc, sizeof(oF) * (size_t)logt);
-    free(beta); free(Iq); free(cs); free(col); free(out1); free(sel); free(out3); free(bt); free(rq); free(rpt); free(rb); free(b2);
+    free(cs); free(col); free(out1); free(sel); free(out3); free(bt); free(rq); free(rpt); free(rb); free(b2);
     return R0 + logr + (logt + logc) + logc;
+}
+/* Elastic_PC::open option 1 up to (not including) shockwave_prove; transcript layout as rs_prover.
+ * commit_levels: the commitment tree (4B leaves) or NULL; paths: queries x log2(4B) hashes. */
+int orc_elastic_open_rs(size_t N, size_t B, const oF *x, int queries, const uint8_t *commit_levels, uint32_t *I_out, oF *rv0_out, oF *aggr_out, uint8_t *cf_root,
+                        oF *reply_out, uint8_t *paths_out, int *ncols_out, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks, oF *rx_out) {
+    const size_t trs = B >> 11, half = B / trs, cols = 2 * half, rows2 = 2 * trs, K = N / B;
+    const int logK = (int)log2((double)K);
+    /* open (:625-655): beta over the chunk variables, r_v[0], the queries */
+    oF *beta = (oF *)malloc(sizeof(oF) * K);
+    orc_precompute_beta(x, logK, beta);
+    orc_generate_randomness(1, rv0_out);
+    uint64_t *Iq = (uint64_t *)malloc(sizeof(uint64_t) * 2 * (size_t)queries);
+    for (int q = 0; q < queries; q++) {
+        Iq[2 * q] = (uint64_t)(rand() % (long)cols); Iq[2 * q + 1] = (uint64_t)(rand() % (long)rows2);
+        I_out[2 * q] = (uint32_t)Iq[2 * q]; I_out[2 * q + 1] = (uint32_t)Iq[2 * q + 1];
+    }
+    orc_elastic_aggregate(N, B, beta, aggr_out, cf_root);
+    if (reply_out) orc_elastic_reply(N, B, Iq, (size_t)queries, reply_out);
+    if (commit_levels && paths_out) {                     /* open_tree_blake(Commitment_MT, I[i], 2B/trs) (:684-687) */
+        const int depth = (int)log2((double)(4 * B));
+        for (int q = 0; q < queries; q++) orc_open_tree_blake(commit_levels, 4 * B, Iq[2 * q], Iq[2 * q + 1], cols, paths_out + (size_t)q * depth * 32);
+    }
+    const int rounds = rs_prover(aggr_out, B, trs, Iq, queries, ncols_out, qpoly, r_out, vr, fin, checks, rx_out);
+    free(beta); free(Iq);
+    return rounds;
+}
+/* Our_PC open_standard with linear_time == false (test_PC option 1, src/Our_PC.cpp:604-692: 790 queries, tensor_row_size = 128) up to (not
+ * including) shockwave_prove(C_f, r_x): r_v[0]; _aggregate (:258-276: the aggregate and C_f = shockwave_commit(aggr, 32), no C_c); the queries
+ * (rand() % (2B/trs), rand() % (2 trs)); _compute_aggregation_reply (:291-305: reply[q][i] = _tensor[i][row_q][col_q], tensor = K x 2trs x cols
+ * or NULL); open_tree_blake paths (commit_levels: the M-leaf tree or NULL); recursive_prover_RS.  Transcript layout as rs_prover. */
+int orc_open_standard_rs(const oF *poly, size_t N, int K, int trs_, const oF *x, int queries, const uint8_t *commit_levels, const oF *tensor, uint32_t *I_out, oF *rv0_out,
+                         oF *aggr_out, uint8_t *cf_root, oF *reply_out, uint8_t *paths_out, int *ncols_out, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks, oF *rx_out) {
+    const size_t B = N / (size_t)K, trs = (size_t)trs_, cols = 2 * B / trs, rows2 = 2 * trs;
+    const int logK = (int)log2((double)K);
+    oF *beta = (oF *)malloc(sizeof(oF) * (size_t)K);
+    orc_precompute_beta(x, logK, beta);
+    orc_generate_randomness(1, rv0_out);
+    for (size_t j = 0; j < B; j++) aggr_out[j] = fint(0);
+    for (int i = 0; i < K; i++) for (size_t j = 0; j < B; j++) aggr_out[j] = f_add(aggr_out[j], f_mul(beta[i], poly[(size_t)i * B + j]));
+    {   /* C_f = shockwave_commit(buff, 32) (src/Virgo.cpp:435-517): only its root is reported */
+        oF *enc = (oF *)malloc(sizeof(oF) * 2 * B); uint8_t *lv = (uint8_t *)malloc(64 * (2 * B / 32) * 2);
+        size_t cnt = orc_shockwave_commit(aggr_out, B, 32, enc, lv);
+        memcpy(cf_root, lv + 32 * (cnt - 1), 32);
+        free(enc); free(lv);
+    }
+    uint64_t *Iq = (uint64_t *)malloc(sizeof(uint64_t) * 2 * (size_t)queries);
+    for (int q = 0; q < queries; q++) {
+        Iq[2 * q] = (uint64_t)(rand() % (long)cols); Iq[2 * q + 1] = (uint64_t)(rand() % (long)rows2);
+        I_out[2 * q] = (uint32_t)Iq[2 * q]; I_out[2 * q + 1] = (uint32_t)Iq[2 * q + 1];
+    }
+    if (reply_out && tensor)
+        for (int q = 0; q < queries; q++) for (int i = 0; i < K; i++) reply_out[(size_t)q * K + i] = tensor[((size_t)i * rows2 + Iq[2 * q + 1]) * cols + Iq[2 * q]];
+    if (commit_levels && paths_out) {
+        const int depth = (int)log2((double)B);
+        for (int q = 0; q < queries; q++) orc_open_tree_blake(commit_levels, B, Iq[2 * q], Iq[2 * q + 1], cols, paths_out + (size_t)q * depth * 32);
+    }
+    const int rounds = rs_prover(aggr_out, B, trs, Iq, queries, ncols_out, qpoly, r_out, vr, fin, checks, rx_out);
+    free(beta); free(Iq);
+    return rounds;
 }
 
 

@@ -125,6 +125,9 @@ size_t orc_elastic_commit(size_t N, size_t B, int opt, uint8_t *levels_out);
 void orc_read_stream(size_t B, oF *out);
 void orc_elastic_aggregate(size_t N, size_t B, const oF *beta, oF *aggr_out, uint8_t *cf_root);
 size_t orc_elastic_reply(size_t N, size_t B, const uint64_t *Iq, size_t nq, oF *reply);
+/* Our_PC open_standard with linear_time == false (test_PC option 1) up to shockwave_prove(C_f, rx); tensor: K x 2trs x cols or NULL */
+int orc_open_standard_rs(const oF *poly, size_t N, int K, int trs, const oF *x, int queries, const uint8_t *commit_levels, const oF *tensor, uint32_t *I_out, oF *rv0_out,
+                         oF *aggr_out, uint8_t *cf_root, oF *reply_out, uint8_t *paths_out, int *ncols_out, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks, oF *rx_out);
 int orc_elastic_open_rs(size_t N, size_t B, const oF *x, int queries, const uint8_t *commit_levels, uint32_t *I_out, oF *rv0_out, oF *aggr_out, uint8_t *cf_root,
                         oF *reply_out, uint8_t *paths_out, int *ncols_out, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks, oF *rx_out);
 

@@ -500,6 +500,32 @@ class Oracle(_Base):
         res["sp_f"] = self.shockwave_prove(aggr, enc_f, 32, rx, lv_f)
         return res
 
+    def open_standard_rs(self, poly, K, trs, x, queries=790, commit_levels=None, tensor=None):
+        """Prover side of Our_PC open_standard with linear_time == false (test_PC option 1, src/Our_PC.cpp:604-692 + recursive_prover_RS,
+        src/PC_utils.cpp:396-512): orc_open_standard_rs, then shockwave_prove(C_f, r_x) with the libc generator running on."""
+        poly = F(poly).reshape(-1, 2); x = F(x).reshape(-1, 2)
+        N = poly.shape[0]; B = N // K; cols = 2 * B // trs
+        logc = cols.bit_length() - 1; logr = (2 * trs).bit_length() - 1; logt = trs.bit_length() - 1
+        maxr = (1024 * 2 * trs).bit_length() - 1 + logr + (logt + logc) + logc
+        I = np.zeros((queries, 2), np.uint32); rv0 = np.zeros(2, np.uint64); aggr = np.zeros((B, 2), np.uint64); root = np.zeros(32, np.uint8)
+        T = F(tensor) if tensor is not None else None
+        reply = np.zeros((queries, K, 2), np.uint64) if T is not None else None
+        depth = B.bit_length() - 1
+        lv = np.ascontiguousarray(commit_levels, np.uint8) if commit_levels is not None else None
+        paths = np.zeros((queries, depth, 32), np.uint8) if lv is not None else None
+        nc = ctypes.c_int()
+        q = np.zeros((maxr, 3, 2), np.uint64); r = np.zeros((maxr, 2), np.uint64); vr = np.zeros((4, 2, 2), np.uint64); fin = np.zeros((4, 2), np.uint64)
+        chk = np.zeros(2, np.int32); rx = np.zeros((logc + logt, 2), np.uint64)
+        f = self.lib.orc_open_standard_rs; f.restype = ctypes.c_int
+        rounds = f(_p(poly), c_sz(N), ctypes.c_int(K), ctypes.c_int(trs), _p(x), ctypes.c_int(queries), _p(lv) if lv is not None else None, _p(T) if T is not None else None,
+                   _p(I), _p(rv0), _p(aggr), _p(root), _p(reply) if reply is not None else None, _p(paths) if paths is not None else None, ctypes.byref(nc),
+                   _p(q), _p(r), _p(vr), _p(fin), _p(chk), _p(rx))
+        res = dict(I=I, rv0=rv0, aggr=aggr, cf_root=root, reply=reply, paths=paths, ncols=np.array([nc.value]), poly=q[:rounds], r=r[:rounds], vr=vr, fin=fin,
+                   checks=chk, rx=rx)
+        enc_f, lv_f = self.shockwave_commit(aggr, 32)
+        res["sp_f"] = self.shockwave_prove(aggr, enc_f, 32, rx, lv_f)
+        return res
+
 
     # ---- streaming multiplication-tree prover (src/sumcheck.cpp:1014-1054, 1150-1393; src/witness_stream.cpp:2413-2510)
     def stream_config(self, kind=0, seed=0):

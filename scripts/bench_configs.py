@@ -38,6 +38,33 @@ def c3():
 out["C3_commit_2e26_ms"] = 1e3 * timed(c3, reps=5)
 del d
 
+# Our_PC, linear_time == false (test_PC option 1: RS x RS, tensor_row_size = 128, 790 queries) at 2^26 and 2^28
+for logN1 in (26, 28):
+    N1 = 1 << logN1
+    d = hb.fill_splitmix(N1, 4); x1 = splitmix_field(logN1, 8)
+    def o1_commit():
+        c = hb.commit_standard((d, N1), 32, 128, 0); c.free()
+    out["O1_commit_rsrs_2e%d_ms" % logN1] = 1e3 * timed(o1_commit, reps=3)
+    c1 = hb.commit_standard((d, N1), 32, 128, 0)
+    def o1_open():
+        r = hb.open_standard_rs((d, N1), c1, x1, 790)
+        assert r["checks"].tolist() == [1, 1]
+    out["O1_open_rsrs_2e%d_ms" % logN1] = 1e3 * timed(o1_open, reps=3)
+    c1.free(); del d
+
+# gate consistency with lookup gates (prove_gate_consistency_lookups) at config 4's trace shape
+g = np.random.default_rng(2); circ_l = 1 << 20; Bl = 1 << 18; z = np.zeros(circ_l, np.uint64)
+Sl = g.integers(0, 3, circ_l).astype(np.int32); Ll = g.integers(0, 1 << 30, circ_l).astype(np.uint64); Rl = g.integers(0, 1 << 30, circ_l).astype(np.uint64)
+P61 = np.uint64((1 << 61) - 1)
+Ol = np.stack([np.where(Sl == 0, Ll + Rl, np.where(Sl == 1, (Ll * Rl) % P61, g.integers(0, 1 << 60, circ_l).astype(np.uint64))), z], 1)
+tsrc_l = hb.trace_source(np.stack([Ll, z], 1), np.stack([Rl, z], 1), Ol, Sl, Bl)
+rl = splitmix_field(20, 3); lrand = splitmix_field(2, 77)
+def gate_lk():
+    r = hb.gate_consistency_lookups_stream(tsrc_l, circ_l // Bl, Bl, rl, lrand)
+    assert r["checks"].tolist() == [1] * 5
+out["gate_consistency_lookups_2e20_s"] = timed(gate_lk, reps=3)
+del tsrc_l
+
 # C4: math phases of the MLP prover (reference on one Xeon core: commit 5.08 s, mul-tree 5.53 s, gate 0.80 s, open 2.84 s)
 import ctypes
 B4 = 1 << 18; circ = 1 << 20

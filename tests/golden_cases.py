@@ -206,6 +206,37 @@ def case_commit(lib):
     return out
 
 
+COMMIT_RS_CASES = ((1 << 18, 32), (1 << 20, 16), (1 << 22, 32))
+
+
+def case_commit_rs(lib):
+    """test_PC(N, 1, K) (src/Our_PC.cpp:764-777): poly = generate_randomness(N) from a fresh generator, linear_time == false, tensor_row_size = 128,
+    commit_standard -- the RS x RS Our_PC commitment of option 1 and of prove_circuit_standard's circuit polynomial; rows of 128 / 1024 / 2048 points"""
+    out = {}
+    for (N, K) in COMMIT_RS_CASES:
+        lib.rng_reset()
+        poly = lib.generate_randomness(N)
+        M = N // K; cols = 2 * M // 128
+        lv, T = lib.commit_standard(poly, K, 128, 0, want_tensor=True)
+        key = "crs_%d_%d_" % (N, K)
+        out[key + "root"] = lv[-1].copy()
+        off, sz, dgs = 0, M, []
+        while sz >= 1:
+            dgs.append(dg(lv[off:off + sz])); off += sz; sz //= 2
+        out[key + "level_dg"] = np.stack(dgs)
+        out[key + "tensor_dg"] = dg(T); out[key + "tensor_s"] = samp(T)
+        paths = []
+        for (c, row) in ((0, 0), (5, 3), (cols - 1, 255), (cols // 2, 128), (7, 127)):
+            if lib.__class__.__name__ == "Ref":
+                paths.append(lib.open_tree_blake(c, row, cols))
+            else:
+                paths.append(lib.open_tree_blake(lv, M, c, row, cols))
+        out[key + "paths"] = np.stack(paths)
+        if lib.__class__.__name__ == "Ref":
+            lib.release_commit()
+    return out
+
+
 def sumcheck_inputs(n):
     v1 = splitmix_field(n, 1); v2 = splitmix_field(n, 2); v3 = splitmix_field(n, 3)
     v2z = v2.copy(); v2z[0:n // 2] = 0
@@ -465,4 +496,4 @@ def case_gate(lib):
 
 
 CASES = dict(streamdrv=case_streamdrv, elastic_open=case_elastic_open, field=case_field, mimc=case_mimc, blake=case_blake, merkle=case_merkle, graph_encode=case_graph_encode,
-             fft=case_fft, tensorcode=case_tensorcode, commit=case_commit, sumcheck=case_sumcheck, elastic=case_elastic, codeproofs=case_codeproofs, streamfold=case_streamfold, lkpfold=case_lkpfold, multree=case_multree, innerpcs=case_innerpcs, gate=case_gate)
+             fft=case_fft, tensorcode=case_tensorcode, commit=case_commit, commit_rs=case_commit_rs, sumcheck=case_sumcheck, elastic=case_elastic, codeproofs=case_codeproofs, streamfold=case_streamfold, lkpfold=case_lkpfold, multree=case_multree, innerpcs=case_innerpcs, gate=case_gate)

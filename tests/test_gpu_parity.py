@@ -282,6 +282,27 @@ def test_commit_standard_vs_golden(hb, N, K):
     c.free()
 
 
+@pytest.mark.parametrize("N,K", golden_cases.COMMIT_RS_CASES)
+def test_commit_standard_rs_vs_golden(hb, N, K):
+    """test_PC(N, 1, K)'s commitment (linear_time == false, tensor_row_size = 128) against the REAL reference: every level, the whole tensor, paths"""
+    g = gold("commit_rs")
+    hb.rng_reset()
+    poly = hb.generate_randomness(N)
+    c = hb.commit_standard(poly, K, 128, 0)
+    key = "crs_%d_%d_" % (N, K)
+    lv = c.levels(); M = N // K; cols = 2 * M // 128
+    assert np.array_equal(lv[-1], g[key + "root"])
+    off, sz, dgs = 0, M, []
+    while sz >= 1:
+        dgs.append(dg(lv[off:off + sz])); off += sz; sz //= 2
+    assert np.array_equal(np.stack(dgs), g[key + "level_dg"])
+    if N <= 1 << 20:
+        assert np.array_equal(dg(c.tensor()), g[key + "tensor_dg"])
+    paths = [c.open_tree_blake(col, row) for (col, row) in ((0, 0), (5, 3), (cols - 1, 255), (cols // 2, 128), (7, 127))]
+    assert np.array_equal(np.stack(paths), g[key + "paths"])
+    c.free()
+
+
 def test_commit_full_range_poly_vs_golden(hb):
     g = gold("commit")
     poly = splitmix_field(1 << 18, 77)
@@ -484,6 +505,33 @@ def test_host_mirror_open_standard(oracle):
     assert np.array_equal(roots[2], want["sp_c"]["whir_root"]) and np.array_equal(roots[3], want["sp_f"]["whir_root"])
     # proof size: at least the replies (5900 x 32 F) plus something for every other message, and well under the tensor itself
     assert queries * K * 16 / 1024.0 < ps.value < 4 * queries * K * 16 / 1024.0
+
+
+def test_host_mirror_test_pc_option1(oracle):
+    """test_PC(N, 1, K) through the C++ mirror (commit_standard + open_standard with linear_time == false, reference signatures): the root
+    equals the REAL reference's (commit_rs.npz), the opening's transcript equals the oracle's, the reference's exit(-1) checks pass."""
+    import ctypes
+    from __graft_entry__ import PKG, build_host
+    build_host()
+    lib = ctypes.CDLL(os.path.join(PKG, "libhobbit_host.so"))
+    libc = ctypes.CDLL(None)
+    N, K, queries, seed, trs = 1 << 20, 16, 790, 77, 128
+    cols = 2 * (N // K) // trs; logc = cols.bit_length() - 1; logr = 8; logt = 7
+    maxr = 11 + logr + logr + (logt + logc) + logc
+    q = np.zeros((maxr, 3, 2), np.uint64); r = np.zeros((maxr, 2), np.uint64); I = np.zeros((queries, 2), np.uint32)
+    root = np.zeros(32, np.uint8); roots = np.zeros((2, 32), np.uint8); checks = np.zeros(3, np.int32); ps = ctypes.c_double(0)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.hobbit_host_test_pc_rs_open.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_uint] + [ctypes.c_void_p] * 7
+    rounds = lib.hobbit_host_test_pc_rs_open(N, K, seed, P(root), P(q), P(r), P(I), P(roots), P(checks), ctypes.byref(ps))
+    lib.hobbit_host_close()
+    assert np.array_equal(root, gold("commit_rs")["crs_%d_%d_root" % (N, K)])
+    oracle.rng_reset(); poly = oracle.generate_randomness(N)
+    x = oracle.generate_randomness(N.bit_length() - 1)
+    libc.srandom(seed); want = oracle.open_standard_rs(poly, K, trs, x, queries)
+    assert checks.tolist() == [1, 1, 1] and rounds == want["poly"].shape[0]
+    assert np.array_equal(q[:rounds], want["poly"]) and np.array_equal(r[:rounds], want["r"]) and np.array_equal(I, want["I"])
+    assert np.array_equal(roots[0], want["cf_root"]) and np.array_equal(roots[1], want["sp_f"]["whir_root"])
+    assert queries * K * 16 / 1024.0 < ps.value
 
 
 # ---- multi-GPU building blocks on one GPU ------------------------------------------------------
@@ -988,6 +1036,51 @@ def test_elastic_open_vs_oracle(hb, oracle, logN, logB):
     assert want["sp_f"]["wchecks"].tolist() == ([1, 1] if has_whir else [0, 0])
     for k in SP_KEYS:
         assert np.array_equal(got["sp_f"][k], want["sp_f"][k]), k
+
+
+@pytest.mark.parametrize("logN,K", [(18, 32), (20, 16), (22, 32), (24, 32), (23, 2)])
+def test_open_standard_rs_vs_oracle(hb, oracle, logN, K):
+    """Our_PC with linear_time == false on test_PC(N, 1, K)'s sequence (src/Our_PC.cpp:764-777: poly = generate_randomness(N), tensor_row_size = 128,
+    commit_standard, x = generate_randomness(log N), open_standard with 790 queries -> recursive_prover_RS): commitment levels, queries, replies,
+    paths, the four sumcheck transcripts and shockwave_prove(C_f, r_x) with its WHIR proof, bit-exact against the oracle; both exit(-1) checks
+    hold.  Row codes of 128 .. 8192 points (2^24: the long-row FFT path) and, with K = 2 at 2^23, of 65536 points (the chunk-at-a-time long
+    transform test_PC option 1 needs from 2^27 on).  The commit for this shape is pinned by oracle/_ref in commit.npz (trs=4)
+    and at trs = 128 in test_oracle_vs_ref."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    N, trs = 1 << logN, 128
+    oracle.rng_reset(); poly = oracle.generate_randomness(N)
+    lv, T = oracle.commit_standard(poly, K, trs, 0, want_tensor=True)
+    x = oracle.generate_randomness(logN)
+    libc.srandom(41); want = oracle.open_standard_rs(poly, K, trs, x, 790, lv, T)
+    del T
+    c = hb.commit_standard(poly, K, trs, 0)
+    assert np.array_equal(c.levels(), lv)
+    libc.srandom(41); got = hb.open_standard_rs(poly, c, x, 790)
+    c.free()
+    assert want["checks"].tolist() == [1, 1] and got["checks"].tolist() == [1, 1]
+    assert int(got["ncols"][0]) == int(want["ncols"][0]) and int(got["reply_len"][0]) == K
+    for k in ("I", "rv0", "cf_root", "reply", "paths", "poly", "r", "vr", "fin", "rx"):
+        assert np.array_equal(got[k], want[k]), k
+    has_whir = int(want["sp_f"]["iters"][0]) > 0
+    assert want["sp_f"]["wchecks"].tolist() == ([1, 1] if has_whir else [0, 0])
+    for k in SP_KEYS:
+        assert np.array_equal(got["sp_f"][k], want["sp_f"][k]), k
+
+
+def test_open_standard_rs_rejects_expander_commitment(hb):
+    """the RS x RS opening refuses an RS x expander commitment (and vice versa hobbit_open_standard refuses an RS x RS one) instead of opening it wrongly"""
+    mod = __import__("__graft_entry__").load_package()
+    N, K = 1 << 18, 32
+    poly, trs = golden_cases.test_pc_inputs(hb, N, K)
+    c = hb.commit_standard(poly, K, trs, 1)
+    with pytest.raises(mod.HobbitError, match="RS x expander"):
+        hb.open_standard_rs(poly, c, splitmix_field(18, 1), 790)
+    c.free()
+    c = hb.commit_standard(poly, K, 128, 0)
+    with pytest.raises(mod.HobbitError, match="bad arguments"):
+        hb.open_standard_rs(poly, c, splitmix_field(18, 1), 0)
+    c.free()
 
 
 def test_elastic_open_skips_zero_chunks(hb, oracle):
