@@ -10,7 +10,8 @@ timed region starts.  --phase commit times the commit alone.
   python bench.py [--gpus N] [--steps K] [--warmup W] [--logn 28] [--chunks 32] [--mode replicas|sharded]
 
 N > 1: launched by torch.distributed.run, one rank per GPU.  Default mode for N > 1 is `sharded`: ONE commitment and ONE opening
-of the same 2^logn polynomial, chunks sharded over the ranks (parallel.py: one digest exchange, one all-gather of subtree roots, one
+of the same 2^logn polynomial, chunks sharded over the ranks (parallel.py: by default the chain relay -- contiguous chunks per rank, the leaf
+chain's running states handed from rank to rank, the tree on the last rank; --exchange alltoall: one digest exchange, one all-gather of subtree roots, one
 all-gather of partial aggregates) -- the north-star's 1/2/4/8 curve, "scaling": "strong".  --mode replicas commits and opens an
 independent polynomial per rank (no data-path collective, "scaling": "weak").
 """
@@ -45,7 +46,7 @@ def commit_op_counts(N, K, edges):
 # which resource binds each bulk kernel: "valu" kernels report frac_valu (issue cycles the instruction stream needs at the
 # sustained clock / measured time) as the primary fraction; the HBM fraction the contract asks for stays in `frac`
 KERNEL_BOUND = {"k_leaf_chain": "valu", "k_fft4096": "valu", "k_encode_A": "valu", "k_encode_B": "valu", "k_encode": "valu", "k_transpose": "hbm",
-                "k_inner_digests": "valu", "k_chain_digests": "valu", "k_aggregate": "hbm"}
+                "k_inner_digests": "valu", "k_chain_digests": "valu", "k_leaf_chain_relay": "valu", "k_aggregate": "hbm"}
 SUSTAINED_GHZ, PEAK_GHZ = 1.78, 2.4       # profiles/r01_microbench.txt: clock held under the VALU-heavy kernels; the chip's peak clock
 TRAFFIC_PROFILE = "r02_hbm_traffic_commit_2e28.json"     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (scripts/hbm_traffic.py)
 
@@ -56,6 +57,7 @@ ROOFLINE_NOTES = {
     "k_encode_A": "bound by gather latency (L2 edge records + LDS) and per-slice reduction overhead",
     "k_encode_B": "bound by seven small dependent SpMV steps (barriers) and gather latency",
     "k_transpose": "HBM bound",
+    "k_leaf_chain_relay": "the leaf chain of the relay commit (one launch per block of leaves): VALU-issue bound like k_leaf_chain",
 }
 
 
@@ -150,6 +152,7 @@ def algorithmic_bytes(N, K, world=1, sharded=False, nz=1.0):
         "k_leaf_chain": 64 * N * nz + 32 * M,           # read the non-zero rows of the tensor once (rows past the codeword length are zero), write the leaves once
         "k_inner_digests": f * (64 * N + 32 * N),       # read the local tensor shard, write its 32-byte digests
         "k_chain_digests": (32 * M * K + 64 * M) * (1.0 / world if sharded else 1.0),
+        "k_leaf_chain_relay": f * 64 * N * nz + 64 * M,  # relay commit: read the local shard's non-zero rows once, read + write the 32-byte running states (per step: all blocks)
     }
 
 
@@ -164,6 +167,9 @@ def main():
                     help="default: sharded when --gpus > 1 (ONE commitment + opening, chunks sharded over the GPUs with the digest exchange + "
                          "subtree-root all-gather of parallel.py: strong scaling, the north-star curve), replicas on one GPU; "
                          "replicas = one independent polynomial per GPU (weak)")
+    ap.add_argument("--exchange", choices=["relay", "alltoall"], default="relay",
+                    help="sharded mode: relay = contiguous chunks per GPU, the leaf chain's 32-byte running states handed from GPU to GPU in blocks "
+                         "(M*32 B per hop); alltoall = strided chunks, inner digests exchanged all-to-all (K*M*32 B in total), per-GPU subtrees")
     ap.add_argument("--phase", choices=["commit", "commit+open", "commit+opencore"], default="commit+open",
                     help="commit+open adds the whole prover side of open_standard (recursive_prover_Spielman with both shockwave_prove/WHIR proofs); "
                          "commit+opencore stops before the two shockwave_prove calls")
@@ -207,7 +213,8 @@ def main():
 
     sharded = args.mode == "sharded"
     if sharded:
-        plan = mod.parallel.ShardPlan(N, K, trs, world)
+        relay = args.exchange == "relay"
+        plan = mod.parallel.ShardPlan(N, K, trs, world, contiguous=relay)
         ops_ = mod.parallel.HipOps(hb, torch.device("cuda", local_rank))
         own = plan.chunks_of(rank)
         d_local = hb.alloc(16 * plan.M * len(own))            # this rank's chunks, contiguous; chunk i = splitmix(seed 2000+i)
@@ -225,7 +232,8 @@ def main():
 
     def step():
         if sharded:
-            last["res"] = mod.parallel.sharded_commit(ops_, dist, plan, rank, (d_local.ptr, len(own)))
+            commit_fn = mod.parallel.sharded_commit_relay if relay else mod.parallel.sharded_commit
+            last["res"] = commit_fn(ops_, dist, plan, rank, (d_local.ptr, len(own)))
             if do_open:
                 ops_.set_local_chunks((d_local.ptr, len(own)))
                 open_last["res"] = mod.parallel.sharded_open(ops_, dist, plan, rank, last["res"], x_open, args.queries)
@@ -316,7 +324,7 @@ def main():
                                        args.logn - 3, args.logn - 3, ", shockwave_prove(C_c) and shockwave_prove(C_f) with their WHIR proofs" if full_open else "", trs))
                        if do_open else
                        "Our_PC commit_standard (test_PC(2^%d,4,%d) commit phase): trs=%d, cols=4096, tensor retained in HBM; open phase not in the timed region" % (args.logn, K, trs),
-                       "N": N, "K": K, "trs": trs, "mode": args.mode, "polynomials_per_gpu": (1.0 / world) if sharded else 1},
+                       "N": N, "K": K, "trs": trs, "mode": args.mode, "exchange": args.exchange if sharded else None, "polynomials_per_gpu": (1.0 / world) if sharded else 1},
             "prover_s": wall_max / args.steps, "step_ms_rank0": step_ms, "hip_event_ms_per_step": ev_ms / args.steps,
             "step_ms_median": float(np.median(step_ms)), "step_ms_mean": float(np.mean(step_ms)),
             "step_ms_outliers": [x for x in step_ms if x > 1.25 * float(np.median(step_ms))],

@@ -937,6 +937,15 @@ int hobbit_chain_digests(hobbit_ctx *ctx, const uint8_t *d_digests, size_t strid
     if (K < 0 || stride_bytes % 16) return ctx->fail(HOBBIT_EINVAL, "chain_digests: bad K / stride");
     return launch_chain_digests(ctx, d_digests, stride_bytes, K, m, d_leaves);
 }
+int hobbit_leaf_chain_relay(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M, int nchunks, int trs, int linear_time, size_t slot_begin, size_t slot_count,
+                            const uint8_t *d_state_in, uint8_t *d_state_out, uint8_t *d_leaves) {
+    if (trs < 4 || trs % 4 || M % (size_t)trs || nchunks <= 0) return ctx->fail(HOBBIT_EINVAL, "leaf_chain_relay: trs must be a multiple of 4 dividing M, nchunks positive");
+    if (slot_begin + slot_count > M || (!d_state_out && !d_leaves)) return ctx->fail(HOBBIT_EINVAL, "leaf_chain_relay: slot range beyond the M leaves, or nowhere to write");
+    const size_t cols = 2 * M / trs, rows2 = 2 * (size_t)trs;
+    if (linear_time && ctx->code.n != trs) return ctx->fail(HOBBIT_ESTATE, "leaf_chain_relay: expander graphs for n = trs not finalized");
+    return launch_leaf_chain_relay(ctx, cF(d_tensor), cols * rows2, nchunks, (uint32_t)cols, (uint32_t)(trs / 2), slot_begin, slot_count, d_state_in, d_state_out, d_leaves,
+                                   linear_time ? (uint32_t)ctx->code.len : (uint32_t)rows2);
+}
 void hobbit_blake3_64_host(const uint8_t *in, uint8_t *out, size_t n) {
     for (size_t i = 0; i < n; i++) { uint32_t m[16], h[8]; memcpy(m, in + 64 * i, 64); blake3_compress64(m, h); memcpy(out + 32 * i, h, 32); }
 }

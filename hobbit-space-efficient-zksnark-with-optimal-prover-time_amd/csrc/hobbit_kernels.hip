@@ -897,6 +897,46 @@ k_leaf_chain(const F *__restrict__ tensor, size_t chunk_stride, int K, uint32_t 
             }
     }
 }
+// Multi-GPU commit by chain relay: the same chain over the K_local chunks of a rank's tensor shard, for the leaf slots
+// g in [g_begin, g_begin + g_count) (slot g = col * half_trs + j: the order the shard is read in), starting from the state the previous
+// rank handed over (state_in, 32 B per slot in slot order; NULL = the zero state of the first chunks) and leaving either the running
+// state for the next rank (state_out, slot order: both sides of the hand-over are coalesced) or -- last rank -- the final leaves in the
+// reference's leaf order j * cols + col.
+__global__ void __launch_bounds__(256)
+k_leaf_chain_relay(const F *__restrict__ tensor, size_t chunk_stride, int K, uint32_t cols, uint32_t half_trs, size_t g_begin, size_t g_count,
+                   const uint8_t *__restrict__ state_in, uint8_t *__restrict__ state_out, uint8_t *__restrict__ leaves, uint32_t zero_from, ZeroDig zdig) {
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < g_count; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t g = g_begin + t;
+        uint32_t st[8];
+        if (state_in) load8w(state_in + 32 * t, st);
+        else {
+#pragma unroll
+            for (int q = 0; q < 8; q++) st[q] = 0;
+        }
+        const F *p = tensor + g * 4;
+        const bool zero = (uint32_t)(g % half_trs) >= zero_from;
+        for (int i = 0; i < K; i++) {
+            uint32_t m[16], h[8];
+            if (zero) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) h[q] = zdig.w[q];
+            } else { load16w(p + (size_t)i * chunk_stride, m); blake3_compress64(m, h); }
+#pragma unroll
+            for (int q = 0; q < 8; q++) { m[q] = h[q]; m[8 + q] = st[q]; }
+            blake3_compress64(m, st);
+        }
+        if (state_out) store8w(state_out + 32 * t, st);
+        if (leaves) { const uint32_t c = (uint32_t)(g / half_trs), j = (uint32_t)(g % half_trs); store8w(leaves + 32 * ((size_t)j * cols + c), st); }
+    }
+}
+int launch_leaf_chain_relay(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, int K, uint32_t cols, uint32_t half_trs, size_t g_begin, size_t g_count,
+                            const uint8_t *state_in, uint8_t *state_out, uint8_t *leaves, uint32_t zero_rows_from) {
+    if (!g_count) return 0;
+    ZeroDig zd; { uint32_t z[16] = {0}; blake3_compress64(z, zd.w); }
+    HB_LAUNCH(ctx, "k_leaf_chain_relay", k_leaf_chain_relay, dim3(grid_for(g_count, 256, 1 << 20)), dim3(256), 0, tensor, chunk_stride, K, cols, half_trs, g_begin,
+              g_count, state_in, state_out, leaves, (zero_rows_from + 3) / 4, zd);
+    return 0;
+}
 // Multi-GPU commit, step 1: inner digests H(t[4j..4j+3][c]) of the chunks a rank
 // owns, written in the reference's LEAF ORDER (leaf = j*cols + c) so that a contiguous leaf range
 // is a contiguous byte range to send: out[(i*M + j*cols + c)*32].

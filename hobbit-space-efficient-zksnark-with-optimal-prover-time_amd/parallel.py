@@ -12,26 +12,46 @@ The reference is single-process; this is new work, not a port.  One process per 
      and builds the subtree over it;
   4. ONE all-gather of the G subtree roots (32 B each); every rank computes the top log2 G levels.
 
+That all-to-all moves K*M*32 bytes in total (8 GiB at 2^28) whatever the world size: fine over the seven links of an 8-GPU node
+(128 MiB per link), but 2 GiB over ONE link at world size 2 -- longer than the whole single-GPU commit.  `sharded_commit_relay` is
+the default for Our_PC instead (the all-to-all stays for the streaming Elastic commit, whose chain state only exists after a whole
+group pass, and as `bench.py --exchange alltoall`):
+
+  1'. rank g owns the CONTIGUOUS chunks [g*K/G, (g+1)*K/G) and computes their tensor codes;
+  2'. the leaf chain is relayed: rank 0 chains its chunks from the zero state, hands the 32-byte running state of every leaf to rank 1,
+      which chains its chunks on top, ... -- M*32 bytes (256 MiB at 2^28) per hop, each hop on its own link, cut into blocks of leaves so
+      that rank g works on block b while rank g-1 works on block b+1.  Nothing is hashed twice and the tensor shard is read once
+      (the all-to-all path reads it a second time for the inner digests);
+  3'. the last rank ends up with the leaves, builds the tree (1 ms at 2^28) and serves the Merkle paths of the opening; the root is
+      broadcast.
+
 The orchestration below is backend-agnostic: `ops` supplies the per-rank compute (the HIP library
 on the GPU, see HipOps; the tests pass a CPU implementation), `dist` is torch.distributed.  The
-exchange uses isend/irecv pairs, which both RCCL and gloo implement.
+exchanges use isend/irecv, which both RCCL and gloo implement.
 """
 import numpy as np
 
 
 class ShardPlan:
-    def __init__(self, N, K, trs, world):
+    """contiguous=False: rank g owns chunks g, g+G, ... (all-to-all commit); True: chunks [g*K/G, (g+1)*K/G) (chain relay)"""
+
+    def __init__(self, N, K, trs, world, contiguous=False):
         assert N % K == 0 and K % world == 0, "world size must divide the number of chunks K"
-        self.N, self.K, self.trs, self.world = N, K, trs, world
+        self.N, self.K, self.trs, self.world, self.contiguous = N, K, trs, world, contiguous
         self.M = N // K
         assert self.M % world == 0
         self.cols = 2 * self.M // trs
         self.m_local = self.M // world
+        self.k_local = K // world
 
     def chunks_of(self, rank):
+        if self.contiguous:
+            return list(range(rank * self.k_local, (rank + 1) * self.k_local))
         return list(range(rank, self.K, self.world))
 
     def owner(self, chunk):
+        if self.contiguous:
+            return chunk // self.k_local, chunk % self.k_local
         return chunk % self.world, chunk // self.world        # (rank, local index)
 
     def leaf_range(self, rank):
@@ -81,6 +101,48 @@ def sharded_commit(ops, dist, plan, rank, local_chunks):
         roots = [my_root]
     top = ops.tree_top(torch.cat(roots).cpu().numpy())         # flat [2G-1, 32] (numpy, host)
     return dict(leaf_range=(lo, hi), subtree=subtree, top=top, root=top[-1])
+
+
+def sharded_commit_relay(ops, dist, plan, rank, local_chunks, blocks=16):
+    """Chain-relay commit (module docstring, 1'-3').  plan must be contiguous.  Returns dict(root, owner = the last rank, levels = the
+    whole tree flat [2M-1, 32] on the owner (None elsewhere)).  Leaves travel in SLOT order (slot = col * trs/2 + j, the order the
+    shard is read in); the last rank writes them out in the reference's leaf order."""
+    import torch
+    assert plan.contiguous, "the relay needs contiguous chunk ownership (ShardPlan(..., contiguous=True))"
+    G, M = plan.world, plan.M
+    last = G - 1
+    while blocks > 1 and M % blocks:
+        blocks //= 2
+    per = M // blocks
+    ops.encode_local(local_chunks, plan)                       # tensor codes of this rank's chunks (no exchange)
+    st_in = ops.empty_state(M, "in") if rank > 0 else None     # uint8 [M, 32], slot order
+    st_out = ops.empty_state(M, "out") if rank < last else None
+    levels = ops.empty_state(2 * M, "levels") if rank == last else None
+    # Receives are posted ONE block ahead, not all up front: RCCL runs a communicator's point-to-point operations in the order they were
+    # posted, so this rank's send of block b would otherwise queue behind the receives of every later block and the ranks downstream
+    # would start only when rank 0 has finished.  Order on the wire: recv b0, recv b1, send b0, recv b2, send b1, ...
+    nxt = dist.irecv(st_in[0:per], rank - 1) if rank > 0 else None
+    sends = []
+    for b in range(blocks):
+        lo = b * per
+        if rank > 0:
+            ops.wait_recv(nxt)                                 # block b of the running state has arrived
+            nxt = dist.irecv(st_in[lo + per:lo + 2 * per], rank - 1) if b + 1 < blocks else None
+        ops.chain_block(plan, lo, per, st_in[lo:lo + per] if rank > 0 else None, st_out[lo:lo + per] if rank < last else None, levels)
+        if rank < last:
+            sends.append(dist.isend(st_out[lo:lo + per], rank + 1))      # overlaps this rank's next block and the next rank's chain
+    for w in sends:
+        w.wait()
+    if sends:
+        ops.after_collective()
+    root = torch.zeros(32, dtype=torch.uint8, device=ops.device)
+    if rank == last:
+        levels = ops.tree_full(levels, M)                      # flat [2M-1, 32]
+        root.copy_(levels[-1])
+    if G > 1:
+        dist.broadcast(root, last)
+        ops.after_collective()
+    return dict(root=root.cpu().numpy(), owner=last, levels=levels)
 
 
 class ElasticPlan:
@@ -169,8 +231,20 @@ def sharded_open(ops, dist, plan, rank, commit_res, x, queries=5900):
         for li, i in enumerate(plan.chunks_of(h)):
             reply[:, i] = r_h[:, li]
     res["reply"] = reply
-    # 5. paths: leaf position (row/4) * cols + col (src/merkle_tree.cpp:309); owner = pos // m_local
+    # 5. paths: leaf position (row/4) * cols + col (src/merkle_tree.cpp:309)
     pos = (rows // 4) * plan.cols + cols
+    if "levels" in commit_res:                                                        # relay commit: the whole tree lives on one rank
+        depth = plan.M.bit_length() - 1
+        owner = commit_res["owner"]
+        host = ops.tree_paths(commit_res["levels"], pos, plan.M) if rank == owner else None      # numpy (queries, log2 M, 32)
+        if G > 1:
+            pt = ops.paths_buffer(queries, depth, host)
+            dist.broadcast(pt, owner)
+            ops.after_collective()
+            host = pt.cpu().numpy()
+        res["paths"] = host
+        return res
+    # all-to-all commit: owner of a leaf = pos // m_local
     depth_l = plan.m_local.bit_length() - 1
     lo, hi = plan.leaf_range(rank)
     sel = np.nonzero((pos >= lo) & (pos < hi))[0]
@@ -224,6 +298,21 @@ class HipOps:
         import torch
         return torch.empty((K, m_local, 32), dtype=torch.uint8, device=self.device)
 
+    def _upload(self, role, host):
+        """host numpy array -> retained device tensor through a retained PINNED host tensor.  torch.from_numpy(x).to(device) copies from
+        pageable memory; on this runtime that now and then takes ~27 ms (a staging buffer being set up) -- measured in the open of the
+        sharded bench as two outlier steps in ten (scripts/relay_phases.py)."""
+        import torch
+        cache = self.__dict__.setdefault("_up", {})
+        ent = cache.get(role)
+        if ent is None or ent[0].shape != host.shape or ent[0].dtype != torch.from_numpy(host[:0]).dtype:
+            pin = torch.empty(host.shape, dtype=torch.from_numpy(host[:0]).dtype).pin_memory()
+            ent = cache[role] = (pin, torch.empty(host.shape, dtype=pin.dtype, device=self.device))
+        ent[0].numpy()[...] = host
+        ent[1].copy_(ent[0], non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return ent[1]
+
     def inner_digests_one(self, local_chunks, li, plan):
         """local_chunks: (device_ptr, n_own): n_own messages of M F each, contiguous, resident.  Tensor code of local chunk li into the
         retained shard, its inner digests into a fresh torch buffer; returns once the library's stream has produced them (the
@@ -264,6 +353,65 @@ class HipOps:
         import torch
         torch.cuda.synchronize(self.device)
 
+    # ---- chain relay
+    def empty_state(self, n, role="tmp"):
+        """one retained buffer per role and size: a commit per step must not allocate (a 512 MiB allocation stalls the queue now and then)"""
+        import torch
+        cache = self.__dict__.setdefault("_state", {})
+        t = cache.get(role)
+        if t is None or t.shape[0] != n:
+            t = cache[role] = torch.empty((n, 32), dtype=torch.uint8, device=self.device)
+        return t
+
+    def encode_local(self, local_chunks, plan):
+        """tensor codes of all local chunks into the retained shard, one library call"""
+        ptr, n_own = local_chunks
+        hb = self.hb
+        if getattr(self, "_tensor", None) is None or self._tensor.ptr is None or self._tensor.nbytes != 16 * 4 * plan.M * n_own:
+            self._tensor = hb.alloc(16 * 4 * plan.M * n_own)
+        hb._chk(hb.lib.hobbit_tensorcode_chunks(hb.ctx, ptr, plan.M, n_own, plan.trs, 1, self._tensor.ptr))
+        self._n_own = n_own
+
+    def wait_recv(self, work):
+        """the received block must be visible to the LIBRARY's stream: wait() orders torch's current stream behind the transfer, and
+        only that stream is drained -- a device-wide synchronize would also wait for every later block's receive"""
+        import torch
+        work.wait()
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def chain_block(self, plan, slot_begin, slot_count, st_in, st_out, levels):
+        hb = self.hb
+        hb._chk(hb.lib.hobbit_leaf_chain_relay(hb.ctx, self._tensor.ptr, plan.M, self._n_own, plan.trs, 1, slot_begin, slot_count,
+                                               st_in.data_ptr() if st_in is not None else None, st_out.data_ptr() if st_out is not None else None,
+                                               levels.data_ptr() if levels is not None else None))
+        hb.sync()                                              # the block is complete before its send is posted
+
+    def tree_full(self, levels, M):
+        hb = self.hb
+        hb._chk(hb.lib.hobbit_merkle_levels(hb.ctx, levels.data_ptr(), M, 1))
+        hb.sync()
+        return levels[:2 * M - 1]
+
+    def tree_paths(self, levels, pos, M):
+        import torch
+        hb = self.hb
+        p = np.ascontiguousarray(pos, np.uint64)
+        depth = M.bit_length() - 1
+        out = np.zeros((len(p), depth, 32), np.uint8)
+        hb._chk(hb.lib.hobbit_merkle_paths(hb.ctx, levels.data_ptr(), M, p.ctypes.data, len(p), out.ctypes.data))
+        return out                                             # host array: only a multi-rank open needs it on the device (to broadcast it)
+
+    def paths_buffer(self, queries, depth, host=None):
+        """retained device tensor for the broadcast of the paths; filled from `host` on the rank that computed them"""
+        import torch
+        if host is not None:
+            return self._upload("paths", host)
+        cache = self.__dict__.setdefault("_up", {})
+        ent = cache.get("paths_rx")
+        if ent is None or ent.shape != (queries, depth, 32):
+            ent = cache["paths_rx"] = torch.empty((queries, depth, 32), dtype=torch.uint8, device=self.device)
+        return ent
+
     # ---- open
     def set_local_chunks(self, local_chunks):
         self._chunks = local_chunks                                  # (device_ptr, n_own)
@@ -299,7 +447,7 @@ class HipOps:
         r = np.ascontiguousarray(rows, np.uint32); c = np.ascontiguousarray(cols, np.uint32)
         out = np.zeros((len(r), n_own, 2), np.uint64)
         hb._chk(hb.lib.hobbit_tensor_gather(hb.ctx, self._tensor.ptr, plan.M, n_own, plan.trs, r.ctypes.data, c.ctypes.data, len(r), out.ctypes.data))
-        return torch.from_numpy(out.view(np.int64)).to(self.device)
+        return self._upload("reply", out.view(np.int64))
 
     def subtree_paths(self, subtree, local_pos, plan):
         import torch
@@ -308,7 +456,7 @@ class HipOps:
         depth = plan.m_local.bit_length() - 1
         out = np.zeros((len(pos), depth, 32), np.uint8)
         hb._chk(hb.lib.hobbit_merkle_paths(hb.ctx, subtree.data_ptr(), plan.m_local, pos.ctypes.data, len(pos), out.ctypes.data))
-        return torch.from_numpy(out).to(self.device)
+        return self._upload("subpaths", out)
 
 
 class ElasticHipOps(HipOps):

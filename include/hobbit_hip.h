@@ -210,6 +210,14 @@ int hobbit_inner_digests(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M, in
 /* Merkle-Damgard chain (src/merkle_tree.cpp:76-86) over K digests per leaf, in place on m leaves:
  * leaf[p] = H(dig_i[p] | leaf[p]) for i = 0..K-1, dig_i at d_digests + i*stride_bytes */
 int hobbit_chain_digests(hobbit_ctx *ctx, const uint8_t *d_digests, size_t stride_bytes, int K, size_t m, uint8_t *d_leaves);
+/* Multi-GPU commit by chain relay (no counterpart in the single-process reference, whose chain is the loop at
+ * src/Our_PC.cpp:162-166): the Merkle-Damgard leaf chain over the `nchunks` chunks of a tensor shard ([chunk][col][2 trs], what
+ * hobbit_tensorcode_chunks writes) for the leaf slots [slot_begin, slot_begin + slot_count), slot = col * (trs/2) + j -- the order the shard
+ * is read in.  d_state_in: the running state handed over by the rank that holds the preceding chunks (slot_count x 32 B in slot order;
+ * NULL = the zero state in front of chunk 0).  d_state_out (slot order, for the next rank) and / or d_leaves (the M-leaf array in the
+ * reference's leaf order j * cols + col: on the rank that holds the last chunks) receive the result. */
+int hobbit_leaf_chain_relay(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M, int nchunks, int trs, int linear_time, size_t slot_begin, size_t slot_count,
+                            const uint8_t *d_state_in, uint8_t *d_state_out, uint8_t *d_leaves);
 /* host-side blake3_hash x n (tree tops of a handful of nodes) */
 void hobbit_blake3_64_host(const uint8_t *h_in, uint8_t *h_out, size_t n);
 

@@ -46,6 +46,42 @@ class OracleOps:
     def after_collective(self):
         pass
 
+    # ---- chain relay (CPU stand-ins)
+    def empty_state(self, n, role="tmp"):
+        return torch.zeros((n, 32), dtype=torch.uint8)
+
+    def encode_local(self, local_chunks, plan):
+        half = plan.trs // 2
+        self._slots = []                                       # per local chunk: the 64-byte leaf groups in SLOT order (col * trs/2 + j)
+        for m in local_chunks:
+            t = self.orc.compute_tensorcode(m, plan.trs, 1)    # (2trs, cols, 2) row-major
+            g = np.ascontiguousarray(t.reshape(half, 4, plan.cols, 2).transpose(2, 0, 1, 3)).view(np.uint8).reshape(plan.cols * half, 64)
+            self._slots.append(g)
+
+    def wait_recv(self, work):
+        work.wait()
+
+    def chain_block(self, plan, lo, cnt, st_in, st_out, levels):
+        st = st_in.numpy().copy() if st_in is not None else np.zeros((cnt, 32), np.uint8)
+        for g in self._slots:
+            st = self.orc.blake3_64(np.concatenate([self.orc.blake3_64(g[lo:lo + cnt]), st], axis=1))
+        if st_out is not None:
+            st_out.copy_(torch.from_numpy(st))
+        if levels is not None:                                 # leaf order j * cols + col
+            half = plan.trs // 2
+            slot = np.arange(lo, lo + cnt)
+            levels.numpy()[(slot % half) * plan.cols + slot // half] = st
+
+    def tree_full(self, levels, M):
+        return torch.from_numpy(self.orc.create_tree_blake(levels.numpy()[:M].copy()))
+
+    def tree_paths(self, levels, pos, M):
+        lv = levels.numpy()
+        return np.stack([self.orc.open_tree_blake(lv, M, int(p), 0, 0) for p in pos])
+
+    def paths_buffer(self, queries, depth, host=None):
+        return torch.from_numpy(host.copy()) if host is not None else torch.zeros((queries, depth, 32), dtype=torch.uint8)
+
     # ---- open (CPU stand-ins for HipOps' open methods)
     def set_local_chunks(self, local_chunks):
         self._chunks = local_chunks
@@ -137,6 +173,35 @@ def _worker(rank, world, port, N, K, q, do_open=False):
         out = {k: o[k] for k in ("I", "poly", "r", "vr", "fin", "scalars", "roots", "reply", "paths")}
         out["sp_c_wq"] = o["sp_c"]["wq"]; out["sp_f_q1"] = o["sp_f"]["q1"]
     q.put((rank, res["subtree"].numpy(), res["top"], res["root"], out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _relay_worker(rank, world, port, N, K, q, do_open=False):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle
+    from __graft_entry__ import load_package
+    mod = load_package()
+    orc = pyoracle.Oracle()
+    trs = N // (K << 11)
+    orc.rng_reset(); poly = orc.generate_randomness(N); orc.expander_init_store(trs)     # same inputs on every rank
+    plan = mod.parallel.ShardPlan(N, K, trs, world, contiguous=True)
+    M = plan.M
+    local = [poly[i * M:(i + 1) * M] for i in plan.chunks_of(rank)]
+    ops = OracleOps(orc, mod.load_library())
+    res = mod.parallel.sharded_commit_relay(ops, dist, plan, rank, local, blocks=8)
+    out = None
+    if do_open:
+        import ctypes
+        x = orc.generate_randomness(N.bit_length() - 1)
+        ctypes.CDLL(None).srandom(2024)
+        ops.set_local_chunks(local)
+        o = mod.parallel.sharded_open(ops, dist, plan, rank, res, x, 300)
+        out = {k: o[k] for k in ("I", "poly", "r", "vr", "fin", "scalars", "roots", "reply", "paths")}
+        out["sp_c_wq"] = o["sp_c"]["wq"]; out["sp_f_q1"] = o["sp_f"]["q1"]
+    q.put((rank, res["levels"].numpy() if res["levels"] is not None else None, res["owner"], res["root"], out))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -280,3 +345,84 @@ def test_shard_plan():
     assert p.leaf_range(7) == (7 << 20, 8 << 20)
     with pytest.raises(AssertionError):
         P(1 << 20, 32, 16, 3)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_relay_commit_matches_single_process(oracle, world):
+    """chain-relay commit (contiguous chunks per rank, the 32-byte running leaf states handed from rank to rank in blocks, the tree on
+    the last rank, root broadcast): every level equals the single-process commit_standard"""
+    from __graft_entry__ import build_hip
+    build_hip()
+    N, K = 1 << 18, 32
+    trs = N // (K << 11)
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_relay_worker, args=(r, world, port, N, K, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = []
+    import queue as _q
+    import time as _t
+    deadline = _t.time() + 240
+    while len(got) < world:
+        try:
+            got.append(q.get(timeout=2))
+        except _q.Empty:
+            assert all(p.exitcode in (None, 0) for p in procs), "a rank died: exit codes %s" % [p.exitcode for p in procs]
+            assert _t.time() < deadline, "timeout waiting for ranks"
+    got.sort(key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    oracle.rng_reset(); poly = oracle.generate_randomness(N); oracle.expander_init_store(trs)
+    want, _ = oracle.commit_standard(poly, K, trs, 1)
+    for g in got:
+        assert g[2] == world - 1 and np.array_equal(g[3], want[-1])          # every rank knows the owner and the root
+        assert (g[1] is not None) == (g[0] == world - 1)
+    assert np.array_equal(got[-1][1], want)
+
+
+def test_relay_open_matches_single_process(oracle):
+    """world 2 on a relay commitment: partial aggregates + all-gather, replicated open, replies from the (contiguous) tensor shards, all
+    Merkle paths from the rank that holds the tree, broadcast -- equal to the single-process open_standard with the same libc stream"""
+    import ctypes
+    from __graft_entry__ import build_hip
+    build_hip()
+    world, N, K, queries = 2, 1 << 20, 32, 300
+    trs = N // (K << 11)
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_relay_worker, args=(r, world, port, N, K, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = []
+    import queue as _q
+    import time as _t
+    deadline = _t.time() + 300
+    while len(got) < world:
+        try:
+            got.append(q.get(timeout=2))
+        except _q.Empty:
+            assert all(p.exitcode in (None, 0) for p in procs), "a rank died: exit codes %s" % [p.exitcode for p in procs]
+            assert _t.time() < deadline, "timeout waiting for ranks"
+    got.sort(key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    oracle.rng_reset(); poly = oracle.generate_randomness(N); oracle.expander_init_store(trs)
+    lv, T = oracle.commit_standard(poly, K, trs, 1, want_tensor=True)
+    x = oracle.generate_randomness(N.bit_length() - 1)
+    libc = ctypes.CDLL(None); libc.random.restype = ctypes.c_long
+    libc.srandom(2024)
+    libc.srandom(ctypes.c_uint(libc.random() & 0xFFFFFFFF))
+    want = oracle.open_standard(poly, K, trs, x, queries, tensor=T)
+    M = N // K
+    for g in got:
+        o = g[4]
+        for k in ("I", "poly", "r", "vr", "fin", "scalars", "roots", "reply"):
+            assert np.array_equal(o[k], want[k]), (g[0], k)
+        assert np.array_equal(o["sp_c_wq"], want["sp_c"]["wq"]) and np.array_equal(o["sp_f_q1"], want["sp_f"]["q1"])
+        for qi in range(0, queries, 17):
+            assert np.array_equal(o["paths"][qi], oracle.open_tree_blake(lv, M, int(want["I"][qi, 0]), int(want["I"][qi, 1]), 2 * M // trs)), (g[0], qi)

@@ -567,6 +567,45 @@ def test_sharded_commit_hip_ops_world1(hb, oracle):
     assert np.array_equal(leaves, want[:M])
 
 
+
+def test_relay_commit_hip_ops(hb, oracle):
+    """GPU operations of the chain-relay commit (hobbit_tensorcode_chunks on a contiguous chunk range, hobbit_leaf_chain_relay per block of
+    leaf slots with the running state in / out, tree on the last rank): world size 1 through sharded_commit_relay, then four emulated ranks
+    on the one GPU -- each rank's shard chained on top of the previous rank's state, block by block -- against commit_standard.  The
+    hand-over protocol itself runs under gloo at world sizes 2 and 4 in tests/test_dist_gloo.py."""
+    import torch
+    from __graft_entry__ import load_package
+    mod = load_package()
+    N, K = 1 << 20, 32
+    trs = N // (K << 11)
+    oracle.rng_reset(); poly = oracle.generate_randomness(N); oracle.expander_init_store(trs)
+    hb.upload_graphs(trs, graphs_from(oracle, trs))
+    want, _ = oracle.commit_standard(poly, K, trs, 1)
+    dev = torch.device("cuda", 0)
+    plan = mod.parallel.ShardPlan(N, K, trs, 1, contiguous=True)
+    d = hb.to_device(poly)
+    res = mod.parallel.sharded_commit_relay(mod.parallel.HipOps(hb, dev), None, plan, 0, (d.ptr, K))
+    assert np.array_equal(res["levels"].cpu().numpy(), want) and np.array_equal(res["root"], want[-1])
+    G = 4
+    plan4 = mod.parallel.ShardPlan(N, K, trs, G, contiguous=True)
+    M = plan4.M; per = M // 8
+    state = None
+    for r in range(G):
+        ops = mod.parallel.HipOps(hb, dev)
+        loc = np.concatenate([poly[i * M:(i + 1) * M] for i in plan4.chunks_of(r)])
+        dl = hb.to_device(loc)
+        ops.encode_local((dl.ptr, K // G), plan4)
+        out = ops.empty_state(M) if r < G - 1 else None
+        lv = ops.empty_state(2 * M) if r == G - 1 else None
+        for b in range(8):
+            ops.chain_block(plan4, b * per, per, state[b * per:(b + 1) * per] if state is not None else None, out[b * per:(b + 1) * per] if out is not None else None, lv)
+        state = out
+    assert np.array_equal(ops.tree_full(lv, M).cpu().numpy(), want)
+    pos = np.array([0, 5, M - 1, M // 2 + 3], np.uint64)
+    got = ops.tree_paths(lv, pos, M)
+    for k, p in enumerate(pos):
+        assert np.array_equal(got[k], oracle.open_tree_blake(want, M, int(p), 0, 0))
+
 def test_sharded_open_hip_ops_world1(hb, oracle):
     """The per-rank GPU operations of the multi-GPU open (local aggregate, field sum of partials, open from the aggregate, replies
     from the tensor shard, subtree paths) at world size 1 against the single-process hobbit_open_standard and the oracle; the
