@@ -430,7 +430,9 @@ class HipOps:
 
     def sum_vectors(self, parts):
         hb = self.hb
+        import torch
         acc = parts[0].clone()
+        torch.cuda.current_stream(self.device).synchronize()   # the clone ran on torch's stream; the sums run on the library's
         for p in parts[1:]:
             hb._chk(hb.lib.hobbit_f_binop(hb.ctx, 0, acc.data_ptr(), p.data_ptr(), acc.data_ptr(), acc.shape[0]))
         hb.sync()
