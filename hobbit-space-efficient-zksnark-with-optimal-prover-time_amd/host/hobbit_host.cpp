@@ -18,6 +18,28 @@ static hobbit_ctx *g_ctx = nullptr;
 static hobbit_commitment *g_commit = nullptr;
 static int g_commit_K = 0, g_commit_trs = 0; static size_t g_commit_cols = 0;
 static void *g_poly_dev = nullptr; static size_t g_poly_n = 0;      // device copy of the committed polynomial, kept for open_standard
+static uint8_t g_commit_root[32];
+// One older commitment stays alive beside the current one: prove_circuit_standard (src/main.cpp:985-1087) commits to the circuit polynomial
+// and to the witness before it opens either.  open_standard finds its commitment by the root of the Commitment_MT it is handed.
+struct CommitRec { hobbit_commitment *c = nullptr; int K = 0, trs = 0; size_t cols = 0; void *poly = nullptr; size_t n = 0; uint8_t root[32]; };
+static CommitRec g_prev;
+static void free_prev() {
+    if (g_prev.c) hobbit_commitment_free(g_prev.c);
+    if (g_prev.poly) hobbit_free(hobbit_host_ctx(), g_prev.poly);
+    g_prev = CommitRec();
+}
+static void swap_with_prev() {
+    CommitRec cur; cur.c = g_commit; cur.K = g_commit_K; cur.trs = g_commit_trs; cur.cols = g_commit_cols; cur.poly = g_poly_dev; cur.n = g_poly_n; memcpy(cur.root, g_commit_root, 32);
+    g_commit = g_prev.c; g_commit_K = g_prev.K; g_commit_trs = g_prev.trs; g_commit_cols = g_prev.cols; g_poly_dev = g_prev.poly; g_poly_n = g_prev.n; memcpy(g_commit_root, g_prev.root, 32);
+    g_prev = cur;
+}
+// make the commitment whose tree is `MT` the current one (no-op when it already is, or when the caller passes no tree)
+static void select_commitment(const vector<vector<_hash>> &MT) {
+    if (MT.empty() || MT.back().empty() || !g_commit) return;
+    if (!memcmp(MT.back()[0].arr, g_commit_root, 32)) return;
+    if (g_prev.c && !memcmp(MT.back()[0].arr, g_prev.root, 32)) { swap_with_prev(); return; }
+    printf("Error: open_standard on a commitment this process no longer holds (the mirror keeps the last two)\n"); exit(-1);
+}
 static hobbit_host_open_transcript g_open;
 hobbit_host_open_transcript &hobbit_host_last_open() { return g_open; }
 
@@ -32,6 +54,7 @@ hobbit_ctx *hobbit_host_ctx() {
     return g_ctx;
 }
 void hobbit_host_shutdown() {
+    if (g_ctx) free_prev();
     if (g_commit) { hobbit_commitment_free(g_commit); g_commit = nullptr; }
     if (g_poly_dev) { hobbit_free(g_ctx, g_poly_dev); g_poly_dev = nullptr; g_poly_n = 0; }
     if (g_ctx) { hobbit_ctx_destroy(g_ctx); g_ctx = nullptr; }
@@ -206,9 +229,11 @@ void hobbit_host_materialize_tensor(vector<vector<vector<F>>> &_tensor) {
 void commit_standard(vector<F> &poly, _hash &comm, vector<vector<_hash>> &MT_hashes, vector<vector<vector<F>>> &_tensor, int K) {   // src/Our_PC.cpp:146-171
     (void)comm;                                                     // the reference never writes it either
     size_t N = poly.size(), M = N / K;
-    if (g_commit) { hobbit_commitment_free(g_commit); g_commit = nullptr; }
+    // the previous commitment (with the device copy of its polynomial) moves to the one-deep stash; what was there is released
+    hobbit_host_ctx();
+    free_prev();
+    if (g_commit) { swap_with_prev(); g_commit = nullptr; g_poly_dev = nullptr; g_poly_n = 0; }
     // the device copy of poly is kept: open_standard receives the same vector and would otherwise pay the PCIe upload again
-    if (g_poly_dev) { hobbit_free(hobbit_host_ctx(), g_poly_dev); g_poly_dev = nullptr; }
     HCHK(hobbit_malloc(hobbit_host_ctx(), N * sizeof(F), &g_poly_dev)); g_poly_n = N;
     HCHK(hobbit_memcpy_h2d(g_ctx, g_poly_dev, poly.data(), N * sizeof(F)));
     HCHK(hobbit_commit_standard(g_ctx, (const hobbit_F *)g_poly_dev, N, K, tensor_row_size, linear_time ? 1 : 0, &g_commit));
@@ -219,6 +244,7 @@ void commit_standard(vector<F> &poly, _hash &comm, vector<vector<_hash>> &MT_has
     size_t levels = (size_t)log2((double)M) + 1, off = 0;
     MT_hashes.resize(levels);
     for (size_t l = 0, sz = M; l < levels; l++, sz /= 2) { MT_hashes[l].resize(sz); memcpy(MT_hashes[l].data(), flat.data() + 32 * off, 32 * sz); off += sz; }
+    memcpy(g_commit_root, MT_hashes.back()[0].arr, 32);
     _tensor.clear(); _tensor.resize(K);
     const char *mat = getenv("HOBBIT_MATERIALIZE_TENSOR");
     if ((mat && atoi(mat)) || (size_t)4 * N * sizeof(F) <= ((size_t)256 << 20)) hobbit_host_materialize_tensor(_tensor);
@@ -334,6 +360,7 @@ static void open_standard_rs(vector<F> &poly, vector<F> &x, vector<vector<_hash>
 }
 void open_standard(vector<F> &poly, vector<F> x, vector<vector<_hash>> &Commitment_MT, vector<vector<vector<F>>> &_tensor, int K, double &vt, double &ps) {
     (void)_tensor;
+    select_commitment(Commitment_MT);
     if (!g_commit || g_commit_K != K) { printf("Error: open_standard without a matching commit_standard\n"); exit(-1); }
     const size_t N = poly.size(), M = N / K;
     BUFFER_SPACE = M;
@@ -841,6 +868,74 @@ vector<F> prove_multiplication_tree_stream_shallow(stream_descriptor fd, int vec
     return out;
 }
 
+// ---- prove_circuit_standard (src/main.cpp:985-1087) ---------------------------------------------------
+size_t circuit_size = 0;
+void (*hobbit_read_trace_hook)(stream_descriptor &, vector<F> &, vector<F> &, vector<F> &, vector<int> &) = nullptr;
+void (*hobbit_read_memory_hook)(stream_descriptor &, vector<F> &, vector<F> &, vector<F> &) = nullptr;
+void reset_stream(stream_descriptor &fd) { fd.pos = 0; fd.idx = 0; fd.stage = 0; fd.offset = 0; fd.finished = false; }
+static struct { uint8_t circuit_root[32], witness_root[32]; F mul_final_eval; vector<F> mul_output; double ps = 0, vt = 0; } g_pcs;
+void prove_circuit_standard() {
+    if (!hobbit_read_trace_hook || !hobbit_read_memory_hook) { printf("Error: prove_circuit_standard needs the witness generator's read_trace / read_memory (hobbit_read_trace_hook, hobbit_read_memory_hook)\n"); exit(-1); }
+    stream_descriptor fd1; fd1.name = "transcript_stream"; fd1.size = circuit_size;
+    reset_stream(fd1);
+    stream_descriptor fd2; fd2.name = "wiring_consistency_check"; fd2.size = 8 * circuit_size;
+    reset_stream(fd2);
+    vector<F> circuit_poly(16 * circuit_size, F(0));
+    vector<F> buff_L(BUFFER_SPACE), buff_R(BUFFER_SPACE), buff_O(BUFFER_SPACE);
+    vector<int> buff_gate(BUFFER_SPACE);
+    vector<F> arr_L(fd1.size, F(0)), arr_R(fd1.size, F(0)), arr_O(fd1.size, F(0)), arr_gate(fd1.size, F(0));
+    size_t counter = 0;
+    for (size_t i = 0; i < fd1.size / BUFFER_SPACE; i++) {                                  // (:1001-1010)
+        hobbit_read_trace_hook(fd1, buff_L, buff_R, buff_O, buff_gate);
+        for (size_t j = 0; j < BUFFER_SPACE; j++) {
+            arr_L[BUFFER_SPACE * i + j] = buff_L[j]; arr_R[BUFFER_SPACE * i + j] = buff_R[j]; arr_O[BUFFER_SPACE * i + j] = buff_O[j];
+            arr_gate[BUFFER_SPACE * i + j] = F(buff_gate[j]);
+            circuit_poly[counter++] = F(buff_gate[j]);
+        }
+    }
+    vector<F> buff_addr(BUFFER_SPACE), buff_value(BUFFER_SPACE), buff_access(BUFFER_SPACE);
+    vector<F> addr(fd2.size), value(fd2.size), access(fd2.size);
+    vector<vector<F>> mul_tree_input(8);
+    double vt = 0.0, ps = 0.0;
+    vector<F> prev_x;
+    for (int i = 0; i < 8; i++) mul_tree_input[i].resize(fd2.size / 8);
+    F a = F((long long)random()), b = F((long long)random());                              // (:1020)
+    for (size_t i = 0; i < fd2.size / BUFFER_SPACE; i++) {                                  // (:1026-1037)
+        hobbit_read_memory_hook(fd2, buff_addr, buff_value, buff_access);
+        for (size_t j = 0; j < BUFFER_SPACE; j++) {
+            addr[BUFFER_SPACE * i + j] = buff_addr[j]; value[BUFFER_SPACE * i + j] = buff_value[j]; access[BUFFER_SPACE * i + j] = buff_access[j];
+            if (i < fd2.size / (2 * BUFFER_SPACE)) { circuit_poly[counter++] = buff_addr[j]; circuit_poly[counter++] = buff_access[j]; }
+        }
+    }
+    for (int i = 0; i < 8; i++)                                                             // (:1039-1044)
+        for (size_t j = 0; j < mul_tree_input[i].size(); j++) {
+            const size_t at = i * mul_tree_input[i].size() + j;
+            mul_tree_input[i][j] = addr[at] + a * value[at] + b * access[at] + F(1);
+        }
+    vector<vector<_hash>> circuit_hashes; vector<vector<vector<F>>> circuit_tensor; _hash comm;
+    linear_time = false; tensor_row_size = 128;
+    commit_standard(circuit_poly, comm, circuit_hashes, circuit_tensor, 32);               // (:1053)
+    memcpy(g_pcs.circuit_root, circuit_hashes.back()[0].arr, 32);
+    tensor_row_size = (int)(4 * circuit_size / (32 * (1ULL << 11)));
+    expander_init_store(tensor_row_size);
+    vector<F> witness(4 * circuit_size, F(0));                                              // (:1060-1069)
+    counter = 0;
+    for (size_t i = 0; i < arr_O.size(); i++) { witness[counter++] = arr_L[i]; witness[counter++] = arr_R[i]; witness[counter++] = arr_O[i]; }
+    for (size_t i = 0; i < circuit_size; i++) witness[counter++] = value[value.size() - circuit_size + i];
+    vector<vector<vector<F>>> witness_tensor; vector<vector<_hash>> witness_hashes;
+    linear_time = true;
+    commit_standard(witness, comm, witness_hashes, witness_tensor, 32);
+    memcpy(g_pcs.witness_root, witness_hashes.back()[0].arr, 32);
+    mul_tree_proof MP = prove_multiplication_tree_new(mul_tree_input, F(322), prev_x, vt, ps);
+    g_pcs.mul_final_eval = MP.final_eval; g_pcs.mul_output = MP.output;
+    prove_gate_consistency_standard(arr_L, arr_R, arr_O, arr_gate, generate_randomness((int)log2((double)arr_L.size())), vt, ps);
+    open_standard(witness, generate_randomness((int)log2((double)(4 * circuit_size))), witness_hashes, witness_tensor, 32, vt, ps);
+    linear_time = false; tensor_row_size = 128;
+    open_standard(circuit_poly, generate_randomness((int)log2((double)(16 * circuit_size))), circuit_hashes, circuit_tensor, 32, vt, ps);
+    g_pcs.ps = ps; g_pcs.vt = vt;
+    printf("Vt : %lf, Ps : %lf\n", vt, ps);
+}
+
 // ---- driver (src/Our_PC.cpp:757-826, option 4, commit phase) ---------------------------------------
 void test_PC(size_t N, int option, int K) {
     if (option != 4 && option != 1) { printf("Error: options 2 and 3 are the Orion / Brakedown comparison baselines, not built on the device path\n"); exit(-1); }
@@ -923,6 +1018,36 @@ int hobbit_host_test_pc_rs_open(size_t N, int K, unsigned seed, uint8_t *root_ou
     *ps_out = ps;
     linear_time = true;
     return t.rounds;
+}
+// prove_circuit_standard over caller-supplied trace / memory arrays (tests): L, R, O: circuit_size F; S: circuit_size int; addr, value, access:
+// 8 * circuit_size F.  Returns the two commitment roots, the mul tree's final evaluation and products, the final challenges of the two openings.
+static struct { const F *L, *R, *O; const int *S; const F *addr, *value, *access; } g_syn;
+static void syn_read_trace(stream_descriptor &fd, vector<F> &bL, vector<F> &bR, vector<F> &bO, vector<int> &bS) {
+    const size_t B = bL.size(), at = fd.pos * B; fd.pos++;
+    for (size_t j = 0; j < B; j++) { bL[j] = g_syn.L[at + j]; bR[j] = g_syn.R[at + j]; bO[j] = g_syn.O[at + j]; bS[j] = g_syn.S[at + j]; }
+}
+static void syn_read_memory(stream_descriptor &fd, vector<F> &ba, vector<F> &bv, vector<F> &bc) {
+    const size_t B = ba.size(), at = fd.pos * B; fd.pos++;
+    for (size_t j = 0; j < B; j++) { ba[j] = g_syn.addr[at + j]; bv[j] = g_syn.value[at + j]; bc[j] = g_syn.access[at + j]; }
+}
+int hobbit_host_prove_circuit_standard(size_t cs, size_t B, unsigned seed, const uint64_t *L, const uint64_t *R, const uint64_t *O, const int *S, const uint64_t *addr,
+                                       const uint64_t *value, const uint64_t *access, uint8_t *roots2, uint64_t *mul_out /* 8 products + final_eval */,
+                                       uint64_t *open_w_r /* witness opening: challenges */, uint64_t *open_c_r /* circuit opening: challenges */, int *rounds2, double *ps_out) {
+    g_syn.L = (const F *)L; g_syn.R = (const F *)R; g_syn.O = (const F *)O; g_syn.S = S;
+    g_syn.addr = (const F *)addr; g_syn.value = (const F *)value; g_syn.access = (const F *)access;
+    hobbit_read_trace_hook = syn_read_trace; hobbit_read_memory_hook = syn_read_memory;
+    circuit_size = cs; BUFFER_SPACE = B;
+    srandom(seed);
+    prove_circuit_standard();
+    memcpy(roots2, g_pcs.circuit_root, 32); memcpy(roots2 + 32, g_pcs.witness_root, 32);
+    for (size_t i = 0; i < 8 && i < g_pcs.mul_output.size(); i++) memcpy(mul_out + 2 * i, &g_pcs.mul_output[i], 16);
+    memcpy(mul_out + 16, &g_pcs.mul_final_eval, 16);
+    hobbit_host_open_transcript &tw = hobbit_host_last_open(); hobbit_host_elastic_transcript &tc = hobbit_host_last_elastic_open();
+    memcpy(open_w_r, tw.r.data(), 16 * (size_t)tw.rounds); memcpy(open_c_r, tc.r.data(), 16 * (size_t)tc.rounds);
+    rounds2[0] = tw.rounds; rounds2[1] = tc.rounds;
+    *ps_out = g_pcs.ps;
+    linear_time = true;
+    return 0;
 }
 int hobbit_host_sumcheck2(const uint64_t *v1, const uint64_t *v2, size_t n, const uint64_t *prev, uint64_t *qpoly, uint64_t *r, uint64_t *vr, uint64_t *fin) {
     vector<F> a(n), b(n); memcpy((void *)a.data(), v1, 16 * n); memcpy((void *)b.data(), v2, 16 * n);

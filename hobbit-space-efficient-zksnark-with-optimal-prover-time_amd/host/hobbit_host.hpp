@@ -202,6 +202,15 @@ void commit(stream_descriptor fd, _hash &comm, vector<vector<_hash>> &MT_hashes)
 void init_commitment(bool mod);
 void read_stream(stream_descriptor &fd, vector<F> &v, int size);  /* default branch only (src/witness_stream.cpp:2348-2352) */
 void open(stream_descriptor fd, vector<F> x, vector<vector<_hash>> &Commitment_MT, double &vt, double &ps);   /* !linear_time (RS x RS) */
+/* src/main.cpp:985-1087: the non-streaming prover.  Everything it proves runs on the device (both commit_standard / open_standard modes,
+ * prove_multiplication_tree_new, prove_gate_consistency_standard); what it READS comes from the witness generator
+ * (read_trace, src/witness_stream.cpp:1701; read_memory), which is not part of this library: a reference build assigns its own two
+ * functions to the hooks, a test assigns synthetic readers.  circuit_size: src/main.cpp global (set by init_stream, :1100). */
+extern size_t circuit_size;
+extern void (*hobbit_read_trace_hook)(stream_descriptor &fd, vector<F> &buff_L, vector<F> &buff_R, vector<F> &buff_O, vector<int> &buff_S);
+extern void (*hobbit_read_memory_hook)(stream_descriptor &fd, vector<F> &buff_addr, vector<F> &buff_value, vector<F> &buff_access);
+void reset_stream(stream_descriptor &fd);                      /* src/witness_stream.cpp:228-234 */
+void prove_circuit_standard();
 void test_Elastic_PC(size_t N, int option);                     /* src/Elastic_PC.cpp:736-771: options 1 (commit + open) and 2 (commit; its open is undefined in the reference) */
 /* the messages of the last Elastic open (the reference returns only vt / ps); layouts as hobbit_elastic_open_out */
 struct hobbit_host_elastic_transcript {
