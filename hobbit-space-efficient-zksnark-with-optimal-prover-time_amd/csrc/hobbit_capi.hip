@@ -32,7 +32,7 @@ struct StageScope {
     ~StageScope() { ctx->stage_depth--; if (top) ctx->deferred.clear(); }
     int finish() {
         if (!top) return 0;
-        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        HB_TRY(ctx->sync());
         for (auto &d : ctx->deferred) memcpy(d.dst, d.src, d.bytes);
         ctx->deferred.clear();
         return 0;
@@ -241,18 +241,18 @@ void hobbit_ctx_destroy(hobbit_ctx *ctx) {
     delete ctx;
 }
 const char *hobbit_last_error(const hobbit_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
-int hobbit_sync(hobbit_ctx *ctx) { HB_CHECK(ctx, hipStreamSynchronize(ctx->stream)); return 0; }
+int hobbit_sync(hobbit_ctx *ctx) { HB_TRY(ctx->sync()); return 0; }
 int hobbit_malloc(hobbit_ctx *ctx, size_t bytes, void **d_ptr) {
     hipSetDevice(ctx->device);
     if (hipMalloc(d_ptr, bytes ? bytes : 16) != hipSuccess) return ctx->fail(HOBBIT_ENOMEM, "hipMalloc failed");
     return 0;
 }
-int hobbit_free(hobbit_ctx *ctx, void *d_ptr) { HB_CHECK(ctx, hipStreamSynchronize(ctx->stream)); HB_CHECK(ctx, hipFree(d_ptr)); return 0; }
+int hobbit_free(hobbit_ctx *ctx, void *d_ptr) { HB_TRY(ctx->sync()); HB_CHECK(ctx, hipFree(d_ptr)); return 0; }
 int hobbit_memcpy_h2d(hobbit_ctx *ctx, void *d, const void *h, size_t bytes) {
-    HB_CHECK(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream)); HB_CHECK(ctx, hipStreamSynchronize(ctx->stream)); return 0;
+    HB_CHECK(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream)); HB_TRY(ctx->sync()); return 0;
 }
 int hobbit_memcpy_d2h(hobbit_ctx *ctx, void *h, const void *d, size_t bytes) {
-    HB_CHECK(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream)); HB_CHECK(ctx, hipStreamSynchronize(ctx->stream)); return 0;
+    HB_CHECK(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream)); HB_TRY(ctx->sync()); return 0;
 }
 int hobbit_memset(hobbit_ctx *ctx, void *d, int value, size_t bytes) { HB_CHECK(ctx, hipMemsetAsync(d, value, bytes, ctx->stream)); return 0; }
 int hobbit_timer_begin(hobbit_ctx *ctx) { HB_CHECK(ctx, hipEventRecord(ctx->t0, ctx->stream)); return 0; }
@@ -263,7 +263,7 @@ int hobbit_timer_end_ms(hobbit_ctx *ctx, float *ms) {
 int hobbit_profile_enable(hobbit_ctx *ctx, int on) { ctx->prof_on = on < 0 ? 0 : on > 2 ? 1 : on; return 0; }
 int hobbit_profile_reset(hobbit_ctx *ctx) { hipStreamSynchronize(ctx->stream); ctx->prof_collect(); ctx->prof.clear(); return 0; }
 int hobbit_profile_get(hobbit_ctx *ctx, const char *kernel, double *total_ms, long long *launches) {
-    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    HB_TRY(ctx->sync());
     ctx->prof_collect();
     auto it = ctx->prof.find(kernel);
     if (it == ctx->prof.end()) { *total_ms = 0; *launches = 0; return 0; }
@@ -532,7 +532,7 @@ int hobbit_commit_standard(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, in
         ctx->spare_tensor = nullptr; ctx->spare_levels = nullptr;
     } else {
         if (ctx->spare_tensor) {          // a parked commitment of another shape: release it BEFORE allocating (it can be 16.5 GiB)
-            HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            HB_TRY(ctx->sync());
             hipFree(ctx->spare_tensor); hipFree(ctx->spare_levels);
             ctx->spare_tensor = nullptr; ctx->spare_levels = nullptr; ctx->spare_tensor_bytes = ctx->spare_levels_bytes = 0;
         }
@@ -840,7 +840,7 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
     HB_CHECK(ctx, hipMemcpyAsync(pin_res, dres, WHIR_DRES * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
     if (o->qreply && q_tot) HB_TRY(d2h_staged(ctx, o->qreply, d_rep, q_tot * 16 * sizeof(F)));
     if (o->qpaths && path_off) HB_TRY(d2h_staged(ctx, o->qpaths, d_paths, path_off));
-    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    HB_TRY(ctx->sync());
     // replay: round checks ("Error in %d", :562-565), eval updates (:566, :631), final check (:648-651)
     F eval = pin_res[0];
     h_checks[0] = 1;
@@ -919,7 +919,7 @@ int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobb
         HB_TRY(hobbit_whir_prove(ctx, reinterpret_cast<hobbit_F *>(aggr), w, reinterpret_cast<hobbit_F *>(wcom), wlv, o->r2, &wo));                          // (:480-481)
     }
     if (o->iters) *o->iters = iters;
-    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    HB_TRY(ctx->sync());
     return sc.finish();
 }
 
@@ -975,7 +975,7 @@ int hobbit_parity_matrix(hobbit_ctx *ctx, const hobbit_F *d_beta, size_t size_a,
     if (c.n != n) return ctx->fail(HOBBIT_ESTATE, "parity_matrix: graphs for this n are not finalized");
     if (size_a < (size_t)c.len) return ctx->fail(HOBBIT_EINVAL, "parity_matrix: A must hold at least the codeword length");
     if (!c.d_pm_rowptr || c.pm_rows != size_a) {
-        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        HB_TRY(ctx->sync());
         if (c.d_pm_rowptr) { hipFree(c.d_pm_rowptr); hipFree(c.d_pm_idx); hipFree(c.d_pm_w); c.d_pm_rowptr = nullptr; }
         std::vector<std::vector<std::pair<uint32_t, F>>> rows(size_a);
         long long lvl = 0;
@@ -1148,7 +1148,7 @@ int hobbit_batch_3product_sumcheck(hobbit_ctx *ctx, const hobbit_F *d_t1, const 
         for (int j = 0; j < batches; j++) if (len[j] == 1 && set[j] == 0) {
             for (int t = 0; t < 3; t++) HB_CHECK(ctx, hipMemcpyAsync(pin + 4 * batches + 3 * j + t, cur + t * tot + off[j], sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
         }
-        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        HB_TRY(ctx->sync());
         for (int j = 0; j < batches; j++) if (len[j] == 1 && set[j] == 0) { for (int t = 0; t < 3; t++) sc[3 * j + t] = pin[4 * batches + 3 * j + t]; set[j] = 2; }
         return 0;
     };
@@ -1157,7 +1157,7 @@ int hobbit_batch_3product_sumcheck(hobbit_ctx *ctx, const hobbit_F *d_t1, const 
     for (int i = 0; i < rounds; i++) {
         for (int j = 0; j < batches; j++) if (len[j] >= 2) HB_TRY(launch_sc3_poly(ctx, cur + off[j], cur + tot + off[j], cur + 2 * tot + off[j], len[j] / 2, part, coef + 4 * j));
         HB_CHECK(ctx, hipMemcpyAsync(pin, coef, 4 * (size_t)batches * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
-        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        HB_TRY(ctx->sync());
         F poly[4] = {fmake(0), fmake(0), fmake(0), fmake(0)};
         for (int j = 0; j < batches; j++) {
             F p[4] = {fmake(0), fmake(0), fmake(0), fmake(0)};
@@ -1306,7 +1306,7 @@ static int rs_prover_dev(hobbit_ctx *ctx, const F *d_aggr, size_t B, size_t trs,
     {   // beta[collumns[i] + j*cols] = r[i] (:489-496)
         uint8_t *pin; HB_TRY(ctx->pinned(2048 * sizeof(F), (void **)&pin));
         if (nc > 2048) return ctx->fail(HOBBIT_EINVAL, "recursive_prover_RS: more than 2048 distinct columns");
-        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));                                    // (the staging buffer's previous contents have been consumed: sumcheck2 synchronised)
+        HB_TRY(ctx->sync());                                    // (the staging buffer's previous contents have been consumed: sumcheck2 synchronised)
         memcpy(pin, rb.data(), nc * sizeof(F));
         HB_CHECK(ctx, hipMemcpyAsync(stage, pin, nc * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
         HB_TRY(launch_spread_cols(ctx, d_ucols, stage, (uint32_t)nc, (uint32_t)trs, cols, b2));
@@ -1360,7 +1360,7 @@ int hobbit_elastic_open_begin(hobbit_ctx *ctx, size_t N, size_t B, int trs, cons
     HB_TRY(launch_zero(ctx, e->d_nz, e->K * sizeof(int)));
     HB_CHECK(ctx, hipMemcpyAsync(e->d_ucols, e->ucols.data(), nc * 4, hipMemcpyHostToDevice, ctx->stream));
     HB_CHECK(ctx, hipMemcpyAsync(e->d_pick, pick.data(), (size_t)queries * 8, hipMemcpyHostToDevice, ctx->stream));
-    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));                                                        // `pick` is a local
+    HB_TRY(ctx->sync());                                                        // `pick` is a local
     *out = e;
     return 0;
 }
@@ -1400,7 +1400,7 @@ int hobbit_elastic_open_finish(hobbit_ctx *ctx, hobbit_elastic_open *e, const ui
         std::vector<int> nz(e->K); std::vector<F> rep(e->K * nq);
         HB_CHECK(ctx, hipMemcpyAsync(nz.data(), e->d_nz, e->K * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         HB_CHECK(ctx, hipMemcpyAsync(rep.data(), e->d_reply, e->K * nq * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
-        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        HB_TRY(ctx->sync());
         size_t filled = 0;
         for (size_t i = 0; i < e->K; i++) if (nz[i]) filled++;
         if (o->reply) { size_t f = 0; for (size_t i = 0; i < e->K; i++) if (nz[i]) { for (size_t q = 0; q < nq; q++) mF(o->reply)[q * filled + f] = rep[i * nq + q]; f++; } }

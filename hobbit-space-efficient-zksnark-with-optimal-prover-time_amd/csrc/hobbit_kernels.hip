@@ -1741,7 +1741,7 @@ static int run_err(hobbit_ctx *ctx, const char *name, const ErrArgs &a, size_t n
     HB_LAUNCH(ctx, name, (k_err_terms<KIND, NC>), dim3(nb), dim3(256), 0, a, n, part);
     HB_LAUNCH(ctx, "k_sc_reduce", k_sc_reduce<NC>, dim3(1), dim3(256), 0, part, nb, coef);
     HB_CHECK(ctx, hipMemcpyAsync(pin, coef, NC * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
-    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    HB_TRY(ctx->sync());
     for (int q = 0; q < NC; q++) h_K[q] = pin[q];
     return 0;
 }
@@ -1899,7 +1899,7 @@ int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev
         ta.resize(n); tb.resize(n);
         HB_CHECK(ctx, hipMemcpyAsync(ta.data(), v1, n * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
         HB_CHECK(ctx, hipMemcpyAsync(tb.data(), v2, n * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
-        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        HB_TRY(ctx->sync());
         sc2_host_tail(ta, tb, rnd, false, 0, rounds, h_qpoly, h_r);
     } else {
         size_t szA = n / 2, szB = n / 4;
@@ -1967,7 +1967,7 @@ int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev
         ta.resize(cur); tb.resize(cur);
         HB_CHECK(ctx, hipMemcpyAsync(ta.data(), s1, cur * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
         HB_CHECK(ctx, hipMemcpyAsync(tb.data(), s2, cur * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
-        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        HB_TRY(ctx->sync());
         sc2_host_tail(ta, tb, rnd, true, i + 1, rounds, h_qpoly, h_r);
     }
     rnd = mimc_hash(rnd, ta[0]); rnd = mimc_hash(rnd, tb[0]);          // src/sumcheck.cpp:2444-2446
@@ -2122,16 +2122,16 @@ static int gate_sumcheck_impl(hobbit_ctx *ctx, const F *const *tabs, size_t n, c
             }
             HB_LAUNCH(ctx, "k_sc_reduce12", k_sc_reduce<NS>, dim3(1), dim3(256), 0, part, nb, coef);
             HB_CHECK(ctx, hipMemcpyAsync(pin, coef, NS * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
-            HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            HB_TRY(ctx->sync());
             ok &= gate_round_host<G>(pin, h_a, rnd, sum, h_poly + 5 * i, h_r + i);
             if (cur <= 2 * SC_TAIL || i == rounds - 1) break;
         }
         for (int q = 0; q < NT; q++) { host[q].resize(cur); HB_CHECK(ctx, hipMemcpyAsync(host[q].data(), t.s[q], cur * sizeof(F), hipMemcpyDeviceToHost, ctx->stream)); }
-        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        HB_TRY(ctx->sync());
         pending = true; i++;
     } else {
         for (int q = 0; q < NT; q++) { host[q].resize(n); HB_CHECK(ctx, hipMemcpyAsync(host[q].data(), tabs[q], n * sizeof(F), hipMemcpyDeviceToHost, ctx->stream)); }
-        HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        HB_TRY(ctx->sync());
     }
     auto fold = [&]() { for (int q = 0; q < NT; q++) for (size_t j = 0; j < cur / 2; j++) host[q][j] = fadd(host[q][2 * j], fmul(rnd, fsub(host[q][2 * j + 1], host[q][2 * j]))); cur /= 2; };
     if (pending) fold();
@@ -2258,7 +2258,7 @@ int launch_sumcheck3(hobbit_ctx *ctx, const F *v1, const F *v2, const F *v3, siz
             HB_LAUNCH(ctx, "k_sc3_poly_fold", k_sc3_poly_fold, dim3(nb), dim3(256), 0, s1, s2, s3, dst, dst + dsz, dst + 2 * dsz, L, rnd, part);
             HB_LAUNCH(ctx, "k_sc_reduce4", k_sc_reduce<4>, dim3(1), dim3(256), 0, part, nb, coef);
             HB_CHECK(ctx, hipMemcpyAsync(pin, coef, 4 * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
-            HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            HB_TRY(ctx->sync());
             h_r[i] = rnd;                                           // randomness[i] = pre-round challenge
             for (int q = 0; q < 4; q++) { rnd = mimc_hash(rnd, pin[q]); h_cpoly[4 * i + q] = pin[q]; }
             s1 = dst; s2 = dst + dsz; s3 = dst + 2 * dsz; cur = L;
@@ -2269,7 +2269,7 @@ int launch_sumcheck3(hobbit_ctx *ctx, const F *v1, const F *v2, const F *v3, siz
     HB_CHECK(ctx, hipMemcpyAsync(ta.data(), s1, cur * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
     HB_CHECK(ctx, hipMemcpyAsync(tb.data(), s2, cur * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
     HB_CHECK(ctx, hipMemcpyAsync(tc.data(), s3, cur * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
-    HB_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    HB_TRY(ctx->sync());
     sc3_host_tail(ta, tb, tc, rnd, i, rounds, h_cpoly, h_r);
     rnd = mimc_hash(rnd, ta[0]); rnd = mimc_hash(rnd, tb[0]);      // v3[0] is not hashed (src/sumcheck.cpp:2043-2046)
     h_vr[0] = ta[0]; h_vr[1] = tb[0]; h_vr[2] = tc[0]; *h_final = rnd;
