@@ -936,6 +936,68 @@ void prove_circuit_standard() {
     printf("Vt : %lf, Ps : %lf\n", vt, ps);
 }
 
+// ---- prove_gate_consistency / _lookups (src/sumcheck.cpp:796-975, 503-795) over the witness generator's read_trace ----------------
+bool has_lookups = false;
+vector<F> lookup_rand;
+int tensor_code = 1;
+static hobbit_host_gate_transcript g_gate;
+hobbit_host_gate_transcript &hobbit_host_last_gate() { return g_gate; }
+struct HostTrace {                                                   // hobbit_trace_source over hobbit_read_trace_hook
+    stream_descriptor fd; size_t B;
+    vector<F> bL, bR, bO; vector<int> bS;
+    DevBuf dL, dR, dO, dS;
+    HostTrace(const stream_descriptor &f, size_t b) : fd(f), B(b), bL(b), bR(b), bO(b), bS(b), dL(b * sizeof(F)), dR(b * sizeof(F)), dO(b * sizeof(F)), dS(b * sizeof(int32_t)) {}
+};
+static int host_trace_source(void *user, size_t n, const hobbit_F **L, const hobbit_F **R, const hobbit_F **O, const int32_t **S) {
+    HostTrace *t = (HostTrace *)user;
+    if (n == 0) { reset_stream(t->fd); return 0; }                                                              // (:871 / :643)
+    if (n != t->B || !hobbit_read_trace_hook) return -1;
+    hobbit_read_trace_hook(t->fd, t->bL, t->bR, t->bO, t->bS);
+    if (hobbit_memcpy_h2d(g_ctx, t->dL.p, t->bL.data(), n * sizeof(F)) || hobbit_memcpy_h2d(g_ctx, t->dR.p, t->bR.data(), n * sizeof(F)) ||
+        hobbit_memcpy_h2d(g_ctx, t->dO.p, t->bO.data(), n * sizeof(F)) || hobbit_memcpy_h2d(g_ctx, t->dS.p, t->bS.data(), n * sizeof(int32_t))) return -1;
+    *L = (const hobbit_F *)t->dL.p; *R = (const hobbit_F *)t->dR.p; *O = (const hobbit_F *)t->dO.p; *S = (const int32_t *)t->dS.p;
+    return 0;
+}
+static void gate_stream_common(stream_descriptor &tr, vector<F> &r, bool lookups, double &vt, double &ps) {
+    if (!hobbit_read_trace_hook) { printf("Error: the streaming gate provers need the witness generator's read_trace (hobbit_read_trace_hook)\n"); exit(-1); }
+    hobbit_host_ctx();
+    const size_t B = BUFFER_SPACE, nch = tr.size / B;
+    const int logB = (int)log2((double)B), lR = (int)log2((double)nch);
+    const int nt = lookups ? 9 : 6, na = lookups ? 5 : 4, nb = lookups ? 8 : 6;
+    hobbit_host_gate_transcript &t = g_gate;
+    t.lookups = lookups;
+    t.R.assign(nch, F(0)); t.a.assign(na, F(0)); t.poly.assign(5 * (size_t)logB, F(0)); t.gr.assign(logB, F(0)); t.fin.assign(nt, F(0));
+    t.Peval.assign((size_t)nb * nch, F(0)); t.b.assign(nb, F(0)); t.q2.assign(3 * (size_t)lR, F(0)); t.r2.assign(lR, F(0)); t.vr2.assign(2, F(0));
+    for (int &c : t.checks) c = 1;
+    HostTrace src(tr, B);
+    if (lookups) {
+        if (!has_lookups || lookup_rand.size() < 2) { printf("Error: prove_gate_consistency_lookups needs has_lookups and lookup_rand (src/main.cpp:888,910)\n"); exit(-1); }
+        HCHK(hobbit_set_lookups(g_ctx, 1, hF(lookup_rand.data())));
+        hobbit_gate_lkp_stream_out o{hF(t.R.data()), hF(t.a.data()), hF(t.poly.data()), hF(t.gr.data()), hF(t.fin.data()), hF(t.Peval.data()), hF(t.b.data()),
+                                     hF(t.q2.data()), hF(t.r2.data()), hF(t.vr2.data()), hF(&t.fin2), t.checks};
+        HCHK(hobbit_gate_consistency_lookups_stream(g_ctx, host_trace_source, &src, nch, B, hF(r.data()), &o));
+        HCHK(hobbit_set_lookups(g_ctx, has_lookups ? 1 : 0, hF(lookup_rand.data())));
+    } else {
+        hobbit_gate_stream_out o{hF(t.R.data()), hF(t.a.data()), hF(t.poly.data()), hF(t.gr.data()), hF(t.fin.data()), hF(t.Peval.data()), hF(t.b.data()),
+                                 hF(t.q2.data()), hF(t.r2.data()), hF(t.vr2.data()), hF(&t.fin2), t.checks};
+        HCHK(hobbit_gate_consistency_stream(g_ctx, host_trace_source, &src, nch, B, hF(r.data()), &o));
+    }
+    if (!t.checks[0]) { printf("Error in gate consistency 1\n"); exit(-1); }                                   // (:840 / :588, :549)
+    if (!t.checks[1]) { printf("Error in gate consistency 2\n"); exit(-1); }                                   // (:912 / :711)
+    if (!t.checks[2]) { printf("Error in gate consistency 3\n"); exit(-1); }                                   // (:968 / :787)
+    if (lookups && !t.checks[3]) { printf("ERRRROR\n"); exit(-1); }                                            // (:638-641)
+    if (lookups && !t.checks[4]) printf("ERRRROR\n");                                                          // (:650-652: the reference only prints)
+    // proof-size accounting of the reference (:827,860,919,971 / :555,612,719,783) + the closing 2-product sumcheck's own
+    ps += (lookups ? 5 : 4) * sizeof(F) / 1024.0;
+    ps += (double)(nch - 1) * (lookups ? 15 : 12) * sizeof(F) / 1024.0;
+    ps += (double)logB * 5 * sizeof(F) / 1024.0;
+    sumcheck2_ps(lR, ps);
+    ps += 5 * sizeof(F) / 1024.0;
+    (void)vt;
+}
+void prove_gate_consistency(stream_descriptor tr, vector<F> r, double &vt, double &ps) { gate_stream_common(tr, r, false, vt, ps); }
+void prove_gate_consistency_lookups(stream_descriptor tr, vector<F> r, double &vt, double &ps) { gate_stream_common(tr, r, true, vt, ps); }
+
 // ---- driver (src/Our_PC.cpp:757-826, option 4, commit phase) ---------------------------------------
 void test_PC(size_t N, int option, int K) {
     if (option != 4 && option != 1) { printf("Error: options 2 and 3 are the Orion / Brakedown comparison baselines, not built on the device path\n"); exit(-1); }
@@ -1048,6 +1110,27 @@ int hobbit_host_prove_circuit_standard(size_t cs, size_t B, unsigned seed, const
     *ps_out = g_pcs.ps;
     linear_time = true;
     return 0;
+}
+// prove_gate_consistency[_lookups] through the mirror over a caller-supplied trace (L, R, O: n F; S: n int): the challenges R and the final
+// folded values come back for the comparison with the oracle
+int hobbit_host_gate_stream(size_t n, size_t B, int lookups, unsigned seed, const uint64_t *L, const uint64_t *R, const uint64_t *O, const int *S, const uint64_t *r,
+                            const uint64_t *lr, uint64_t *R_out, uint64_t *fin_out, uint64_t *q2_out, int *checks, double *ps_out) {
+    g_syn.L = (const F *)L; g_syn.R = (const F *)R; g_syn.O = (const F *)O; g_syn.S = S;
+    hobbit_read_trace_hook = syn_read_trace;
+    BUFFER_SPACE = B;
+    stream_descriptor tr; tr.name = "transcript_stream"; tr.size = n; reset_stream(tr);
+    const int logB = (int)log2((double)B);
+    vector<F> rv(logB); memcpy((void *)rv.data(), r, 16 * (size_t)logB);
+    if (lookups) { has_lookups = true; lookup_rand.assign(4, F(0)); memcpy((void *)lookup_rand.data(), lr, 32); }
+    srandom(seed);
+    double vt = 0, ps = 0;
+    if (lookups) prove_gate_consistency_lookups(tr, rv, vt, ps); else prove_gate_consistency(tr, rv, vt, ps);
+    has_lookups = false;
+    hobbit_host_gate_transcript &t = hobbit_host_last_gate();
+    memcpy(R_out, t.R.data(), 16 * t.R.size()); memcpy(fin_out, t.fin.data(), 16 * t.fin.size()); memcpy(q2_out, t.q2.data(), 16 * t.q2.size());
+    for (int i = 0; i < 5; i++) checks[i] = t.checks[i];
+    *ps_out = ps;
+    return (int)t.fin.size();
 }
 int hobbit_host_sumcheck2(const uint64_t *v1, const uint64_t *v2, size_t n, const uint64_t *prev, uint64_t *qpoly, uint64_t *r, uint64_t *vr, uint64_t *fin) {
     vector<F> a(n), b(n); memcpy((void *)a.data(), v1, 16 * n); memcpy((void *)b.data(), v2, 16 * n);

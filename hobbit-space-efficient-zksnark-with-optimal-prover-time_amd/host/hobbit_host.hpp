@@ -211,6 +211,17 @@ extern void (*hobbit_read_trace_hook)(stream_descriptor &fd, vector<F> &buff_L, 
 extern void (*hobbit_read_memory_hook)(stream_descriptor &fd, vector<F> &buff_addr, vector<F> &buff_value, vector<F> &buff_access);
 void reset_stream(stream_descriptor &fd);                      /* src/witness_stream.cpp:228-234 */
 void prove_circuit_standard();
+/* src/sumcheck.h:90-91, src/sumcheck.cpp:796 / :503: the streaming gate-consistency provers.  The trace is read through
+ * hobbit_read_trace_hook (BUFFER_SPACE gates per call); has_lookups / lookup_rand: src/main.cpp:70 / :67 (prove_gate_consistency_lookups
+ * reads lookup_rand[0..1] and needs has_lookups set, as compute{3,4}p_error_terms do in the reference). */
+extern bool has_lookups;
+extern vector<F> lookup_rand;
+extern int tensor_code;                                        /* src/Elastic_PC.cpp:14 (1 = the tensor code; the only value the device path implements) */
+void prove_gate_consistency(stream_descriptor tr, vector<F> r, double &vt, double &ps);
+void prove_gate_consistency_lookups(stream_descriptor tr, vector<F> r, double &vt, double &ps);
+/* the messages of the last streaming gate prover (the reference returns none): layouts as hobbit_gate_stream_out / hobbit_gate_lkp_stream_out */
+struct hobbit_host_gate_transcript { vector<F> R, a, poly, gr, fin, Peval, b, q2, r2, vr2; F fin2; int checks[5] = {0, 0, 0, 0, 0}; bool lookups = false; };
+hobbit_host_gate_transcript &hobbit_host_last_gate();
 void test_Elastic_PC(size_t N, int option);                     /* src/Elastic_PC.cpp:736-771: options 1 (commit + open) and 2 (commit; its open is undefined in the reference) */
 /* the messages of the last Elastic open (the reference returns only vt / ps); layouts as hobbit_elastic_open_out */
 struct hobbit_host_elastic_transcript {

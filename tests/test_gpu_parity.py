@@ -586,6 +586,41 @@ def test_host_mirror_prove_circuit_standard(oracle):
     assert ps.value > 0
 
 
+@pytest.mark.parametrize("lookups", [0, 1])
+def test_host_mirror_gate_consistency_stream(oracle, lookups):
+    """prove_gate_consistency / prove_gate_consistency_lookups with the reference's signatures (stream_descriptor, r, vt, ps) through the C++
+    mirror, the trace served by hobbit_read_trace_hook chunk by chunk (uploaded per read, reset and re-read for the Peval pass): challenges,
+    folded values and the closing sumcheck equal the oracle's; the reference's exit(-1) checks pass; ps is the reference's accounting."""
+    import ctypes
+    from __graft_entry__ import PKG, build_host
+    from oracle.pyoracle import gate_standard_inputs
+    build_host()
+    lib = ctypes.CDLL(os.path.join(PKG, "libhobbit_host.so"))
+    libc = ctypes.CDLL(None)
+    B, nch, seed = 1 << 12, 8, 99
+    n = B * nch; logB = 12; lR = 3
+    if lookups:
+        L, R, O, S = lookup_trace(B, nch, 40)
+    else:
+        parts = [gate_standard_inputs(B, 50 + c) for c in range(nch)]
+        L, R, O = [np.concatenate([p[i] for p in parts]) for i in range(3)]
+        S = np.concatenate([p[3][:, 0] for p in parts]).astype(np.int32)
+    r = splitmix_field(logB, 3); lr = splitmix_field(2, 77)
+    nt = 9 if lookups else 6
+    Rout = np.zeros((nch, 2), np.uint64); fin = np.zeros((nt, 2), np.uint64); q2 = np.zeros((lR, 3, 2), np.uint64); checks = np.zeros(5, np.int32); ps = ctypes.c_double(0)
+    Pv = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.hobbit_host_gate_stream.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint] + [ctypes.c_void_p] * 11
+    assert lib.hobbit_host_gate_stream(n, B, lookups, seed, Pv(L), Pv(R), Pv(O), Pv(S), Pv(r), Pv(lr), Pv(Rout), Pv(fin), Pv(q2), Pv(checks), ctypes.byref(ps)) == nt
+    lib.hobbit_host_close()
+    libc.srandom(seed)
+    want = oracle.gate_consistency_lookups_stream(L, R, O, S, B, r, lr) if lookups else oracle.gate_consistency_stream(L, R, O, S, B, r)
+    assert checks.tolist() == [1] * 5
+    assert np.array_equal(Rout, want["R"]) and np.array_equal(fin, want["fin9" if lookups else "fin6"]) and np.array_equal(q2, want["q2"])
+    per_chunk = 15 if lookups else 12
+    want_ps = ((5 if lookups else 4) + (nch - 1) * per_chunk + logB * 5 + (3 * lR + 2) + 5) * 16 / 1024.0
+    assert abs(ps.value - want_ps) < 1e-9
+
+
 # ---- multi-GPU building blocks on one GPU ------------------------------------------------------
 def test_sharded_commit_hip_ops_world1(hb, oracle):
     """The per-rank GPU operations of the chunk-sharded commit (tensor codes of the local chunks,
