@@ -946,6 +946,28 @@ int hobbit_leaf_chain_relay(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M,
     return launch_leaf_chain_relay(ctx, cF(d_tensor), cols * rows2, nchunks, (uint32_t)cols, (uint32_t)(trs / 2), slot_begin, slot_count, d_state_in, d_state_out, d_leaves,
                                    linear_time ? (uint32_t)ctx->code.len : (uint32_t)rows2);
 }
+// SURVEY.md 8(b)'s export list by its own names: thin forms of what the library already has
+int hobbit_leaf_chain(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M, int nchunks, int trs, int linear_time, uint8_t *d_leaves) {
+    if (trs < 4 || trs % 4 || M % (size_t)trs || nchunks <= 0 || !d_leaves) return ctx->fail(HOBBIT_EINVAL, "leaf_chain: trs must be a multiple of 4 dividing M, nchunks positive");
+    const size_t cols = 2 * M / trs, rows2 = 2 * (size_t)trs;
+    if (linear_time && ctx->code.n != trs) return ctx->fail(HOBBIT_ESTATE, "leaf_chain: expander graphs for n = trs not finalized");
+    return launch_leaf_chain_relay(ctx, cF(d_tensor), cols * rows2, nchunks, (uint32_t)cols, (uint32_t)(trs / 2), 0, M, nullptr, nullptr, d_leaves,
+                                   linear_time ? (uint32_t)ctx->code.len : (uint32_t)rows2, 1);
+}
+int hobbit_axpy_aggregate(hobbit_ctx *ctx, const hobbit_F *d_chunk, const hobbit_F *h_coeff, hobbit_F *d_acc, size_t n) {
+    return hobbit_fold_axpy(ctx, d_acc, d_chunk, h_coeff, n);
+}
+int hobbit_stream_fold(hobbit_ctx *ctx, int kind, const hobbit_F *const *d_tables, const int32_t *d_gate, size_t n, hobbit_F *h_K) {
+    if (!d_tables || !h_K) return ctx->fail(HOBBIT_EINVAL, "stream_fold: null argument");
+    const int nt = kind == 2 ? 4 : kind == 3 ? 5 : kind == 4 ? 7 : kind == 13 ? 6 : 0, nc = kind == 2 ? 2 : kind == 4 ? 4 : 3;
+    if (!nt) return ctx->fail(HOBBIT_EINVAL, "stream_fold: kind must be 2, 3, 4 (compute{2,3,4}p_error_terms) or 13 (one batch of batch_prod)");
+    const F *t[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < nt; i++) t[i] = cF(d_tables[i]);
+    F k[4];
+    HB_TRY(launch_err_terms(ctx, kind, t, d_gate, n, k));
+    for (int q = 0; q < nc; q++) mF(h_K)[q] = fadd(cF(h_K)[q], k[q]);
+    return 0;
+}
 void hobbit_blake3_64_host(const uint8_t *in, uint8_t *out, size_t n) {
     for (size_t i = 0; i < n; i++) { uint32_t m[16], h[8]; memcpy(m, in + 64 * i, 64); blake3_compress64(m, h); memcpy(out + 32 * i, h, 32); }
 }

@@ -904,11 +904,12 @@ k_leaf_chain(const F *__restrict__ tensor, size_t chunk_stride, int K, uint32_t 
 // reference's leaf order j * cols + col.
 __global__ void __launch_bounds__(256)
 k_leaf_chain_relay(const F *__restrict__ tensor, size_t chunk_stride, int K, uint32_t cols, uint32_t half_trs, size_t g_begin, size_t g_count,
-                   const uint8_t *__restrict__ state_in, uint8_t *__restrict__ state_out, uint8_t *__restrict__ leaves, uint32_t zero_from, ZeroDig zdig) {
+                   const uint8_t *__restrict__ state_in, uint8_t *__restrict__ state_out, uint8_t *leaves, uint32_t zero_from, ZeroDig zdig, int leaves_inout) {
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < g_count; t += (size_t)gridDim.x * blockDim.x) {
         const size_t g = g_begin + t;
         uint32_t st[8];
         if (state_in) load8w(state_in + 32 * t, st);
+        else if (leaves_inout) load8w(leaves + 32 * ((size_t)(g % half_trs) * cols + (size_t)(g / half_trs)), st);    // continue from the leaves already there (leaf order)
         else {
 #pragma unroll
             for (int q = 0; q < 8; q++) st[q] = 0;
@@ -930,11 +931,11 @@ k_leaf_chain_relay(const F *__restrict__ tensor, size_t chunk_stride, int K, uin
     }
 }
 int launch_leaf_chain_relay(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, int K, uint32_t cols, uint32_t half_trs, size_t g_begin, size_t g_count,
-                            const uint8_t *state_in, uint8_t *state_out, uint8_t *leaves, uint32_t zero_rows_from) {
+                            const uint8_t *state_in, uint8_t *state_out, uint8_t *leaves, uint32_t zero_rows_from, int leaves_inout) {
     if (!g_count) return 0;
     ZeroDig zd; { uint32_t z[16] = {0}; blake3_compress64(z, zd.w); }
     HB_LAUNCH(ctx, "k_leaf_chain_relay", k_leaf_chain_relay, dim3(grid_for(g_count, 256, 1 << 20)), dim3(256), 0, tensor, chunk_stride, K, cols, half_trs, g_begin,
-              g_count, state_in, state_out, leaves, (zero_rows_from + 3) / 4, zd);
+              g_count, state_in, state_out, leaves, (zero_rows_from + 3) / 4, zd, leaves_inout);
     return 0;
 }
 // Multi-GPU commit, step 1: inner digests H(t[4j..4j+3][c]) of the chunks a rank

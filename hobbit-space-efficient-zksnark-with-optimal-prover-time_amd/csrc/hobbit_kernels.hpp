@@ -23,7 +23,7 @@ int launch_blake3_64(hobbit_ctx *ctx, const uint8_t *in, uint8_t *out, size_t n)
 int launch_hash_md(hobbit_ctx *ctx, const F *xyzw, const uint8_t *prev, uint8_t *out, size_t n);
 int launch_merkle_levels(hobbit_ctx *ctx, uint8_t *levels, size_t n, int quirk);
 int launch_leaf_chain_relay(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, int K, uint32_t cols, uint32_t half_trs, size_t g_begin, size_t g_count,
-                            const uint8_t *state_in, uint8_t *state_out, uint8_t *leaves, uint32_t zero_rows_from);
+                            const uint8_t *state_in, uint8_t *state_out, uint8_t *leaves, uint32_t zero_rows_from, int leaves_inout = 0);
 int launch_leaf_chain(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, int K, uint32_t cols, uint32_t half_trs, uint8_t *leaves, uint32_t zero_rows_from);
 int launch_inner_digests(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, int nchunks, uint32_t cols, uint32_t half_trs, uint8_t *out);
 int launch_chain_digests(hobbit_ctx *ctx, const uint8_t *digests, size_t stride_bytes, int K, size_t m, uint8_t *leaves);

@@ -218,6 +218,15 @@ int hobbit_chain_digests(hobbit_ctx *ctx, const uint8_t *d_digests, size_t strid
  * reference's leaf order j * cols + col: on the rank that holds the last chunks) receive the result. */
 int hobbit_leaf_chain_relay(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M, int nchunks, int trs, int linear_time, size_t slot_begin, size_t slot_count,
                             const uint8_t *d_state_in, uint8_t *d_state_out, uint8_t *d_leaves);
+/* SURVEY.md 8(b) names these three exports; they are thin forms of the calls above and below.
+ * hobbit_leaf_chain: the Merkle-Damgard leaf chain (src/Our_PC.cpp:162-166) over `nchunks` chunks of a tensor ([chunk][col][2 trs]) on
+ *   top of the M leaves ALREADY in d_leaves (leaf order; zero them for a fresh commitment) -- in-out, as the reference's loop.
+ * hobbit_axpy_aggregate: acc[j] += coeff * chunk[j] (_aggregate's inner loop, src/Our_PC.cpp:267-272; Elastic_PC.cpp:330-333).
+ * hobbit_stream_fold: kind 2 / 3 / 4 = compute{2,3,4}p_error_terms, 13 = one batch of batch_prod (src/sumcheck.cpp:374-432, 1093-1136);
+ *   d_tables in the order of the typed entry points (hobbit_compute2p_error_terms ... hobbit_batch_prod); h_K is accumulated into. */
+int hobbit_leaf_chain(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M, int nchunks, int trs, int linear_time, uint8_t *d_leaves);
+int hobbit_axpy_aggregate(hobbit_ctx *ctx, const hobbit_F *d_chunk, const hobbit_F *h_coeff, hobbit_F *d_acc, size_t n);
+int hobbit_stream_fold(hobbit_ctx *ctx, int kind, const hobbit_F *const *d_tables, const int32_t *d_gate, size_t n, hobbit_F *h_K);
 /* host-side blake3_hash x n (tree tops of a handful of nodes) */
 void hobbit_blake3_64_host(const uint8_t *h_in, uint8_t *h_out, size_t n);
 

@@ -978,6 +978,36 @@ def test_streamfold_vs_golden(hb):
         assert np.array_equal(got[k], g[k]), k
 
 
+def test_survey_named_exports(hb, oracle):
+    """hobbit_leaf_chain (in-out, leaf order), hobbit_axpy_aggregate, hobbit_stream_fold: SURVEY 8(b)'s names over the same kernels"""
+    import ctypes
+    N, K = 1 << 18, 32; trs = N // (K << 11); M = N // K
+    poly, _ = golden_cases.test_pc_inputs(hb, N, K)
+    c = hb.commit_standard(poly, K, trs, 1)
+    want = c.levels()[:M]
+    d = hb.to_device(poly)
+    t = hb.alloc(16 * 4 * M * K); lv = hb.alloc(32 * M)
+    hb._chk(hb.lib.hobbit_tensorcode_chunks(hb.ctx, d.ptr, M, K, trs, 1, t.ptr))
+    hb._chk(hb.lib.hobbit_memset(hb.ctx, lv.ptr, 0, 32 * M))
+    hb._chk(hb.lib.hobbit_leaf_chain(hb.ctx, t.ptr, M, K // 2, trs, 1, lv.ptr))                              # first half of the chunks,
+    hb._chk(hb.lib.hobbit_leaf_chain(hb.ctx, t.ptr + 16 * 4 * M * (K // 2), M, K // 2, trs, 1, lv.ptr))      # then the rest on top
+    got = np.zeros((M, 32), np.uint8); hb._chk(hb.lib.hobbit_memcpy_d2h(hb.ctx, got.ctypes.data, lv.ptr, 32 * M))
+    assert np.array_equal(got, want)
+    c.free()
+    n = 4096
+    tabs = [splitmix_field(n, 400 + i) for i in range(8)]
+    dt = [hb.to_device(x) for x in tabs]
+    coeff = splitmix_field(1, 9)
+    hb._chk(hb.lib.hobbit_axpy_aggregate(hb.ctx, dt[0].ptr, coeff.ctypes.data, dt[1].ptr, n))
+    acc = np.zeros((n, 2), np.uint64); hb._chk(hb.lib.hobbit_memcpy_d2h(hb.ctx, acc.ctypes.data, dt[1].ptr, 16 * n))
+    assert np.array_equal(acc, oracle.f_add(tabs[1], oracle.f_mul(np.repeat(coeff, n, 0), tabs[0])))
+    gate = (np.arange(n) * 7 % 5 < 2).astype(np.int32); dg_ = hb.to_device(gate)
+    ptrs = (ctypes.c_void_p * 8)(*[dt[i].ptr for i in (0, 2, 3, 4, 5, 6, 7, 7)])
+    K3 = np.zeros((3, 2), np.uint64)
+    hb._chk(hb.lib.hobbit_stream_fold(hb.ctx, 3, ptrs, dg_.ptr, n, K3.ctypes.data))
+    assert np.array_equal(K3, hb.err3p(tabs[0], gate, tabs[2], tabs[3], tabs[4], tabs[5]))
+
+
 def test_lkpfold_vs_golden(hb):
     """compute{3,4}p_error_terms under has_lookups (hobbit_set_lookups), every selector value of the lookup prover, against the REAL reference"""
     g = gold("lkpfold")
