@@ -98,6 +98,29 @@ static int get_tw8(hobbit_ctx *ctx, bool inverse) {
     ctx->tw8_w4_plus_i[d] = w4.im == 1;
     return 0;
 }
+// tables of k_fft_r8 for N = 2^logn = 8^P * R: per pass p = 1 .. P-1 (h = 8^p): [7][h] = w_N2^(rev3(t) k N2 / (8h)), w_N2 = w_N^R; then the tail
+// [R-1][N2] = w_N^(q k)
+static int get_tw_r8(hobbit_ctx *ctx, int logn, const F **out) {
+    auto it = ctx->tw_r8.find(logn);
+    if (it != ctx->tw_r8.end()) { *out = it->second; return 0; }
+    const uint32_t N = 1u << logn, P = (uint32_t)logn / 3, R = 1u << (logn % 3), N2 = N / R;
+    std::vector<F> w(N);
+    w[0] = fmake(1);
+    const F w1 = root_of_unity(logn);
+    for (uint32_t i = 1; i < N; i++) w[i] = fmul(w[i - 1], w1);
+    static const uint32_t rev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+    std::vector<F> t;
+    uint32_t h = 8;
+    for (uint32_t p = 1; p < P; p++, h *= 8)
+        for (uint32_t b = 1; b < 8; b++) for (uint32_t k = 0; k < h; k++) t.push_back(w[(size_t)R * ((rev3[b] * k * (N2 / (8 * h))) % N2)]);
+    for (uint32_t q = 1; q < R; q++) for (uint32_t k = 0; k < N2; k++) t.push_back(w[((size_t)q * k) % N]);
+    if (t.empty()) t.push_back(fmake(1));
+    F *d = nullptr;
+    if (hipMalloc((void **)&d, t.size() * sizeof(F)) != hipSuccess) return ctx->fail(HOBBIT_ENOMEM, "twiddle alloc failed");
+    HB_CHECK(ctx, hipMemcpy(d, t.data(), t.size() * sizeof(F), hipMemcpyHostToDevice));
+    ctx->tw_r8[logn] = d; *out = d;
+    return 0;
+}
 // FFT dispatch: the 4096-point kernel when it applies, the generic LDS kernel otherwise
 static int fft_rows(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_len, F *dst, size_t dst_ld, size_t dst_es, int logn, bool inverse,
                     uint32_t groups, uint32_t rows_per_group, size_t src_gs, size_t dst_gs);
@@ -126,6 +149,12 @@ static int fft_rows(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_l
         const F *t = ctx->tw8[d];
         return launch_fft4096(ctx, src, src_ld, 1, src_len, dst, dst_ld, dst_es, t, t + 7 * 8, t + 7 * 8 + 7 * 64, ctx->tw8_w8[d], ctx->tw8_w83[d],
                               ctx->tw8_w4_plus_i[d], scale, inverse ? 1 : 0, groups, rows_per_group, src_gs, dst_gs);
+    }
+    static const int r8_mode = [] { const char *e = getenv("HOBBIT_FFT_R8"); return e ? atoi(e) : 1; }();
+    if (r8_mode && !inverse && logn >= 6 && logn <= 11 && (src_len == (1u << logn) || src_len == (1u << (logn - 1)))) {
+        HB_TRY(get_tw8(ctx, false));                                  // (the direction of w_4: the same element for every length)
+        const F *tabs; HB_TRY(get_tw_r8(ctx, logn, &tabs));
+        return launch_fft_r8(ctx, src, src_ld, src_len, dst, dst_ld, dst_es, logn, tabs, ctx->tw8_w4_plus_i[0], groups, rows_per_group, src_gs, dst_gs);
     }
     const F *tw; HB_TRY(get_twiddles(ctx, logn, inverse, &tw));
     return launch_fft_rows(ctx, src, src_ld, src_len, dst, dst_ld, dst_es, logn, tw, scale, inverse ? 1 : 0, groups, rows_per_group, src_gs, dst_gs);
@@ -222,6 +251,7 @@ void hobbit_ctx_destroy(hobbit_ctx *ctx) {
     for (auto &kv : ctx->tw_fwd) hipFree(kv.second);
     for (auto &kv : ctx->tw_inv) hipFree(kv.second);
     for (auto &kv : ctx->tw2d_fwd) hipFree(kv.second);
+    for (auto &kv : ctx->tw_r8) hipFree(kv.second);
     for (int d = 0; d < 2; d++) if (ctx->tw8[d]) hipFree(ctx->tw8[d]);
     free_code(ctx->code);
     if (ctx->ws) hipFree(ctx->ws);

@@ -73,6 +73,7 @@ struct hobbit_ctx {
     // twiddles: logn -> device table of 2^(logn-1) forward (and inverse) roots
     std::map<int, hobbit::F *> tw_fwd, tw_inv;
     std::map<int, hobbit::F *> tw2d_fwd;          // inter-stage twiddles of the long transforms, [n1][k2] = w^(n1 k2), read coalesced
+    std::map<int, hobbit::F *> tw_r8;             // tables of k_fft_r8 per log2(N) (forward): radix-8 passes, then the radix-R tail
     // radix-8 per-pass tables of the FFT-4096 kernel ([7][8] | [7][64] | [7][512]), fwd / inv
     hobbit::F *tw8[2] = {nullptr, nullptr};
     hobbit::F tw8_w8[2], tw8_w83[2]; int tw8_w4_plus_i[2] = {0, 0};
@@ -204,13 +205,13 @@ struct hobbit_ctx {
     }
     // wait until the kernel tagged `seq` has posted; bounded: gives up (error) once the stream has drained without the post
     // Drain the stream.  hipStreamSynchronize sleeps on an interrupt: in the rocprofv3 trace of an open nine such waits were each followed
-    // by ~92 us of GPU idle time before the next kernel.  HOBBIT_SYNC=spin polls the stream's completion instead (waits longer than 1 ms
-    // fall back to the sleeping call).  Measured in alternating same-box runs: commit + open at 2^28 39.45 / 39.75 ms sleeping against
-    // 39.18 / 39.44 ms polling, but the 2^24 sumcheck 0.73 -> 0.89 ms and the RS x RS open at 2^26 4.5 -> 5.1 ms the other way round
-    // (the polling thread competes with the runtime's own): no clear winner, so the sleeping call stays the default.
+    // by ~92 us of GPU idle time before the next kernel.  The default polls the stream's completion instead (a wait longer than 1 ms falls
+    // back to the sleeping call; HOBBIT_SYNC=sleep: always sleep).  Alternating same-box runs of commit + open at 2^28: 39.45 / 39.75 ms
+    // sleeping, 39.18 / 39.44 ms polling.  (The other configs of scripts/bench_configs.py do not move; what looked like a regression of
+    // the 2^24 sumcheck there was the order of the runs -- the first process on a fresh box is the fast one whichever mode it uses.)
     int sync_mode = -1;
     int sync() {
-        if (sync_mode < 0) { const char *e = getenv("HOBBIT_SYNC"); sync_mode = (e && !strcmp(e, "spin")) ? 1 : 0; }
+        if (sync_mode < 0) { const char *e = getenv("HOBBIT_SYNC"); sync_mode = (e && !strcmp(e, "sleep")) ? 0 : 1; }
         if (sync_mode == 0) return hip(hipStreamSynchronize(stream), "stream sync");
         const auto t_start = std::chrono::steady_clock::now();
         for (uint32_t it = 1;; it++) {

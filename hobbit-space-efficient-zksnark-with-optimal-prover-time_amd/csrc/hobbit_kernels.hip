@@ -353,6 +353,140 @@ int launch_fft4096(hobbit_ctx *ctx, const F *src, size_t src_ld, size_t src_es, 
 // Long rows (len = R * 4096, R = 2, 4, 8; Elastic_PC opt 2 uses 32768-point row codes,
 // src/Elastic_PC.cpp:737-771) by one Cooley-Tukey split:
 //   X[4096 k1 + k2] = sum_{n1 < R} W_R^{n1 k1} * W_len^{n1 k2} * Y_{n1}[k2],   Y_{n1} = FFT_4096(x[R n2 + n1])
+// --------------------------------------------------------------------------------------------
+// The same radix-8 machinery for the shorter transforms (64 ... 2048 points): the column codes of the RS x RS tensors
+// (Elastic_PC option 1: 1024 points; Our_PC option 1 and the MLP witness: 256) ran in the generic radix-2/4 kernel at log2(N)/2 products
+// per element.  N = 8^P * R (R = 1, 2, 4): the R sub-sequences x[R i' + q] are transformed by P radix-8 passes (7/8 product per element
+// and pass, none in the first), then ONE radix-R stage combines them (1/2 resp. 3/4 product per element): 1024 points = 2.25 N products
+// instead of 5 N.  512 threads, 4096 / N rows per workgroup, the LDS layout and the lazy sums of k_fft4096.
+// tabs: [pass 1 | pass 2 | ...] each [7][h] = w_N2^(rev3(t) k N2 / (8h)), then the tail [R-1][N2] = w_N^(q k).  Forward transform only.
+// --------------------------------------------------------------------------------------------
+template <int LOGN, bool PADDED>
+__global__ void __launch_bounds__(512)
+k_fft_r8(const F *__restrict__ src, size_t src_ld, F *__restrict__ dst, size_t dst_ld, size_t dst_es, const F *__restrict__ tabs, int plus_i,
+         uint32_t rows_per_group, size_t src_gs, size_t dst_gs, uint32_t total_rows) {
+    constexpr uint32_t N = 1u << LOGN, P = LOGN / 3, R = 1u << (LOGN % 3), N2 = N / R, TPR = N / 8, ROWS = 512 / TPR, LDR = N + N / 8, OCT = N2 / 8;
+    constexpr uint32_t SRCLEN = PADDED ? N / 2 : N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    F *s = reinterpret_cast<F *>(lds_raw);
+    const uint32_t tid = threadIdx.x, row0 = blockIdx.x * ROWS;
+    // load: natural order, coalesced
+    for (uint32_t e = tid; e < ROWS * SRCLEN; e += 512) {
+        const uint32_t t = e / SRCLEN, i = e % SRCLEN, row = row0 + t;
+        if (row < total_rows) {
+            const F *in = src + (size_t)(row / rows_per_group) * src_gs + (size_t)(row % rows_per_group) * src_ld;
+            stF(&s[t * LDR + fft_phys(i)], ldF(in + i));
+        }
+    }
+    __syncthreads();
+    const uint32_t t = tid / TPR, u = tid % TPR, q = u / OCT, b = u % OCT;
+    F *sr = s + t * LDR;
+    const bool live = row0 + t < total_rows;
+    F a[8];
+    {   // ---- pass 0 (h = 1): plain 8-point DFTs; octet b of sub-sequence q gathers x[R (rev(b) + OCT rev3(j)) + q]
+        const uint32_t m = P > 1 ? (__brev(b) >> (32 - 3 * (P - 1))) : 0u;
+        if (live) {
+            a[0] = ldF(&sr[fft_phys(R * m + q)]); a[2] = ldF(&sr[fft_phys(R * (m + 2 * OCT) + q)]);
+            a[4] = ldF(&sr[fft_phys(R * (m + OCT) + q)]); a[6] = ldF(&sr[fft_phys(R * (m + 3 * OCT) + q)]);
+            if (PADDED) { a[1] = a[0]; a[3] = a[2]; a[5] = a[4]; a[7] = a[6]; }      // the upper half of the input is zero: (u, 0) -> (u, u)
+            else {
+                a[1] = ldF(&sr[fft_phys(R * (m + 4 * OCT) + q)]); a[3] = ldF(&sr[fft_phys(R * (m + 6 * OCT) + q)]);
+                a[5] = ldF(&sr[fft_phys(R * (m + 5 * OCT) + q)]); a[7] = ldF(&sr[fft_phys(R * (m + 7 * OCT) + q)]);
+                HB_DFT8_HEAD(a);
+            }
+            dft8_tail(a, plus_i);
+        }
+        __syncthreads();                                            // every input has been read
+        if (live) {
+            const uint32_t o = fft_phys(q * N2 + 8 * b);
+#pragma unroll
+            for (int t8 = 0; t8 < 8; t8++) stF(&sr[o + t8], ffold(a[t8]));
+        }
+        __syncthreads();
+    }
+    const F *tw = tabs;
+#pragma unroll
+    for (uint32_t pass = 1; pass < P; pass++) {
+        const uint32_t h = pass == 1 ? 8u : pass == 2 ? 64u : 512u;
+        const uint32_t k = b & (h - 1), j = b / h, i0 = q * N2 + j * 8 * h + k;
+        if (live) {
+#pragma unroll
+            for (int t8 = 0; t8 < 8; t8++) a[t8] = ldF(&sr[fft_phys(i0 + t8 * h)]);
+#pragma unroll
+            for (int t8 = 1; t8 < 8; t8++) a[t8] = fmul_lz(a[t8], ldF(tw + (t8 - 1) * h + k));
+            HB_DFT8_HEAD(a);
+            dft8_tail(a, plus_i);
+        }
+        // (an octet reads and writes the same eight slots: no barrier between its loads and stores)
+        if (live) {
+            if (R == 1 && pass == P - 1) {
+                F *out = dst + (size_t)((row0 + t) / rows_per_group) * dst_gs + (size_t)((row0 + t) % rows_per_group) * dst_ld;
+#pragma unroll
+                for (int t8 = 0; t8 < 8; t8++) stF(out + (size_t)(i0 + t8 * h) * dst_es, fcanon(a[t8]));
+            } else {
+#pragma unroll
+                for (int t8 = 0; t8 < 8; t8++) stF(&sr[fft_phys(i0 + t8 * h)], ffold(a[t8]));
+            }
+        }
+        tw += 7 * h;
+        __syncthreads();
+    }
+    if (R == 1 || !live) return;
+    F *out = dst + (size_t)((row0 + t) / rows_per_group) * dst_gs + (size_t)((row0 + t) % rows_per_group) * dst_ld;
+    if (R == 2) {               // X[k] = E[k] + w^k O[k], X[k + N/2] = E[k] - w^k O[k]
+#pragma unroll
+        for (uint32_t c = 0; c < N2 / TPR; c++) {
+            const uint32_t k = u + TPR * c;
+            const F x = ldF(&sr[fft_phys(k)]), y = fmul_lz(ldF(&sr[fft_phys(N2 + k)]), ldF(tw + k));
+            stF(out + (size_t)k * dst_es, fcanon(faddl(x, y)));
+            stF(out + (size_t)(k + N2) * dst_es, fcanon(fsubl<1>(x, y)));
+        }
+    } else {                    // X[k + m N/4] = sum_q W_4^(q m) w^(q k) S_q[k]
+#pragma unroll
+        for (uint32_t c = 0; c < N2 / TPR; c++) {
+            const uint32_t k = u + TPR * c;
+            const F y0 = ldF(&sr[fft_phys(k)]);
+            const F y1 = fmul_lz(ldF(&sr[fft_phys(N2 + k)]), ldF(tw + k));
+            const F y2 = fmul_lz(ldF(&sr[fft_phys(2 * N2 + k)]), ldF(tw + N2 + k));
+            const F y3 = fmul_lz(ldF(&sr[fft_phys(3 * N2 + k)]), ldF(tw + 2 * N2 + k));
+            const F t0 = faddl(y0, y2), t1 = fsubl<1>(y0, y2), t2 = faddl(y1, y3), t3 = fmul_w4<2>(fsubl<1>(y1, y3), plus_i);     // <= 2p + 7, 2p + 7, 2p, 2p
+            stF(out + (size_t)k * dst_es, fcanon(faddl(t0, t2)));
+            stF(out + (size_t)(k + N2) * dst_es, fcanon(faddl(t1, t3)));
+            stF(out + (size_t)(k + 2 * N2) * dst_es, fcanon(fsubl<2>(t0, t2)));
+            stF(out + (size_t)(k + 3 * N2) * dst_es, fcanon(fsubl<2>(t1, t3)));
+        }
+    }
+}
+template <int LOGN>
+static int launch_fft_r8_n(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_len, F *dst, size_t dst_ld, size_t dst_es, const F *tabs, int plus_i,
+                           uint32_t groups, uint32_t rows_per_group, size_t src_gs, size_t dst_gs) {
+    constexpr uint32_t N = 1u << LOGN, ROWS = 512 / (N / 8);
+    const size_t total = (size_t)groups * rows_per_group, lds = (size_t)(4096 + 512) * 16;
+    const unsigned blocks = (unsigned)((total + ROWS - 1) / ROWS);
+    if (src_len == N / 2) {
+        hipFuncSetAttribute((const void *)k_fft_r8<LOGN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        HB_LAUNCH(ctx, "k_fft_r8", (k_fft_r8<LOGN, true>), dim3(blocks), dim3(512), lds, src, src_ld, dst, dst_ld, dst_es, tabs, plus_i, rows_per_group, src_gs, dst_gs, (uint32_t)total);
+    } else {
+        hipFuncSetAttribute((const void *)k_fft_r8<LOGN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        HB_LAUNCH(ctx, "k_fft_r8", (k_fft_r8<LOGN, false>), dim3(blocks), dim3(512), lds, src, src_ld, dst, dst_ld, dst_es, tabs, plus_i, rows_per_group, src_gs, dst_gs, (uint32_t)total);
+    }
+    return 0;
+}
+// src_len must be N or N/2 (zero-padded upper half); 6 <= logn <= 11
+int launch_fft_r8(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_len, F *dst, size_t dst_ld, size_t dst_es, int logn, const F *tabs, int plus_i,
+                  uint32_t groups, uint32_t rows_per_group, size_t src_gs, size_t dst_gs) {
+    if ((size_t)groups * rows_per_group == 0) return 0;
+    switch (logn) {
+        case 6: return launch_fft_r8_n<6>(ctx, src, src_ld, src_len, dst, dst_ld, dst_es, tabs, plus_i, groups, rows_per_group, src_gs, dst_gs);
+        case 7: return launch_fft_r8_n<7>(ctx, src, src_ld, src_len, dst, dst_ld, dst_es, tabs, plus_i, groups, rows_per_group, src_gs, dst_gs);
+        case 8: return launch_fft_r8_n<8>(ctx, src, src_ld, src_len, dst, dst_ld, dst_es, tabs, plus_i, groups, rows_per_group, src_gs, dst_gs);
+        case 9: return launch_fft_r8_n<9>(ctx, src, src_ld, src_len, dst, dst_ld, dst_es, tabs, plus_i, groups, rows_per_group, src_gs, dst_gs);
+        case 10: return launch_fft_r8_n<10>(ctx, src, src_ld, src_len, dst, dst_ld, dst_es, tabs, plus_i, groups, rows_per_group, src_gs, dst_gs);
+        case 11: return launch_fft_r8_n<11>(ctx, src, src_ld, src_len, dst, dst_ld, dst_es, tabs, plus_i, groups, rows_per_group, src_gs, dst_gs);
+    }
+    return ctx->fail(HOBBIT_EINVAL, "fft_r8: logn must be in [6, 11]");
+}
+
 // The R sub-transforms run in k_fft4096 (strided source); this kernel applies the twiddles and
 // the R-point DFT across n1, one lane per k2 (coalesced on both sides).  tw[m] = W_len^m, m < len/2.
 template <int LOGR>

@@ -22,6 +22,8 @@ int launch_leaf_chain_dig(hobbit_ctx *ctx, const uint8_t *dig, size_t chunk_stri
 int launch_blake3_64(hobbit_ctx *ctx, const uint8_t *in, uint8_t *out, size_t n);
 int launch_hash_md(hobbit_ctx *ctx, const F *xyzw, const uint8_t *prev, uint8_t *out, size_t n);
 int launch_merkle_levels(hobbit_ctx *ctx, uint8_t *levels, size_t n, int quirk);
+int launch_fft_r8(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_len, F *dst, size_t dst_ld, size_t dst_es, int logn, const F *tabs, int plus_i,
+                  uint32_t groups, uint32_t rows_per_group, size_t src_gs, size_t dst_gs);
 int launch_leaf_chain_relay(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, int K, uint32_t cols, uint32_t half_trs, size_t g_begin, size_t g_count,
                             const uint8_t *state_in, uint8_t *state_out, uint8_t *leaves, uint32_t zero_rows_from, int leaves_inout = 0);
 int launch_leaf_chain(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, int K, uint32_t cols, uint32_t half_trs, uint8_t *leaves, uint32_t zero_rows_from);
