@@ -944,9 +944,11 @@ class Hobbit:
                 self.set_lookups(None)
         return out
 
-    def elastic_commit(self, N, B, opt, gcc_arg_order=1, chunk=None, keep_levels=False):
+    def elastic_commit(self, N, B, opt, gcc_arg_order=1, chunk=None, keep_levels=False, levels="host"):
         """test_Elastic_PC's commit (src/Elastic_PC.cpp:736-771): opt 1 RSxRS trs=B/2^11, opt 2 RSxexpander trs=B/2^14.
-        chunk: a DeviceBuffer holding the stream's (repeating) chunk, generated here on the host if None."""
+        chunk: a DeviceBuffer holding the stream's (repeating) chunk, generated here on the host if None.
+        levels="host": the whole tree comes back as a numpy array (what the reference's MT_hashes is; 64 B per leaf over PCIe);
+        levels="device": returns (root, DeviceBuffer with the flat tree) -- the tree stays in HBM, as Our_PC's Commitment handle keeps it."""
         if opt == 1:
             lin, trs = 0, B >> 11
         else:
@@ -960,6 +962,11 @@ class Hobbit:
             self._chk(self.lib.hobbit_elastic_push(self.ctx, e, chunk.ptr))
         lv = self.alloc(32 * 8 * B)
         self._chk(self.lib.hobbit_elastic_finish(self.ctx, e, lv.ptr))
+        if levels == "device":
+            root = np.zeros(32, np.uint8)
+            self._chk(self.lib.hobbit_memcpy_d2h(self.ctx, root.ctypes.data, lv.ptr + 32 * (8 * B - 2), 32))
+            self.lib.hobbit_elastic_free(e)
+            return root, lv
         out = self.to_host(lv, (8 * B - 1, 32), np.uint8)
         self.lib.hobbit_elastic_free(e)
         return (out, lv) if keep_levels else out

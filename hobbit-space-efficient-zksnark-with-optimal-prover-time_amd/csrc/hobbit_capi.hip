@@ -252,6 +252,7 @@ void hobbit_ctx_destroy(hobbit_ctx *ctx) {
     for (auto &kv : ctx->tw_inv) hipFree(kv.second);
     for (auto &kv : ctx->tw2d_fwd) hipFree(kv.second);
     for (auto &kv : ctx->tw_r8) hipFree(kv.second);
+    ctx->pool_drain();
     for (int d = 0; d < 2; d++) if (ctx->tw8[d]) hipFree(ctx->tw8[d]);
     free_code(ctx->code);
     if (ctx->ws) hipFree(ctx->ws);
@@ -272,12 +273,29 @@ void hobbit_ctx_destroy(hobbit_ctx *ctx) {
 }
 const char *hobbit_last_error(const hobbit_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 int hobbit_sync(hobbit_ctx *ctx) { HB_TRY(ctx->sync()); return 0; }
+// Temporaries of up to 256 MiB come from / go back to the context's size-keyed pool (the host mirror and the Python harness allocate
+// and free a buffer per call); larger buffers go to the runtime directly and are released for real.
+static const size_t HB_POOLED_MAX = (size_t)256 << 20;
 int hobbit_malloc(hobbit_ctx *ctx, size_t bytes, void **d_ptr) {
     hipSetDevice(ctx->device);
-    if (hipMalloc(d_ptr, bytes ? bytes : 16) != hipSuccess) return ctx->fail(HOBBIT_ENOMEM, "hipMalloc failed");
+    if (!bytes) bytes = 16;
+    if (bytes <= HB_POOLED_MAX) {
+        if (ctx->pool_get(bytes, d_ptr)) return ctx->fail(HOBBIT_ENOMEM, "hipMalloc failed");
+        ctx->pooled[*d_ptr] = bytes;
+        return 0;
+    }
+    if (hipMalloc(d_ptr, bytes) != hipSuccess) {
+        ctx->pool_drain();
+        if (hipMalloc(d_ptr, bytes) != hipSuccess) return ctx->fail(HOBBIT_ENOMEM, "hipMalloc failed");
+    }
     return 0;
 }
-int hobbit_free(hobbit_ctx *ctx, void *d_ptr) { HB_TRY(ctx->sync()); HB_CHECK(ctx, hipFree(d_ptr)); return 0; }
+int hobbit_free(hobbit_ctx *ctx, void *d_ptr) {
+    if (!d_ptr) return 0;
+    auto it = ctx->pooled.find(d_ptr);
+    if (it != ctx->pooled.end()) { const size_t bytes = it->second; ctx->pooled.erase(it); ctx->pool_put(bytes, d_ptr); return 0; }
+    HB_TRY(ctx->sync()); HB_CHECK(ctx, hipFree(d_ptr)); return 0;
+}
 int hobbit_memcpy_h2d(hobbit_ctx *ctx, void *d, const void *h, size_t bytes) {
     HB_CHECK(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream)); HB_TRY(ctx->sync()); return 0;
 }
@@ -567,7 +585,11 @@ int hobbit_commit_standard(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, in
             ctx->spare_tensor = nullptr; ctx->spare_levels = nullptr; ctx->spare_tensor_bytes = ctx->spare_levels_bytes = 0;
         }
         if (hipMalloc((void **)&c->d_tensor, tbytes) != hipSuccess || hipMalloc((void **)&c->d_levels, 64 * M) != hipSuccess) {
-            hobbit_commitment_free(c); return ctx->fail(HOBBIT_ENOMEM, "commit_standard: tensor allocation failed");
+            ctx->pool_drain();                                    // give back what the pool parks, then once more
+            if (c->d_tensor) { hipFree(c->d_tensor); c->d_tensor = nullptr; }
+            if (hipMalloc((void **)&c->d_tensor, tbytes) != hipSuccess || hipMalloc((void **)&c->d_levels, 64 * M) != hipSuccess) {
+                hobbit_commitment_free(c); return ctx->fail(HOBBIT_ENOMEM, "commit_standard: tensor allocation failed");
+            }
         }
     }
     uint8_t *dig = nullptr;
@@ -659,8 +681,8 @@ int hobbit_elastic_begin(hobbit_ctx *ctx, size_t B, int trs, int linear_time, in
     for (int i = 0; i < 4; i++) e->t[i] = nullptr;
     e->state = nullptr;
     bool ok = true;
-    for (int i = 0; i < 4 && ok; i++) ok = hipMalloc((void **)&e->t[i], 4 * B * sizeof(F)) == hipSuccess;
-    ok = ok && hipMalloc((void **)&e->state, 4 * B * 32) == hipSuccess;
+    for (int i = 0; i < 4 && ok; i++) ok = ctx->pool_get(4 * B * sizeof(F), (void **)&e->t[i]) == 0;
+    ok = ok && ctx->pool_get(4 * B * 32, (void **)&e->state) == 0;
     if (!ok) { hobbit_elastic_free(e); return ctx->fail(HOBBIT_ENOMEM, "elastic_begin: allocation failed"); }
     HB_TRY(launch_zero(ctx, e->state, 4 * B * 32));       // buff_hash starts at zero (:186-193)
     *out = e;
@@ -691,9 +713,8 @@ int hobbit_elastic_finish(hobbit_ctx *ctx, hobbit_elastic *e, uint8_t *d_levels)
 }
 void hobbit_elastic_free(hobbit_elastic *e) {
     if (!e) return;
-    hipStreamSynchronize(e->ctx->stream);
-    for (int i = 0; i < 4; i++) if (e->t[i]) hipFree(e->t[i]);
-    if (e->state) hipFree(e->state);
+    for (int i = 0; i < 4; i++) e->ctx->pool_put(4 * e->B * sizeof(F), e->t[i]);
+    e->ctx->pool_put(4 * e->B * 32, e->state);
     delete e;
 }
 
@@ -1302,6 +1323,7 @@ struct hobbit_elastic_open {
     std::vector<F> beta; std::vector<uint32_t> qc, qr, ucols, qci; F rv0;
     size_t n_aggr, n_reply; bool committed;
     F *d_aggr, *d_T, *d_G, *d_reply, *d_encf; uint8_t *d_lvf; uint32_t *d_ucols; uint64_t *d_pick; int *d_nz;
+    size_t bytes[9];              // sizes of the nine buffers above (for the context's buffer pool); capacities, not the distinct-column count
 };
 // precompute_beta (src/utils.cpp:251-296) on the host for a handful of variables
 static void host_eq_table(const HF *r, int k, std::vector<F> &out) {
@@ -1376,9 +1398,8 @@ static int rs_prover_dev(hobbit_ctx *ctx, const F *d_aggr, size_t B, size_t trs,
 }
 void hobbit_elastic_open_free(hobbit_elastic_open *e) {
     if (!e) return;
-    hipStreamSynchronize(e->ctx->stream);
-    for (void *p : {(void *)e->d_aggr, (void *)e->d_T, (void *)e->d_G, (void *)e->d_reply, (void *)e->d_encf, (void *)e->d_lvf, (void *)e->d_ucols, (void *)e->d_pick, (void *)e->d_nz})
-        if (p) hipFree(p);
+    void *ptrs[9] = {e->d_aggr, e->d_T, e->d_G, e->d_reply, e->d_encf, e->d_lvf, e->d_ucols, e->d_pick, e->d_nz};
+    for (int i = 0; i < 9; i++) e->ctx->pool_put(e->bytes[i], ptrs[i]);
     delete e;
 }
 int hobbit_elastic_open_begin(hobbit_ctx *ctx, size_t N, size_t B, int trs, const hobbit_F *h_x, int queries, hobbit_elastic_open **out) {
@@ -1402,11 +1423,12 @@ int hobbit_elastic_open_begin(hobbit_ctx *ctx, size_t N, size_t B, int trs, cons
         e->qci[q] = (uint32_t)(std::lower_bound(e->ucols.begin(), e->ucols.end(), e->qc[q]) - e->ucols.begin());
         pick[q] = (uint64_t)e->qci[q] * e->rows2 + e->qr[q];
     }
-    bool ok = hipMalloc((void **)&e->d_aggr, B * sizeof(F)) == hipSuccess && hipMalloc((void **)&e->d_T, (size_t)trs * 4096 * sizeof(F)) == hipSuccess &&
-              hipMalloc((void **)&e->d_G, nc * e->rows2 * sizeof(F)) == hipSuccess && hipMalloc((void **)&e->d_reply, e->K * (size_t)queries * sizeof(F)) == hipSuccess &&
-              hipMalloc((void **)&e->d_encf, 2 * B * sizeof(F)) == hipSuccess && hipMalloc((void **)&e->d_lvf, 64 * (2 * B / 32)) == hipSuccess &&
-              hipMalloc((void **)&e->d_ucols, nc * 4) == hipSuccess && hipMalloc((void **)&e->d_pick, (size_t)queries * 8) == hipSuccess &&
-              hipMalloc((void **)&e->d_nz, e->K * sizeof(int)) == hipSuccess;
+    const size_t sizes[9] = {B * sizeof(F), (size_t)trs * 4096 * sizeof(F), (size_t)queries * e->rows2 * sizeof(F), e->K * (size_t)queries * sizeof(F), 2 * B * sizeof(F),
+                             64 * (2 * B / 32), (size_t)queries * 4, (size_t)queries * 8, e->K * sizeof(int)};
+    void **slots[9] = {(void **)&e->d_aggr, (void **)&e->d_T, (void **)&e->d_G, (void **)&e->d_reply, (void **)&e->d_encf, (void **)&e->d_lvf, (void **)&e->d_ucols,
+                       (void **)&e->d_pick, (void **)&e->d_nz};
+    bool ok = true;
+    for (int i = 0; i < 9; i++) { e->bytes[i] = sizes[i]; if (ok) ok = ctx->pool_get(sizes[i], slots[i]) == 0; }
     if (!ok) { hobbit_elastic_open_free(e); return ctx->fail(HOBBIT_ENOMEM, "elastic_open_begin: allocation failed"); }
     HB_TRY(launch_zero(ctx, e->d_aggr, B * sizeof(F)));
     HB_TRY(launch_zero(ctx, e->d_nz, e->K * sizeof(int)));
@@ -1478,9 +1500,9 @@ int hobbit_open_standard_rs(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, c
     std::vector<F> beta; host_eq_table(cF(h_x), logK, beta);                                                // precompute_beta(x1, beta) (:619-621)
     const F rv0 = fadd(fmake((uint64_t)random()), fmake((uint64_t)rand()));                                 // r_v[0] = generate_randomness(1)[0] (:623)
     F *d_aggr = nullptr, *d_encf = nullptr; uint8_t *d_lvf = nullptr; uint32_t *d_ucols = nullptr;
-    auto release = [&]() { hipStreamSynchronize(ctx->stream); for (void *p : {(void *)d_aggr, (void *)d_encf, (void *)d_lvf, (void *)d_ucols}) if (p) hipFree(p); };
-    if (hipMalloc((void **)&d_aggr, B * sizeof(F)) != hipSuccess || hipMalloc((void **)&d_encf, 2 * B * sizeof(F)) != hipSuccess ||
-        hipMalloc((void **)&d_lvf, 64 * (2 * B / 32)) != hipSuccess || hipMalloc((void **)&d_ucols, nq * 4) != hipSuccess) { release(); return ctx->fail(HOBBIT_ENOMEM, "open_standard_rs: allocation failed"); }
+    auto release = [&]() { ctx->pool_put(B * sizeof(F), d_aggr); ctx->pool_put(2 * B * sizeof(F), d_encf); ctx->pool_put(64 * (2 * B / 32), d_lvf); ctx->pool_put(nq * 4, d_ucols); };
+    if (ctx->pool_get(B * sizeof(F), (void **)&d_aggr) || ctx->pool_get(2 * B * sizeof(F), (void **)&d_encf) || ctx->pool_get(64 * (2 * B / 32), (void **)&d_lvf) ||
+        ctx->pool_get(nq * 4, (void **)&d_ucols)) { release(); return ctx->fail(HOBBIT_ENOMEM, "open_standard_rs: allocation failed"); }
     int rc = [&]() -> int {
         HB_TRY(launch_aggregate(ctx, cF(d_poly), B, K, beta.data(), d_aggr));                               // _aggregate (:267-272)
         HB_TRY(hobbit_shockwave_commit(ctx, reinterpret_cast<hobbit_F *>(d_aggr), B, 32, reinterpret_cast<hobbit_F *>(d_encf), d_lvf));   // C_f (:274-275)

@@ -94,6 +94,31 @@ struct hobbit_ctx {
         }
         *p = ws2; return 0;
     }
+    // Size-keyed free list for the device buffers of short-lived objects (a streaming commit or opening allocates five to nine buffers and
+    // releases them at its end: at the MLP config's shape the hipFree calls cost as much as the whole commit, 0.9 ms).  One stream per
+    // context, so a buffer handed back while kernels still read it is safe to hand out again: the next user is ordered behind them.
+    std::multimap<size_t, void *> pool; size_t pool_bytes = 0;
+    std::map<void *, size_t> pooled;             // live hobbit_malloc allocations that came from the pool (pointer -> size)
+    int pool_get(size_t bytes, void **p) {
+        auto it = pool.find(bytes);
+        if (it != pool.end()) { *p = it->second; pool_bytes -= bytes; pool.erase(it); return 0; }
+        if (hipMalloc(p, bytes) != hipSuccess) {             // make room: drop everything parked, try once more
+            pool_drain();
+            if (hipMalloc(p, bytes) != hipSuccess) { *p = nullptr; err = "device allocation failed"; return HOBBIT_ENOMEM; }
+        }
+        return 0;
+    }
+    void pool_put(size_t bytes, void *p) {
+        if (!p) return;
+        if (pool.size() >= 48 || pool_bytes + bytes > ((size_t)8 << 30)) { hipStreamSynchronize(stream); hipFree(p); return; }
+        pool.emplace(bytes, p); pool_bytes += bytes;
+    }
+    void pool_drain() {
+        if (pool.empty()) return;
+        hipStreamSynchronize(stream);
+        for (auto &kv : pool) hipFree(kv.second);
+        pool.clear(); pool_bytes = 0;
+    }
     // small pinned host buffer for the per-round coefficient read-back of the sumchecks
     void *pin = nullptr; size_t pin_bytes = 0;
     int pinned(size_t bytes, void **p) {
