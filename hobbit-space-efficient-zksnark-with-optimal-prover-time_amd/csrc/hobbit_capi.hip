@@ -997,6 +997,24 @@ int hobbit_leaf_chain_relay(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M,
     return launch_leaf_chain_relay(ctx, cF(d_tensor), cols * rows2, nchunks, (uint32_t)cols, (uint32_t)(trs / 2), slot_begin, slot_count, d_state_in, d_state_out, d_leaves,
                                    linear_time ? (uint32_t)ctx->code.len : (uint32_t)rows2);
 }
+// A real check of an open_tree_blake path (the reference's verify_claim_opt_blake only does proof-size bookkeeping, in SHA3): walk the
+// `depth` siblings from the leaf at `pos` to the root with create_tree_blake's parent rule (src/merkle_tree.cpp:275-280).  With the
+// reference's left|left quirk a parent is H(L | L), L the even node of the pair: the running node at an even position, the sibling the
+// path carries at an odd one -- so in the reference's tree only the path's even-side nodes are bound to the root; quirk == 0 checks an
+// ordinary H(L | R) tree.  Returns 1 if the walk ends in `root`, 0 if not.  Host only.
+int hobbit_verify_path_host(const uint8_t *leaf, uint64_t pos, const uint8_t *path, int depth, const uint8_t *root, int quirk_left_left) {
+    if (!leaf || !root || depth < 0 || (depth && !path)) return 0;
+    uint8_t node[32]; memcpy(node, leaf, 32);
+    for (int l = 0; l < depth; l++, pos >>= 1) {
+        const uint8_t *sib = path + 32 * (size_t)l;
+        uint32_t m[16], h[8];
+        const uint8_t *Lh = (pos & 1) ? sib : node, *Rh = quirk_left_left ? Lh : ((pos & 1) ? node : sib);
+        memcpy(m, Lh, 32); memcpy(m + 8, Rh, 32);
+        blake3_compress64(m, h);
+        memcpy(node, h, 32);
+    }
+    return memcmp(node, root, 32) == 0;
+}
 // SURVEY.md 8(b)'s export list by its own names: thin forms of what the library already has
 int hobbit_leaf_chain(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M, int nchunks, int trs, int linear_time, uint8_t *d_leaves) {
     if (trs < 4 || trs % 4 || M % (size_t)trs || nchunks <= 0 || !d_leaves) return ctx->fail(HOBBIT_EINVAL, "leaf_chain: trs must be a multiple of 4 dividing M, nchunks positive");

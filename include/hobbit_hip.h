@@ -218,6 +218,10 @@ int hobbit_chain_digests(hobbit_ctx *ctx, const uint8_t *d_digests, size_t strid
  * reference's leaf order j * cols + col: on the rank that holds the last chunks) receive the result. */
 int hobbit_leaf_chain_relay(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M, int nchunks, int trs, int linear_time, size_t slot_begin, size_t slot_count,
                             const uint8_t *d_state_in, uint8_t *d_state_out, uint8_t *d_leaves);
+/* Verifier side of open_tree_blake (the reference's verify_claim_opt_blake, src/merkle_tree.cpp:326-362, never compares
+ * anything): recompute the root from a leaf hash, its position and its `depth` siblings.  quirk_left_left = 1: the reference's tree
+ * (parent = H(L | L), src/merkle_tree.cpp:275-280); 0: an ordinary H(L | R) tree.  Returns 1 / 0.  Host only, no context. */
+int hobbit_verify_path_host(const uint8_t *leaf, uint64_t pos, const uint8_t *path, int depth, const uint8_t *root, int quirk_left_left);
 /* SURVEY.md 8(b) names these three exports; they are thin forms of the calls above and below.
  * hobbit_leaf_chain: the Merkle-Damgard leaf chain (src/Our_PC.cpp:162-166) over `nchunks` chunks of a tensor ([chunk][col][2 trs]) on
  *   top of the M leaves ALREADY in d_leaves (leaf order; zero them for a fresh commitment) -- in-out, as the reference's loop.

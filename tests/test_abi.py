@@ -74,3 +74,38 @@ def test_host_mimc_lazy_reduction_matches_oracle(mod, oracle):
     for i in range(X.shape[0]):
         lib.hobbit_mimc(X[i].ctypes.data_as(ctypes.c_void_p), K[i].ctypes.data_as(ctypes.c_void_p), got[i].ctypes.data_as(ctypes.c_void_p))
     assert np.array_equal(got, want)
+
+
+def test_verify_path_host_against_the_oracle_tree():
+    """hobbit_verify_path_host (host only: runs without a GPU): the oracle's create_tree_blake / open_tree_blake on 2^10 leaves, genuine
+    paths walk to the root under the reference's left|left rule and a forged leaf 0 does not; an ordinary
+    H(L | R) tree verifies with quirk = 0 for every leaf."""
+    import ctypes
+    import numpy as np
+    from __graft_entry__ import load_package
+    from oracle import pyoracle
+    lib = load_package().load_library()
+    orc = pyoracle.Oracle()
+    rng = np.random.default_rng(5)
+    leaves = rng.integers(0, 256, (1024, 32)).astype(np.uint8)
+    lv = orc.create_tree_blake(leaves)
+    root = lv[-1]
+    V = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.hobbit_verify_path_host.restype = ctypes.c_int
+    lib.hobbit_verify_path_host.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    for pos in (0, 2, 5, 510, 1023):
+        path = np.ascontiguousarray(orc.open_tree_blake(lv, 1024, pos, 0, 0))
+        assert lib.hobbit_verify_path_host(V(leaves[pos]), pos, V(path), 10, V(root), 1) == 1          # a genuine path always walks to the root
+    # under the quirk a node is bound to the root only while its position stays even: leaf 0 is, a forged leaf 0 fails
+    path = np.ascontiguousarray(orc.open_tree_blake(lv, 1024, 0, 0, 0))
+    bad = leaves[0].copy(); bad[0] ^= 1
+    assert lib.hobbit_verify_path_host(V(bad), 0, V(path), 10, V(root), 1) == 0
+    # an ordinary tree built here: parent = H(L | R)
+    lvl = [leaves]
+    while lvl[-1].shape[0] > 1:
+        lvl.append(orc.blake3_64(lvl[-1].reshape(-1, 64)))
+    for pos in (0, 1, 333, 1023):
+        path = np.stack([lvl[l][(pos >> l) ^ 1] for l in range(10)])
+        assert lib.hobbit_verify_path_host(V(leaves[pos]), pos, V(path), 10, V(lvl[-1][0]), 0) == 1
+        path[3, 0] ^= 1
+        assert lib.hobbit_verify_path_host(V(leaves[pos]), pos, V(path), 10, V(lvl[-1][0]), 0) == 0
