@@ -1228,6 +1228,37 @@ def test_open_standard_rs_vs_oracle(hb, oracle, logN, K):
         assert np.array_equal(got["sp_f"][k], want["sp_f"][k]), k
 
 
+def test_open_standard_rs_2e28_selfchecks(hb):
+    """test_PC option 1 at the north-star size (131072-point row codes through the chunk-at-a-time long transform; no CPU oracle at this
+    size): both exit(-1) checks and the WHIR checks hold, two runs with the same libc seed give the same transcript, replies are the
+    committed tensor's entries, and queried leaves -- recomputed on the host from the four tensor rows of all K chunks -- walk up their
+    Merkle paths to the root (hobbit_verify_path_host, the reference's left|left parents)."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    N, K, trs = 1 << 28, 32, 128
+    cols = 2 * (N // K) // trs
+    d = hb.fill_splitmix(N, 777)
+    c = hb.commit_standard((d, N), K, trs, 0)
+    x = splitmix_field(28, 78)
+    libc.srandom(6); a = hb.open_standard_rs((d, N), c, x, 790)
+    libc.srandom(6); b = hb.open_standard_rs((d, N), c, x, 790)
+    assert a["checks"].tolist() == [1, 1] and a["sp_f"]["wchecks"].tolist() == [1, 1]
+    for k in ("I", "reply", "paths", "poly", "r", "vr", "fin", "rx", "cf_root"):
+        assert np.array_equal(a[k], b[k]), k
+    root = c.root()
+    V = lambda v: v.ctypes.data_as(ctypes.c_void_p)
+    hb.lib.hobbit_verify_path_host.restype = ctypes.c_int
+    for q in (0, 100, 789):
+        col, row = int(a["I"][q, 0]), int(a["I"][q, 1])
+        for i in (0, K - 1):
+            assert np.array_equal(a["reply"][q, i], c.tensor_row(i, row)[col])
+        leaf = leaf_from_tensor(hb, c, col, row)
+        pos = (row // 4) * cols + col
+        path = np.ascontiguousarray(a["paths"][q])
+        assert hb.lib.hobbit_verify_path_host(V(leaf), ctypes.c_uint64(pos), V(path), path.shape[0], V(root), 1) == 1
+    c.free()
+
+
 def test_open_standard_rs_rejects_expander_commitment(hb):
     """the RS x RS opening refuses an RS x expander commitment (and vice versa hobbit_open_standard refuses an RS x RS one) instead of opening it wrongly"""
     mod = __import__("__graft_entry__").load_package()
