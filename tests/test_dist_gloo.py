@@ -383,13 +383,14 @@ def test_relay_commit_matches_single_process(oracle, world):
     assert np.array_equal(got[-1][1], want)
 
 
-def test_relay_open_matches_single_process(oracle):
-    """world 2 on a relay commitment: partial aggregates + all-gather, replicated open, replies from the (contiguous) tensor shards, all
+@pytest.mark.parametrize("world", [2, 4])
+def test_relay_open_matches_single_process(oracle, world):
+    """world 2 and 4 on a relay commitment: partial aggregates + all-gather, replicated open, replies from the (contiguous) tensor shards, all
     Merkle paths from the rank that holds the tree, broadcast -- equal to the single-process open_standard with the same libc stream"""
     import ctypes
     from __graft_entry__ import build_hip
     build_hip()
-    world, N, K, queries = 2, 1 << 20, 32, 300
+    N, K, queries = 1 << 20, 32, 300
     trs = N // (K << 11)
     ctx = mp.get_context("spawn")
     port = _free_port()
