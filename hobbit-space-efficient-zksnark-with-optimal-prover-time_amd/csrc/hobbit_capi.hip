@@ -198,6 +198,11 @@ static int fft_long(hobbit_ctx *ctx, const F *src, size_t src_ld, size_t src_len
     }
     if (tw2 && lr >= 2 && lr <= 8 && batch <= 65535) {
         // one pass: twiddle on load, 16 columns x R rows per workgroup, final order on store (t1 -> dst; src was consumed above)
+        static const int r8_cols = [] { const char *e = getenv("HOBBIT_FFT_COLS_R8"); return e ? atoi(e) : 1; }();
+        if (r8_cols && lr >= 5 && !inverse) {
+            const F *tabs; HB_TRY(get_tw_r8(ctx, lr, &tabs));
+            return launch_fft_cols_r8(ctx, t1, len, lr, dst, tw2, tabs, ctx->tw8_w4_plus_i[0], batch);
+        }
         const F *twr; HB_TRY(get_twiddles(ctx, lr, inverse, &twr));
         return launch_fft_cols(ctx, t1, len, lr, dst, tw2, twr, batch);
     }

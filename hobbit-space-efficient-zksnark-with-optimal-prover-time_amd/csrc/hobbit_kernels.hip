@@ -487,6 +487,114 @@ int launch_fft_r8(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_len
     return ctx->fail(HOBBIT_EINVAL, "fft_r8: logn must be in [6, 11]");
 }
 
+// The same passes for the SECOND half of a long transform (k_fft_cols's job: N-point transforms down the columns of y[n1][k2], N = len / 4096
+// = 32 ... 256, inter-stage twiddle on load, result X[k1 * 4096 + k2]).  A workgroup owns C = 4096 / N adjacent columns; the column index is
+// the fastest thread index, so global loads and stores are C * 16-byte runs and -- with an odd LDS row stride -- the butterflies of the 64 lanes
+// of a wave fall on different banks.  Products per element: 1 (twiddle) + 7/8 per radix-8 pass after the first + 1/2 or 3/4 for the tail,
+// against 1 + log2(N)/2 in the radix-2/4 stages of k_fft_cols.
+template <int LOGN>
+__global__ void __launch_bounds__(512)
+k_fft_cols_r8(const F *__restrict__ y, size_t gs, F *__restrict__ out, const F *__restrict__ tw2, const F *__restrict__ tabs, int plus_i) {
+    constexpr uint32_t N = 1u << LOGN, P = LOGN / 3, T = 1u << (LOGN % 3), N2 = N / T, TPR = N / 8, C = 4096 / N, LDR = N + N / 8 + 1, OCT = N2 / 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    F *s = reinterpret_cast<F *>(lds_raw);
+    const uint32_t tid = threadIdx.x, k20 = blockIdx.x * C;
+    const F *src = y + (size_t)blockIdx.y * gs;
+    F *dst = out + (size_t)blockIdx.y * gs;
+    for (uint32_t e = tid; e < C * N; e += 512) {
+        const uint32_t n1 = e / C, t = e % C;
+        const size_t at = (size_t)n1 * 4096 + k20 + t;
+        F v = ldF(src + at);
+        if (n1) v = fmul(v, ldF(tw2 + at));                               // W_len^(n1 k2); row 0 of the table is all ones
+        stF(&s[t * LDR + fft_phys(n1)], v);
+    }
+    __syncthreads();
+    const uint32_t t = tid % C, u = tid / C, q = u / OCT, b = u % OCT;
+    F *sr = s + t * LDR;
+    F a[8];
+    {   // pass 0: plain 8-point DFTs on the T interleaved sub-sequences
+        const uint32_t m = P > 1 ? (__brev(b) >> (32 - 3 * (P - 1))) : 0u;
+        a[0] = ldF(&sr[fft_phys(T * m + q)]); a[2] = ldF(&sr[fft_phys(T * (m + 2 * OCT) + q)]);
+        a[4] = ldF(&sr[fft_phys(T * (m + OCT) + q)]); a[6] = ldF(&sr[fft_phys(T * (m + 3 * OCT) + q)]);
+        a[1] = ldF(&sr[fft_phys(T * (m + 4 * OCT) + q)]); a[3] = ldF(&sr[fft_phys(T * (m + 6 * OCT) + q)]);
+        a[5] = ldF(&sr[fft_phys(T * (m + 5 * OCT) + q)]); a[7] = ldF(&sr[fft_phys(T * (m + 7 * OCT) + q)]);
+        HB_DFT8_HEAD(a);
+        dft8_tail(a, plus_i);
+        __syncthreads();
+        if (P == 1 && T == 1) {
+#pragma unroll
+            for (int t8 = 0; t8 < 8; t8++) stF(dst + (size_t)t8 * 4096 + k20 + t, fcanon(a[t8]));
+            return;
+        }
+        const uint32_t o = fft_phys(q * N2 + 8 * b);
+#pragma unroll
+        for (int t8 = 0; t8 < 8; t8++) stF(&sr[o + t8], ffold(a[t8]));
+        __syncthreads();
+    }
+    const F *tw = tabs;
+#pragma unroll
+    for (uint32_t pass = 1; pass < P; pass++) {
+        const uint32_t h = pass == 1 ? 8u : 64u;
+        const uint32_t k = b & (h - 1), j = b / h, i0 = q * N2 + j * 8 * h + k;
+#pragma unroll
+        for (int t8 = 0; t8 < 8; t8++) a[t8] = ldF(&sr[fft_phys(i0 + t8 * h)]);
+#pragma unroll
+        for (int t8 = 1; t8 < 8; t8++) a[t8] = fmul_lz(a[t8], ldF(tw + (t8 - 1) * h + k));
+        HB_DFT8_HEAD(a);
+        dft8_tail(a, plus_i);
+        if (T == 1 && pass == P - 1) {
+#pragma unroll
+            for (int t8 = 0; t8 < 8; t8++) stF(dst + (size_t)(i0 + t8 * h) * 4096 + k20 + t, fcanon(a[t8]));
+        } else {
+#pragma unroll
+            for (int t8 = 0; t8 < 8; t8++) stF(&sr[fft_phys(i0 + t8 * h)], ffold(a[t8]));
+        }
+        tw += 7 * h;
+        __syncthreads();
+    }
+    if (T == 1) return;
+    if (T == 2) {
+#pragma unroll
+        for (uint32_t c = 0; c < N2 / TPR; c++) {
+            const uint32_t k = u + TPR * c;
+            const F x = ldF(&sr[fft_phys(k)]), yv = fmul_lz(ldF(&sr[fft_phys(N2 + k)]), ldF(tw + k));
+            stF(dst + (size_t)k * 4096 + k20 + t, fcanon(faddl(x, yv)));
+            stF(dst + (size_t)(k + N2) * 4096 + k20 + t, fcanon(fsubl<1>(x, yv)));
+        }
+    } else {
+#pragma unroll
+        for (uint32_t c = 0; c < N2 / TPR; c++) {
+            const uint32_t k = u + TPR * c;
+            const F y0 = ldF(&sr[fft_phys(k)]);
+            const F y1 = fmul_lz(ldF(&sr[fft_phys(N2 + k)]), ldF(tw + k));
+            const F y2 = fmul_lz(ldF(&sr[fft_phys(2 * N2 + k)]), ldF(tw + N2 + k));
+            const F y3 = fmul_lz(ldF(&sr[fft_phys(3 * N2 + k)]), ldF(tw + 2 * N2 + k));
+            const F t0 = faddl(y0, y2), t1 = fsubl<1>(y0, y2), t2 = faddl(y1, y3), t3 = fmul_w4<2>(fsubl<1>(y1, y3), plus_i);
+            stF(dst + (size_t)k * 4096 + k20 + t, fcanon(faddl(t0, t2)));
+            stF(dst + (size_t)(k + N2) * 4096 + k20 + t, fcanon(faddl(t1, t3)));
+            stF(dst + (size_t)(k + 2 * N2) * 4096 + k20 + t, fcanon(fsubl<2>(t0, t2)));
+            stF(dst + (size_t)(k + 3 * N2) * 4096 + k20 + t, fcanon(fsubl<2>(t1, t3)));
+        }
+    }
+}
+template <int LOGN>
+static int launch_fft_cols_r8_n(hobbit_ctx *ctx, const F *y, size_t gs, F *out, const F *tw2, const F *tabs, int plus_i, uint32_t batch) {
+    constexpr uint32_t N = 1u << LOGN, C = 4096 / N, LDR = N + N / 8 + 1;
+    const size_t lds = (size_t)C * LDR * 16;
+    hipFuncSetAttribute((const void *)k_fft_cols_r8<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    HB_LAUNCH(ctx, "k_fft_cols", (k_fft_cols_r8<LOGN>), dim3(4096 / C, batch), dim3(512), lds, y, gs, out, tw2, tabs, plus_i);
+    return 0;
+}
+int launch_fft_cols_r8(hobbit_ctx *ctx, const F *y, size_t gs, int logr, F *out, const F *tw2, const F *tabs, int plus_i, uint32_t batch) {
+    switch (logr) {
+        case 5: return launch_fft_cols_r8_n<5>(ctx, y, gs, out, tw2, tabs, plus_i, batch);
+        case 6: return launch_fft_cols_r8_n<6>(ctx, y, gs, out, tw2, tabs, plus_i, batch);
+        case 7: return launch_fft_cols_r8_n<7>(ctx, y, gs, out, tw2, tabs, plus_i, batch);
+        case 8: return launch_fft_cols_r8_n<8>(ctx, y, gs, out, tw2, tabs, plus_i, batch);
+    }
+    return ctx->fail(HOBBIT_EINVAL, "fft_cols_r8: R must be in [32, 256]");
+}
+
 // The R sub-transforms run in k_fft4096 (strided source); this kernel applies the twiddles and
 // the R-point DFT across n1, one lane per k2 (coalesced on both sides).  tw[m] = W_len^m, m < len/2.
 template <int LOGR>

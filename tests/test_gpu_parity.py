@@ -1048,13 +1048,13 @@ def test_mul_tree_2e20_vs_oracle(hb, oracle):
 
 
 # ---- long FFTs and the inner PCS commitments of the opening ----------------------------------------
-@pytest.mark.parametrize("logn", [13, 14, 16, 19, 22])       # 22: beyond the 2-D twiddle table, the five-pass form
+@pytest.mark.parametrize("logn", [13, 14, 16, 17, 18, 19, 20, 22])       # 17..20: the radix-8 second half; 22: beyond the 2-D twiddle table, the five-pass form
 def test_fft_long_vs_oracle(hb, oracle, logn):
     x = splitmix_field(1 << logn, 900 + logn)
     assert np.array_equal(hb.fft(x), oracle.fft(x))
 
 
-@pytest.mark.parametrize("logn", [14, 15, 17, 19, 20])
+@pytest.mark.parametrize("logn", [14, 15, 17, 18, 19, 20])
 def test_fft_long_batched_vs_oracle(hb, oracle, logn):
     """Long transforms up to 2^21 take the one-pass second half (k_fft_cols, R = 4 ... 256; R = 128 and 256 are the inner
     commitments of the 2^28 opening).  Rows 0, 3 and 7 of a batch against the oracle, in place."""
