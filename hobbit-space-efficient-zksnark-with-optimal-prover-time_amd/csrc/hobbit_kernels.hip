@@ -267,10 +267,15 @@ template <bool PADDED>
 __global__ void __launch_bounds__(512)
 k_fft4096(const F *__restrict__ src, size_t src_ld, size_t src_es, F *__restrict__ dst, size_t dst_ld, size_t dst_es, const F *__restrict__ tw1,
           const F *__restrict__ tw2, const F *__restrict__ tw3, Fft4kConst cst, F scale, int do_scale, uint32_t rows_per_group, size_t src_gs,
-          size_t dst_gs) {
+          size_t dst_gs, int line_remap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     F *s = reinterpret_cast<F *>(lds_raw);
-    const uint32_t grp = blockIdx.x / rows_per_group, r = blockIdx.x % rows_per_group;
+    // Transposed stores (dst_ld == 1): row r's element lands 16 B into the 128-byte line it shares with rows 8g .. 8g+7.  Workgroups b, b+8,
+    // b+16, ... share an XCD and its L2, so with line_remap the eight rows of a line group go to eight consecutive slots of ONE XCD, whose
+    // L2 can merge the pieces into whole lines (within every run of 64 blocks: block (xcd, j) -> row 8 xcd + j).  Placement only.
+    uint32_t bid = blockIdx.x;
+    if (line_remap) bid = (bid & ~63u) + 8 * (bid & 7u) + ((bid >> 3) & 7u);
+    const uint32_t grp = bid / rows_per_group, r = bid % rows_per_group;
     const F *in = src + (size_t)grp * src_gs + (size_t)r * src_ld;
     F *out = dst + (size_t)grp * dst_gs + (size_t)r * dst_ld;
     const uint32_t tid = threadIdx.x;
@@ -340,12 +345,14 @@ int launch_fft4096(hobbit_ctx *ctx, const F *src, size_t src_ld, size_t src_es, 
     Fft4kConst cst; cst.w8 = w8; cst.w8_3 = w8_3; cst.w4_plus_i = w4_plus_i;
     if (src_len == 2048) {
         hipFuncSetAttribute((const void *)k_fft4096<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static const int remap_mode = [] { const char *e = getenv("HOBBIT_FFT_LINE_REMAP"); return e ? atoi(e) : 1; }();
+        const int remap = (remap_mode && dst_ld == 1 && dst_es > 1 && rows_per_group % 64 == 0) ? 1 : 0;
         HB_LAUNCH(ctx, "k_fft4096", k_fft4096<true>, dim3((unsigned)blocks), dim3(512), lds, src, src_ld, src_es, dst, dst_ld, dst_es, tw1, tw2, tw3, cst,
-                  scale, do_scale, rows_per_group, src_gs, dst_gs);
+                  scale, do_scale, rows_per_group, src_gs, dst_gs, remap);
     } else {
         hipFuncSetAttribute((const void *)k_fft4096<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         HB_LAUNCH(ctx, "k_fft4096_full", k_fft4096<false>, dim3((unsigned)blocks), dim3(512), lds, src, src_ld, src_es, dst, dst_ld, dst_es, tw1, tw2, tw3,
-                  cst, scale, do_scale, rows_per_group, src_gs, dst_gs);
+                  cst, scale, do_scale, rows_per_group, src_gs, dst_gs, 0);
     }
     return 0;
 }
