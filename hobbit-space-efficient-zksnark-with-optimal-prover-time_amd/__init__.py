@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "hobbit_elastic_open_begin", "hobbit_elastic_open_aggregate_push", "hobbit_elastic_open_aggregate_finish", "hobbit_elastic_open_reply_push",
     "hobbit_elastic_open_finish", "hobbit_elastic_open_free", "hobbit_generate_randomness",
     "hobbit_read_mul_tree_layer", "hobbit_read_mul_tree_data", "hobbit_generate_claims_opt", "hobbit_sumcheck3_stream_batch", "hobbit_mul_tree_stream_shallow",
-    "hobbit_gate_consistency_stream", "hobbit_set_lookups", "hobbit_gate_consistency_lookups_stream", "hobbit_open_standard_rs", "hobbit_leaf_chain_relay", "hobbit_verify_path_host", "hobbit_leaf_chain", "hobbit_axpy_aggregate", "hobbit_stream_fold",
+    "hobbit_gate_consistency_stream", "hobbit_set_lookups", "hobbit_gate_consistency_lookups_stream", "hobbit_open_standard_rs", "hobbit_leaf_chain_relay", "hobbit_verify_path_host", "hobbit_fingerprint_map", "hobbit_leaf_chain", "hobbit_axpy_aggregate", "hobbit_stream_fold",
     "hobbit_tensorcode_chunks", "hobbit_inner_digests", "hobbit_chain_digests", "hobbit_blake3_64_host",
     "hobbit_parity_matrix", "hobbit_phi_g", "hobbit_prepare_matrix_cols", "hobbit_prove_linear_code", "hobbit_prove_fft",
     "hobbit_prove_fft_matrix",
@@ -105,7 +105,7 @@ def load_library(path=LIB_PATH):
         "hobbit_read_mul_tree_layer": [V, V, V, S, I, V], "hobbit_read_mul_tree_data": [V, V, V, S, I, I, I, V],
         "hobbit_generate_claims_opt": [V, V, V, S, S, V, I, I, I, I, V], "hobbit_sumcheck3_stream_batch": [V, V, V, S, S, V, I, I, I, I, V, I, V],
         "hobbit_mul_tree_stream_shallow": [V, V, V, S, S, I, S, V, I, V, I, V], "hobbit_gate_consistency_stream": [V, V, V, S, S, V, V],
-        "hobbit_set_lookups": [V, I, V], "hobbit_open_standard_rs": [V, V, S, V, V, I, V], "hobbit_leaf_chain_relay": [V, V, S, I, I, I, S, S, V, V, V], "hobbit_leaf_chain": [V, V, S, I, I, I, V], "hobbit_verify_path_host": [V, ctypes.c_uint64, V, I, V, I],
+        "hobbit_set_lookups": [V, I, V], "hobbit_open_standard_rs": [V, V, S, V, V, I, V], "hobbit_leaf_chain_relay": [V, V, S, I, I, I, S, S, V, V, V], "hobbit_leaf_chain": [V, V, S, I, I, I, V], "hobbit_verify_path_host": [V, ctypes.c_uint64, V, I, V, I], "hobbit_fingerprint_map": [V, V, V, V, V, V, V, S],
         "hobbit_axpy_aggregate": [V, V, V, V, S], "hobbit_stream_fold": [V, I, V, V, S, V], "hobbit_gate_consistency_lookups_stream": [V, V, V, S, S, V, V],
         "hobbit_tensorcode_chunks": [V, V, S, I, I, I, V], "hobbit_inner_digests": [V, V, S, I, I, V],
         "hobbit_chain_digests": [V, V, S, I, S, V], "hobbit_blake3_64_host": [V, V, S],

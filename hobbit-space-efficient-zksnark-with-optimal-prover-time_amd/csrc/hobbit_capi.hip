@@ -1020,6 +1020,10 @@ int hobbit_verify_path_host(const uint8_t *leaf, uint64_t pos, const uint8_t *pa
     }
     return memcmp(node, root, 32) == 0;
 }
+int hobbit_fingerprint_map(hobbit_ctx *ctx, const hobbit_F *d_addr, const hobbit_F *d_value, const hobbit_F *d_freq, const hobbit_F *h_a, const hobbit_F *h_b, hobbit_F *d_out, size_t n) {
+    if (!d_addr || !d_value || !h_a || !d_out || (d_freq && !h_b)) return ctx->fail(HOBBIT_EINVAL, "fingerprint_map: null argument");
+    return launch_fingerprint(ctx, cF(d_addr), cF(d_value), d_freq ? cF(d_freq) : nullptr, *cF(h_a), d_freq ? *cF(h_b) : fmake(0), mF(d_out), n);
+}
 // SURVEY.md 8(b)'s export list by its own names: thin forms of what the library already has
 int hobbit_leaf_chain(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M, int nchunks, int trs, int linear_time, uint8_t *d_leaves) {
     if (trs < 4 || trs % 4 || M % (size_t)trs || nchunks <= 0 || !d_leaves) return ctx->fail(HOBBIT_EINVAL, "leaf_chain: trs must be a multiple of 4 dividing M, nchunks positive");

@@ -2020,6 +2020,21 @@ int launch_axpy_i32(hobbit_ctx *ctx, F *y, const int32_t *sel, F a, int one_minu
     return 0;
 }
 
+// memory / lookup fingerprints of the wiring-consistency streams (src/witness_stream.cpp:2196, 2290-2305; src/main.cpp:1039-1044):
+// out[i] = addr[i] + 1 + a * value[i] (+ b * freq[i])
+__global__ void k_fingerprint(const F *__restrict__ addr, const F *__restrict__ value, const F *__restrict__ freq, F a, F b, F *__restrict__ out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        F v = fadd(fadd(ldF(addr + i), fmake(1)), fmul(a, ldF(value + i)));
+        if (freq) v = fadd(v, fmul(b, ldF(freq + i)));
+        stF(out + i, v);
+    }
+}
+int launch_fingerprint(hobbit_ctx *ctx, const F *addr, const F *value, const F *freq, F a, F b, F *out, size_t n) {
+    if (!n) return 0;
+    HB_LAUNCH(ctx, "k_fingerprint", k_fingerprint, dim3(grid_for(n, 256)), dim3(256), 0, addr, value, freq, a, b, out, n);
+    return 0;
+}
+
 // ---- prove_gate_consistency_lookups (src/sumcheck.cpp:503-795) device pieces ---------------------------------------
 // One chunk's selector rewrites (:568-585) and lookup output column: s2 = selectors for the R call (2 -> 3), s3 = for the lookup call
 // (0 -> -1, 2 -> 4), blo = lookup_rand[0] L + lookup_rand[1] R - O on lookup rows, 0 elsewhere.

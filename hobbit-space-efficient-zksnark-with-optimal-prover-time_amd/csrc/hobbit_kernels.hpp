@@ -56,6 +56,7 @@ int launch_sc3_poly(hobbit_ctx *ctx, const F *s1, const F *s2, const F *s3, size
 int launch_fold3(hobbit_ctx *ctx, const F *s1, const F *s2, const F *s3, F *d1, F *d2, F *d3, size_t L, F r);
 int launch_mul_layer(hobbit_ctx *ctx, const F *x, size_t n_out, F *in1, F *in2, F *tr);
 int launch_transpose_tw(hobbit_ctx *ctx, const F *in, size_t gs, uint32_t R, F *out, const F *tw, uint32_t half, const F *tw2, uint32_t groups);
+int launch_fingerprint(hobbit_ctx *ctx, const F *addr, const F *value, const F *freq, F a, F b, F *out, size_t n);
 int launch_fft_cols_r8(hobbit_ctx *ctx, const F *y, size_t gs, int logr, F *out, const F *tw2, const F *tabs, int plus_i, uint32_t batch);
 int launch_fft_cols(hobbit_ctx *ctx, const F *y, size_t gs, int logr, F *out, const F *tw2, const F *twr, uint32_t batch);
 int launch_build_tw2d(hobbit_ctx *ctx, const F *tw, uint32_t half, uint32_t R, F *out);

@@ -218,6 +218,11 @@ int hobbit_chain_digests(hobbit_ctx *ctx, const uint8_t *d_digests, size_t strid
  * reference's leaf order j * cols + col: on the rank that holds the last chunks) receive the result. */
 int hobbit_leaf_chain_relay(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M, int nchunks, int trs, int linear_time, size_t slot_begin, size_t slot_count,
                             const uint8_t *d_state_in, uint8_t *d_state_out, uint8_t *d_leaves);
+/* Memory / lookup fingerprints of the wiring-consistency streams (src/witness_stream.cpp:2196, 2290-2305, and the same map in
+ * prove_circuit_standard, src/main.cpp:1039-1044): d_out[i] = d_addr[i] + 1 + a * d_value[i] + b * d_freq[i]  (d_freq NULL: without the last
+ * term).  The three columns come from the witness generator (read_memory); the map itself and everything after it run on the device. */
+int hobbit_fingerprint_map(hobbit_ctx *ctx, const hobbit_F *d_addr, const hobbit_F *d_value, const hobbit_F *d_freq, const hobbit_F *h_a, const hobbit_F *h_b, hobbit_F *d_out, size_t n);
+
 /* Verifier side of open_tree_blake (the reference's verify_claim_opt_blake, src/merkle_tree.cpp:326-362, never compares
  * anything): recompute the root from a leaf hash, its position and its `depth` siblings.  quirk_left_left = 1: the reference's tree
  * (parent = H(L | L), src/merkle_tree.cpp:275-280); 0: an ordinary H(L | R) tree.  Returns 1 / 0.  Host only, no context. */

@@ -1012,6 +1012,22 @@ def test_survey_named_exports(hb, oracle):
     assert np.array_equal(K3, hb.err3p(tabs[0], gate, tabs[2], tabs[3], tabs[4], tabs[5]))
 
 
+def test_fingerprint_map(hb, oracle):
+    """addr + 1 + a value + b freq (the wiring-consistency fingerprints) on the device against the oracle's field operations"""
+    n = 5000
+    addr, value, freq = [splitmix_field(n, 610 + i) for i in range(3)]
+    a, b = splitmix_field(1, 620), splitmix_field(1, 621)
+    da, dv, df = hb.to_device(addr), hb.to_device(value), hb.to_device(freq)
+    out = hb.alloc(16 * n)
+    one = np.zeros_like(addr); one[:, 0] = 1
+    base = oracle.f_add(oracle.f_add(addr, one), oracle.f_mul(np.repeat(a, n, 0), value))
+    for with_freq in (1, 0):
+        hb._chk(hb.lib.hobbit_fingerprint_map(hb.ctx, da.ptr, dv.ptr, df.ptr if with_freq else None, a.ctypes.data, b.ctypes.data, out.ptr, n))
+        got = np.zeros((n, 2), np.uint64); hb._chk(hb.lib.hobbit_memcpy_d2h(hb.ctx, got.ctypes.data, out.ptr, 16 * n))
+        want = oracle.f_add(base, oracle.f_mul(np.repeat(b, n, 0), freq)) if with_freq else base
+        assert np.array_equal(got, want)
+
+
 def test_lkpfold_vs_golden(hb):
     """compute{3,4}p_error_terms under has_lookups (hobbit_set_lookups), every selector value of the lookup prover, against the REAL reference"""
     g = gold("lkpfold")
