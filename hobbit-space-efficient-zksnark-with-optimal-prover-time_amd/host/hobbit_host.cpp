@@ -998,6 +998,103 @@ static void gate_stream_common(stream_descriptor &tr, vector<F> &r, bool lookups
 void prove_gate_consistency(stream_descriptor tr, vector<F> r, double &vt, double &ps) { gate_stream_common(tr, r, false, vt, ps); }
 void prove_gate_consistency_lookups(stream_descriptor tr, vector<F> r, double &vt, double &ps) { gate_stream_common(tr, r, true, vt, ps); }
 
+// ---- proof wire format (hobbit_host.hpp) ---------------------------------------------------------------
+namespace {
+struct Wr {
+    std::vector<uint8_t> b;
+    void raw(const void *p, size_t n) { const uint8_t *q = (const uint8_t *)p; b.insert(b.end(), q, q + n); }
+    void u32(uint32_t v) { raw(&v, 4); }
+    void u64(uint64_t v) { raw(&v, 8); }
+    void sec(uint32_t tag, const void *p, size_t n) { u32(tag); u64(n); raw(p, n); }
+    template <class T> void vec(uint32_t tag, const std::vector<T> &v) { sec(tag, v.data(), v.size() * sizeof(T)); }
+};
+struct Rd {
+    const uint8_t *p; size_t n, at = 0; bool ok = true;
+    Rd(const uint8_t *q, size_t m) : p(q), n(m) {}
+    bool raw(void *d, size_t k) { if (!ok || k > n - at) return ok = false; memcpy(d, p + at, k); at += k; return true; }
+    uint32_t u32() { uint32_t v = 0; raw(&v, 4); return v; }
+    uint64_t u64() { uint64_t v = 0; raw(&v, 8); return v; }
+    bool next(uint32_t &tag, const uint8_t *&pay, size_t &len) {
+        if (at == n) return false;
+        tag = u32(); const uint64_t l = u64();
+        if (!ok || l > n - at) { ok = false; return false; }
+        pay = p + at; len = (size_t)l; at += len; return true;
+    }
+};
+template <class T> bool take(const uint8_t *pay, size_t len, std::vector<T> &v) { if (len % sizeof(T)) return false; v.resize(len / sizeof(T)); if (len) memcpy((void *)v.data(), pay, len); return true; }
+enum : uint32_t { T_COLS = 1, T_ROWS, T_REPLY, T_PATHS, T_QPOLY, T_R, T_VR, T_FIN, T_SCAL, T_ROOTS, T_SPC, T_SPF, T_RV0, T_CFROOT, T_RX, T_NCOLS,
+                  S_I = 100, S_Q1, S_R1, S_VR1, S_FIN1, S_Q2, S_R2, S_VR2, S_FIN2, S_WQ, S_WA, S_WSCAL, S_REPLY, S_PATHS, S_WROOTS, S_WHIRROOT, S_WQIDX, S_WQN, S_WQREPLY,
+                  S_WQPATHS, S_WFINAL, S_ITERS };
+std::vector<uint8_t> ser_sp(const hobbit_host_shockwave_transcript &t) {
+    Wr w;
+    w.vec(S_I, t.I); w.vec(S_Q1, t.q1); w.vec(S_R1, t.r1); w.vec(S_VR1, t.vr1); w.sec(S_FIN1, &t.fin1, sizeof(F)); w.vec(S_Q2, t.q2); w.vec(S_R2, t.r2); w.vec(S_VR2, t.vr2);
+    w.sec(S_FIN2, &t.fin2, sizeof(F)); w.vec(S_WQ, t.wq); w.vec(S_WA, t.wa); w.vec(S_WSCAL, t.wscal); w.vec(S_REPLY, t.reply); w.vec(S_PATHS, t.paths); w.vec(S_WROOTS, t.wroots);
+    w.sec(S_WHIRROOT, t.whir_root, 32); w.vec(S_WQIDX, t.wqidx); w.vec(S_WQN, t.wqn); w.vec(S_WQREPLY, t.wqreply); w.vec(S_WQPATHS, t.wqpaths); w.vec(S_WFINAL, t.wfinal);
+    const uint32_t it = (uint32_t)t.iters; w.sec(S_ITERS, &it, 4);
+    return w.b;
+}
+bool de_sp(const uint8_t *buf, size_t n, hobbit_host_shockwave_transcript &t) {
+    Rd r(buf, n); uint32_t tag; const uint8_t *pay; size_t len; bool ok = true;
+    while (ok && r.next(tag, pay, len)) switch (tag) {
+        case S_I: ok = take(pay, len, t.I); break; case S_Q1: ok = take(pay, len, t.q1); break; case S_R1: ok = take(pay, len, t.r1); break; case S_VR1: ok = take(pay, len, t.vr1); break;
+        case S_FIN1: ok = len == sizeof(F); if (ok) memcpy((void *)&t.fin1, pay, len); break; case S_Q2: ok = take(pay, len, t.q2); break; case S_R2: ok = take(pay, len, t.r2); break;
+        case S_VR2: ok = take(pay, len, t.vr2); break; case S_FIN2: ok = len == sizeof(F); if (ok) memcpy((void *)&t.fin2, pay, len); break; case S_WQ: ok = take(pay, len, t.wq); break;
+        case S_WA: ok = take(pay, len, t.wa); break; case S_WSCAL: ok = take(pay, len, t.wscal); break; case S_REPLY: ok = take(pay, len, t.reply); break;
+        case S_PATHS: ok = take(pay, len, t.paths); break; case S_WROOTS: ok = take(pay, len, t.wroots); break; case S_WHIRROOT: ok = len == 32; if (ok) memcpy(t.whir_root, pay, 32); break;
+        case S_WQIDX: ok = take(pay, len, t.wqidx); break; case S_WQN: ok = take(pay, len, t.wqn); break; case S_WQREPLY: ok = take(pay, len, t.wqreply); break;
+        case S_WQPATHS: ok = take(pay, len, t.wqpaths); break; case S_WFINAL: ok = take(pay, len, t.wfinal); break;
+        case S_ITERS: ok = len == 4; if (ok) { uint32_t it; memcpy(&it, pay, 4); t.iters = (int)it; } break;
+        default: break;
+    }
+    return ok && r.ok;
+}
+void header(Wr &w, uint32_t kind, uint32_t nsec) { w.raw("HBPF", 4); w.u32(1); w.u32(kind); w.u32(nsec); }
+bool check_header(Rd &r, uint32_t kind) { char m[4]; if (!r.raw(m, 4) || memcmp(m, "HBPF", 4)) return false; if (r.u32() != 1 || r.u32() != kind) return false; r.u32(); return r.ok; }
+}  // namespace
+std::vector<uint8_t> hobbit_host_serialize_open(const hobbit_host_open_transcript &t) {
+    Wr w; header(w, 1, 12);
+    w.vec(T_COLS, t.cols); w.vec(T_ROWS, t.rows); w.vec(T_REPLY, t.reply); w.vec(T_PATHS, t.paths); w.vec(T_QPOLY, t.qpoly); w.vec(T_R, t.r); w.vec(T_VR, t.vr); w.vec(T_FIN, t.fin);
+    w.vec(T_SCAL, t.scalars); w.sec(T_ROOTS, t.roots, 64);
+    { auto s = ser_sp(t.sp_c); w.sec(T_SPC, s.data(), s.size()); } { auto s = ser_sp(t.sp_f); w.sec(T_SPF, s.data(), s.size()); }
+    return w.b;
+}
+bool hobbit_host_deserialize_open(const uint8_t *buf, size_t n, hobbit_host_open_transcript &t) {
+    Rd r(buf, n); if (!check_header(r, 1)) return false;
+    uint32_t tag; const uint8_t *pay; size_t len; bool ok = true;
+    while (ok && r.next(tag, pay, len)) switch (tag) {
+        case T_COLS: ok = take(pay, len, t.cols); break; case T_ROWS: ok = take(pay, len, t.rows); break; case T_REPLY: ok = take(pay, len, t.reply); break;
+        case T_PATHS: ok = take(pay, len, t.paths); break; case T_QPOLY: ok = take(pay, len, t.qpoly); break; case T_R: ok = take(pay, len, t.r); break; case T_VR: ok = take(pay, len, t.vr); break;
+        case T_FIN: ok = take(pay, len, t.fin); break; case T_SCAL: ok = take(pay, len, t.scalars); break; case T_ROOTS: ok = len == 64; if (ok) memcpy(t.roots, pay, 64); break;
+        case T_SPC: ok = de_sp(pay, len, t.sp_c); break; case T_SPF: ok = de_sp(pay, len, t.sp_f); break;
+        default: break;
+    }
+    if (ok && r.ok) { t.queries = (int)t.cols.size(); t.rounds = (int)t.r.size(); }
+    return ok && r.ok && t.cols.size() == t.rows.size();
+}
+std::vector<uint8_t> hobbit_host_serialize_rs_open(const hobbit_host_elastic_transcript &t) {
+    Wr w; header(w, 2, 12);
+    const size_t nr = (size_t)t.rounds;
+    w.vec(T_COLS, t.cols); w.vec(T_ROWS, t.rows);
+    w.sec(T_REPLY, t.reply.data(), (size_t)t.queries * (size_t)t.reply_len * sizeof(F)); w.vec(T_PATHS, t.paths);
+    w.sec(T_QPOLY, t.qpoly.data(), 3 * nr * sizeof(F)); w.sec(T_R, t.r.data(), nr * sizeof(F)); w.vec(T_VR, t.vr); w.vec(T_FIN, t.fin);
+    w.sec(T_RV0, &t.rv0, sizeof(F)); w.sec(T_CFROOT, t.cf_root, 32); w.vec(T_RX, t.rx);
+    { auto s = ser_sp(t.sp_f); w.sec(T_SPF, s.data(), s.size()); }
+    return w.b;
+}
+bool hobbit_host_deserialize_rs_open(const uint8_t *buf, size_t n, hobbit_host_elastic_transcript &t) {
+    Rd r(buf, n); if (!check_header(r, 2)) return false;
+    uint32_t tag; const uint8_t *pay; size_t len; bool ok = true;
+    while (ok && r.next(tag, pay, len)) switch (tag) {
+        case T_COLS: ok = take(pay, len, t.cols); break; case T_ROWS: ok = take(pay, len, t.rows); break; case T_REPLY: ok = take(pay, len, t.reply); break;
+        case T_PATHS: ok = take(pay, len, t.paths); break; case T_QPOLY: ok = take(pay, len, t.qpoly); break; case T_R: ok = take(pay, len, t.r); break; case T_VR: ok = take(pay, len, t.vr); break;
+        case T_FIN: ok = take(pay, len, t.fin); break; case T_RV0: ok = len == sizeof(F); if (ok) memcpy((void *)&t.rv0, pay, len); break;
+        case T_CFROOT: ok = len == 32; if (ok) memcpy(t.cf_root, pay, 32); break; case T_RX: ok = take(pay, len, t.rx); break; case T_SPF: ok = de_sp(pay, len, t.sp_f); break;
+        default: break;
+    }
+    if (ok && r.ok) { t.queries = (int)t.cols.size(); t.rounds = (int)t.r.size(); t.reply_len = t.queries ? (int)(t.reply.size() / (size_t)t.queries) : 0; }
+    return ok && r.ok && t.cols.size() == t.rows.size();
+}
+
 // ---- driver (src/Our_PC.cpp:757-826, option 4, commit phase) ---------------------------------------
 void test_PC(size_t N, int option, int K) {
     if (option != 4 && option != 1) { printf("Error: options 2 and 3 are the Orion / Brakedown comparison baselines, not built on the device path\n"); exit(-1); }
@@ -1131,6 +1228,29 @@ int hobbit_host_gate_stream(size_t n, size_t B, int lookups, unsigned seed, cons
     for (int i = 0; i < 5; i++) checks[i] = t.checks[i];
     *ps_out = ps;
     return (int)t.fin.size();
+}
+// round trip of the wire format on the transcripts of the last open_standard (kind 1) / last RS x RS opening (kind 2): returns the proof size
+// in bytes, or a negative number naming what failed
+long hobbit_host_wire_roundtrip(int kind) {
+    std::vector<uint8_t> a, b;
+    if (kind == 1) {
+        a = hobbit_host_serialize_open(hobbit_host_last_open());
+        hobbit_host_open_transcript t;
+        if (!hobbit_host_deserialize_open(a.data(), a.size(), t)) return -1;
+        b = hobbit_host_serialize_open(t);
+        if (hobbit_host_deserialize_open(a.data(), a.size() - 7, t)) return -3;          // a truncated proof must be rejected
+    } else {
+        a = hobbit_host_serialize_rs_open(hobbit_host_last_elastic_open());
+        hobbit_host_elastic_transcript t;
+        if (!hobbit_host_deserialize_rs_open(a.data(), a.size(), t)) return -1;
+        b = hobbit_host_serialize_rs_open(t);
+        if (hobbit_host_deserialize_rs_open(a.data(), a.size() - 7, t)) return -3;
+    }
+    if (a != b) return -2;
+    std::vector<uint8_t> c = a; c[0] ^= 1;
+    hobbit_host_open_transcript t1; hobbit_host_elastic_transcript t2;
+    if (kind == 1 ? hobbit_host_deserialize_open(c.data(), c.size(), t1) : hobbit_host_deserialize_rs_open(c.data(), c.size(), t2)) return -4;     // wrong magic
+    return (long)a.size();
 }
 int hobbit_host_sumcheck2(const uint64_t *v1, const uint64_t *v2, size_t n, const uint64_t *prev, uint64_t *qpoly, uint64_t *r, uint64_t *vr, uint64_t *fin) {
     vector<F> a(n), b(n); memcpy((void *)a.data(), v1, 16 * n); memcpy((void *)b.data(), v2, 16 * n);

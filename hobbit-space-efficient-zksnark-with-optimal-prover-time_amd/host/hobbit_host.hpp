@@ -231,6 +231,17 @@ struct hobbit_host_elastic_transcript {
     hobbit_host_shockwave_transcript sp_f;
 };
 hobbit_host_elastic_transcript &hobbit_host_last_elastic_open();
+/* On-wire form of an opening proof.  The reference never serialises a proof (struct proof / mul_tree_proof stay in
+ * memory, src/sumcheck.h:8-43), so this layout is ours; little-endian throughout:
+ *   header  "HBPF" | u32 version = 1 | u32 kind (1 = open_standard, RS x expander; 2 = RS x RS opening: open_standard with !linear_time or
+ *           Elastic_PC::open) | u32 number of sections
+ *   section u32 tag | u64 payload bytes | payload   (field elements as 16-byte {real, img}; hashes as 32 bytes; indices as u32 / i32)
+ * The nested shockwave_prove transcripts are sections whose payload is itself a sequence of sections.  Unknown tags are skipped by the
+ * reader, a truncated or malformed buffer is rejected.  A proof carries messages only -- no checks, no timings. */
+std::vector<uint8_t> hobbit_host_serialize_open(const hobbit_host_open_transcript &t);
+bool hobbit_host_deserialize_open(const uint8_t *buf, size_t n, hobbit_host_open_transcript &t);
+std::vector<uint8_t> hobbit_host_serialize_rs_open(const hobbit_host_elastic_transcript &t);
+bool hobbit_host_deserialize_rs_open(const uint8_t *buf, size_t n, hobbit_host_elastic_transcript &t);
 void test_Elastic_PC_commit(size_t N, int option);              /* commit phase of test_Elastic_PC (src/Elastic_PC.cpp:736-771) */
 /* src/sumcheck.h:84, src/sumcheck.cpp:1150 : the streaming multiplication-tree prover over read_stream (default stream only) */
 vector<F> prove_multiplication_tree_stream_shallow(stream_descriptor fd, int vectors, int size, F previous_r, int distance, vector<F> prev_x, bool naive, double &vt, double &ps);

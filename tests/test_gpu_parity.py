@@ -499,6 +499,11 @@ def test_host_mirror_open_standard(oracle):
     P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     lib.hobbit_host_test_pc_open.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_uint] + [ctypes.c_void_p] * 6
     assert lib.hobbit_host_test_pc_open(N, K, seed, P(q), P(r), P(I), P(roots), P(checks), ctypes.byref(ps)) == rounds
+    # the proof on the wire: serialise -> parse -> serialise is the identity, a truncated or mis-tagged buffer is rejected; it carries at
+    # least the replies and all (not de-duplicated) Merkle paths
+    lib.hobbit_host_wire_roundtrip.restype = ctypes.c_long
+    wire = lib.hobbit_host_wire_roundtrip(1)
+    assert wire > queries * K * 16 + queries * ((N // K).bit_length() - 1) * 32, wire
     lib.hobbit_host_close()
     oracle.rng_reset(); poly = oracle.generate_randomness(N); oracle.expander_init_store(trs)
     x = oracle.generate_randomness(N.bit_length() - 1)
@@ -527,6 +532,8 @@ def test_host_mirror_test_pc_option1(oracle):
     P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     lib.hobbit_host_test_pc_rs_open.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_uint] + [ctypes.c_void_p] * 7
     rounds = lib.hobbit_host_test_pc_rs_open(N, K, seed, P(root), P(q), P(r), P(I), P(roots), P(checks), ctypes.byref(ps))
+    lib.hobbit_host_wire_roundtrip.restype = ctypes.c_long
+    assert lib.hobbit_host_wire_roundtrip(2) > queries * K * 16
     lib.hobbit_host_close()
     assert np.array_equal(root, gold("commit_rs")["crs_%d_%d_root" % (N, K)])
     oracle.rng_reset(); poly = oracle.generate_randomness(N)
