@@ -1088,6 +1088,39 @@ __global__ void __launch_bounds__(1024) k_merkle_top(const uint8_t *__restrict__
         off += sz; pb ^= 1;
     }
 }
+// `g` consecutive levels in one launch: a workgroup hashes 1024 nodes of the level that has `sz` nodes (from 2048 nodes of `prev`) and then
+// the 512, 256, ... nodes above them that depend on nothing else, out of LDS -- the opening builds about eight trees of 2^19 .. 2^20
+// leaves, and one launch per level was nine launches of a few microseconds each per tree.  sz must be a multiple of 1024, 1 <= g <= 11;
+// `cur` points at the level of sz nodes, the levels above it follow in the flat layout.
+__global__ void __launch_bounds__(1024) k_merkle_sub(const uint8_t *__restrict__ prev, uint8_t *__restrict__ cur, size_t sz, int g, int quirk) {
+    __shared__ uint32_t buf[2][1024 * 8];
+    const uint32_t tid = threadIdx.x;
+    const size_t node = (size_t)blockIdx.x * 1024 + tid;
+    uint32_t m[16], h[8];
+    load8w(prev + 64 * node, m);
+    if (quirk) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) m[8 + j] = m[j];
+    } else load8w(prev + 64 * node + 32, m + 8);
+    blake3_compress64(m, h); store8w(cur + 32 * node, h);
+#pragma unroll
+    for (int j = 0; j < 8; j++) buf[0][tid * 8 + j] = h[j];
+    size_t off = sz, lsz = sz; uint32_t width = 1024; int pb = 0;
+    for (int lv = 1; lv < g; lv++) {
+        width >>= 1; lsz >>= 1;
+        __syncthreads();
+        if (tid < width) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) m[j] = buf[pb][(2 * tid) * 8 + j];
+#pragma unroll
+            for (int j = 0; j < 8; j++) m[8 + j] = quirk ? m[j] : buf[pb][(2 * tid + 1) * 8 + j];
+            blake3_compress64(m, h); store8w(cur + 32 * (off + (size_t)blockIdx.x * width + tid), h);
+#pragma unroll
+            for (int j = 0; j < 8; j++) buf[pb ^ 1][tid * 8 + j] = h[j];
+        }
+        off += lsz; pb ^= 1;
+    }
+}
 // Our_PC leaf chain over all K chunks (src/Our_PC.cpp:162-166).  The tensor is codeword-major
 // ([chunk][col][2 trs]), so the 4 field elements of leaf (j, col) are 64 contiguous bytes.  One
 // thread owns one leaf and keeps its Merkle-Damgard state in registers across the chunk loop:
@@ -1420,14 +1453,24 @@ int launch_hash_md(hobbit_ctx *ctx, const F *xyzw, const uint8_t *prev, uint8_t 
     return 0;
 }
 int launch_merkle_levels(hobbit_ctx *ctx, uint8_t *levels, size_t n, int quirk) {
+    static const int sub_mode = [] { const char *e = getenv("HOBBIT_MERKLE_SUB"); return e ? atoi(e) : 1; }();
     size_t off = 0, tot = n;
-    for (size_t sz = n / 2; sz >= 1; sz /= 2) {
+    for (size_t sz = n / 2; sz >= 1;) {
         if (sz <= 1024) {                                   // this level and all above it in one workgroup
             HB_LAUNCH(ctx, "k_merkle_top", k_merkle_top, dim3(1), dim3(1024), 0, levels + 32 * off, levels + 32 * tot, (uint32_t)sz, quirk);
             break;
         }
+        // levels of more than 1024 nodes: up to 11 of them per launch (every workgroup's 1024 nodes carry their own ancestors), but only
+        // while the level is small enough that the idle upper levels of a workgroup cost less than the launches they replace
+        int wide = 0; for (size_t t = sz; t > 1024; t >>= 1) wide++;
+        if (sub_mode && sz % 1024 == 0 && sz <= ((size_t)1 << 21) && (n & (n - 1)) == 0) {
+            const int g = wide < 11 ? wide : 11;
+            HB_LAUNCH(ctx, "k_merkle_level", k_merkle_sub, dim3((unsigned)(sz / 1024)), dim3(1024), 0, levels + 32 * off, levels + 32 * tot, sz, g, quirk);
+            for (int lv = 0; lv < g; lv++) { off = tot; tot += sz; sz >>= 1; }
+            continue;
+        }
         HB_LAUNCH(ctx, "k_merkle_level", k_merkle_level, dim3(grid_for(sz, 256)), dim3(256), 0, levels + 32 * off, levels + 32 * tot, sz, quirk);
-        off = tot; tot += sz;
+        off = tot; tot += sz; sz >>= 1;
     }
     return 0;
 }
