@@ -151,6 +151,21 @@ static long long expander_rec(long long n, int dep) {               // src/expan
     upload_graph(dep, 0, _C[dep]); upload_graph(dep, 1, D[dep]);
     return n + L + (long long)(n * (k_r - 1) - L);
 }
+// Upload whatever graphs the host arrays _C / D hold for a code of length n (walk of src/expanders.h:78-92 without drawing): for a build in
+// which a copy of the reference's own expander_init_store (inline in src/expanders.h) drew them and nothing told the device.
+static long long upload_rec(long long n, int dep) {
+    if (n <= k_distance_threshold) return n;
+    if (_C[dep].L != n) { printf("Error: no expander graph of %lld left nodes at depth %d in _C (expander_init_store has not run for this size)\n", n, dep); exit(-1); }
+    long long L = upload_rec((long long)(k_alpha * n), dep + 1);
+    upload_graph(dep, 0, _C[dep]); upload_graph(dep, 1, D[dep]);
+    return n + L + (long long)(n * (k_r - 1) - L);
+}
+void hobbit_host_upload_graphs(long long n) {
+    HCHK(hobbit_graph_reset(hobbit_host_ctx()));
+    long long total = upload_rec(n, 0), len = 0;
+    HCHK(hobbit_graph_finalize(g_ctx, n, &len));
+    if (len != total) { printf("Error in hobbit_host_upload_graphs\n"); exit(-1); }
+}
 long long expander_init_store(long long n, int dep) {
     if (dep == 0) HCHK(hobbit_graph_reset(hobbit_host_ctx()));
     long long total = expander_rec(n, dep);
@@ -1136,6 +1151,18 @@ int hobbit_host_test_pc_root(size_t N, int K, uint8_t *root_out) {
     commit_standard(poly, comm, MT, T, K);
     memcpy(root_out, MT.back()[0].arr, 32);
     return (int)MT.size();
+}
+// hobbit_host_upload_graphs: wipe the device's graphs, re-upload them from _C / D, commit again -- the root must not change
+int hobbit_host_graph_reupload_check(size_t N, int K) {
+    srandom(1);
+    vector<F> poly = generate_randomness((int)N);
+    linear_time = true; tensor_row_size = (int)(N / (K * 1ULL << 11));
+    expander_init_store(tensor_row_size);
+    _hash comm; vector<vector<_hash>> MT, MT2; vector<vector<vector<F>>> T;
+    commit_standard(poly, comm, MT, T, K);
+    hobbit_host_upload_graphs(tensor_row_size);
+    commit_standard(poly, comm, MT2, T, K);
+    return memcmp(MT.back()[0].arr, MT2.back()[0].arr, 32) == 0 ? 1 : 0;
 }
 // commit + open through the C++ mirror on test_PC's inputs; returns the transcript pieces a test compares with the oracle
 int hobbit_host_test_pc_open(size_t N, int K, unsigned seed, uint64_t *qpoly, uint64_t *r, uint32_t *cols_rows, uint8_t *sp_roots /* C_f, C_c, whir_c, whir_f */, int *checks5, double *ps_out) {

@@ -96,6 +96,7 @@ void fft(vector<F> &arr, int logn, bool flag);
 void _fft(F *arr, int logn, bool flag);
 /* src/expanders.h:78 ; src/linear_code_encode.h:62 */
 long long expander_init_store(long long n, int dep = 0);
+void hobbit_host_upload_graphs(long long n);                    /* device upload of the graphs already in _C / D (drawn by another copy of expander_init_store) */
 int encode_monolithic(const F *src, F *dst, long long n, int dep = 0);
 /* src/Blake3_hash.h:9 */
 void blake3_hash(uint8_t *src, uint8_t *dst);

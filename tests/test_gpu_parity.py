@@ -423,6 +423,8 @@ def test_cpp_host_mirror_test_pc_and_sumcheck(oracle):
     lib.hobbit_host_test_pc_root.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
     levels = lib.hobbit_host_test_pc_root(1 << 20, 32, root.ctypes.data_as(ctypes.c_void_p))   # test_PC(2^20,4,32) input sequence
     assert levels == 16 and np.array_equal(root, g["c_1048576_32_root"])
+    lib.hobbit_host_graph_reupload_check.argtypes = [ctypes.c_size_t, ctypes.c_int]
+    assert lib.hobbit_host_graph_reupload_check(1 << 20, 32) == 1          # graphs re-uploaded from the host arrays _C / D give the same commitment
     n = 1 << 10
     v1, v2, _, _, _ = golden_cases.sumcheck_inputs(n)
     pr = np.array([33, 0], np.uint64)
