@@ -8,7 +8,7 @@ mod = load_package(); hb = mod.Hobbit(0)
 N, K = 1 << 28, 32; trs = N // (K << 11)
 d = hb.fill_splitmix(N, 1000); hb.rng_reset(); hb.expander_init_store(trs)
 x = np.stack([np.arange(1, 29, dtype=np.uint64), np.arange(7, 35, dtype=np.uint64)], axis=1)
-for it in range(8):
+for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
     hb.sync()
     t0 = time.perf_counter(); c = hb.commit_standard((d, N), K, trs, 1); t1 = time.perf_counter()
     r = hb.open_core((d, N), c, x, 5900, full=True); t2 = time.perf_counter(); c.free(); t3 = time.perf_counter()
