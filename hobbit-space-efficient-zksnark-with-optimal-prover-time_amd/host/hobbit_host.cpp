@@ -544,11 +544,16 @@ vector<F> prepare_matrix(vector<vector<F>> M, vector<F> r) {       // src/utils.
 }
 
 // ---- Elastic_PC streaming commit (src/Elastic_PC.cpp:174-285, 728-771) ------------------------------
+// HOBBIT_HOST_REFERENCE_BUILD: the mirror is loaded in FRONT of the reference's own objects (tests/test_mlp_end_to_end.py: symbol
+// interposition, nothing of the reference is recompiled or edited) -- the witness generator's stream readers are then the reference's,
+// serving every stream, and the stand-alone readers below (synthetic default streams only) are left out.
+#ifndef HOBBIT_HOST_REFERENCE_BUILD
 void read_stream_PC(stream_descriptor &fd, F *v, int size) {       // src/witness_stream.cpp:2405-2411 (default branch)
     if (fd.name == "PC_layer" || fd.name == "witness" || fd.name == "circuit") { printf("Error: stream '%s' belongs to the witness generator (out of scope)\n", fd.name.c_str()); exit(-1); }
     F n = F(322322);
     for (int i = 0; i < size; i++) { v[i] = n; n = n * n + F(i); }
 }
+#endif
 void init_commitment(bool mod) {                                    // src/Elastic_PC.cpp:728-734
     linear_time = mod;
     tensor_row_size = (int)(BUFFER_SPACE / (1ULL << 11));
@@ -582,11 +587,13 @@ void commit(stream_descriptor fd, _hash &comm, vector<vector<_hash>> &MT_hashes)
     MT_hashes.resize(levels);
     for (size_t l = 0, sz = T; l < levels; l++, sz /= 2) { MT_hashes[l].resize(sz); lv.to_host(MT_hashes[l].data(), 32 * sz, 32 * off); off += sz; }
 }
+#ifndef HOBBIT_HOST_REFERENCE_BUILD
 void read_stream(stream_descriptor &fd, vector<F> &v, int size) {   // src/witness_stream.cpp:2106, default branch :2348-2352
     if (fd.name == "input" || fd.name == "circuit" || fd.name == "witness" || fd.name == "transcript_stream" || fd.name.find("lookup") == 0 ||
         fd.name.find("wiring_consistency_check") == 0) { printf("Error: stream '%s' belongs to the witness generator (out of scope)\n", fd.name.c_str()); exit(-1); }
     for (int i = 0; i < size; i++) v[i] = F((i % 1024) + 1);
 }
+#endif
 // src/Elastic_PC.cpp:625-726, !linear_time (RS x RS).  Prover side on the device (hobbit_elastic_open_*: libc draws in the reference's
 // order, the stream re-read twice through read_stream as the reference does); the verifier emulation is reduced to its ps accounting.
 void open(stream_descriptor fd, vector<F> x, vector<vector<_hash>> &Commitment_MT, double &vt, double &ps) {
@@ -602,14 +609,15 @@ void open(stream_descriptor fd, vector<F> x, vector<vector<_hash>> &Commitment_M
     hobbit_elastic_open *e = nullptr;
     HCHK(hobbit_elastic_open_begin(hobbit_host_ctx(), fd.size, B, trs, hF(x.data()), queries, &e));
     vector<F> buff(B); DevBuf d(B * sizeof(F));
+    stream_descriptor fd_a = fd, fd_r = fd;                          // aggregate and compute_aggregation_reply each take the descriptor BY VALUE (:316, :487)
     for (size_t i = 0; i < K; i++) {                                 // aggregate (:327-334)
-        read_stream(fd, buff, (int)B);
+        read_stream(fd_a, buff, (int)B);
         HCHK(hobbit_memcpy_h2d(g_ctx, d.p, buff.data(), B * sizeof(F)));
         HCHK(hobbit_elastic_open_aggregate_push(g_ctx, e, (const hobbit_F *)d.p));
     }
     HCHK(hobbit_elastic_open_aggregate_finish(g_ctx, e));
     for (size_t i = 0; i < K; i++) {                                 // compute_aggregation_reply (:506-531)
-        read_stream(fd, buff, (int)B);
+        read_stream(fd_r, buff, (int)B);
         HCHK(hobbit_memcpy_h2d(g_ctx, d.p, buff.data(), B * sizeof(F)));
         HCHK(hobbit_elastic_open_reply_push(g_ctx, e, (const hobbit_F *)d.p));
     }
@@ -782,7 +790,7 @@ static int host_stream_source(void *user, size_t n, const hobbit_F **out) {
     HostStream *hs = (HostStream *)user;
     if (n == 0) { hs->fd.pos = 0; hs->fd.idx = 0; hs->fd.stage = 0; hs->fd.offset = 0; hs->fd.finished = false; return 0; }          // reset_stream (src/witness_stream.cpp:228-234)
     auto t0 = std::chrono::steady_clock::now();
-    if (hs->buf.size() < n) hs->buf.resize(n);
+    if (hs->buf.size() != n) hs->buf.resize(n);                     // (some branches of the reference's read_stream size their work by v.size())
     read_stream(hs->fd, hs->buf, (int)n);
     if (hs->cap < n) { delete hs->dev; hs->dev = new DevBuf(n * sizeof(F)); hs->cap = n; }
     if (hobbit_memcpy_h2d(g_ctx, hs->dev->p, hs->buf.data(), n * sizeof(F)) != 0) return 1;
@@ -887,7 +895,10 @@ vector<F> prove_multiplication_tree_stream_shallow(stream_descriptor fd, int vec
 size_t circuit_size = 0;
 void (*hobbit_read_trace_hook)(stream_descriptor &, vector<F> &, vector<F> &, vector<F> &, vector<int> &) = nullptr;
 void (*hobbit_read_memory_hook)(stream_descriptor &, vector<F> &, vector<F> &, vector<F> &) = nullptr;
+#ifndef HOBBIT_HOST_REFERENCE_BUILD
 void reset_stream(stream_descriptor &fd) { fd.pos = 0; fd.idx = 0; fd.stage = 0; fd.offset = 0; fd.finished = false; }
+#endif
+#ifndef HOBBIT_HOST_REFERENCE_BUILD            /* (src/main.cpp keeps its own prove_circuit_standard there) */
 static struct { uint8_t circuit_root[32], witness_root[32]; F mul_final_eval; vector<F> mul_output; double ps = 0, vt = 0; } g_pcs;
 void prove_circuit_standard() {
     if (!hobbit_read_trace_hook || !hobbit_read_memory_hook) { printf("Error: prove_circuit_standard needs the witness generator's read_trace / read_memory (hobbit_read_trace_hook, hobbit_read_memory_hook)\n"); exit(-1); }
@@ -950,6 +961,7 @@ void prove_circuit_standard() {
     g_pcs.ps = ps; g_pcs.vt = vt;
     printf("Vt : %lf, Ps : %lf\n", vt, ps);
 }
+#endif
 
 // ---- prove_gate_consistency / _lookups (src/sumcheck.cpp:796-975, 503-795) over the witness generator's read_trace ----------------
 bool has_lookups = false;
@@ -1216,6 +1228,7 @@ static void syn_read_memory(stream_descriptor &fd, vector<F> &ba, vector<F> &bv,
     const size_t B = ba.size(), at = fd.pos * B; fd.pos++;
     for (size_t j = 0; j < B; j++) { ba[j] = g_syn.addr[at + j]; bv[j] = g_syn.value[at + j]; bc[j] = g_syn.access[at + j]; }
 }
+#ifndef HOBBIT_HOST_REFERENCE_BUILD
 int hobbit_host_prove_circuit_standard(size_t cs, size_t B, unsigned seed, const uint64_t *L, const uint64_t *R, const uint64_t *O, const int *S, const uint64_t *addr,
                                        const uint64_t *value, const uint64_t *access, uint8_t *roots2, uint64_t *mul_out /* 8 products + final_eval */,
                                        uint64_t *open_w_r /* witness opening: challenges */, uint64_t *open_c_r /* circuit opening: challenges */, int *rounds2, double *ps_out) {
@@ -1235,6 +1248,7 @@ int hobbit_host_prove_circuit_standard(size_t cs, size_t B, unsigned seed, const
     linear_time = true;
     return 0;
 }
+#endif
 // prove_gate_consistency[_lookups] through the mirror over a caller-supplied trace (L, R, O: n F; S: n int): the challenges R and the final
 // folded values come back for the comparison with the oracle
 int hobbit_host_gate_stream(size_t n, size_t B, int lookups, unsigned seed, const uint64_t *L, const uint64_t *R, const uint64_t *O, const int *S, const uint64_t *r,
