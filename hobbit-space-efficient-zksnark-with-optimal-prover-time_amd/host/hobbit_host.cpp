@@ -785,13 +785,30 @@ void shockwave_prove(shockwave_data *data, vector<F> x, double &vt, double &ps) 
 }
 // the streaming multiplication-tree prover over read_stream: the stream is re-generated on the host exactly as the reference does, every
 // read is uploaded and handed to the library as a chunk source
-struct HostStream { stream_descriptor fd; vector<F> buf; DevBuf *dev = nullptr; size_t cap = 0; };
+struct HostStream { stream_descriptor fd; vector<F> buf; DevBuf *dev = nullptr; size_t cap = 0; size_t small_n = 0; };
+#ifdef HOBBIT_HOST_REFERENCE_BUILD
+#include <dlfcn.h>
+static int &seval_ring_len() {                                     // the Seval ring's length, `int BUFFER_SPACE_tr` (src/main.cpp:58); a data symbol of
+    static int *p = (int *)dlsym(RTLD_DEFAULT, "BUFFER_SPACE_tr"); //  the library loaded AFTER this one, so looked up at run time
+    if (!p) { printf("Error: BUFFER_SPACE_tr not found (reference build of the mirror without the reference loaded)\n"); exit(-1); }
+    return *p;
+}
+#endif
 static int host_stream_source(void *user, size_t n, const hobbit_F **out) {
     HostStream *hs = (HostStream *)user;
     if (n == 0) { hs->fd.pos = 0; hs->fd.idx = 0; hs->fd.stage = 0; hs->fd.offset = 0; hs->fd.finished = false; return 0; }          // reset_stream (src/witness_stream.cpp:228-234)
     auto t0 = std::chrono::steady_clock::now();
     if (hs->buf.size() != n) hs->buf.resize(n);                     // (some branches of the reference's read_stream size their work by v.size())
+#ifdef HOBBIT_HOST_REFERENCE_BUILD
+    // a product layer no longer than BUFFER_SPACE is read with the oracle's ring shortened to match (src/sumcheck.cpp:1802-1808): the
+    // reference's trace readers copy a whole ring into the buffer without a bound
+    const bool small = hs->small_n && n == hs->small_n;
+    if (small) seval_ring_len() = (int)(n / 16);
     read_stream(hs->fd, hs->buf, (int)n);
+    if (small) seval_ring_len() = (int)(BUFFER_SPACE / 8);
+#else
+    read_stream(hs->fd, hs->buf, (int)n);
+#endif
     if (hs->cap < n) { delete hs->dev; hs->dev = new DevBuf(n * sizeof(F)); hs->cap = n; }
     if (hobbit_memcpy_h2d(g_ctx, hs->dev->p, hs->buf.data(), n * sizeof(F)) != 0) return 1;
     routine_time += std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::steady_clock::now() - t0).count();       // "streaming time" (src/sumcheck.cpp:1185-1188)
@@ -837,7 +854,8 @@ struct S3Buffers {   // host buffers behind one hobbit_stream3_out
 static void s3_check(const S3Buffers &b, double &ps, int batches, int rounds1, int rounds2) {
     if (!b.checks[1]) { printf("Error in sumcheck 1\n"); exit(-1); }                                            // src/sumcheck.cpp:1280-1283
     if (!b.checks[2]) { printf("Error in sumcheck 2\n"); exit(-1); }                                            // (:1362-1365)
-    ps += (1 + batches) * sizeof(F) / 1024.0;                                                                   // (:1214)
+    ps += (1 + batches) * sizeof(F) / 1024.0;                                                                   // (:1212)
+    ps += (double)(((size_t)1 << rounds2) - 1) * (1 + batches) * sizeof(F) / 1024.0;                            // one batch_prod per half chunk after the first (:1128; R ends 2^rounds2 long)
     ps += rounds1 * 4 * sizeof(F) / 1024.0 + 2 * batches * sizeof(F) / 1024.0;                                  // batch_3product_sumcheck
     ps += rounds2 * 3 * sizeof(F) / 1024.0 + 2 * sizeof(F) / 1024.0;                                            // the closing 2-product sumcheck
 }
@@ -865,6 +883,7 @@ vector<F> prove_multiplication_tree_stream_shallow(stream_descriptor fd, int vec
     if (total > 2 * B && !naive) commit_layers(fd, fd_com, MT_layers, layers / distance, distance - 1, distance);        // (:1791-1795)
     HostStream hs; hs.fd = fd;
     const size_t n1 = total > 2 * B ? fd.size >> layers : total; const size_t sz = n1 / vectors;
+    if (total > 2 * B && n1 <= B) hs.small_n = 2 * n1;              // read_mul_tree_layer's read length for that layer (src/witness_stream.cpp:2436)
     const int lt = (int)log2((double)n1), depth = (int)log2((double)sz); size_t nr = 0; for (int i = 0; i < lt; i++) nr += (size_t)i;
     vector<F> out(vectors), q(4 * (nr + 1)), r(nr + 1), vr(3 * (size_t)depth + 3), fin(depth + 1), final_r(lt); F oe, fe; int tl = 0, nst = 0, sl = 0;
     vector<S3Buffers *> bufs; vector<hobbit_stream3_out> steps;
@@ -880,6 +899,8 @@ vector<F> prove_multiplication_tree_stream_shallow(stream_descriptor fd, int vec
                                         prev_x.empty() ? nullptr : hF(prev_x.data()), naive ? 1 : 0, &mo));
     delete hs.dev;
     const int logB = (int)log2((double)B);
+    for (int l = 0, rl = vectors == 1 ? 1 : (int)log2((double)vectors); l < tl; l++, rl++)                        // the in-memory tree's layers (:1772/:1820 ->
+        ps += ((size_t)rl * 5 + 3) * sizeof(F) / 1024.0;                                                         //  _generate_3product_sumcheck_proof, :2031,2048)
     for (int i = 0; i < nst; i++) {
         printf("OK %d\n", nst - 1 - i);                                                                           // (:1857)
         if (!bufs[i]->checks[0]) printf("Error in sumcheck 0 0\n");

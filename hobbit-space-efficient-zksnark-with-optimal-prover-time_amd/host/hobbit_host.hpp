@@ -23,6 +23,14 @@ namespace virgo {
 class fieldElement {
 public:
     fieldElement() : real(0), img(0) {}
+#ifdef HOBBIT_HOST_REFERENCE_BUILD
+    // The reference declares these two (src/fieldElement.hpp:24,44): a user-provided copy constructor makes the class non-trivial for the
+    // purposes of calls, so an F passed or returned by value travels through a hidden pointer instead of two registers.  The mirror must
+    // agree with the reference's objects on that when both sit in one process (found the hard way: prove_multiplication_tree_stream_shallow
+    // takes `F previous_r` by value).
+    fieldElement(const fieldElement &b) : real(b.real), img(b.img) {}
+    fieldElement &operator=(const fieldElement &b) { real = b.real; img = b.img; return *this; }
+#endif
     fieldElement(long long x);
     fieldElement(long long x, long long y);
     fieldElement operator+(const fieldElement &o) const;

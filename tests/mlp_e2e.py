@@ -31,6 +31,12 @@ def main():
         if not h:
             sys.exit("dlopen %s: %s" % (path, dlerror().decode()))
         return h
+    if os.environ.get("HOBBIT_E2E_BACKTRACE"):
+        import subprocess                           # debugging aid: a backtrace on SIGSEGV/SIGABRT (tests/aux/segv_bt.c), built on demand
+        so = os.path.join(ROOT, "tests", "aux", "libsegv_bt.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["gcc", "-O1", "-g", "-fPIC", "-shared", "-o", so, os.path.join(ROOT, "tests", "aux", "segv_bt.c")])
+        bt = ctypes.CDLL(so); bt.segv_bt_install()
     load(os.path.join(PKG, "libhobbit_hip.so"))
     h_mir = load(os.path.join(PKG, "libhobbit_host_refmode.so"))          # first in the lookup order
     h_ref = load(os.path.join(ROOT, "oracle", "_ref", "libhobbit_ref.so"))
