@@ -902,7 +902,7 @@ vector<F> prove_multiplication_tree_stream_shallow(stream_descriptor fd, int vec
     for (int l = 0, rl = vectors == 1 ? 1 : (int)log2((double)vectors); l < tl; l++, rl++)                        // the in-memory tree's layers (:1772/:1820 ->
         ps += ((size_t)rl * 5 + 3) * sizeof(F) / 1024.0;                                                         //  _generate_3product_sumcheck_proof, :2031,2048)
     for (int i = 0; i < nst; i++) {
-        printf("OK %d\n", nst - 1 - i);                                                                           // (:1857)
+        printf(layers <= distance || naive ? "OK %d\n" : "~OK %d\n", nst - 1 - i);                                // (:1861, :1889)
         if (!bufs[i]->checks[0]) printf("Error in sumcheck 0 0\n");
         const int batches = (int)bufs[i]->nc.size();
         s3_check(*bufs[i], ps, batches, logB, (int)bufs[i]->r2.size());

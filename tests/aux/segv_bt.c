@@ -13,3 +13,15 @@ static void handler(int sig) {
     _exit(128 + sig);
 }
 void segv_bt_install(void) { signal(SIGSEGV, handler); signal(SIGABRT, handler); signal(SIGBUS, handler); }
+
+/* and on every C++ throw (the library is loaded RTLD_GLOBAL ahead of libstdc++, so the PLT calls land here first) */
+#include <dlfcn.h>
+void __cxa_throw(void *obj, void *tinfo, void (*dest)(void *)) {
+    void *bt[64];
+    int n = backtrace(bt, 64);
+    fprintf(stderr, "__cxa_throw, backtrace:\n");
+    backtrace_symbols_fd(bt, n, 2);
+    void (*real)(void *, void *, void (*)(void *)) = (void (*)(void *, void *, void (*)(void *)))dlsym(RTLD_NEXT, "__cxa_throw");
+    real(obj, tinfo, dest);
+    abort();
+}

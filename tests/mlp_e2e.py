@@ -35,11 +35,11 @@ def main():
         import subprocess                           # debugging aid: a backtrace on SIGSEGV/SIGABRT (tests/aux/segv_bt.c), built on demand
         so = os.path.join(ROOT, "tests", "aux", "libsegv_bt.so")
         if not os.path.exists(so):
-            subprocess.check_call(["gcc", "-O1", "-g", "-fPIC", "-shared", "-o", so, os.path.join(ROOT, "tests", "aux", "segv_bt.c")])
-        bt = ctypes.CDLL(so); bt.segv_bt_install()
+            subprocess.check_call(["gcc", "-O1", "-g", "-fPIC", "-shared", "-o", so, os.path.join(ROOT, "tests", "aux", "segv_bt.c"), "-ldl"])
+        bt = ctypes.CDLL(so, mode=RTLD_GLOBAL | RTLD_LAZY); bt.segv_bt_install()
     load(os.path.join(PKG, "libhobbit_hip.so"))
     h_mir = load(os.path.join(PKG, "libhobbit_host_refmode.so"))          # first in the lookup order
-    h_ref = load(os.path.join(ROOT, "oracle", "_ref", "libhobbit_ref.so"))
+    h_ref = load(os.path.join(ROOT, "oracle", "_ref", os.environ.get("HOBBIT_E2E_REFLIB", "libhobbit_ref.so")))
     # the mirror's gate prover reads the trace through a hook: the reference's read_trace
     hook = dlsym(h_mir, b"hobbit_read_trace_hook")
     rt = dlsym(h_ref, b"_Z10read_traceR17stream_descriptorRSt6vectorIN5virgo12fieldElementESaIS3_EES6_S6_RS1_IiSaIiEE")

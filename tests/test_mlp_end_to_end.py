@@ -52,12 +52,29 @@ def test_mlp_prover_end_to_end():
     print("MLP end to end: Pt %.3f s (streaming %.3f s), Ps %.4f KB" % (pt, st, ps))
 
 
-@pytest.mark.parametrize("args", [(2, 16, 16, 1), (6, 16, 14, 1)], ids=["range_lookup", "sql_range"])
+@pytest.mark.parametrize("args", [(5, 18, 8, 1), (6, 18, 16, 1), (2, 18, 18, 1)], ids=["aes", "sql_range", "range_lookup"])
 def test_lookup_circuits_end_to_end(args):
-    """has_lookups branch of prove_circuit (src/main.cpp:887-945): two live commitments, two streaming multiplication trees, the lookup
-    gate prover, two opens, then the reference's own product check over its lookup tables"""
+    """has_lookups branch of prove_circuit (src/main.cpp:887-945; test_aes.sh / sql_test.sh shapes at B = 2^18): two live commitments, two
+    streaming multiplication trees (the range circuit's is 6 layers deep: the batched variant with commit_layers / generate_claims_opt /
+    open_layers), the lookup gate prover, two opens, then the reference's own product check over its lookup tables"""
     rc, out = run(list(args))
     assert rc == 0, out[-2000:]
-    assert ">> Error" not in out, out[-2000:]
+    assert ">> Error" not in out and "Error in" not in out, out[-2000:]
     assert out.rstrip().splitlines()[-1] == "OK", out[-2000:]
+    final_line(out)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libhobbit_ref_O0streams.so")), reason="oracle/_ref O0-streams flavour not built")
+@pytest.mark.parametrize("args", [(1, 18, 18, 1), (7, 18, 18, 1)], ids=["arithmetic", "dummy"])
+def test_arbitrary_circuit_end_to_end(args):
+    """prove_arbitrary_circuit (src/main.cpp:812-857; test_arb.sh shape at B = 2^18): the MLP flow plus an open of the "circuit" stream,
+    whose last chunks are all zero (compute_aggregation_reply skips them: shorter replies).  The reference's read_memory_circuit has no
+    return statement, so this one loads the flavour of oracle/_ref whose stream readers are compiled as the reference's CMakeLists.txt
+    compiles them, without optimisation (oracle/Makefile)."""
+    env = dict(os.environ, HOBBIT_E2E_REFLIB="libhobbit_ref_O0streams.so")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mlp_e2e.py")] + [str(a) for a in args], capture_output=True, text=True, timeout=300, env=env)
+    out = p.stdout + p.stderr
+    assert p.returncode == 0, out[-2000:]
+    assert "Error" not in out, out[-2000:]
+    assert len([l for l in out.splitlines() if l.startswith("PC : ps")]) == 2
     final_line(out)
