@@ -45,6 +45,18 @@ hobbit_host_open_transcript &hobbit_host_last_open() { return g_open; }
 
 #define HCHK(call) do { int rc__ = (call); if (rc__ != 0) { printf("Error in %s: %s\n", #call, hobbit_last_error(g_ctx)); exit(-1); } } while (0)
 
+// HOBBIT_HOST_TIMING=1: every streaming entry point prints its wall time and the share spent in the stream readers / the uploads
+static const bool g_timing = getenv("HOBBIT_HOST_TIMING") != nullptr;
+static double g_t_read = 0, g_t_up = 0;
+static inline double now_s() { return std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct PhaseTimer {
+    const char *name; double t0, r0, u0;
+    explicit PhaseTimer(const char *n) : name(n), t0(now_s()), r0(g_t_read), u0(g_t_up) {}
+    ~PhaseTimer() { if (g_timing) printf("[hobbit] %-28s wall %9.3f ms  stream readers %9.3f ms  uploads %8.3f ms\n", name, 1e3 * (now_s() - t0), 1e3 * (g_t_read - r0), 1e3 * (g_t_up - u0)); }
+};
+#define TIMED_READ(stmt) do { double t__ = now_s(); stmt; g_t_read += now_s() - t__; } while (0)
+#define TIMED_UP(stmt) do { double t__ = now_s(); stmt; g_t_up += now_s() - t__; } while (0)
+
 hobbit_ctx *hobbit_host_ctx() {
     if (!g_ctx) {
         const char *d = getenv("HOBBIT_DEVICE");
@@ -561,7 +573,7 @@ void init_commitment(bool mod) {                                    // src/Elast
 }
 static int pc_layer_chunk(stream_descriptor &raw, int layer, size_t B, void *d_out);
 void commit(stream_descriptor fd, _hash &comm, vector<vector<_hash>> &MT_hashes) {   // src/Elastic_PC.cpp:174-285
-    (void)comm;
+    (void)comm; PhaseTimer pt__("commit");
     if (fd.size / BUFFER_SPACE < 4) printf("Decrease buffer size %d\n", (int)(fd.size / BUFFER_SPACE));
     hobbit_elastic *e = nullptr;
     HCHK(hobbit_elastic_begin(hobbit_host_ctx(), BUFFER_SPACE, tensor_row_size, linear_time ? 1 : 0, 1, &e));
@@ -574,8 +586,8 @@ void commit(stream_descriptor fd, _hash &comm, vector<vector<_hash>> &MT_hashes)
             stream_descriptor raw = fd; raw.name = "test";
             if (pc_layer_chunk(raw, (int)fd.layer, BUFFER_SPACE, d.p) != 0) { printf("Error: PC_layer chunk\n"); exit(-1); }
         } else {
-            read_stream_PC(fd, buff.data(), (int)BUFFER_SPACE);
-            HCHK(hobbit_memcpy_h2d(g_ctx, d.p, buff.data(), BUFFER_SPACE * sizeof(F)));
+            TIMED_READ(read_stream_PC(fd, buff.data(), (int)BUFFER_SPACE));
+            TIMED_UP(HCHK(hobbit_memcpy_h2d(g_ctx, d.p, buff.data(), BUFFER_SPACE * sizeof(F))));
         }
         HCHK(hobbit_elastic_push(g_ctx, e, (const hobbit_F *)d.p));
     }
@@ -603,6 +615,7 @@ void open(stream_descriptor fd, vector<F> x, vector<vector<_hash>> &Commitment_M
         printf("Error: Elastic_PC::open with linear_time (option 2) is undefined in the reference (update_reply_spielman reads past its vector); not built\n");
         exit(-1);
     }
+    PhaseTimer pt__("open");
     const int queries = 700; aggregation_queries = queries;
     const size_t B = BUFFER_SPACE, K = fd.size / B; const int trs = tensor_row_size;
     const int logc = 12, logr = (int)log2((double)(2 * trs)), logt = logr - 1, depth = (int)log2((double)(4 * B));
@@ -611,14 +624,14 @@ void open(stream_descriptor fd, vector<F> x, vector<vector<_hash>> &Commitment_M
     vector<F> buff(B); DevBuf d(B * sizeof(F));
     stream_descriptor fd_a = fd, fd_r = fd;                          // aggregate and compute_aggregation_reply each take the descriptor BY VALUE (:316, :487)
     for (size_t i = 0; i < K; i++) {                                 // aggregate (:327-334)
-        read_stream(fd_a, buff, (int)B);
-        HCHK(hobbit_memcpy_h2d(g_ctx, d.p, buff.data(), B * sizeof(F)));
+        TIMED_READ(read_stream(fd_a, buff, (int)B));
+        TIMED_UP(HCHK(hobbit_memcpy_h2d(g_ctx, d.p, buff.data(), B * sizeof(F))));
         HCHK(hobbit_elastic_open_aggregate_push(g_ctx, e, (const hobbit_F *)d.p));
     }
     HCHK(hobbit_elastic_open_aggregate_finish(g_ctx, e));
     for (size_t i = 0; i < K; i++) {                                 // compute_aggregation_reply (:506-531)
-        read_stream(fd_r, buff, (int)B);
-        HCHK(hobbit_memcpy_h2d(g_ctx, d.p, buff.data(), B * sizeof(F)));
+        TIMED_READ(read_stream(fd_r, buff, (int)B));
+        TIMED_UP(HCHK(hobbit_memcpy_h2d(g_ctx, d.p, buff.data(), B * sizeof(F))));
         HCHK(hobbit_elastic_open_reply_push(g_ctx, e, (const hobbit_F *)d.p));
     }
     // the commitment tree, flat, back on the device for the paths
@@ -804,13 +817,13 @@ static int host_stream_source(void *user, size_t n, const hobbit_F **out) {
     // reference's trace readers copy a whole ring into the buffer without a bound
     const bool small = hs->small_n && n == hs->small_n;
     if (small) seval_ring_len() = (int)(n / 16);
-    read_stream(hs->fd, hs->buf, (int)n);
+    TIMED_READ(read_stream(hs->fd, hs->buf, (int)n));
     if (small) seval_ring_len() = (int)(BUFFER_SPACE / 8);
 #else
-    read_stream(hs->fd, hs->buf, (int)n);
+    TIMED_READ(read_stream(hs->fd, hs->buf, (int)n));
 #endif
     if (hs->cap < n) { delete hs->dev; hs->dev = new DevBuf(n * sizeof(F)); hs->cap = n; }
-    if (hobbit_memcpy_h2d(g_ctx, hs->dev->p, hs->buf.data(), n * sizeof(F)) != 0) return 1;
+    { double t__ = now_s(); if (hobbit_memcpy_h2d(g_ctx, hs->dev->p, hs->buf.data(), n * sizeof(F)) != 0) return 1; g_t_up += now_s() - t__; }
     routine_time += std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::steady_clock::now() - t0).count();       // "streaming time" (src/sumcheck.cpp:1185-1188)
     *out = (const hobbit_F *)hs->dev->p;
     return 0;
@@ -876,6 +889,7 @@ void generate_3product_sumcheck_beta_stream_batch_optimized(stream_descriptor fd
     for (int i = 0; i < batches; i++) new_r[i].assign(b.nr.begin() + (size_t)i * b.o.new_r_ld, b.nr.begin() + (size_t)i * b.o.new_r_ld + 1 + (logB - i * distance) + lR);
 }
 vector<F> prove_multiplication_tree_stream_shallow(stream_descriptor fd, int vectors, int size, F previous_r, int distance, vector<F> prev_x, bool naive, double &vt, double &ps) {   // src/sumcheck.cpp:1746-1915
+    PhaseTimer pt__("multiplication tree (stream)");
     const size_t total = (size_t)size * vectors, B = BUFFER_SPACE;
     int layers = total > 2 * B ? (int)log2((double)(total / (2 * B))) : 0;
     if (layers % distance != 0 && layers > distance) layers = distance + layers - (layers % distance);
@@ -1000,14 +1014,17 @@ static int host_trace_source(void *user, size_t n, const hobbit_F **L, const hob
     HostTrace *t = (HostTrace *)user;
     if (n == 0) { reset_stream(t->fd); return 0; }                                                              // (:871 / :643)
     if (n != t->B || !hobbit_read_trace_hook) return -1;
-    hobbit_read_trace_hook(t->fd, t->bL, t->bR, t->bO, t->bS);
+    TIMED_READ(hobbit_read_trace_hook(t->fd, t->bL, t->bR, t->bO, t->bS));
+    double t__ = now_s();
     if (hobbit_memcpy_h2d(g_ctx, t->dL.p, t->bL.data(), n * sizeof(F)) || hobbit_memcpy_h2d(g_ctx, t->dR.p, t->bR.data(), n * sizeof(F)) ||
         hobbit_memcpy_h2d(g_ctx, t->dO.p, t->bO.data(), n * sizeof(F)) || hobbit_memcpy_h2d(g_ctx, t->dS.p, t->bS.data(), n * sizeof(int32_t))) return -1;
+    g_t_up += now_s() - t__;
     *L = (const hobbit_F *)t->dL.p; *R = (const hobbit_F *)t->dR.p; *O = (const hobbit_F *)t->dO.p; *S = (const int32_t *)t->dS.p;
     return 0;
 }
 static void gate_stream_common(stream_descriptor &tr, vector<F> &r, bool lookups, double &vt, double &ps) {
     if (!hobbit_read_trace_hook) { printf("Error: the streaming gate provers need the witness generator's read_trace (hobbit_read_trace_hook)\n"); exit(-1); }
+    PhaseTimer pt__(lookups ? "gate consistency (lookups)" : "gate consistency");
     hobbit_host_ctx();
     const size_t B = BUFFER_SPACE, nch = tr.size / B;
     const int logB = (int)log2((double)B), lR = (int)log2((double)nch);
