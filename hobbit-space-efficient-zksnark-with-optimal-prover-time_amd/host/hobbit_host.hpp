@@ -68,6 +68,7 @@ class cubic_poly { public: F a, b, c, d; cubic_poly() {} cubic_poly(const F &aa,
     F eval(const F &x) const { return (((a * x) + b) * x + c) * x + d; } };
 
 /* src/sumcheck.h:21-43 (the members the hot-path functions fill) */
+#ifndef HOBBIT_HOST_REFERENCE_BUILD
 struct proof {
     int type = 0;
     vector<vector<F>> randomness;
@@ -76,6 +77,31 @@ struct proof {
     vector<F> vr;
     F final_rand;
 };
+#else
+/* in front of the reference's own objects a `proof` (and the mul_tree_proof that holds a vector of them) is returned BY VALUE into storage
+ * the reference's code laid out and will destroy: every member of src/sumcheck.h:21-43, in its order */
+struct proof {
+    int type = 0;
+    vector<vector<F>> randomness;
+    vector<quadratic_poly> q_poly;
+    vector<cubic_poly> c_poly;
+    vector<F> output;
+    vector<F> vr;
+    vector<F> gr;
+    vector<F> liu_sum;
+    vector<vector<F>> sig;
+    vector<vector<F>> final_claims_v;
+    F divident, divisor, quotient, remainder;
+    vector<vector<vector<F>>> w_hashes;
+    vector<F> r, individual_sums;
+    vector<vector<F>> Partial_sums;
+    vector<quadratic_poly> q_poly1;
+    vector<quadratic_poly> q_poly2;
+    F final_rand;
+    F final_sum;
+    int K = 0;
+};
+#endif
 
 /* src/expanders.h:7-16 */
 class graph {

@@ -78,3 +78,17 @@ def test_arbitrary_circuit_end_to_end(args):
     assert "Error" not in out, out[-2000:]
     assert len([l for l in out.splitlines() if l.startswith("PC : ps")]) == 2
     final_line(out)
+
+
+def test_prove_circuit_standard_end_to_end():
+    """`./pigeon 11 18 18 1`: the reference's OWN prove_circuit_standard (src/main.cpp:985-1087; compiled out of the reference-build
+    mirror) over the mirror's commit_standard (RS x RS circuit polynomial, then RS x expander witness: two live commitments),
+    prove_multiplication_tree_new (mul_tree_proof returned by value into the reference's layout), prove_gate_consistency_standard and both
+    open_standard modes on the real trace / memory streams; every consistency check of those functions exits non-zero on failure."""
+    rc, out = run([11, 18, 18, 1])
+    assert rc == 0, out[-2000:]
+    assert "Error" not in out and "error" not in out, out[-2000:]
+    assert out.count(">>OK") == 2, out[-2000:]
+    m = re.search(r"Pt : ([0-9.]+), Vt : ([0-9.]+), Ps : ([0-9.]+)", out)
+    assert m, out[-2000:]
+    assert float(m.group(3)) > 0
