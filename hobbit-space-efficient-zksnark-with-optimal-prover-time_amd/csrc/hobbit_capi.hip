@@ -273,6 +273,7 @@ void hobbit_ctx_destroy(hobbit_ctx *ctx) {
     if (ctx->spare_tensor) hipFree(ctx->spare_tensor);
     if (ctx->spare_levels) hipFree(ctx->spare_levels);
     hipEventDestroy(ctx->t0); hipEventDestroy(ctx->t1);
+    if (ctx->side) { hipStreamSynchronize(ctx->side); for (auto &e : ctx->side_ev) if (e) hipEventDestroy(e); hipStreamDestroy(ctx->side); }
     if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -539,14 +540,36 @@ static int tensorcode_chunks(hobbit_ctx *ctx, const F *d_msg, size_t M, int K, i
     // transposed layout directly (one launch less, the scattered stores stay in L2).
     if ((size_t)K * trs * cols * sizeof(F) >= ((size_t)64 << 20)) {
         F *rm; HB_TRY(ctx->workspace2((size_t)K * trs * cols * sizeof(F), (void **)&rm));
-        HB_TRY(fft_rows(ctx, d_msg, half, (uint32_t)half, rm, cols, 1, logc, false, (uint32_t)K, (uint32_t)trs, M, (size_t)trs * cols));
         const char *es_env = getenv("HOBBIT_ENC_STRIDED"); const bool enc_strided = es_env && es_env[0] == '1';
-        if (lin && enc_strided && trs > 13 && ctx->code.n == trs && ((size_t)K * cols) % 64 == 0) {
-            // EXPERIMENT (off by default, measured slower: DESIGN.md 4): no transpose pass, the encode reads its message as a strided
-            // column of the row-major FFT output (8 adjacent columns on one XCD) and writes message + parity contiguously
-            return launch_encode_strided(ctx, rm, 0, (uint32_t)cols, (uint32_t)cols, (size_t)trs * cols, d_out, rows2, trs, (size_t)K * cols, 1, nullptr);
+        // Two-stream pipeline over chunk groups (default on; HOBBIT_COMMIT_PIPE=0 turns it off, =G asks for G groups): group g's layout
+        // change (HBM-bound, next to no VALU work) runs on the side stream while group g+1's row FFT (VALU-bound, one pass over the
+        // data) runs on the main one.  Same kernels, same bytes, bit-identical tensor; DESIGN.md section 4 has the A/B.
+        const char *pp_env = getenv("HOBBIT_COMMIT_PIPE");
+        int pipe = pp_env ? atoi(pp_env) : (K % 8 == 0 ? 8 : K % 4 == 0 ? 4 : K % 2 == 0 ? 2 : 0);
+        if (pipe > 64) pipe = 64;
+        if (pipe > 1 && K % pipe == 0 && !enc_strided) {
+            HB_TRY(ctx->side_init());
+            const int per = K / pipe; hipStream_t mainS = ctx->stream;
+            HB_CHECK(ctx, hipEventRecord(ctx->side_ev[64], mainS)); HB_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->side_ev[64], 0));   // d_out / rm are free for the side stream
+            for (int g = 0; g < pipe; g++) {
+                const size_t c0 = (size_t)g * per;
+                HB_TRY(fft_rows(ctx, d_msg + c0 * M, half, (uint32_t)half, rm + c0 * trs * cols, cols, 1, logc, false, (uint32_t)per, (uint32_t)trs, M, (size_t)trs * cols));
+                HB_CHECK(ctx, hipEventRecord(ctx->side_ev[g], mainS)); HB_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->side_ev[g], 0));
+                ctx->stream = ctx->side;
+                const int rc = launch_transpose(ctx, rm + c0 * trs * cols, (size_t)trs * cols, (uint32_t)trs, (uint32_t)cols, d_out + c0 * cols * rows2, cols * rows2, rows2, (uint32_t)per);
+                ctx->stream = mainS;
+                if (rc) return rc;
+            }
+            HB_CHECK(ctx, hipEventRecord(ctx->side_ev[65], ctx->side)); HB_CHECK(ctx, hipStreamWaitEvent(mainS, ctx->side_ev[65], 0));
+        } else {
+            HB_TRY(fft_rows(ctx, d_msg, half, (uint32_t)half, rm, cols, 1, logc, false, (uint32_t)K, (uint32_t)trs, M, (size_t)trs * cols));
+            if (lin && enc_strided && trs > 13 && ctx->code.n == trs && ((size_t)K * cols) % 64 == 0) {
+                // EXPERIMENT (off by default, measured slower: DESIGN.md 4): no transpose pass, the encode reads its message as a strided
+                // column of the row-major FFT output (8 adjacent columns on one XCD) and writes message + parity contiguously
+                return launch_encode_strided(ctx, rm, 0, (uint32_t)cols, (uint32_t)cols, (size_t)trs * cols, d_out, rows2, trs, (size_t)K * cols, 1, nullptr);
+            }
+            HB_TRY(launch_transpose(ctx, rm, (size_t)trs * cols, (uint32_t)trs, (uint32_t)cols, d_out, cols * rows2, rows2, (uint32_t)K));
         }
-        HB_TRY(launch_transpose(ctx, rm, (size_t)trs * cols, (uint32_t)trs, (uint32_t)cols, d_out, cols * rows2, rows2, (uint32_t)K));
         const char *dg_env = getenv("HOBBIT_ENC_DIGESTS");
         if (lin && d_dig && trs > 13 && trs % 4 == 0 && ctx->code.n == trs && dg_env && dg_env[0] == '1') {     // EXPERIMENT, off by default (measured slower: DESIGN.md 4)
             *d_dig = reinterpret_cast<uint8_t *>(rm);                   // K*M digests of 32 B = the scratch's K*trs*cols elements of 16 B

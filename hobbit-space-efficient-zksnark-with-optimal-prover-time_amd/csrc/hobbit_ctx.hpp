@@ -65,6 +65,14 @@ struct hobbit_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
+    // second stream + events: the commit's layout change (HBM-bound) of one chunk group runs beside the next group's row FFT (VALU-bound)
+    hipStream_t side = nullptr; hipEvent_t side_ev[66] = {};
+    int side_init() {
+        if (side) return 0;
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { err = "side stream create failed"; return HOBBIT_EHIP; }
+        for (auto &e : side_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { err = "side event create failed"; return HOBBIT_EHIP; }
+        return 0;
+    }
     std::string err;
     // profiler
     int prof_on = 0;
