@@ -261,6 +261,14 @@ def main():
     _spin = hb.alloc(16 << 24)
     for _ in range(int(os.environ.get("HOBBIT_BENCH_SPIN", "2000"))):
         hb._chk(hb.lib.hobbit_fill_splitmix(hb.ctx, _spin.ptr, 1 << 24, 7))
+    # The interpreter's cyclic garbage collector is switched off over the timed region, as the standard library's `timeit` does: with
+    # torch imported a full (generation-2) collection walks ~10^6 objects and stops the host thread for 30-35 ms, i.e. the GPU idles
+    # through most of a step; it fired in about one step of a hundred (the +34 ms outlier of BENCH_r01 and of this round's earlier runs).
+    # Nothing in a step creates reference cycles.  HOBBIT_BENCH_GC=1 leaves the collector on (for the A/B).
+    import gc
+    gc_off = not os.environ.get("HOBBIT_BENCH_GC")
+    if gc_off:
+        gc.collect(); gc.disable()
     barrier()
     t0 = time.perf_counter()
     hb.timer_begin()
@@ -272,6 +280,8 @@ def main():
     ev_ms = hb.timer_end_ms()
     barrier()
     wall = time.perf_counter() - t0
+    if gc_off:
+        gc.enable()
     prof = hb.profile_report()
     prof.pop("k_fill_splitmix", None)          # the untimed filler in front of the barrier
     hb.profile(1); hb.profile_reset()
