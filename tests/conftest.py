@@ -1,6 +1,10 @@
 import os
 import sys
 import pytest
+# torch first: it bundles its own libamdhip64 under the same SONAME the library links from /opt/rocm, and whichever is loaded first serves
+# both.  When libhobbit_hip.so came first (a partial run, e.g. `pytest tests/test_gpu_parity.py -k shard`), a later `import torch` in a
+# test found "No HIP GPUs are available"; a full run imports torch at collection time anyway (tests/test_dist_gloo.py).
+import torch  # noqa: F401,E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
