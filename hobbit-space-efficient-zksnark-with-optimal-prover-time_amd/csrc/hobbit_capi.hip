@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstring>
 #include <map>
+#include <thread>
 #include "hobbit_kernels.hpp"
 #include "hobbit_blake3.hpp"
 
@@ -250,6 +251,7 @@ int hobbit_ctx_create(int device, hobbit_ctx **out) { return hobbit_ctx_create_o
 
 void hobbit_ctx_destroy(hobbit_ctx *ctx) {
     if (!ctx) return;
+    if (ctx->helper) { hobbit_ctx_destroy(ctx->helper); ctx->helper = nullptr; }
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     ctx->prof_collect();
@@ -817,11 +819,45 @@ static size_t whir_scratch_elems(size_t N) {
            + 3 * 1024 /* partials */ + WHIR_DIN * 6 /* per-iteration inputs z | pows | query indices */ + WHIR_DRES /* coefficients, roots, y, finals */
            + 256 * 16 /* query replies */ + 8192 /* query paths: < 4096 hashes */ + 64;
 }
+// Every host-drawn input of one _whir_prove, taken from libc in the reference's order BEFORE anything is queued (none depends on device
+// data): a caller can draw the plan of one proof, hand the proof to another thread / context and go on drawing for the next.
+struct WhirIterPlan { F a[4]; bool last = false; int repeats = 0; std::vector<F> z, pw; std::vector<uint64_t> ridx; };
+struct WhirPlan { std::vector<WhirIterPlan> it; int final_repeats = 0; size_t remaining = 0; bool final_round = false; std::vector<uint64_t> final_ridx; };
+static int whir_plan(size_t N, WhirPlan &P) {
+    const int k = 4, logN = ilog2_exact(N);
+    if (logN < 9 || logN > 24) return HOBBIT_EINVAL;
+    int iter = 0, repeats = 100;
+    for (;;) {
+        if (iter >= 6) return HOBBIT_EINVAL;
+        WhirIterPlan ip;
+        for (int i = 0; i < k; i++) ip.a[i] = fmake((uint64_t)random());           // a.push_back(random()) (:561)
+        iter++;
+        const size_t cur = N >> (k * iter), fsz = (2 * N) >> iter;
+        const int queries = (int)(100.0 / log2((double)fsz / (double)cur));
+        if (logN - iter * k <= k) { ip.last = true; P.it.push_back(std::move(ip)); repeats = queries; P.remaining = (size_t)1 << (logN - iter * k); break; }
+        const int v = logN - iter * k;
+        compute_zetas_host(ip.z, ip.ridx, repeats, v, (2 * N) >> (iter + k));
+        const F sch = fmake((uint64_t)random());
+        ip.pw.resize(repeats); { F p = sch; for (int i = 0; i < repeats; i++) { ip.pw[i] = p; p = fmul(p, sch); } }
+        ip.repeats = repeats;
+        P.it.push_back(std::move(ip));
+        repeats = queries;
+    }
+    P.final_repeats = repeats;
+    {   // closing draws (:652-655) and the last query round's indices (:656), leaving the libc stream where the reference leaves it
+        const int lr = ilog2_exact(P.remaining);
+        F cst = fmake(0); for (int i = 0; i < lr; i++) { if (i % 100 == 0) cst = fmake((uint64_t)random()); (void)rand(); }
+        (void)cst;
+        if (repeats > 0 && lr > 0) { std::vector<F> z; compute_zetas_host(z, P.final_ridx, repeats, lr, (2 * N) >> (iter * k)); P.final_round = true; }
+    }
+    return 0;
+}
 // _whir_prove (src/Virgo.cpp:519-686).  Nothing the host decides here depends on device data: the fold challenges, the out-of-domain
 // points and the query indices are libc draws, and the running evaluation only feeds the reference's exit(-1) checks.  So the whole
 // proof is queued without a single synchronisation -- host-drawn inputs go through one pinned staging slot per iteration (one
 // async copy each), every result lands in a device result area -- and is read back once at the end, where the checks are replayed.
-int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_F *d_com, const uint8_t *d_com_levels, const hobbit_F *h_x, hobbit_whir_out *o) {
+static int whir_prove_run(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_F *d_com, const uint8_t *d_com_levels, const hobbit_F *h_x, hobbit_whir_out *o,
+                         const WhirPlan &plan) {
     const int k = 4, logN = ilog2_exact(N);
     if (logN < 9 || logN > 24 || !o) return ctx->fail(HOBBIT_EINVAL, "whir_prove: N must be a power of two in [2^9, 2^24]");
     hobbit_F *h_qpoly = o->qpoly, *h_a = o->a, *h_scal = o->scal; uint8_t *h_fri_roots = o->fri_roots; int *h_checks = o->checks;
@@ -861,10 +897,11 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
         return 0;
     };
     for (;;) {
-        if (iter >= 6) return ctx->fail(HOBBIT_EINVAL, "whir_prove: more iterations than the staging area holds");
+        if (iter >= 6 || (size_t)iter >= plan.it.size()) return ctx->fail(HOBBIT_EINVAL, "whir_prove: more iterations than the staging area / the plan holds");
+        const WhirIterPlan &ip = plan.it[iter];
         for (int i = 0; i < k; i++) {
             const size_t L = N >> (iter * k + i + 1);
-            const F a = fmake((uint64_t)random());                               // a.push_back(random()) (:561)
+            const F a = ip.a[i];
             a_all.push_back(a);
             HB_TRY(launch_whir_round(ctx, poly, beta, L, a, part, res_it(iter) + 3 * i));
         }
@@ -873,11 +910,14 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
         F *keep = (iter & 1) ? keepA : keepB;                                    // layer sizes halve: odd layers need <= 2N, even <= N elements
         HB_TRY(whir_fri_layer(ctx, poly, cur, fsz, fp, keep, reinterpret_cast<uint8_t *>(res_it(iter - 1) + 12)));
         const int queries = (int)(100.0 / log2((double)fsz / (double)cur));
-        if (logN - iter * k <= k) { repeats = queries; remaining = (size_t)1 << (logN - iter * k); break; }
+        if (logN - iter * k <= k) {
+            if (!ip.last) return ctx->fail(HOBBIT_ESTATE, "whir_prove: plan out of step");
+            repeats = queries; remaining = (size_t)1 << (logN - iter * k); break;
+        }
         const int v = logN - iter * k;
-        std::vector<F> z; compute_zetas_host(z, ridx, repeats, v, (2 * N) >> (iter + k));
-        const F sch = fmake((uint64_t)random());
-        std::vector<F> pw(repeats); { F p = sch; for (int i = 0; i < repeats; i++) { pw[i] = p; p = fmul(p, sch); } }
+        if (ip.last || ip.repeats != repeats) return ctx->fail(HOBBIT_ESTATE, "whir_prove: plan out of step");
+        const std::vector<F> &z = ip.z; ridx = ip.ridx;
+        const std::vector<F> &pw = ip.pw;
         pw_all.push_back(pw);
         // stage z | pows | indices of this iteration and ship them with one asynchronous copy
         F *pslot = pin_in + (size_t)(iter - 1) * WHIR_DIN, *dslot = din + (size_t)(iter - 1) * WHIR_DIN;
@@ -901,13 +941,11 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
     HB_TRY(launch_dot(ctx, beta, poly, remaining, part, res_fin));
     HB_TRY(launch_copy(ctx, res_fin + 4, poly, remaining * sizeof(F)));
     HB_TRY(launch_copy(ctx, res_fin + 4 + remaining, beta, remaining * sizeof(F)));
-    {   // closing draws (:652-655) and the last query round (:656), leaving the libc stream where the reference leaves it
+    {   // the last query round (:656); its indices (and the closing draws in front of them, :652-655) are in the plan
         const int lr = ilog2_exact(remaining);
-        F cst = fmake(0); for (int i = 0; i < lr; i++) { if (i % 100 == 0) cst = fmake((uint64_t)random()); (void)rand(); }
-        (void)cst;
-        std::vector<F> z;
-        if (repeats > 0 && lr > 0) {
-            compute_zetas_host(z, ridx, repeats, lr, (2 * N) >> (iter * k));
+        if (remaining != plan.remaining || repeats != plan.final_repeats || plan.final_round != (repeats > 0 && lr > 0)) return ctx->fail(HOBBIT_ESTATE, "whir_prove: plan out of step");
+        if (plan.final_round) {
+            ridx = plan.final_ridx;
             if (ridx.size() > 128) return ctx->fail(HOBBIT_EINVAL, "whir_prove: staging slot too small");
             F *pslot = pin_in + (size_t)5 * WHIR_DIN, *dslot = din + (size_t)5 * WHIR_DIN;     // the last slot: only indices
             memcpy(pslot + 2048 + 128, ridx.data(), ridx.size() * 8);
@@ -941,14 +979,29 @@ int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const h
     if (o->iters) *o->iters = iter;
     return sc.finish();
 }
+int hobbit_whir_prove(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_F *d_com, const uint8_t *d_com_levels, const hobbit_F *h_x, hobbit_whir_out *o) {
+    WhirPlan plan;
+    if (whir_plan(N, plan) != 0) return ctx->fail(HOBBIT_EINVAL, "whir_prove: N must be a power of two in [2^9, 2^24]");
+    return whir_prove_run(ctx, d_poly, N, d_com, d_com_levels, h_x, o, plan);
+}
 // shockwave_prove (src/Virgo.cpp:435-517), prover side
 // workspace4 elements of one shockwave_prove: [0, nested) belongs to the nested whir_commit / whir_prove calls, its own vectors follow
 static size_t shockwave_nested_elems(size_t w) { return 4 * w + whir_scratch_elems(w) + 64; }
 static size_t shockwave_own_elems(size_t w, int k) {
     return w + 2 * w + 2 * w + 64 + 256 + 256 /* idx */ + 2 * w + 2 * w /* whir_commit outputs: com, levels */ + 240 * (size_t)k /* replies */ + 240 * 64 /* paths */ + 64;
 }
-int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobbit_F *d_enc, const uint8_t *d_levels, size_t N, int k, const hobbit_F *h_x, int xlen,
-                           hobbit_shockwave_out *o) {
+// the libc draws of one shockwave_prove, in the reference's order: the 240 query columns (:463-467), then _whir_prove's (whir_plan)
+struct ShockPlan { std::vector<uint64_t> I; bool committed = false; WhirPlan whir; };
+static int shockwave_plan(size_t N, int k, ShockPlan &P) {
+    if (k <= 0 || N % (size_t)k) return HOBBIT_EINVAL;
+    const size_t w = N / k, W = 2 * w;
+    P.I.resize(240);
+    for (int i = 0; i < 240; i++) P.I[i] = (uint64_t)(rand() % (long)W);
+    P.committed = w > 256;
+    return P.committed ? whir_plan(w, P.whir) : 0;
+}
+static int shockwave_prove_run(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobbit_F *d_enc, const uint8_t *d_levels, size_t N, int k, const hobbit_F *h_x, int xlen,
+                               hobbit_shockwave_out *o, const ShockPlan &plan) {
     const int lk = ilog2_exact((size_t)k);
     if (lk < 0 || k > 64 || N % (size_t)k || xlen < lk || !o) return ctx->fail(HOBBIT_EINVAL, "shockwave_prove: bad k / N / x");
     const size_t w = N / k, W = 2 * w;
@@ -971,8 +1024,9 @@ int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobb
         HB_TRY(hobbit_whir_commit(ctx, reinterpret_cast<hobbit_F *>(aggr), w, reinterpret_cast<hobbit_F *>(wcom), wlv));
         if (o->whir_root) HB_TRY(d2h_staged(ctx, o->whir_root, wlv + 32 * (w - 2), 32));
     }
-    std::vector<uint64_t> I(240); std::vector<F> one(240, fmake(1));
-    for (int i = 0; i < 240; i++) { I[i] = (uint64_t)(rand() % (long)W); if (o->I) o->I[i] = (uint32_t)I[i]; }      // (:463-467)
+    if (plan.I.size() != 240 || plan.committed != committed) return ctx->fail(HOBBIT_ESTATE, "shockwave_prove: plan out of step");
+    const std::vector<uint64_t> &I = plan.I; std::vector<F> one(240, fmake(1));
+    if (o->I) for (int i = 0; i < 240; i++) o->I[i] = (uint32_t)I[i];                                                // (:463-467)
     HB_TRY(launch_zero(ctx, b1v, W * sizeof(F)));
     HB_TRY(h2d_staged(ctx, ones, one.data(), 240 * sizeof(F)));
     HB_TRY(h2d_staged(ctx, didx, I.data(), 240 * 8));
@@ -995,11 +1049,19 @@ int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobb
     if (committed) {
         // _whir_prove works on a copy of aggr inside its own scratch (from the start of workspace4): aggr and the commitment live beyond it
         hobbit_whir_out wo = {o->wq, o->wa, o->wroots, o->wscal, o->wchecks, &iters, o->wqidx, o->wqreply, o->wqpaths, o->wfinal, o->wqn};
-        HB_TRY(hobbit_whir_prove(ctx, reinterpret_cast<hobbit_F *>(aggr), w, reinterpret_cast<hobbit_F *>(wcom), wlv, o->r2, &wo));                          // (:480-481)
+        HB_TRY(whir_prove_run(ctx, reinterpret_cast<hobbit_F *>(aggr), w, reinterpret_cast<hobbit_F *>(wcom), wlv, o->r2, &wo, plan.whir));                    // (:480-481)
     }
     if (o->iters) *o->iters = iters;
     HB_TRY(ctx->sync());
     return sc.finish();
+}
+int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobbit_F *d_enc, const uint8_t *d_levels, size_t N, int k, const hobbit_F *h_x, int xlen,
+                           hobbit_shockwave_out *o) {
+    const int lk = ilog2_exact((size_t)k);
+    if (lk < 0 || k > 64 || N % (size_t)k || xlen < lk || !o) return ctx->fail(HOBBIT_EINVAL, "shockwave_prove: bad k / N / x");
+    ShockPlan plan;
+    if (shockwave_plan(N, k, plan) != 0) return ctx->fail(HOBBIT_EINVAL, "shockwave_prove: bad k / N, or a width outside _whir_prove's range");
+    return shockwave_prove_run(ctx, d_matrix, d_enc, d_levels, N, k, h_x, xlen, o, plan);
 }
 
 // ---- multi-GPU commit building blocks -------------------------------------------
@@ -2196,6 +2258,29 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     { F c4 = fadd(fadd(q4[0], q4[1]), fadd(q4[2], q4[2])); F want = fadd(fmul(a, cF(o->vr)[4]), cF(o->vr)[3]); o->checks[1] = feq(c4, want); }
     Q += 3 * R3; Rr += R3;
     tr.mark("betas, P4");
+    // shockwave_prove(C_c, P4.r minus its last entry) (src/PC_utils.cpp:368): nothing after it depends on it (it only adds to the proof),
+    // and every challenge in it is a libc draw.  So its draws are taken HERE, where the reference takes them (ShockPlan), and the proof
+    // itself runs on the helper context from a second host thread, beside P5 and shockwave_prove(C_f) below -- three chains of small
+    // dependent launches and host round trips that each leave the GPU mostly idle.  HOBBIT_OPEN_THREADS=0, a full per-kernel
+    // profile (mode 1) or HOBBIT_TRACE keep everything on this thread.
+    const char *ot_env = getenv("HOBBIT_OPEN_THREADS");
+    const bool sp_threaded = full && o->sp_c && !(ot_env && ot_env[0] == '0') && ctx->prof_on != 1 && !tr.on;
+    ShockPlan plan_c; std::thread sp_thread; int sp_rc = 0;
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } sp_join{sp_thread};      // every return path below joins
+    if (sp_threaded) {
+        if (!ctx->helper) {
+            if (hobbit_ctx_create(ctx->device, &ctx->helper) != 0) return ctx->fail(HOBBIT_EHIP, "open: helper context creation failed");
+            ctx->helper->sync_mode = ctx->sync_mode;
+        }
+        if (shockwave_plan(nc_el, 32, plan_c) != 0) return ctx->fail(HOBBIT_EINVAL, "open: C_c has no shockwave plan");
+        HB_TRY(ctx->sync());                                                     // C, encc, lvc and P4's challenges are final
+        hobbit_ctx *hc = ctx->helper; const hobbit_F *rc4 = r_p4; const int rl = R3 - 1; hobbit_shockwave_out *oc = o->sp_c;
+        const hobbit_F *dC = reinterpret_cast<hobbit_F *>(C), *dE = reinterpret_cast<hobbit_F *>(encc); const uint8_t *dL = lvc; const size_t ncel = nc_el;
+        sp_thread = std::thread([hc, dC, dE, dL, ncel, rc4, rl, oc, &plan_c, &sp_rc] {
+            hipSetDevice(hc->device);
+            sp_rc = shockwave_prove_run(hc, dC, dE, dL, ncel, 32, rc4, rl, oc, plan_c);
+        });
+    }
     // y1 = evaluate_vector(M', P4.r minus its last entry) (:372-373); P5 = prove_fft_matrix(initial tensor, r, y1) (:383)
     F y1;
     HB_TRY(hobbit_eval_vector(ctx, reinterpret_cast<hobbit_F *>(Mp), (size_t)trs * cols, r_p4, reinterpret_cast<hobbit_F *>(&y1)));
@@ -2204,15 +2289,21 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     { const HF *q5 = cF(Q); F c5 = fadd(fadd(q5[0], q5[1]), fadd(q5[2], q5[2])); o->checks[2] = feq(c5, y1); }
     tr.mark("y1, P5");   // src/sumcheck.cpp:3016-3019
     if (!full) return sc.finish();
-    // shockwave_prove(C_c, P4.r minus its last entry) (src/PC_utils.cpp:368) -- in the reference it runs before P5; P5 draws nothing
-    // from libc, so running it here leaves every draw where the reference has it
-    HB_TRY(hobbit_shockwave_prove(ctx, reinterpret_cast<hobbit_F *>(C), reinterpret_cast<hobbit_F *>(encc), lvc, nc_el, 32, r_p4, R3 - 1, o->sp_c));
-    tr.mark("shockwave_prove C_c");
+    if (!sp_threaded) {
+        // shockwave_prove(C_c, P4.r minus its last entry) (src/PC_utils.cpp:368) -- in the reference it runs before P5; P5 draws nothing
+        // from libc, so running it here leaves every draw where the reference has it
+        HB_TRY(hobbit_shockwave_prove(ctx, reinterpret_cast<hobbit_F *>(C), reinterpret_cast<hobbit_F *>(encc), lvc, nc_el, 32, r_p4, R3 - 1, o->sp_c));
+        tr.mark("shockwave_prove C_c");
+    }
     // shockwave_prove(C_f, P5.randomness minus its last entry) (:384-385); P5.randomness = [sumcheck r | r1 = P4.r[logc .. logc+log2 trs)] (src/sumcheck.cpp:3021-3023)
     std::vector<hobbit_F> x5((size_t)logc + (size_t)(R1 - 1));
     memcpy(x5.data(), Rr, sizeof(hobbit_F) * (size_t)logc); memcpy(x5.data() + logc, r_p4 + logc, sizeof(hobbit_F) * (size_t)(R1 - 1));
     HB_TRY(hobbit_shockwave_prove(ctx, reinterpret_cast<hobbit_F *>(d_aggr), reinterpret_cast<hobbit_F *>(encf), lvf, M, 32, x5.data(), (int)x5.size() - 1, o->sp_f));
     tr.mark("shockwave_prove C_f");
+    if (sp_threaded) {
+        sp_thread.join();
+        if (sp_rc) return ctx->fail(sp_rc, (std::string("shockwave_prove(C_c) on the helper context: ") + ctx->helper->err).c_str());
+    }
     if (tr.on) fprintf(stderr, "[hobbit open] scratch at exit:  ws %zu ws2 %zu ws3 %zu ws4 %zu pin %zu\n", ctx->ws_bytes, ctx->ws2_bytes, ctx->ws3_bytes, ctx->ws4_bytes, ctx->pin_bytes);
     return sc.finish();
 }

@@ -73,6 +73,9 @@ struct hobbit_ctx {
         for (auto &e : side_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { err = "side event create failed"; return HOBBIT_EHIP; }
         return 0;
     }
+    // helper context (own stream, scratch, staging, mailbox) for the one part of the open that is independent of what follows it:
+    // shockwave_prove(C_c) runs there on a second host thread beside P5 and shockwave_prove(C_f) (open_impl)
+    hobbit_ctx *helper = nullptr;
     std::string err;
     // profiler
     int prof_on = 0;
