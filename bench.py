@@ -342,7 +342,7 @@ def main():
             "blake3_compressions_per_s": comp * (1 if sharded else world) / (wall_max / args.steps),
             "op_counts": {"f_mul": mul, "f_add": add, "blake3_compress": comp, "expander_edges": edges, "open_f_mul": omul, "open_f_add": oadd},
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items())},
-            "kernels_ms_note": "k_fft4096 and k_transpose run on two streams, overlapped (chunk group g's transpose beside group g+1's FFT): their durations sum to more than their wall-clock span",
+            "kernels_ms_note": "k_fft4096 and k_transpose run on two streams, overlapped (chunk group g's transpose beside group g+1's FFT): their durations sum to more than their wall-clock span; kernels_ms_extra_profiled_step / launches_extra_profiled_step come from one extra untimed step with every launch bracketed, which runs the open on ONE thread and stream (the timed steps run shockwave_prove(C_c) on a helper context from a second thread and the inner commitments on a third stream)",
             "kernels_ms_extra_profiled_step": {k: v[0] for k, v in sorted(prof_full.items())},
             "launches_extra_profiled_step": {"total": int(sum(v[1] for v in prof_full.values())),
                                              "open": int(sum(v[1] for k, v in prof_full.items() if not (k.startswith("k_leaf_chain") or k in ("k_fft4096", "k_transpose", "k_encode_A", "k_encode_B", "k_encode", "k_merkle_level", "k_merkle_top"))))},

@@ -252,6 +252,7 @@ int hobbit_ctx_create(int device, hobbit_ctx **out) { return hobbit_ctx_create_o
 void hobbit_ctx_destroy(hobbit_ctx *ctx) {
     if (!ctx) return;
     if (ctx->helper) { hobbit_ctx_destroy(ctx->helper); ctx->helper = nullptr; }
+    if (ctx->helper2) { hobbit_ctx_destroy(ctx->helper2); ctx->helper2 = nullptr; }
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     ctx->prof_collect();
@@ -2184,8 +2185,33 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     F *sw = d_b1 + rows2 + 2 * (size_t)queries + 64;
     F *encf = sw, *encc = encf + 2 * M;
     uint8_t *lvf = nullptr, *lvc = nullptr;
-    {
-        lvf = reinterpret_cast<uint8_t *>(encc + 2 * nc_el); lvc = lvf + 64 * (2 * M / 32);
+    // The open as a dependency graph rather than a list (HOBBIT_OPEN_THREADS=0, a full per-kernel profile (mode 1) or HOBBIT_TRACE keep
+    // the reference's order on one thread and one stream).  After the aggregate's tensor code four things are independent:
+    //   A  the two inner commitments -- needed only by the shockwave_prove calls at the very end: queued on helper2's stream;
+    //   B  the query answers (main stream);
+    //   C  P1 -> P2 -- start from constants, every libc draw they use is taken up front below: helper context, second host thread;
+    //   D  P3 -- likewise: main thread;
+    // P4 needs C and D; after it shockwave_prove(C_c) (helper context, second thread) runs beside P5 -> shockwave_prove(C_f).  Each of
+    // these chains is a sequence of small dependent launches and host round trips that leaves the GPU mostly idle on its own.
+    const char *ot_env = getenv("HOBBIT_OPEN_THREADS");
+    const bool par = full && o->sp_c && !(ot_env && ot_env[0] == '0') && ctx->prof_on != 1 && !tr.on;
+    if (par) {
+        for (hobbit_ctx **h : {&ctx->helper, &ctx->helper2}) if (!*h) {
+            if (hobbit_ctx_create(ctx->device, h) != 0) return ctx->fail(HOBBIT_EHIP, "open: helper context creation failed");
+            (*h)->sync_mode = ctx->sync_mode;
+        }
+        HB_TRY(ctx->side_init());
+    }
+    const char *oc_env = getenv("HOBBIT_OPEN_COMMITS_SIDE");
+    const bool commits_side = par && !(oc_env && oc_env[0] == '0');
+    lvf = reinterpret_cast<uint8_t *>(encc + 2 * nc_el); lvc = lvf + 64 * (2 * M / 32);
+    if (commits_side) {
+        hobbit_ctx *hc = ctx->helper2;
+        HB_CHECK(ctx, hipEventRecord(ctx->side_ev[62], ctx->stream)); HB_CHECK(ctx, hipStreamWaitEvent(hc->stream, ctx->side_ev[62], 0));
+        if (hobbit_shockwave_commit(hc, reinterpret_cast<hobbit_F *>(d_aggr), M, 32, reinterpret_cast<hobbit_F *>(encf), lvf) ||
+            hobbit_shockwave_commit(hc, reinterpret_cast<hobbit_F *>(C), nc_el, 32, reinterpret_cast<hobbit_F *>(encc), lvc)) return ctx->fail(HOBBIT_EHIP, hc->err);
+        HB_CHECK(ctx, hipEventRecord(ctx->side_ev[63], hc->stream));
+    } else {
         HB_TRY(hobbit_shockwave_commit(ctx, reinterpret_cast<hobbit_F *>(d_aggr), M, 32, reinterpret_cast<hobbit_F *>(encf), lvf));
         HB_TRY(hobbit_shockwave_commit(ctx, reinterpret_cast<hobbit_F *>(C), nc_el, 32, reinterpret_cast<hobbit_F *>(encc), lvc));
         if (o->roots) {
@@ -2225,29 +2251,44 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
         HB_TRY(launch_scatter(ctx, tmpi, tmpv, idx.size(), d_b));
     }
     tr.mark("queries+gather+paths, host tables");
-    // recursive_prover_Spielman: aggr_c = [M' | C] . s (:298-309)
-    HB_TRY(launch_matvec_rows(ctx, BIG, rows2, cols, d_s, d_ac));
-    // P1 = prove_linear_code(aggr_c, trs) with r1 = generate_randomness(log2 2trs) (:310; src/sumcheck.cpp:3223-3235)
     hobbit_F *Q = o->qpoly, *Rr = o->r;
-    HB_TRY(hobbit_prove_linear_code(ctx, reinterpret_cast<hobbit_F *>(d_ac), rows2, trs, reinterpret_cast<hobbit_F *>(r1.data()), Q, Rr, o->vr, o->fin));
-    const hobbit_F *r_p1 = Rr; const hobbit_F *q_p1 = Q; (void)q_p1;
-    Q += 3 * R1; Rr += R1;
-    tr.mark("s, aggr_c, P1");
-    // evals = beta(P1.r)^T [M' | C] (:311-320); P2 = sumcheck(s, evals, F(021) -- octal) (:322)
-    HB_TRY(hobbit_eq_table(ctx, r_p1, R1, reinterpret_cast<hobbit_F *>(d_b1)));
-    HB_TRY(launch_vecmat(ctx, BIG, rows2, cols, d_b1, d_ev));
-    hobbit_F p17 = {021, 0};
-    HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(d_s), reinterpret_cast<hobbit_F *>(d_ev), cols, &p17, Q, Rr, o->vr + 2, o->fin + 1));
-    const hobbit_F *r_p2 = Rr; const HF *q2 = cF(Q);
-    { F c2 = fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])); o->checks[0] = feq(c2, cF(o->vr)[1]); }       // "Error recursion 1" (:323-326)
-    Q += 3 * logc; Rr += logc;
-    tr.mark("evals, P2");
-    // P3 (:339) against buff2 (built above)
-    hobbit_F p121 = {121, 0};
-    HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(BIG), reinterpret_cast<hobbit_F *>(d_b), big, &p121, Q, Rr, o->vr + 4, o->fin + 2));
-    const hobbit_F *r_p3 = Rr;
-    Q += 3 * R3; Rr += R3;
-    tr.mark("buff2, P3");
+    hobbit_F *const Q1 = Q, *const Rr1 = Rr, *const Q2 = Q1 + 3 * R1, *const Rr2 = Rr1 + R1, *const Q3 = Q2 + 3 * logc, *const Rr3 = Rr2 + logc;
+    const hobbit_F *r_p1 = Rr1, *r_p2 = Rr2, *r_p3 = Rr3;
+    hobbit_F p17 = {021, 0}, p121 = {121, 0};
+    // C: aggr_c = [M' | C] . s (:298-309); P1 = prove_linear_code(aggr_c, trs) with r1 = generate_randomness(log2 2trs) (:310;
+    // src/sumcheck.cpp:3223-3235); evals = beta(P1.r)^T [M' | C] (:311-320); P2 = sumcheck(s, evals, F(021) -- octal) (:322)
+    auto chain_c = [=](hobbit_ctx *cx) -> int {
+        HB_TRY(launch_matvec_rows(cx, BIG, rows2, cols, d_s, d_ac));
+        HB_TRY(hobbit_prove_linear_code(cx, reinterpret_cast<hobbit_F *>(d_ac), rows2, trs, reinterpret_cast<const hobbit_F *>(r1.data()), Q1, Rr1, o->vr, o->fin));
+        HB_TRY(hobbit_eq_table(cx, r_p1, R1, reinterpret_cast<hobbit_F *>(d_b1)));
+        HB_TRY(launch_vecmat(cx, BIG, rows2, cols, d_b1, d_ev));
+        return hobbit_sumcheck2(cx, reinterpret_cast<hobbit_F *>(d_s), reinterpret_cast<hobbit_F *>(d_ev), cols, &p17, Q2, Rr2, o->vr + 2, o->fin + 1);
+    };
+    // D: P3 (:339) against buff2 (built above).  On the helper context from a second thread while this thread runs C on the main context
+    // (prove_linear_code needs the context's expander graphs; a plain sumcheck needs nothing).
+    auto chain_d = [=](hobbit_ctx *cx) -> int {
+        return hobbit_sumcheck2(cx, reinterpret_cast<hobbit_F *>(BIG), reinterpret_cast<hobbit_F *>(d_b), big, &p121, Q3, Rr3, o->vr + 4, o->fin + 2);
+    };
+    const char *p3_env = getenv("HOBBIT_OPEN_P3_THREAD");
+    const bool p3_thread = par && p3_env && p3_env[0] == '1';        // measured neutral (36.58 vs 36.55 ms per step): off unless asked for
+    std::thread d_thread; int d_rc = 0;
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } d_join{d_thread};          // every return path below joins
+    if (p3_thread) {
+        hobbit_ctx *hc = ctx->helper;
+        HB_CHECK(ctx, hipEventRecord(ctx->side_ev[61], ctx->stream)); HB_CHECK(ctx, hipStreamWaitEvent(hc->stream, ctx->side_ev[61], 0));   // BIG, buff2 are final for the helper
+        d_thread = std::thread([hc, &chain_d, &d_rc] { hipSetDevice(hc->device); d_rc = chain_d(hc); });
+    }
+    HB_TRY(chain_c(ctx));
+    tr.mark("s, aggr_c, P1, evals, P2");
+    if (p3_thread) {
+        d_thread.join();
+        if (d_rc) return ctx->fail(d_rc, std::string("P3 on the helper context: ") + ctx->helper->err);
+    } else {
+        HB_TRY(chain_d(ctx));
+        tr.mark("buff2, P3");
+    }
+    { const HF *q2 = cF(Q2); F c2 = fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])); o->checks[0] = feq(c2, cF(o->vr)[1]); }       // "Error recursion 1" (:323-326)
+    Q = Q3 + 3 * R3; Rr = Rr3 + R3;
     // a, beta(P2.r | P1.r) + a * beta(P3.r) (:342-349); P4 against [M' | C] (:362); "Error recursion 2" (:364-367)
     std::vector<hobbit_F> rcat(R3);
     memcpy(rcat.data(), r_p2, sizeof(hobbit_F) * logc); memcpy(rcat.data() + logc, r_p1, sizeof(hobbit_F) * R1);
@@ -2263,18 +2304,22 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     // itself runs on the helper context from a second host thread, beside P5 and shockwave_prove(C_f) below -- three chains of small
     // dependent launches and host round trips that each leave the GPU mostly idle.  HOBBIT_OPEN_THREADS=0, a full per-kernel
     // profile (mode 1) or HOBBIT_TRACE keep everything on this thread.
-    const char *ot_env = getenv("HOBBIT_OPEN_THREADS");
-    const bool sp_threaded = full && o->sp_c && !(ot_env && ot_env[0] == '0') && ctx->prof_on != 1 && !tr.on;
-    ShockPlan plan_c; std::thread sp_thread; int sp_rc = 0;
-    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } sp_join{sp_thread};      // every return path below joins
-    if (sp_threaded) {
-        if (!ctx->helper) {
-            if (hobbit_ctx_create(ctx->device, &ctx->helper) != 0) return ctx->fail(HOBBIT_EHIP, "open: helper context creation failed");
-            ctx->helper->sync_mode = ctx->sync_mode;
+    if (commits_side) {                                                          // the inner commitments are complete from here on
+        HB_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev[63], 0));
+        if (o->roots) {
+            HB_TRY(d2h_staged(ctx, o->roots, lvf + 32 * (2 * (2 * M / 32) - 2), 32));
+            HB_TRY(d2h_staged(ctx, o->roots + 32, lvc + 32 * (2 * (2 * nc_el / 32) - 2), 32));
         }
+    }
+    const bool sp_threaded = par;
+    ShockPlan plan_c; std::thread sp_thread; int sp_rc = 0;
+    Joiner sp_join{sp_thread};                                                   // every return path below joins
+    if (sp_threaded) {
         if (shockwave_plan(nc_el, 32, plan_c) != 0) return ctx->fail(HOBBIT_EINVAL, "open: C_c has no shockwave plan");
         HB_TRY(ctx->sync());                                                     // C, encc, lvc and P4's challenges are final
-        hobbit_ctx *hc = ctx->helper; const hobbit_F *rc4 = r_p4; const int rl = R3 - 1; hobbit_shockwave_out *oc = o->sp_c;
+        hobbit_ctx *hc = ctx->helper;
+        if (commits_side) HB_CHECK(ctx, hipStreamWaitEvent(hc->stream, ctx->side_ev[63], 0));       // the inner commitments (helper2's stream)
+        const hobbit_F *rc4 = r_p4; const int rl = R3 - 1; hobbit_shockwave_out *oc = o->sp_c;
         const hobbit_F *dC = reinterpret_cast<hobbit_F *>(C), *dE = reinterpret_cast<hobbit_F *>(encc); const uint8_t *dL = lvc; const size_t ncel = nc_el;
         sp_thread = std::thread([hc, dC, dE, dL, ncel, rc4, rl, oc, &plan_c, &sp_rc] {
             hipSetDevice(hc->device);
@@ -2302,7 +2347,7 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     tr.mark("shockwave_prove C_f");
     if (sp_threaded) {
         sp_thread.join();
-        if (sp_rc) return ctx->fail(sp_rc, (std::string("shockwave_prove(C_c) on the helper context: ") + ctx->helper->err).c_str());
+        if (sp_rc) return ctx->fail(sp_rc, std::string("shockwave_prove(C_c) on the helper context: ") + ctx->helper->err);
     }
     if (tr.on) fprintf(stderr, "[hobbit open] scratch at exit:  ws %zu ws2 %zu ws3 %zu ws4 %zu pin %zu\n", ctx->ws_bytes, ctx->ws2_bytes, ctx->ws3_bytes, ctx->ws4_bytes, ctx->pin_bytes);
     return sc.finish();

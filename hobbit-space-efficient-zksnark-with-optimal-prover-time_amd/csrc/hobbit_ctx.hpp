@@ -75,7 +75,7 @@ struct hobbit_ctx {
     }
     // helper context (own stream, scratch, staging, mailbox) for the one part of the open that is independent of what follows it:
     // shockwave_prove(C_c) runs there on a second host thread beside P5 and shockwave_prove(C_f) (open_impl)
-    hobbit_ctx *helper = nullptr;
+    hobbit_ctx *helper = nullptr, *helper2 = nullptr;      // helper2: stream + scratch of the inner commitments, queued from the main thread
     std::string err;
     // profiler
     int prof_on = 0;
