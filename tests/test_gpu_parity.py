@@ -904,6 +904,43 @@ def test_open_standard_vs_oracle(hb, oracle, N, K):
     c.free()
 
 
+@pytest.mark.gpu
+def test_execution_modes_bit_identical(hb, monkeypatch):
+    """The step as a dependency graph -- chunk groups' layout changes on a side stream beside the next group's row FFT
+    (HOBBIT_COMMIT_PIPE), shockwave_prove(C_c) on a helper context from a second host thread with its libc draws taken first
+    (HOBBIT_OPEN_THREADS), the inner commitments on a third stream (HOBBIT_OPEN_COMMITS_SIDE), P3 beside P1/P2 (HOBBIT_OPEN_P3_THREAD) --
+    and the plain list on one stream and one thread must produce the same commitment and the same transcript, message for message, and
+    leave the libc generator in the same state."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    N, K = 1 << 24, 32
+    trs = N // (K << 11)
+    d = hb.fill_splitmix(N, 99)
+    hb.rng_reset(); hb.expander_init_store(trs)
+    x = splitmix_field(24, 5)
+    runs = []
+    for env in ({}, {"HOBBIT_COMMIT_PIPE": "0", "HOBBIT_OPEN_THREADS": "0"}, {"HOBBIT_COMMIT_PIPE": "4", "HOBBIT_OPEN_COMMITS_SIDE": "0"},
+                {"HOBBIT_COMMIT_PIPE": "16", "HOBBIT_OPEN_P3_THREAD": "1"}):
+        with monkeypatch.context() as m:
+            for k, v in env.items():
+                m.setenv(k, v)
+            c = hb.commit_standard((d, N), K, trs, 1)
+            root = c.root().tobytes()
+            libc.srandom(31); a = hb.open_standard((d, N), c, x, 5900, want_paths=True)
+            after = int(libc.random())
+            c.free()
+        runs.append((root, a, after))
+    root0, a0, after0 = runs[0]
+    assert a0["checks"].tolist() == [1, 1, 1]
+    for root, a, after in runs[1:]:
+        assert root == root0 and after == after0
+        for k in ("I", "reply", "paths", "poly", "r", "vr", "fin", "scalars", "roots", "checks"):
+            assert np.array_equal(a[k], a0[k]), k
+        for sp in ("sp_c", "sp_f"):
+            for k in a0[sp]:
+                assert np.array_equal(a[sp][k], a0[sp][k]), (sp, k)
+
+
 def test_open_standard_2e26_selfchecks(hb):
     """Full-size property check (no CPU oracle at this size): commit + open of a 2^26-coefficient polynomial generated on the
     device; every consistency check the reference would exit(-1) on must hold, the query replies must be the committed tensor's
