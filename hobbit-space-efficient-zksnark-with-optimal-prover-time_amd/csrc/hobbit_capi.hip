@@ -2276,7 +2276,8 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     if (p3_thread) {
         hobbit_ctx *hc = ctx->helper;
         HB_CHECK(ctx, hipEventRecord(ctx->side_ev[61], ctx->stream)); HB_CHECK(ctx, hipStreamWaitEvent(hc->stream, ctx->side_ev[61], 0));   // BIG, buff2 are final for the helper
-        d_thread = std::thread([hc, &chain_d, &d_rc] { hipSetDevice(hc->device); d_rc = chain_d(hc); });
+        try { d_thread = std::thread([hc, &chain_d, &d_rc] { hipSetDevice(hc->device); d_rc = chain_d(hc); }); }
+        catch (const std::exception &e) { return ctx->fail(HOBBIT_ESTATE, std::string("open: cannot start the helper thread: ") + e.what()); }
     }
     HB_TRY(chain_c(ctx));
     tr.mark("s, aggr_c, P1, evals, P2");
@@ -2321,10 +2322,12 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
         if (commits_side) HB_CHECK(ctx, hipStreamWaitEvent(hc->stream, ctx->side_ev[63], 0));       // the inner commitments (helper2's stream)
         const hobbit_F *rc4 = r_p4; const int rl = R3 - 1; hobbit_shockwave_out *oc = o->sp_c;
         const hobbit_F *dC = reinterpret_cast<hobbit_F *>(C), *dE = reinterpret_cast<hobbit_F *>(encc); const uint8_t *dL = lvc; const size_t ncel = nc_el;
-        sp_thread = std::thread([hc, dC, dE, dL, ncel, rc4, rl, oc, &plan_c, &sp_rc] {
-            hipSetDevice(hc->device);
-            sp_rc = shockwave_prove_run(hc, dC, dE, dL, ncel, 32, rc4, rl, oc, plan_c);
-        });
+        try {
+            sp_thread = std::thread([hc, dC, dE, dL, ncel, rc4, rl, oc, &plan_c, &sp_rc] {
+                hipSetDevice(hc->device);
+                sp_rc = shockwave_prove_run(hc, dC, dE, dL, ncel, 32, rc4, rl, oc, plan_c);
+            });
+        } catch (const std::exception &e) { return ctx->fail(HOBBIT_ESTATE, std::string("open: cannot start the helper thread: ") + e.what()); }
     }
     // y1 = evaluate_vector(M', P4.r minus its last entry) (:372-373); P5 = prove_fft_matrix(initial tensor, r, y1) (:383)
     F y1;
