@@ -2235,8 +2235,25 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     const F a = fmake((uint64_t)random()); o->scalars[3] = *reinterpret_cast<const hobbit_F *>(&a);
     if (o->cols) memcpy(o->cols, qc.data(), 4 * (size_t)queries);
     if (o->rows) memcpy(o->rows, qr.data(), 4 * (size_t)queries);
-    if (c && o->reply) HB_TRY(hobbit_commitment_gather(ctx, c, qr.data(), qc.data(), (size_t)queries, o->reply));     // replies (:291-305)
-    if (c && o->paths) HB_TRY(hobbit_commitment_paths(ctx, c, qc.data(), qr.data(), (size_t)queries, o->paths));      // Merkle paths (:645-647)
+    // B: the query answers feed nothing below.  With the inner commitments on helper2's stream they are queued behind them there (the
+    // staging arena stays this context's; scratch is lent from helper2), off the chain P1 -> ... -> shockwave_prove(C_f).
+    const char *qs_env = getenv("HOBBIT_OPEN_QUERIES_SIDE");
+    const bool queries_side = commits_side && c && !(qs_env && qs_env[0] == '0');
+    if (queries_side) {
+        hobbit_ctx *hc = ctx->helper2; hipStream_t mainS = ctx->stream;
+        const size_t lend = (size_t)queries * ((size_t)K * sizeof(F) + 8 + 32 * 40) + 4096;
+        void *lp; if (hc->workspace2(lend, &lp) != 0) return ctx->fail(HOBBIT_ENOMEM, hc->err);      // (in stream order behind the commitments' last use of it)
+        ctx->stream = hc->stream; ctx->ws_lent = lp; ctx->ws_lent_bytes = lend;
+        int rc = 0;
+        if (o->reply) rc = hobbit_commitment_gather(ctx, c, qr.data(), qc.data(), (size_t)queries, o->reply);            // replies (:291-305)
+        if (!rc && o->paths) rc = hobbit_commitment_paths(ctx, c, qc.data(), qr.data(), (size_t)queries, o->paths);      // Merkle paths (:645-647)
+        ctx->stream = mainS; ctx->ws_lent = nullptr; ctx->ws_lent_bytes = 0;
+        if (rc) return rc;
+        HB_CHECK(ctx, hipEventRecord(ctx->side_ev[60], hc->stream));
+    } else {
+        if (c && o->reply) HB_TRY(hobbit_commitment_gather(ctx, c, qr.data(), qc.data(), (size_t)queries, o->reply));     // replies (:291-305)
+        if (c && o->paths) HB_TRY(hobbit_commitment_paths(ctx, c, qc.data(), qr.data(), (size_t)queries, o->paths));      // Merkle paths (:645-647)
+    }
     for (size_t i = 1; i < cols; i++) sv[i] = fmul(sv[i - 1], sv[0]);                                                   // s powers (:293-297)
     HB_TRY(h2d_staged(ctx, d_s, sv.data(), cols * sizeof(F)));
     {   // buff2: s2 powers at the queried positions, last write wins (:331-336)
@@ -2305,6 +2322,7 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     // itself runs on the helper context from a second host thread, beside P5 and shockwave_prove(C_f) below -- three chains of small
     // dependent launches and host round trips that each leave the GPU mostly idle.  HOBBIT_OPEN_THREADS=0, a full per-kernel
     // profile (mode 1) or HOBBIT_TRACE keep everything on this thread.
+    if (queries_side) HB_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev[60], 0));      // ... and the query answers (their read-back is staged)
     if (commits_side) {                                                          // the inner commitments are complete from here on
         HB_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev[63], 0));
         if (o->roots) {

@@ -280,7 +280,14 @@ struct hobbit_ctx {
             }
         }
     }
+    // a caller may lend `workspace` another buffer for the calls it queues on a stream of its own (open_impl: the query answers on the
+    // inner commitments' stream), so that they do not share scratch with what runs on the context's stream at the same time
+    void *ws_lent = nullptr; size_t ws_lent_bytes = 0;
     int workspace(size_t bytes, void **p) {
+        if (ws_lent) {
+            if (bytes > ws_lent_bytes) { err = "lent workspace too small"; return HOBBIT_ESTATE; }
+            *p = ws_lent; return 0;
+        }
         if (bytes > ws_bytes) {
             if (ws) { hipStreamSynchronize(stream); hipFree(ws); ws = nullptr; ws_bytes = 0; }
             hipError_t e = hipMalloc(&ws, bytes);

@@ -908,7 +908,8 @@ def test_open_standard_vs_oracle(hb, oracle, N, K):
 def test_execution_modes_bit_identical(hb, monkeypatch):
     """The step as a dependency graph -- chunk groups' layout changes on a side stream beside the next group's row FFT
     (HOBBIT_COMMIT_PIPE), shockwave_prove(C_c) on a helper context from a second host thread with its libc draws taken first
-    (HOBBIT_OPEN_THREADS), the inner commitments on a third stream (HOBBIT_OPEN_COMMITS_SIDE), P3 beside P1/P2 (HOBBIT_OPEN_P3_THREAD) --
+    (HOBBIT_OPEN_THREADS), the inner commitments and the query answers on a third stream (HOBBIT_OPEN_COMMITS_SIDE, HOBBIT_OPEN_QUERIES_SIDE), P3 beside
+    P1/P2 (HOBBIT_OPEN_P3_THREAD) --
     and the plain list on one stream and one thread must produce the same commitment and the same transcript, message for message, and
     leave the libc generator in the same state."""
     import ctypes
@@ -920,7 +921,7 @@ def test_execution_modes_bit_identical(hb, monkeypatch):
     x = splitmix_field(24, 5)
     runs = []
     for env in ({}, {"HOBBIT_COMMIT_PIPE": "0", "HOBBIT_OPEN_THREADS": "0"}, {"HOBBIT_COMMIT_PIPE": "4", "HOBBIT_OPEN_COMMITS_SIDE": "0"},
-                {"HOBBIT_COMMIT_PIPE": "16", "HOBBIT_OPEN_P3_THREAD": "1"}):
+                {"HOBBIT_COMMIT_PIPE": "16", "HOBBIT_OPEN_P3_THREAD": "1", "HOBBIT_OPEN_QUERIES_SIDE": "0"}):
         with monkeypatch.context() as m:
             for k, v in env.items():
                 m.setenv(k, v)
