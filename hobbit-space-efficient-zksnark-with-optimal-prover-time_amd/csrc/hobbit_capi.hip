@@ -2188,11 +2188,12 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     // The open as a dependency graph rather than a list (HOBBIT_OPEN_THREADS=0, a full per-kernel profile (mode 1) or HOBBIT_TRACE keep
     // the reference's order on one thread and one stream).  After the aggregate's tensor code four things are independent:
     //   A  the two inner commitments -- needed only by the shockwave_prove calls at the very end: queued on helper2's stream;
-    //   B  the query answers (main stream);
-    //   C  P1 -> P2 -- start from constants, every libc draw they use is taken up front below: helper context, second host thread;
-    //   D  P3 -- likewise: main thread;
-    // P4 needs C and D; after it shockwave_prove(C_c) (helper context, second thread) runs beside P5 -> shockwave_prove(C_f).  Each of
-    // these chains is a sequence of small dependent launches and host round trips that leaves the GPU mostly idle on its own.
+    //   B  the query answers -- feed nothing: queued behind A on the same stream;
+    //   C  P1 -> P2 -- start from constants, every libc draw they use is taken up front below: this thread, this context;
+    //   D  P3 -- likewise; beside C on the helper context from a second thread only when HOBBIT_OPEN_P3_THREAD=1 (measured neutral).
+    // P4 needs C and D; after it shockwave_prove(C_c) (helper context, second thread, its libc draws taken here first) runs beside
+    // P5 -> shockwave_prove(C_f).  Each of these chains is a sequence of small dependent launches and host round trips that leaves the
+    // GPU mostly idle on its own.  DESIGN.md section 4 has the A/B of every step.
     const char *ot_env = getenv("HOBBIT_OPEN_THREADS");
     const bool par = full && o->sp_c && !(ot_env && ot_env[0] == '0') && ctx->prof_on != 1 && !tr.on;
     if (par) {
