@@ -2257,16 +2257,23 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     }
     for (size_t i = 1; i < cols; i++) sv[i] = fmul(sv[i - 1], sv[0]);                                                   // s powers (:293-297)
     HB_TRY(h2d_staged(ctx, d_s, sv.data(), cols * sizeof(F)));
-    {   // buff2: s2 powers at the queried positions, last write wins (:331-336)
+    // buff2: s2 powers at the queried positions, last write wins (:331-336).  P3 takes it as a sorted (index, value) list -- 5900 non-zeros
+    // of 2^25 -- unless HOBBIT_OPEN_SPARSE_P3=0 asks for the dense table.
+    const char *sp_env = getenv("HOBBIT_OPEN_SPARSE_P3"); const bool sparse_p3 = !(sp_env && sp_env[0] == '0');
+    F *const tmpv = d_b1 + rows2; uint64_t *const tmpi = reinterpret_cast<uint64_t *>(tmpv + queries + 1);      // arena tail
+    size_t nnz = 0;
+    {
         std::map<uint64_t, F> last; F pw = s2;
         for (int q = 0; q < queries; q++) { last[Iv[q]] = pw; pw = fmul(pw, s2); }
         std::vector<uint64_t> idx; std::vector<F> val;
         for (auto &kv : last) { idx.push_back(kv.first); val.push_back(kv.second); }
-        HB_TRY(launch_zero(ctx, d_b, big * sizeof(F)));
-        F *tmpv = d_b1 + rows2; uint64_t *tmpi = reinterpret_cast<uint64_t *>(tmpv + queries + 1);      // arena tail
+        nnz = idx.size();
         HB_TRY(h2d_staged(ctx, tmpv, val.data(), val.size() * sizeof(F)));
         HB_TRY(h2d_staged(ctx, tmpi, idx.data(), idx.size() * 8));
-        HB_TRY(launch_scatter(ctx, tmpi, tmpv, idx.size(), d_b));
+        if (!sparse_p3) {
+            HB_TRY(launch_zero(ctx, d_b, big * sizeof(F)));
+            HB_TRY(launch_scatter(ctx, tmpi, tmpv, idx.size(), d_b));
+        }
     }
     tr.mark("queries+gather+paths, host tables");
     hobbit_F *Q = o->qpoly, *Rr = o->r;
@@ -2285,6 +2292,7 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
     // D: P3 (:339) against buff2 (built above).  On the helper context from a second thread while this thread runs C on the main context
     // (prove_linear_code needs the context's expander graphs; a plain sumcheck needs nothing).
     auto chain_d = [=](hobbit_ctx *cx) -> int {
+        if (sparse_p3) return launch_sumcheck2_sparse(cx, BIG, tmpi, tmpv, nnz, big, *cF(&p121), mF(Q3), mF(Rr3), mF(o->vr + 4), mF(o->fin + 2));
         return hobbit_sumcheck2(cx, reinterpret_cast<hobbit_F *>(BIG), reinterpret_cast<hobbit_F *>(d_b), big, &p121, Q3, Rr3, o->vr + 4, o->fin + 2);
     };
     const char *p3_env = getenv("HOBBIT_OPEN_P3_THREAD");

@@ -2197,13 +2197,130 @@ int launch_fill_F(hobbit_ctx *ctx, F *p, size_t stride, size_t n, F v) {
     return 0;
 }
 
+// ---- 2-product sumcheck whose SECOND table is sparse (the open's P3: 5900 non-zeros of 2^25, src/PC_utils.cpp:331-339) -------------------
+// The round polynomials only see the quads in which the sparse table is non-zero, so the large levels need no dense pass over it and no
+// products over the dense table: per round trip one plain 4 -> 1 fold of the dense table (k_sc2_fold4) and ONE workgroup that folds the
+// sparse list two levels (sorted (index, value) pairs in, one pair per surviving quad out) and evaluates G(r, t) on the surviving quads
+// (k_sc2_sparse_round, which also posts to the mailbox: no separate reduction launch).  Same field sums as the dense kernels, so the
+// transcript is bit-identical.  Below SC_DOUBLE_MIN the list is scattered into a dense table and the dense path takes over.
+__global__ void __launch_bounds__(256) k_sc2_fold4(const F *__restrict__ s, F *__restrict__ d, size_t nout, F r0, F r1) {
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < nout; g += (size_t)gridDim.x * blockDim.x) {
+        const F *e = s + 4 * g;
+        const F e0 = ldF(e), e1 = ldF(e + 1), e2 = ldF(e + 2), e3 = ldF(e + 3);
+        const F f0 = fadd(e0, fmul(r0, fsub(e1, e0))), f1 = fadd(e2, fmul(r0, fsub(e3, e2)));
+        stF(d + g, fadd(f0, fmul(r1, fsub(f1, f0))));
+    }
+}
+// gather the (up to four, consecutive in the sorted list) entries of the quad that entry e leads
+__device__ __forceinline__ void sparse_quad(const uint64_t *__restrict__ idx, const F *__restrict__ val, uint32_t e, uint32_t m, uint64_t q, F (&b)[4]) {
+    b[0] = b[1] = b[2] = b[3] = fmake(0);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        if (e + k < m) {
+            const uint64_t ix = idx[e + k];
+            if ((ix >> 2) == q) { const F v = ldF(val + e + k); const uint32_t p = (uint32_t)(ix & 3); if (p == 0) b[0] = v; else if (p == 1) b[1] = v; else if (p == 2) b[2] = v; else b[3] = v; }
+        }
+    }
+}
+template <bool FOLD>
+__global__ void __launch_bounds__(1024) k_sc2_sparse_round(const uint64_t *__restrict__ idx_in, const F *__restrict__ val_in, const uint32_t *__restrict__ m_in, uint32_t m_arg,
+                                                           uint64_t *__restrict__ idx_out, F *__restrict__ val_out, uint32_t *__restrict__ m_out,
+                                                           const F *__restrict__ dense, F r0, F r1, Mailbox *mb, uint32_t seq) {
+    __shared__ uint32_t scan[1024];
+    __shared__ F red2[9][16];
+    const uint32_t t = threadIdx.x;
+    uint32_t m = m_in ? *m_in : m_arg;             // (the caller's own list: its length is a launch argument)
+    const uint64_t *idx = idx_in; const F *val = val_in;
+    if (FOLD) {                                   // two levels: one output pair per quad that holds a non-zero
+        const uint32_t per = (m + 1023) / 1024, lo = min(m, t * per), hi = min(m, lo + per);
+        uint32_t c = 0;
+        for (uint32_t e = lo; e < hi; e++) c += (e == 0 || (idx_in[e] >> 2) != (idx_in[e - 1] >> 2)) ? 1u : 0u;
+        scan[t] = c;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {   // inclusive Hillis-Steele scan
+            const uint32_t v = t >= d ? scan[t - d] : 0;
+            __syncthreads();
+            scan[t] += v;
+            __syncthreads();
+        }
+        uint32_t base = scan[t] - c;
+        const uint32_t total = scan[1023];
+        for (uint32_t e = lo; e < hi; e++) {
+            const uint64_t q = idx_in[e] >> 2;
+            if (e == 0 || (idx_in[e - 1] >> 2) != q) {
+                F b[4]; sparse_quad(idx_in, val_in, e, m, q, b);
+                const F k0 = fadd(b[0], fmul(r0, fsub(b[1], b[0]))), k1 = fadd(b[2], fmul(r0, fsub(b[3], b[2])));
+                idx_out[base] = q; stF(val_out + base, fadd(k0, fmul(r1, fsub(k1, k0)))); base++;
+            }
+        }
+        if (t == 0) *m_out = total;
+        __threadfence_block();
+        __syncthreads();
+        m = total; idx = idx_out; val = val_out;
+    }
+    // G(r, t) over the quads of this level that hold a non-zero: the nine values of k_sc2_double
+    F c[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++) c[q] = fmake(0);
+    {
+        const uint32_t per = (m + 1023) / 1024, lo = min(m, t * per), hi = min(m, lo + per);
+        for (uint32_t e = lo; e < hi; e++) {
+            const uint64_t Q = idx[e] >> 2;
+            if (e == 0 || (idx[e - 1] >> 2) != Q) {
+                F b[4]; sparse_quad(idx, val, e, m, Q, b);
+                const F *ap = dense + 4 * Q;
+                const F a0 = ldF(ap), a1 = ldF(ap + 1), a2 = ldF(ap + 2), a3 = ldF(ap + 3);
+                c[0] = fadd(c[0], fmul(a0, b[0])); c[1] = fadd(c[1], fmul(a1, b[1])); c[3] = fadd(c[3], fmul(a2, b[2])); c[4] = fadd(c[4], fmul(a3, b[3]));
+                const F da01 = fsub(a1, a0), da23 = fsub(a3, a2), db01 = fsub(b[1], b[0]), db23 = fsub(b[3], b[2]);
+                c[2] = fadd(c[2], fmul(da01, db01)); c[5] = fadd(c[5], fmul(da23, db23));
+                c[6] = fadd(c[6], fmul(fsub(a2, a0), fsub(b[2], b[0]))); c[7] = fadd(c[7], fmul(fsub(a3, a1), fsub(b[3], b[1])));
+                c[8] = fadd(c[8], fmul(fsub(da23, da01), fsub(db23, db01)));
+            }
+        }
+    }
+    const int lane = t & 63, wv = t >> 6;
+#pragma unroll
+    for (int q = 0; q < 9; q++) { F sm = wave_sum(c[q]); if (lane == 0) red2[q][wv] = sm; }
+    __syncthreads();
+    if (t == 0) {
+        for (int q = 0; q < 9; q++) {
+            F sm = red2[q][0];
+            for (int w = 1; w < 16; w++) sm = fadd(sm, red2[q][w]);
+            uint64_t *o = reinterpret_cast<uint64_t *>(&mb->vals[q]);
+            __hip_atomic_store(o, sm.re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(o + 1, sm.im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __hip_atomic_store(&mb->flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+__global__ void __launch_bounds__(256) k_scatter_counted(const uint64_t *__restrict__ idx, const F *__restrict__ val, const uint32_t *__restrict__ m, F *__restrict__ out) {
+    const uint32_t n = *m;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) stF(out + idx[i], ldF(val + i));
+}
+
+static int sumcheck2_impl(hobbit_ctx *ctx, const F *v1, const F *v2, const uint64_t *sp_idx, const F *sp_val, size_t sp_m, size_t n, F prev_r, HF *h_qpoly, HF *h_r,
+                          HF *h_vr, HF *h_final);
 int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev_r, HF *h_qpoly, HF *h_r, HF *h_vr, HF *h_final) {
+    return sumcheck2_impl(ctx, v1, v2, nullptr, nullptr, 0, n, prev_r, h_qpoly, h_r, h_vr, h_final);
+}
+// v2 given as sp_m sorted, distinct (index, value) pairs on the device (every other entry zero)
+int launch_sumcheck2_sparse(hobbit_ctx *ctx, const F *v1, const uint64_t *d_idx, const F *d_val, size_t m, size_t n, F prev_r, HF *h_qpoly, HF *h_r, HF *h_vr, HF *h_final) {
+    if (!m || m > ((size_t)1 << 20)) return ctx->fail(HOBBIT_EINVAL, "sumcheck2_sparse: between 1 and 2^20 non-zeros");
+    return sumcheck2_impl(ctx, v1, nullptr, d_idx, d_val, m, n, prev_r, h_qpoly, h_r, h_vr, h_final);
+}
+static int sumcheck2_impl(hobbit_ctx *ctx, const F *v1, const F *v2, const uint64_t *sp_idx, const F *sp_val, size_t sp_m, size_t n, F prev_r, HF *h_qpoly, HF *h_r,
+                          HF *h_vr, HF *h_final) {
     int rounds = 0; while (((size_t)1 << rounds) < n) rounds++;
     if (((size_t)1 << rounds) != n || n < 2) return ctx->fail(HOBBIT_EINVAL, "sumcheck2: n must be a power of two >= 2");
     const int MAXB = 1024;
     F rnd = prev_r;
     std::vector<F> ta, tb;
     if (n <= SC_TAIL) {                       // small instance: all rounds on the host
+        if (sp_idx) {
+            F *dv2; HB_TRY(ctx->workspace(n * sizeof(F), (void **)&dv2));
+            HB_TRY(launch_zero(ctx, dv2, n * sizeof(F)));
+            HB_TRY(launch_scatter(ctx, sp_idx, sp_val, sp_m, dv2));
+            v2 = dv2;
+        }
         ta.resize(n); tb.resize(n);
         HB_CHECK(ctx, hipMemcpyAsync(ta.data(), v1, n * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
         HB_CHECK(ctx, hipMemcpyAsync(tb.data(), v2, n * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
@@ -2211,8 +2328,19 @@ int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev
         sc2_host_tail(ta, tb, rnd, false, 0, rounds, h_qpoly, h_r);
     } else {
         size_t szA = n / 2, szB = n / 4;
-        F *ws; HB_TRY(ctx->workspace((2 * szA + 2 * szB + (size_t)MAXB * 9 + 4) * sizeof(F), (void **)&ws));
+        const bool sparse = sp_idx && n >= 16 * SC_DOUBLE_MIN;            // (shorter tables: scatter at once, dense path)
+        const size_t sp_elems = sp_idx ? 2 * (sp_m + (sp_m + 1) / 2) + 8 + (sparse ? 0 : n) : 0;      // two (value | index) lists + counters (+ a dense copy)
+        F *ws; HB_TRY(ctx->workspace((2 * szA + 2 * szB + (size_t)MAXB * 9 + 4 + sp_elems) * sizeof(F), (void **)&ws));
         F *A1 = ws, *A2 = A1 + szA, *B1 = A2 + szA, *B2 = B1 + szB, *part = B2 + szB;
+        F *spw = part + (size_t)MAXB * 9 + 4;
+        F *lval[2] = {spw, spw + sp_m + (sp_m + 1) / 2}; uint64_t *lidx[2] = {reinterpret_cast<uint64_t *>(lval[0] + sp_m), reinterpret_cast<uint64_t *>(lval[1] + sp_m)};
+        uint32_t *lcnt = reinterpret_cast<uint32_t *>(spw + 2 * (sp_m + (sp_m + 1) / 2));       // [0]: the caller's count, [1], [2]: the two lists'
+        if (sp_idx && !sparse) {
+            F *dv2 = spw + 2 * (sp_m + (sp_m + 1) / 2) + 8;
+            HB_TRY(launch_zero(ctx, dv2, n * sizeof(F)));
+            HB_TRY(launch_scatter(ctx, sp_idx, sp_val, sp_m, dv2));
+            v2 = dv2;
+        }
         Mailbox *mb; unsigned *ticket; HB_TRY(ctx->mailbox(&mb, &ticket));
         const F *s1 = v1, *s2 = v2;
         F *d1 = A1, *d2 = A2;
@@ -2223,10 +2351,23 @@ int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev
             const F *S1 = v1, *S2 = v2; size_t S_size = n;            // the materialised tables: level i - 2 (or the inputs)
             F *D1 = B1, *D2 = B2;                                     // T_2 has n/4 elements: fits B; later levels fit either
             bool pend = false; F pr0 = fmake(0), pr1 = fmake(0);      // (r_{i-2}, r_{i-1}): still to be applied to S
+            const uint64_t *cidx = sp_idx; const F *cval = sp_val; const uint32_t *ccnt = nullptr; int lnext = 0;  // the sparse list at the level S1 is at
             while ((n >> i) >= SC_DOUBLE_MIN) {
                 const size_t Q = (n >> i) / 4;
                 const int nb = grid_for(4 * Q, 256, MAXB);
                 const uint32_t seq = ++ctx->mbox_seq;
+                if (sparse) {
+                    if (!pend) HB_LAUNCH(ctx, "k_sc2_sparse_round", k_sc2_sparse_round<false>, dim3(1), dim3(1024), 0, cidx, cval, ccnt, (uint32_t)sp_m, (uint64_t *)nullptr,
+                                         (F *)nullptr, (uint32_t *)nullptr, S1, pr0, pr1, mb, seq);
+                    else {
+                        HB_LAUNCH(ctx, "k_sc2_fold4", k_sc2_fold4, dim3(grid_for(4 * Q, 256, 4096)), dim3(256), 0, S1, D1, 4 * Q, pr0, pr1);      // the dense table: level i - 2 -> level i
+                        HB_LAUNCH(ctx, "k_sc2_sparse_round", k_sc2_sparse_round<true>, dim3(1), dim3(1024), 0, cidx, cval, ccnt, (uint32_t)sp_m, lidx[lnext], lval[lnext],
+                                  lcnt + 1 + lnext, (const F *)D1, pr0, pr1, mb, seq);
+                        cidx = lidx[lnext]; cval = lval[lnext]; ccnt = lcnt + 1 + lnext; lnext ^= 1;
+                        S1 = D1; S_size = 4 * Q;
+                        if (D1 == B1) { D1 = A1; D2 = A2; } else { D1 = B1; D2 = B2; }
+                    }
+                } else {
                 if (!pend) HB_LAUNCH(ctx, "k_sc2_double", k_sc2_double<false>, dim3(nb), dim3(256), 0, S1, S2, (F *)nullptr, (F *)nullptr, Q, pr0, pr1, part);
                 else {
                     HB_LAUNCH(ctx, "k_sc2_double", k_sc2_double<true>, dim3(nb), dim3(256), 0, S1, S2, D1, D2, Q, pr0, pr1, part);
@@ -2234,6 +2375,7 @@ int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev
                     if (D1 == B1) { D1 = A1; D2 = A2; } else { D1 = B1; D2 = B2; }
                 }
                 HB_LAUNCH(ctx, "k_sc_reduce", k_sc_reduce_post<9>, dim3(1), dim3(256), 0, part, nb, mb, seq);
+                }
                 HB_TRY(ctx->mbox_wait(seq));
                 F G[9]; for (int q = 0; q < 9; q++) G[q] = mb->vals[q];            // G(r, t) at (0,0) (1,0) (inf,0) | (0,1) (1,1) (inf,1) | (0,inf) (1,inf) (inf,inf)
                 // round i: G(r, 0) + G(r, 1) as (a, b, c) from its values at r = inf, 1, 0
@@ -2250,6 +2392,12 @@ int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev
             }
             // bridge to the round-by-round loop: it expects s = T_{i-1} and rnd = r_{i-1}.  S = T_{i-2}: fold it once with r_{i-2}
             // (the polynomial this launch also sums is round i-1's, already known: its partials are not reduced).
+            if (sparse) {                                             // the second table, dense from here on: level i - 2, beside S1 (n >= 16 SC_DOUBLE_MIN: S1 is A1 or B1)
+                F *m2 = (S1 == A1) ? A2 : B2;
+                HB_TRY(launch_zero(ctx, m2, S_size * sizeof(F)));
+                HB_LAUNCH(ctx, "k_scatter_counted", k_scatter_counted, dim3(32), dim3(256), 0, cidx, cval, ccnt, m2);
+                S2 = m2;
+            }
             F *b1 = (S1 == A1) ? B1 : A1, *b2 = (S1 == A1) ? B2 : A2;
             const size_t L = S_size / 4;
             HB_LAUNCH(ctx, "k_sc2_fold_poly", k_sc2_fold_poly, dim3(grid_for(L, 256, MAXB)), dim3(256), 0, S1, S2, b1, b2, L, pr0, part);

@@ -67,6 +67,7 @@ int launch_eq_step_batched(hobbit_ctx *ctx, const F *old, F *nw, size_t m, size_
 int launch_eq_head_batched(hobbit_ctx *ctx, F *out, size_t ld, const F *z, int v, int h, int reps);
 int launch_fill_F(hobbit_ctx *ctx, F *p, size_t stride, size_t n, F v);
 int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev_r, HF *h_qpoly, HF *h_r, HF *h_vr, HF *h_final);
+int launch_sumcheck2_sparse(hobbit_ctx *ctx, const F *v1, const uint64_t *d_idx, const F *d_val, size_t m, size_t n, F prev_r, HF *h_qpoly, HF *h_r, HF *h_vr, HF *h_final);
 int launch_gate_lkp_sumcheck(hobbit_ctx *ctx, const F *const tabs[9], size_t n, const HF *h_a, HF *h_rand, HF *h_sum, HF *h_poly, HF *h_r, HF *h_final, int *h_check);
 int launch_lkp_prepare(hobbit_ctx *ctx, const int32_t *S, const F *L, const F *R, const F *O, int32_t *s2, int32_t *s3, F *blo, size_t n);
 int launch_lkp_sel_fold(hobbit_ctx *ctx, const int32_t *S, F rnd, F *aL, F *aR, F *lkp, F *mul, size_t n);

@@ -909,7 +909,7 @@ def test_execution_modes_bit_identical(hb, monkeypatch):
     """The step as a dependency graph -- chunk groups' layout changes on a side stream beside the next group's row FFT
     (HOBBIT_COMMIT_PIPE), shockwave_prove(C_c) on a helper context from a second host thread with its libc draws taken first
     (HOBBIT_OPEN_THREADS), the inner commitments and the query answers on a third stream (HOBBIT_OPEN_COMMITS_SIDE, HOBBIT_OPEN_QUERIES_SIDE), P3 beside
-    P1/P2 (HOBBIT_OPEN_P3_THREAD) --
+    P1/P2 (HOBBIT_OPEN_P3_THREAD), P3 against its second table as a sparse list (HOBBIT_OPEN_SPARSE_P3) --
     and the plain list on one stream and one thread must produce the same commitment and the same transcript, message for message, and
     leave the libc generator in the same state."""
     import ctypes
@@ -920,7 +920,7 @@ def test_execution_modes_bit_identical(hb, monkeypatch):
     hb.rng_reset(); hb.expander_init_store(trs)
     x = splitmix_field(24, 5)
     runs = []
-    for env in ({}, {"HOBBIT_COMMIT_PIPE": "0", "HOBBIT_OPEN_THREADS": "0"}, {"HOBBIT_COMMIT_PIPE": "4", "HOBBIT_OPEN_COMMITS_SIDE": "0"},
+    for env in ({}, {"HOBBIT_COMMIT_PIPE": "0", "HOBBIT_OPEN_THREADS": "0", "HOBBIT_OPEN_SPARSE_P3": "0"}, {"HOBBIT_COMMIT_PIPE": "4", "HOBBIT_OPEN_COMMITS_SIDE": "0"},
                 {"HOBBIT_COMMIT_PIPE": "16", "HOBBIT_OPEN_P3_THREAD": "1", "HOBBIT_OPEN_QUERIES_SIDE": "0"}):
         with monkeypatch.context() as m:
             for k, v in env.items():
