@@ -1507,7 +1507,7 @@ int launch_leaf_chain(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, int
     constexpr int NL = 1;   // 2 interleaved chains measured no faster: the kernel sits at the VALU issue limit (profiles/r01_microbench.txt)
     ZeroDig zd; { uint32_t z[16] = {0}; blake3_compress64(z, zd.w); }
     const char *e = getenv("HOBBIT_LEAF_ZERO_SKIP");
-    const uint32_t zero_from = (e && e[0] == '0') ? 0xFFFFFFFFu : (e && e[0] == 'X') ? 0u /* timing experiment only: wrong digests */ : (zero_rows_from + 3) / 4;
+    const uint32_t zero_from = (e && e[0] == '0') ? 0xFFFFFFFFu : (zero_rows_from + 3) / 4;
     HB_LAUNCH(ctx, "k_leaf_chain", k_leaf_chain<NL>, dim3(grid_for((total + NL - 1) / NL, 256, 1 << 20)), dim3(256), 0, tensor, chunk_stride, K, cols,
               half_trs, leaves, zero_from, zd);
     return 0;
