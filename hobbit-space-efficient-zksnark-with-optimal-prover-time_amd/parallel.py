@@ -111,6 +111,8 @@ def sharded_commit_relay(ops, dist, plan, rank, local_chunks, blocks=16):
     assert plan.contiguous, "the relay needs contiguous chunk ownership (ShardPlan(..., contiguous=True))"
     G, M = plan.world, plan.M
     last = G - 1
+    if G == 1:
+        blocks = 1                                             # nothing to relay: one chain launch
     while blocks > 1 and M % blocks:
         blocks //= 2
     per = M // blocks
