@@ -268,7 +268,9 @@ def main():
     import gc
     gc_off = not os.environ.get("HOBBIT_BENCH_GC")
     if gc_off:
-        gc.collect(); gc.disable()
+        if os.environ.get("HOBBIT_BENCH_GC_NOCOLLECT") is None:
+            gc.collect()
+        gc.disable()
     barrier()
     t0 = time.perf_counter()
     hb.timer_begin()

@@ -99,7 +99,7 @@ def sharded_commit(ops, dist, plan, rank, local_chunks):
         ops.after_collective()
     else:
         roots = [my_root]
-    top = ops.tree_top(torch.cat(roots).cpu().numpy())         # flat [2G-1, 32] (numpy, host)
+    top = ops.tree_top(ops.to_host("roots", torch.cat(roots)).copy())   # flat [2G-1, 32] (numpy, host)
     return dict(leaf_range=(lo, hi), subtree=subtree, top=top, root=top[-1])
 
 
@@ -144,7 +144,7 @@ def sharded_commit_relay(ops, dist, plan, rank, local_chunks, blocks=16):
     if G > 1:
         dist.broadcast(root, last)
         ops.after_collective()
-    return dict(root=root.cpu().numpy(), owner=last, levels=levels)
+    return dict(root=ops.to_host("root", root).copy(), owner=last, levels=levels)
 
 
 class ElasticPlan:
@@ -204,16 +204,16 @@ def sharded_open(ops, dist, plan, rank, commit_res, x, queries=5900):
     if G > 1:
         import ctypes
         libc = ctypes.CDLL(None); libc.random.restype = ctypes.c_long
-        seed = torch.tensor([libc.random() if rank == 0 else 0], dtype=torch.int64, device=ops.device)
+        seed = ops.upload("seed", np.array([libc.random() if rank == 0 else 0], np.int64))      # (pinned staging both ways: see HipOps._upload)
         dist.broadcast(seed, 0)
         ops.after_collective()
-        libc.srandom(ctypes.c_uint(int(seed.item()) & 0xFFFFFFFF))
+        libc.srandom(ctypes.c_uint(int(ops.to_host("seed", seed)[0]) & 0xFFFFFFFF))
     res = ops.open_from_aggregate(aggr, plan, queries)
     cols = np.asarray(res["cols"], np.int64); rows = np.asarray(res["rows"], np.int64)
     if G > 1:
         # every rank must have drawn the same libc sequence inside the replicated open: a divergence (a library on one rank drawing
         # from libc, a different call history) would silently answer different queries -- compare with rank 0's and fail loudly
-        q_mine = torch.from_numpy(np.stack([cols, rows])).to(ops.device)
+        q_mine = ops.upload("queries", np.stack([cols, rows]))
         q0 = q_mine.clone()
         dist.broadcast(q0, 0)
         ops.after_collective()
@@ -229,7 +229,7 @@ def sharded_open(ops, dist, plan, rank, commit_res, x, queries=5900):
         rep = [mine]
     reply = np.zeros((queries, plan.K, 2), np.uint64)
     for h in range(G):
-        r_h = rep[h].cpu().numpy().view(np.uint64)
+        r_h = ops.to_host("reply", rep[h]).view(np.uint64)          # (consumed before the next to_host("reply"))
         for li, i in enumerate(plan.chunks_of(h)):
             reply[:, i] = r_h[:, li]
     res["reply"] = reply
@@ -243,7 +243,7 @@ def sharded_open(ops, dist, plan, rank, commit_res, x, queries=5900):
             pt = ops.paths_buffer(queries, depth, host)
             dist.broadcast(pt, owner)
             ops.after_collective()
-            host = pt.cpu().numpy()
+            host = ops.to_host("paths", pt).copy()
         res["paths"] = host
         return res
     # all-to-all commit: owner of a leaf = pos // m_local
@@ -263,7 +263,7 @@ def sharded_open(ops, dist, plan, rank, commit_res, x, queries=5900):
     depth_t = G.bit_length() - 1
     paths = np.zeros((queries, depth_l + depth_t, 32), np.uint8)
     owner = pos // plan.m_local
-    stacked = np.stack([a.cpu().numpy() for a in allp])                               # (G, queries, depth_l, 32)
+    stacked = np.stack([ops.to_host("subpaths", a).copy() for a in allp])               # (G, queries, depth_l, 32)
     paths[:, :depth_l] = stacked[owner, np.arange(queries)]
     off, sz, p = 0, G, owner.copy()
     for l in range(depth_t):                                                          # siblings in the top levels
@@ -300,6 +300,9 @@ class HipOps:
         import torch
         return torch.empty((K, m_local, 32), dtype=torch.uint8, device=self.device)
 
+    def upload(self, role, host):
+        return self._upload(role, np.ascontiguousarray(host))
+
     def _upload(self, role, host):
         """host numpy array -> retained device tensor through a retained PINNED host tensor.  torch.from_numpy(x).to(device) copies from
         pageable memory; on this runtime that now and then takes ~27 ms (a staging buffer being set up) -- measured in the open of the
@@ -314,6 +317,19 @@ class HipOps:
         ent[1].copy_(ent[0], non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
         return ent[1]
+
+    def to_host(self, role, t):
+        """device tensor -> numpy through a retained PINNED host tensor (one per role and shape): `t.cpu()` copies into pageable memory,
+        which on this runtime stalls for 30-40 ms now and then (the same effect as in _upload; one step in ~40 of the sharded bench).
+        The returned array is a view of the retained buffer: valid until the next to_host of the same role."""
+        import torch
+        cache = self.__dict__.setdefault("_down", {})
+        pin = cache.get(role)
+        if pin is None or pin.shape != t.shape or pin.dtype != t.dtype:
+            pin = cache[role] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+        pin.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return pin.numpy()
 
     def inner_digests_one(self, local_chunks, li, plan):
         """local_chunks: (device_ptr, n_own): n_own messages of M F each, contiguous, resident.  Tensor code of local chunk li into the

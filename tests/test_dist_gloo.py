@@ -43,6 +43,12 @@ class OracleOps:
         from __graft_entry__ import load_package
         return load_package().parallel_tree_top(self.lib, roots)
 
+    def to_host(self, role, t):
+        return t.cpu().numpy()
+
+    def upload(self, role, host):
+        return torch.from_numpy(np.ascontiguousarray(host))
+
     def after_collective(self):
         pass
 
