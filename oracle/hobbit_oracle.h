@@ -132,6 +132,11 @@ int orc_elastic_open_rs(size_t N, size_t B, const oF *x, int queries, const uint
                         oF *reply_out, uint8_t *paths_out, int *ncols_out, oF *qpoly, oF *r_out, oF *vr, oF *fin, int *checks, oF *rx_out);
 
 /* streaming sumcheck drivers (see hobbit_oracle.c) */
+size_t orc_elastic_aggregate2(size_t N, size_t B, const oF *beta, const uint64_t *Iq, size_t nq, oF *aggr_out, uint8_t *cf_root, uint8_t *cc_root, oF *aux_out, oF *tensor_out);
+size_t orc_elastic_reply2(size_t N, size_t B, const uint64_t *Iq, size_t nq, oF *reply, int stale_parity_quirk);
+int orc_elastic_open_spielman(size_t N, size_t B, const oF *x, int queries, const uint8_t *commit_levels, int stale_parity_quirk, uint32_t *I_out, oF *rv0_out,
+                              oF *aggr_out, uint8_t *roots, oF *reply_out, uint8_t *paths_out, int *nr_out, oF *aux_out, oF *scal, oF *qpoly, oF *r_out,
+                              oF *vr, oF *fin, int *checks, oF *rx_out);
 void orc_stream_config(int kind, uint64_t seed);
 void orc_read_mul_tree_layer(size_t size, int layer, oF *out);
 void orc_read_mul_tree_data(size_t size, int layer, int distance, int batches, oF *out);

@@ -353,6 +353,24 @@ class _Base:
         self.fn("elastic_reply")(c_sz(N), c_sz(B), _p(Iq), c_sz(Iq.shape[0]), _p(reply))
         return reply
 
+    # ---- Elastic_PC open, RS x expander (option 2): aggregate()'s linear_time branch (src/Elastic_PC.cpp:348-413) and update_reply_spielman (:431-485).
+    # expander_init_store(B >> 14) must have been called (test_Elastic_PC option 2 draws the graphs before the commit).
+    def elastic_aggregate2(self, N, B, beta, I, want_tensor=False):
+        b = F(beta).reshape(-1, 2); Iq = np.ascontiguousarray(I, np.uint64).reshape(-1, 2)
+        trs = max(B >> 14, 1); nq = Iq.shape[0]
+        aggr = np.zeros((B, 2), np.uint64); roots = np.zeros((2, 32), np.uint8)
+        aux = np.zeros((nq, 2 * trs, 2), np.uint64)
+        ten = np.zeros((trs, 2 * B // trs, 2), np.uint64) if want_tensor else None
+        f = self.fn("elastic_aggregate2"); f.restype = c_sz
+        nr = f(c_sz(N), c_sz(B), _p(b), _p(Iq), c_sz(nq), _p(aggr), _p(roots[0]), _p(roots[1]), _p(aux), _p(ten) if ten is not None else None)
+        return dict(aggr=aggr, cf_root=roots[0].copy(), cc_root=roots[1].copy(), aux=aux[:nr].copy(), tensor=ten)
+
+    def elastic_reply2(self, N, B, I):
+        Iq = np.ascontiguousarray(I, np.uint64).reshape(-1, 2)
+        reply = np.zeros((Iq.shape[0], N // B, 2), np.uint64)
+        self.fn("elastic_reply2")(c_sz(N), c_sz(B), _p(Iq), c_sz(Iq.shape[0]), _p(reply))
+        return reply
+
 class Oracle(_Base):
     pfx = "orc_"
 
@@ -498,6 +516,47 @@ class Oracle(_Base):
                    checks=chk, rx=rx)
         enc_f, lv_f = self.shockwave_commit(aggr, 32)
         res["sp_f"] = self.shockwave_prove(aggr, enc_f, 32, rx, lv_f)
+        return res
+
+    def elastic_reply2(self, N, B, I, stale_parity_quirk=1):
+        Iq = np.ascontiguousarray(I, np.uint64).reshape(-1, 2)
+        reply = np.zeros((Iq.shape[0], N // B, 2), np.uint64)
+        f = self.lib.orc_elastic_reply2; f.restype = c_sz
+        filled = f(c_sz(N), c_sz(B), _p(Iq), c_sz(Iq.shape[0]), _p(reply), ctypes.c_int(stale_parity_quirk))
+        return reply[:, :filled]
+
+    def elastic_open2(self, N, B, x, queries=5900, commit_levels=None, want_reply=True, stale_parity_quirk=1, prove=True):
+        """Prover side of Elastic_PC::open, option 2 (src/Elastic_PC.cpp:625-726 under linear_time): orc_elastic_open_spielman, then
+        shockwave_prove(C_c, P3.randomness[0]) and shockwave_prove(C_f, r_x) (src/PC_utils.cpp:252, 269) with the libc generator running on
+        (nothing between them draws).  expander_init_store(B >> 14) must have been called."""
+        x = F(x).reshape(-1, 2)
+        trs = B >> 14; cols = 2 * B // trs; K = N // B
+        logc = cols.bit_length() - 1; R1 = (2 * trs).bit_length() - 1; logt = R1 - 1
+        maxr = R1 + logc + (queries * 2 * trs).bit_length() + logc
+        I = np.zeros((queries, 2), np.uint32); rv0 = np.zeros(2, np.uint64); aggr = np.zeros((B, 2), np.uint64); roots = np.zeros((2, 32), np.uint8)
+        reply = np.zeros((queries, K, 2), np.uint64) if want_reply else None
+        depth = (4 * B).bit_length() - 1
+        lv = np.ascontiguousarray(commit_levels, np.uint8) if commit_levels is not None else None
+        paths = np.zeros((queries, depth, 32), np.uint8) if lv is not None else None
+        nr = ctypes.c_int(); aux = np.zeros((queries, 2 * trs, 2), np.uint64); scal = np.zeros((3, 2), np.uint64)
+        q = np.zeros((maxr, 3, 2), np.uint64); r = np.zeros((maxr, 2), np.uint64); vr = np.zeros((4, 2, 2), np.uint64); fin = np.zeros((4, 2), np.uint64)
+        chk = np.zeros(1, np.int32); rx = np.zeros((logc + logt - 1, 2), np.uint64)
+        f = self.lib.orc_elastic_open_spielman; f.restype = ctypes.c_int
+        rounds = f(c_sz(N), c_sz(B), _p(x), ctypes.c_int(queries), _p(lv) if lv is not None else None, ctypes.c_int(stale_parity_quirk), _p(I), _p(rv0), _p(aggr), _p(roots),
+                   _p(reply) if reply is not None else None, _p(paths) if paths is not None else None, ctypes.byref(nr), _p(aux), _p(scal), _p(q), _p(r), _p(vr), _p(fin),
+                   _p(chk), _p(rx))
+        aux = aux[:nr.value].copy()
+        res = dict(I=I, rv0=rv0, aggr=aggr, cf_root=roots[0].copy(), cc_root=roots[1].copy(), reply=reply, paths=paths, nr=np.array([nr.value]), aux=aux, scal=scal,
+                   poly=q[:rounds], r=r[:rounds], vr=vr, fin=fin, checks=chk, rx=rx)
+        if prove:
+            npad = 1 << (max(aux.size // 2, 1) - 1).bit_length()
+            flat = np.zeros((npad, 2), np.uint64); flat[:aux.size // 2] = aux.reshape(-1, 2)
+            R3 = npad.bit_length() - 1
+            p3r = r[R1 + logc:R1 + logc + R3]
+            enc_c, lv_c = self.shockwave_commit(flat, 32)
+            res["sp_c"] = self.shockwave_prove(flat, enc_c, 32, p3r, lv_c)
+            enc_f, lv_f = self.shockwave_commit(aggr, 32)
+            res["sp_f"] = self.shockwave_prove(aggr, enc_f, 32, rx, lv_f)
         return res
 
     def open_standard_rs(self, poly, K, trs, x, queries=790, commit_levels=None, tensor=None):

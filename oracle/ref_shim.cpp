@@ -45,6 +45,8 @@ struct proof batch_3product_sumcheck(vector<vector<F>> &arr1, vector<vector<F>> 
 
 // src/Elastic_PC.cpp:315, 316, 487: the query list is a file-scope global there; aggregate / compute_aggregation_reply are not in the header
 extern vector<vector<size_t>> I;
+extern vector<vector<F>> aux_commit;                                                                                                         // src/Elastic_PC.cpp:315
+extern shockwave_data *C_f, *C_c;                                                                                                            // src/Virgo.cpp globals, as src/Elastic_PC.cpp:11 declares them
 extern int aggregation_queries;                                                                                                              // src/Elastic_PC.cpp:10
 void aggregate(stream_descriptor fd, vector<F> beta1, vector<F> random_points, vector<vector<_hash>> &MT_hashes, vector<F> &aggregated_vector,
                vector<vector<F>> &aggregated_tensor);                                                                                        // src/Elastic_PC.cpp:316
@@ -449,6 +451,37 @@ void ref_elastic_aggregate(size_t N, size_t B, const uint64_t *beta, uint64_t *a
 // "test" stream is non-zero, so no chunk is skipped).
 void ref_elastic_reply(size_t N, size_t B, const uint64_t *Iq, size_t nq, uint64_t *reply) {
     BUFFER_SPACE = B; linear_time = false; tensor_row_size = (int)(B >> 11); aggregation_queries = (int)nq;
+    stream_descriptor fd; fd.name = "test"; fd.size = N; fd.pos = 0;
+    vector<vector<size_t>> II(nq); for (size_t q = 0; q < nq; q++) II[q] = {(size_t)Iq[2 * q], (size_t)Iq[2 * q + 1]};
+    vector<vector<F>> r;
+    compute_aggregation_reply(fd, II, r);
+    size_t K = N / B;
+    for (size_t q = 0; q < nq; q++) memcpy(reply + 2 * q * K, r[q].data(), 16 * r[q].size());
+}
+
+// ---- Elastic_PC open, RS x expander (opt 2): aggregate()'s linear_time branch (src/Elastic_PC.cpp:348-413) and compute_aggregation_reply ->
+// update_reply_spielman (:431-485).  Neither reaches SHA3.  The caller has run ref_expander_init_store(B >> 14) (test_Elastic_PC option 2, :767).
+// Iq = nq x (col, row) as open() draws them (:650-655).  Returns the number of "remaining" columns (those with a queried parity row);
+// aux: their expander codewords, nr x 2trs; tensor_out (nullable): aggregated_tensor, trs x 2B/trs.
+size_t ref_elastic_aggregate2(size_t N, size_t B, const uint64_t *beta, const uint64_t *Iq, size_t nq, uint64_t *aggr_out, uint8_t *cf_root, uint8_t *cc_root,
+                              uint64_t *aux_out, uint64_t *tensor_out) {
+    BUFFER_SPACE = B; linear_time = true; tensor_row_size = (int)(B >> 14); aggregation_queries = (int)nq;
+    I.assign(nq, vector<size_t>()); for (size_t q = 0; q < nq; q++) I[q] = {(size_t)Iq[2 * q], (size_t)Iq[2 * q + 1]};
+    stream_descriptor fd; fd.name = "test"; fd.size = N; fd.pos = 0;
+    size_t K = N / B;
+    vector<F> b = vecF(beta, K), rv(K, F(1)), aggr; vector<vector<F>> at; vector<vector<_hash>> MT;
+    aggregate(fd, b, rv, MT, aggr, at);
+    memcpy(aggr_out, aggr.data(), 16 * aggr.size());
+    memcpy(cf_root, C_f->MT.back()[0].arr, 32);
+    memcpy(cc_root, C_c->MT.back()[0].arr, 32);
+    size_t nr = aux_commit.size();
+    if (aux_out) for (size_t i = 0; i < nr; i++) memcpy(aux_out + 2 * i * aux_commit[i].size(), aux_commit[i].data(), 16 * aux_commit[i].size());
+    if (tensor_out) for (size_t i = 0; i < at.size(); i++) memcpy(tensor_out + 2 * i * at[i].size(), at[i].data(), 16 * at[i].size());
+    delete C_f; C_f = nullptr; delete C_c; C_c = nullptr;
+    return nr;
+}
+void ref_elastic_reply2(size_t N, size_t B, const uint64_t *Iq, size_t nq, uint64_t *reply) {
+    BUFFER_SPACE = B; linear_time = true; tensor_row_size = (int)(B >> 14); aggregation_queries = (int)nq;
     stream_descriptor fd; fd.name = "test"; fd.size = N; fd.pos = 0;
     vector<vector<size_t>> II(nq); for (size_t q = 0; q < nq; q++) II[q] = {(size_t)Iq[2 * q], (size_t)Iq[2 * q + 1]};
     vector<vector<F>> r;

@@ -293,6 +293,23 @@ def elastic_open_inputs(N, B, nq=700, seed=901):
     return x, I
 
 
+ELASTIC_OPEN2_CASES = ((1 << 20, 1 << 16), (1 << 22, 1 << 18), (1 << 24, 1 << 20))
+
+
+def elastic_open2_inputs(N, B, nq=5900, seed=902):
+    """Elastic_PC::open's own draws under linear_time (src/Elastic_PC.cpp:626-655; option 2: 5900 queries, tensor_row_size = B / 2^14) from a
+    seeded libc generator, as elastic_open_inputs does for option 1.  Returns (x, I)."""
+    import ctypes
+    libc = ctypes.CDLL(None); libc.random.restype = ctypes.c_long
+    trs = B >> 14; cols = 2 * B // trs
+    x = splitmix_field(N.bit_length() - 1, 903)
+    libc.srandom(seed); libc.random(); libc.rand()
+    I = np.zeros((nq, 2), np.uint64)
+    for q in range(nq):
+        I[q, 0] = libc.rand() % cols; I[q, 1] = libc.rand() % (2 * trs)
+    return x, I
+
+
 def elastic_open_queries(B, nq, seed):
     trs = B >> 11
     return np.random.default_rng(seed).integers(0, [2 * B // trs, 2 * trs], (nq, 2)).astype(np.uint64)
@@ -311,6 +328,28 @@ def case_elastic_open(lib):
         rep = lib.elastic_reply(N, B, I)
         out[key + "I_dg"] = dg(I); out[key + "reply_dg"] = dg(rep); out[key + "reply_s"] = samp(rep.reshape(-1, 2))
     out["read_stream"] = dg(lib.read_stream(4096))
+    return out
+
+
+def case_elastic_open2(lib):
+    """Elastic_PC::open option 2 (RS x expander, test_Elastic_PC(N, 2)), the stream passes that do not reach SHA3, run in the real reference AS
+    BUILT: aggregate()'s linear_time branch (src/Elastic_PC.cpp:348-413: the aggregate, C_f, the expander codewords aux_commit of the queried
+    columns that have a parity-row query, C_c over them) and compute_aggregation_reply -> update_reply_spielman (:431-533, including its
+    read of buff2 past size(): oracle/check_elastic_open2_determinism.py), on the coefficients and queries open() itself derives.
+    B = 2^16: tensor_row_size 4 (the expander code is the identity, parity rows are zero); B = 2^18: 16; B = 2^20: 64, test_OurPC.sh's own shape."""
+    out = {}
+    for (N, B) in ELASTIC_OPEN2_CASES:
+        key = "eo2_%d_%d_" % (N, B)
+        lib.rng_reset()
+        if hasattr(lib, "encode_reset_scratch"):
+            lib.encode_reset_scratch()
+        lib.expander_init_store(B >> 14)
+        x, I = elastic_open2_inputs(N, B)
+        a = lib.elastic_aggregate2(N, B, lib.precompute_beta(x[:(N // B).bit_length() - 1]), I)
+        out[key + "aggr_dg"] = dg(a["aggr"]); out[key + "cf_root"] = a["cf_root"]; out[key + "cc_root"] = a["cc_root"]
+        out[key + "nr"] = np.array([a["aux"].shape[0]]); out[key + "aux_dg"] = dg(a["aux"]); out[key + "aux_s"] = samp(a["aux"].reshape(-1, 2))
+        rep = lib.elastic_reply2(N, B, I)
+        out[key + "I_dg"] = dg(I); out[key + "reply_dg"] = dg(rep); out[key + "reply_s"] = samp(rep.reshape(-1, 2))
     return out
 
 
@@ -495,5 +534,5 @@ def case_gate(lib):
     return out
 
 
-CASES = dict(streamdrv=case_streamdrv, elastic_open=case_elastic_open, field=case_field, mimc=case_mimc, blake=case_blake, merkle=case_merkle, graph_encode=case_graph_encode,
+CASES = dict(streamdrv=case_streamdrv, elastic_open=case_elastic_open, elastic_open2=case_elastic_open2, field=case_field, mimc=case_mimc, blake=case_blake, merkle=case_merkle, graph_encode=case_graph_encode,
              fft=case_fft, tensorcode=case_tensorcode, commit=case_commit, commit_rs=case_commit_rs, sumcheck=case_sumcheck, elastic=case_elastic, codeproofs=case_codeproofs, streamfold=case_streamfold, lkpfold=case_lkpfold, multree=case_multree, innerpcs=case_innerpcs, gate=case_gate)
