@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "hobbit_commitment_gather", "hobbit_commitment_path", "hobbit_commitment_paths",
     "hobbit_elastic_begin", "hobbit_elastic_push", "hobbit_elastic_push_inner", "hobbit_elastic_finish", "hobbit_elastic_free",
     "hobbit_elastic_open_begin", "hobbit_elastic_open_aggregate_push", "hobbit_elastic_open_aggregate_finish", "hobbit_elastic_open_reply_push",
-    "hobbit_elastic_open_finish", "hobbit_elastic_open_free", "hobbit_generate_randomness",
+    "hobbit_elastic_open_finish", "hobbit_elastic_open_free", "hobbit_elastic_open_begin_lin", "hobbit_elastic_open_dims", "hobbit_generate_randomness",
     "hobbit_read_mul_tree_layer", "hobbit_read_mul_tree_data", "hobbit_generate_claims_opt", "hobbit_sumcheck3_stream_batch", "hobbit_mul_tree_stream_shallow",
     "hobbit_gate_consistency_stream", "hobbit_set_lookups", "hobbit_gate_consistency_lookups_stream", "hobbit_open_standard_rs", "hobbit_leaf_chain_relay", "hobbit_verify_path_host", "hobbit_fingerprint_map", "hobbit_leaf_chain", "hobbit_axpy_aggregate", "hobbit_stream_fold",
     "hobbit_tensorcode_chunks", "hobbit_inner_digests", "hobbit_chain_digests", "hobbit_blake3_64_host",
@@ -101,6 +101,7 @@ def load_library(path=LIB_PATH):
         "hobbit_elastic_free": [V], "hobbit_elastic_push_inner": [V, V, V, V],
         "hobbit_elastic_open_begin": [V, S, S, I, V, I, V], "hobbit_elastic_open_aggregate_push": [V, V, V], "hobbit_elastic_open_aggregate_finish": [V, V],
         "hobbit_elastic_open_reply_push": [V, V, V], "hobbit_elastic_open_finish": [V, V, V, V], "hobbit_elastic_open_free": [V],
+        "hobbit_elastic_open_begin_lin": [V, S, S, I, V, I, V], "hobbit_elastic_open_dims": [V, V, V, V],
         "hobbit_generate_randomness": [S, V],
         "hobbit_read_mul_tree_layer": [V, V, V, S, I, V], "hobbit_read_mul_tree_data": [V, V, V, S, I, I, I, V],
         "hobbit_generate_claims_opt": [V, V, V, S, S, V, I, I, I, I, V], "hobbit_sumcheck3_stream_batch": [V, V, V, S, S, V, I, I, I, I, V, I, V],
@@ -751,6 +752,57 @@ class Hobbit:
         res["I"] = np.stack([res["cols"], res["rows"]], axis=1)
         if sp:
             res["sp_f"] = self._sp_trim(sp[0], B, 32)
+        return res
+
+    def elastic_open2(self, N, B, x, queries=5900, commit_levels=None, chunks=None):
+        """Elastic_PC::open, option 2 (RS x expander; src/Elastic_PC.cpp:625-726 under linear_time), prover side.  The expander graphs for
+        tensor_row_size = B >> 14 must have been uploaded (upload_graphs).  chunks: None = the reference's repeating read_stream chunk; or a
+        callable i -> host array (B, 2) / DeviceBuffer, called once per pass and chunk in stream order."""
+        x = Fh(x).reshape(-1, 2)
+        trs = B >> 14; cols = 2 * B // trs; K = N // B
+        logc = cols.bit_length() - 1; R1 = (2 * trs).bit_length() - 1; logt = R1 - 1
+        e = c_vp()
+        self._chk(self.lib.hobbit_elastic_open_begin_lin(self.ctx, N, B, trs, _hp(x), queries, ctypes.byref(e)))
+        try:
+            nc, nr, npad = c_int(), c_int(), c_sz()
+            self.lib.hobbit_elastic_open_dims(e, ctypes.byref(nc), ctypes.byref(nr), ctypes.byref(npad))
+            nc, nr, npad = nc.value, nr.value, npad.value
+            resident = self.to_device(self.read_stream(B)) if chunks is None else None
+
+            def chunk(i):
+                if resident is not None:
+                    return resident
+                c = chunks(i)
+                return c if isinstance(c, DeviceBuffer) else self.to_device(Fh(c).reshape(-1, 2))
+            for i in range(K):
+                self._chk(self.lib.hobbit_elastic_open_aggregate_push(self.ctx, e, chunk(i).ptr))
+            self._chk(self.lib.hobbit_elastic_open_aggregate_finish(self.ctx, e))
+            for i in range(K):
+                self._chk(self.lib.hobbit_elastic_open_reply_push(self.ctx, e, chunk(i).ptr))
+            R3 = npad.bit_length() - 1
+            rounds = R1 + logc + R3 + logc
+            depth = (4 * B).bit_length() - 1
+            res = dict(cols=np.zeros(queries, np.uint32), rows=np.zeros(queries, np.uint32), rv0=np.zeros(2, np.uint64), reply=np.zeros((queries, K, 2), np.uint64),
+                       reply_len=np.zeros(1, np.int32), paths=np.zeros((queries, depth, 32), np.uint8) if commit_levels is not None else None,
+                       cf_root=np.zeros(32, np.uint8), ncols=np.zeros(1, np.int32), poly=np.zeros((rounds, 3, 2), np.uint64), r=np.zeros((rounds, 2), np.uint64),
+                       vr=np.zeros((4, 2, 2), np.uint64), fin=np.zeros((4, 2), np.uint64), checks=np.zeros(1, np.int32), rx=np.zeros((logc + logt - 1, 2), np.uint64),
+                       cc_root=np.zeros(32, np.uint8), nr=np.zeros(1, np.int32), scal=np.zeros((3, 2), np.uint64))
+            names = ("cols", "rows", "rv0", "reply", "reply_len", "paths", "cf_root", "ncols", "poly", "r", "vr", "fin", "checks", "rx")
+            names2 = ("cc_root", "nr", "scal")
+
+            class Out(ctypes.Structure):
+                _fields_ = [(n, c_vp) for n in names + ("sp_f",) + names2 + ("sp_c",)]
+            spf = self._sp_buffers(B, 32); spc = self._sp_buffers(npad, 32)
+            o = Out(*([(res[k].ctypes.data if res[k] is not None else None) for k in names] + [ctypes.addressof(spf[1])] +
+                      [res[k].ctypes.data for k in names2] + [ctypes.addressof(spc[1])]))
+            lv = commit_levels.ptr if isinstance(commit_levels, DeviceBuffer) else commit_levels
+            self._chk(self.lib.hobbit_elastic_open_finish(self.ctx, e, lv, ctypes.byref(o)))
+        finally:
+            self.lib.hobbit_elastic_open_free(e)
+        rl = int(res["reply_len"][0])
+        res["reply"] = res["reply"].reshape(-1, 2)[:queries * rl].reshape(queries, rl, 2)
+        res["I"] = np.stack([res["cols"], res["rows"]], axis=1)
+        res["sp_f"] = self._sp_trim(spf[0], B, 32); res["sp_c"] = self._sp_trim(spc[0], npad, 32)
         return res
 
     def open_standard_rs(self, poly, c, x, queries=790, want_paths=True, shockwave=True):

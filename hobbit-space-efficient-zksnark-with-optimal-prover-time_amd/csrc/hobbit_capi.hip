@@ -1233,8 +1233,18 @@ int hobbit_prove_fft(hobbit_ctx *ctx, const hobbit_F *d_m, size_t s, const hobbi
     HB_TRY(hobbit_phi_g(ctx, h_r, k, &one, 0, (hobbit_F *)FG));
     return hobbit_sumcheck2(ctx, (const hobbit_F *)FG, (const hobbit_F *)mm, S, h_r + (k - 1), h_qpoly, h_rr, h_vr, h_final);
 }
+// h_prev: the transcript seed r[r.size()-1] (src/sumcheck.cpp:3012); recursive_prover_Spielman_stream hands prove_fft_matrix an r that is one
+// entry longer than the k2 + k1 variables it uses (src/PC_utils.cpp:255-266), so the seed is not always h_r[k1 + k2 - 1]
+static int prove_fft_matrix_seeded(hobbit_ctx *ctx, const hobbit_F *d_M, size_t rows, size_t cols, const hobbit_F *h_r, const hobbit_F *h_prev, hobbit_F *h_qpoly,
+                                   hobbit_F *h_rr, hobbit_F *h_vr, hobbit_F *h_final);
 int hobbit_prove_fft_matrix(hobbit_ctx *ctx, const hobbit_F *d_M, size_t rows, size_t cols, const hobbit_F *h_r, hobbit_F *h_qpoly, hobbit_F *h_rr,
                             hobbit_F *h_vr, hobbit_F *h_final) {
+    const int k2 = ilog2_exact(2 * cols), k1 = ilog2_exact(rows);
+    if (k2 < 1 || k1 < 0) return ctx->fail(HOBBIT_EINVAL, "prove_fft_matrix: rows and cols must be powers of two");
+    return prove_fft_matrix_seeded(ctx, d_M, rows, cols, h_r, h_r + (k1 + k2 - 1), h_qpoly, h_rr, h_vr, h_final);
+}
+static int prove_fft_matrix_seeded(hobbit_ctx *ctx, const hobbit_F *d_M, size_t rows, size_t cols, const hobbit_F *h_r, const hobbit_F *h_prev, hobbit_F *h_qpoly,
+                                   hobbit_F *h_rr, hobbit_F *h_vr, hobbit_F *h_final) {
     const size_t C2 = 2 * cols; int k2 = ilog2_exact(C2), k1 = ilog2_exact(rows);
     if (k2 < 1 || k1 < 0) return ctx->fail(HOBBIT_EINVAL, "prove_fft_matrix: rows and cols must be powers of two");
     // arr = prepare_matrix(transpose(M padded), r1): column evaluations, upper half zero; Fg1 = phiG(r2)
@@ -1247,7 +1257,7 @@ int hobbit_prove_fft_matrix(hobbit_ctx *ctx, const hobbit_F *d_M, size_t rows, s
     // sumcheck2 uses ctx->workspace itself: move the two tables to workspace2 first
     F *t2; HB_TRY(ctx->workspace2(2 * C2 * sizeof(F), (void **)&t2));
     HB_TRY(launch_copy(ctx, t2, tmp, 2 * C2 * sizeof(F)));
-    return hobbit_sumcheck2(ctx, (const hobbit_F *)(t2 + C2), (const hobbit_F *)t2, C2, h_r + (k1 + k2 - 1), h_qpoly, h_rr, h_vr, h_final);
+    return hobbit_sumcheck2(ctx, (const hobbit_F *)(t2 + C2), (const hobbit_F *)t2, C2, h_prev, h_qpoly, h_rr, h_vr, h_final);
 }
 
 // ---- open building blocks ---------------------------------------------------------------------
@@ -1437,6 +1447,10 @@ struct hobbit_elastic_open {
     size_t n_aggr, n_reply; bool committed;
     F *d_aggr, *d_T, *d_G, *d_reply, *d_encf; uint8_t *d_lvf; uint32_t *d_ucols; uint64_t *d_pick; int *d_nz;
     size_t bytes[9];              // sizes of the nine buffers above (for the context's buffer pool); capacities, not the distinct-column count
+    // option 2 (linear_time, RS x expander): the "remaining" columns (a queried parity row), the aggregate's row codes M, aux_commit and C_c
+    bool lin; std::vector<uint32_t> rem; size_t np;
+    F *d_M, *d_aux, *d_encc; uint8_t *d_lvc; uint32_t *d_rem;
+    size_t bytes2[5];
 };
 // precompute_beta (src/utils.cpp:251-296) on the host for a handful of variables
 static void host_eq_table(const HF *r, int k, std::vector<F> &out) {
@@ -1513,7 +1527,135 @@ void hobbit_elastic_open_free(hobbit_elastic_open *e) {
     if (!e) return;
     void *ptrs[9] = {e->d_aggr, e->d_T, e->d_G, e->d_reply, e->d_encf, e->d_lvf, e->d_ucols, e->d_pick, e->d_nz};
     for (int i = 0; i < 9; i++) e->ctx->pool_put(e->bytes[i], ptrs[i]);
+    void *ptrs2[5] = {e->d_M, e->d_aux, e->d_encc, e->d_lvc, e->d_rem};
+    if (e->lin) for (int i = 0; i < 5; i++) e->ctx->pool_put(e->bytes2[i], ptrs2[i]);
     delete e;
+}
+
+// ---- Elastic_PC open, RS x expander (test_Elastic_PC option 2, linear_time == true): src/Elastic_PC.cpp:625-726 with aggregate()'s linear_time
+// branch (:348-413), update_reply_spielman (:431-485) and recursive_prover_Spielman_stream (src/PC_utils.cpp:168-270) ------------------------
+// The reference AS BUILT (oracle/check_elastic_open2_determinism.py: the real reference returns the same bytes from fresh processes): for a
+// queried column with a parity-row query update_reply_spielman copies the un-encoded column over the first tensor_row_size entries of buff2
+// and leaves the rest as it was -- the parity of the last column that went through encode_monolithic in this chunk, zeros before any did.
+// Per reply slot the begin function works out which column's codeword that is, once; the passes then encode every distinct column and gather.
+static int elastic_open_begin_lin(hobbit_ctx *ctx, size_t N, size_t B, int trs, const hobbit_F *h_x, int queries, hobbit_elastic_open **out) {
+    if (trs <= 0 || trs > 4096 || ilog2_exact(B) < 0 || ilog2_exact((size_t)trs) < 0 || B % (size_t)trs || 2 * B / (size_t)trs < 64 || 2 * B / (size_t)trs > ((size_t)1 << 24))
+        return ctx->fail(HOBBIT_EINVAL, "elastic_open (linear_time): needs power-of-two B and trs <= 4096 with row codes of 64 .. 2^24 points (the reference: trs = B/2^14)");
+    if (N % B || ilog2_exact(N / B) < 0 || queries <= 0 || !h_x) return ctx->fail(HOBBIT_EINVAL, "elastic_open: N/B must be a power of two");
+    hobbit_elastic_open *e = new hobbit_elastic_open();
+    e->ctx = ctx; e->N = N; e->B = B; e->K = N / B; e->trs = trs; e->queries = queries; e->cols = (uint32_t)(2 * B / (size_t)trs); e->rows2 = (uint32_t)(2 * trs);
+    e->n_aggr = e->n_reply = 0; e->committed = false; e->lin = true;
+    e->d_aggr = e->d_T = e->d_G = e->d_reply = e->d_encf = nullptr; e->d_lvf = nullptr; e->d_ucols = nullptr; e->d_pick = nullptr; e->d_nz = nullptr;
+    e->d_M = e->d_aux = e->d_encc = nullptr; e->d_lvc = nullptr; e->d_rem = nullptr;
+    host_eq_table(cF(h_x), ilog2_exact(e->K), e->beta);                                                     // precompute_beta(x1, beta) (:638-643)
+    e->rv0 = fadd(fmake((uint64_t)random()), fmake((uint64_t)rand()));                                      // r_v[0] = generate_randomness(1)[0] (:645)
+    const size_t nq = (size_t)queries;
+    e->qc.resize(nq); e->qr.resize(nq);
+    for (size_t q = 0; q < nq; q++) { e->qc[q] = (uint32_t)(rand() % (long)e->cols); e->qr[q] = (uint32_t)(rand() % (long)e->rows2); }   // (:650-655)
+    e->ucols = e->qc; std::sort(e->ucols.begin(), e->ucols.end()); e->ucols.erase(std::unique(e->ucols.begin(), e->ucols.end()), e->ucols.end());
+    const size_t nc = e->ucols.size();
+    e->qci.resize(nq);
+    std::vector<char> flag(nc, 0);                                                                          // a queried row >= tensor_row_size (:376-391, :462-468)
+    for (size_t q = 0; q < nq; q++) {
+        e->qci[q] = (uint32_t)(std::lower_bound(e->ucols.begin(), e->ucols.end(), e->qc[q]) - e->ucols.begin());
+        if (e->qr[q] >= (uint32_t)trs) flag[e->qci[q]] = 1;
+    }
+    for (size_t c = 0; c < nc; c++) if (flag[c]) e->rem.push_back(e->ucols[c]);
+    const size_t nr = e->rem.size();
+    e->np = 1; while (e->np < nr * e->rows2) e->np <<= 1;
+    if (e->np < 128) e->np = 128;
+    // the parity a reply slot reads: its own column's when the column was encoded, else that of the last encoded column before it (row nc = zeros)
+    std::vector<uint32_t> par(nc); { uint32_t last = (uint32_t)nc; for (size_t c = 0; c < nc; c++) { if (!flag[c]) last = (uint32_t)c; par[c] = last; } }
+    // reply row `counter` is the counter-th query in (sorted column, then query order) (:476-478 over column_map)
+    std::vector<uint32_t> start(nc + 1, 0), ord(nq);
+    for (size_t q = 0; q < nq; q++) start[e->qci[q] + 1]++;
+    for (size_t c = 0; c < nc; c++) start[c + 1] += start[c];
+    { std::vector<uint32_t> fill(start.begin(), start.end() - 1); for (size_t q = 0; q < nq; q++) ord[fill[e->qci[q]]++] = (uint32_t)q; }
+    std::vector<uint64_t> pick(nq);
+    for (size_t k = 0; k < nq; k++) {
+        const uint32_t q = ord[k], c = e->qci[q], row = e->qr[q];
+        pick[k] = (uint64_t)(row < (uint32_t)trs ? c : par[c]) * e->rows2 + row;
+    }
+    const size_t sizes[9] = {B * sizeof(F), 2 * B * sizeof(F), (nc + 1) * e->rows2 * sizeof(F), e->K * nq * sizeof(F), 2 * B * sizeof(F),
+                             64 * (2 * B / 32), nq * 4, nq * 8, e->K * sizeof(int)};
+    void **slots[9] = {(void **)&e->d_aggr, (void **)&e->d_T, (void **)&e->d_G, (void **)&e->d_reply, (void **)&e->d_encf, (void **)&e->d_lvf, (void **)&e->d_ucols,
+                       (void **)&e->d_pick, (void **)&e->d_nz};
+    const size_t sizes2[5] = {2 * B * sizeof(F), e->np * sizeof(F), 2 * e->np * sizeof(F), 64 * (2 * e->np / 32), (nr ? nr : 1) * 4};
+    void **slots2[5] = {(void **)&e->d_M, (void **)&e->d_aux, (void **)&e->d_encc, (void **)&e->d_lvc, (void **)&e->d_rem};
+    bool ok = true;
+    for (int i = 0; i < 9; i++) { e->bytes[i] = sizes[i]; if (ok) ok = ctx->pool_get(sizes[i], slots[i]) == 0; }
+    for (int i = 0; i < 5; i++) { e->bytes2[i] = sizes2[i]; if (ok) ok = ctx->pool_get(sizes2[i], slots2[i]) == 0; }
+    if (!ok) { hobbit_elastic_open_free(e); return ctx->fail(HOBBIT_ENOMEM, "elastic_open_begin: allocation failed"); }
+    HB_TRY(launch_zero(ctx, e->d_aggr, B * sizeof(F)));
+    HB_TRY(launch_zero(ctx, e->d_nz, e->K * sizeof(int)));
+    HB_TRY(launch_zero(ctx, e->d_G, (nc + 1) * e->rows2 * sizeof(F)));                                     // the zero row; the tails past the codeword length stay zero
+    HB_CHECK(ctx, hipMemcpyAsync(e->d_ucols, e->ucols.data(), nc * 4, hipMemcpyHostToDevice, ctx->stream));
+    HB_CHECK(ctx, hipMemcpyAsync(e->d_pick, pick.data(), nq * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (nr) HB_CHECK(ctx, hipMemcpyAsync(e->d_rem, e->rem.data(), nr * 4, hipMemcpyHostToDevice, ctx->stream));
+    HB_TRY(ctx->sync());                                                        // `pick` is a local
+    *out = e;
+    return 0;
+}
+// recursive_prover_Spielman_stream(aggr_vector, aggr_tensor = d_M, aux_commit = d_aux, I) (src/PC_utils.cpp:168-270).  Transcripts P1, P2, P3, P5 back
+// to back in o->qpoly / o->r (rounds log2 2trs, log2 cols, log2 np, log2 cols); o->scal = s[0], s2, y1; checks[0] = prove_fft_matrix's exit(-1) test.
+static int spielman_stream_dev(hobbit_ctx *ctx, hobbit_elastic_open *e, hobbit_elastic_open_out *o) {
+    const size_t B = e->B, trs = (size_t)e->trs, cols = e->cols, rows2 = e->rows2, half = cols / 2, nq = (size_t)e->queries, nr = e->rem.size(), np = e->np;
+    const int logc = ilog2_exact(cols), R1 = ilog2_exact(rows2), logt = R1 - 1, R3 = ilog2_exact(np);
+    if (!nr) return ctx->fail(HOBBIT_EINVAL, "elastic_open (linear_time): no queried parity row (the reference indexes an empty vector here)");
+    if (nq > np) return ctx->fail(HOBBIT_EINVAL, "elastic_open (linear_time): more queries than padded aux_commit entries (the reference writes past its vector here)");
+    if (!o->sp_c || !o->sp_f || !o->scal) return ctx->fail(HOBBIT_EINVAL, "elastic_open (linear_time): sp_c, sp_f and scal are required");
+    if (o->cc_root) HB_TRY(hobbit_memcpy_d2h(ctx, o->cc_root, e->d_lvc + 32 * (2 * (2 * np / 32) - 2), 32));
+    if (o->nrem) *o->nrem = (int)nr;
+    F *arena; HB_TRY(ctx->workspace3((nr + 2 * rows2 + 2 * cols + np + 64) * sizeof(F), (void **)&arena));
+    F *d_s = arena, *d_ac = d_s + nr, *d_b1 = d_ac + rows2, *d_ev = d_b1 + rows2, *d_sM = d_ev + cols, *d_b2 = d_sM + cols;
+    StageScope sc(ctx);
+    std::vector<F> sv(nr);
+    sv[0] = fmake((uint64_t)random()); *mF(&o->scal[0]) = sv[0];                                           // s[0] = random() (:209-213)
+    for (size_t i = 1; i < nr; i++) sv[i] = fmul(sv[i - 1], sv[0]);
+    HB_TRY(h2d_staged(ctx, d_s, sv.data(), nr * sizeof(F)));
+    HB_TRY(launch_vecmat(ctx, e->d_aux, nr, rows2, d_s, d_ac));                                             // aggr_c = sum_i s[i] codewords[i] (:214-219)
+    std::vector<F> r1(R1);
+    { F cst = fmake(0); for (int i = 0; i < R1; i++) { if (i % 100 == 0) cst = fmake((uint64_t)random()); r1[i] = fadd(cst, fmake((uint64_t)rand())); } }   // prove_linear_code's generate_randomness
+    hobbit_F *Q = o->qpoly, *Rr = o->r;
+    hobbit_F *const Q1 = Q, *const Rr1 = Rr, *const Q2 = Q1 + 3 * R1, *const Rr2 = Rr1 + R1, *const Q3 = Q2 + 3 * logc, *const Rr3 = Rr2 + logc, *const Q5 = Q3 + 3 * R3,
+             *const Rr5 = Rr3 + R3;
+    if (ctx->code.n != e->trs) { long long l; HB_TRY(hobbit_graph_finalize(ctx, e->trs, &l)); }
+    HB_TRY(hobbit_prove_linear_code(ctx, reinterpret_cast<hobbit_F *>(d_ac), rows2, (long long)trs, reinterpret_cast<const hobbit_F *>(r1.data()), Q1, Rr1, o->vr, o->fin));   // P1 (:221)
+    HB_TRY(hobbit_eq_table(ctx, Rr1, R1, reinterpret_cast<hobbit_F *>(d_b1)));
+    HB_TRY(launch_vecmat(ctx, e->d_M, trs, cols, d_b1, d_ev));                                              // evals[i] = sum_{j < trs} beta[j] M[j][i] (:226-230)
+    HB_TRY(launch_zero(ctx, d_sM, cols * sizeof(F)));
+    HB_TRY(launch_spread_cols(ctx, e->d_rem, d_s, (uint32_t)nr, 1, cols, d_sM));                            // sM[remaining_columns[j]] = s[j] (:231-234)
+    hobbit_F p17 = {021, 0}, p121 = {121, 0};
+    HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(d_sM), reinterpret_cast<hobbit_F *>(d_ev), cols, &p17, Q2, Rr2, o->vr + 2, o->fin + 1));   // P2 (:237)
+    std::vector<F> pw(nq);
+    F s2 = fmake((uint64_t)random()); *mF(&o->scal[1]) = s2;                                                // (:242)
+    for (size_t i = 0; i < nq; i++) { pw[i] = s2; s2 = fmul(s2, s2); }                                      // buff2[i] = s2; s2 = s2*s2 (:243-246): repeated squares at 0 .. nq-1
+    HB_TRY(launch_zero(ctx, d_b2, np * sizeof(F)));
+    HB_TRY(h2d_staged(ctx, d_b2, pw.data(), nq * sizeof(F)));
+    HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(e->d_aux), reinterpret_cast<hobbit_F *>(d_b2), np, &p121, Q3, Rr3, o->vr + 4, o->fin + 2));   // P3 (:248)
+    HB_TRY(hobbit_shockwave_prove(ctx, reinterpret_cast<hobbit_F *>(e->d_aux), reinterpret_cast<hobbit_F *>(e->d_encc), e->d_lvc, np, 32, Rr3, R3, o->sp_c));   // (:252)
+    // r = P1.randomness[0] (all of it: the pop_back at :256 follows the copy) | P2.randomness[0]; evaluate_vector and prove_fft_matrix use its first
+    // log2(trs * cols) entries, the transcript of P5 is seeded with its last one (:255-266)
+    std::vector<hobbit_F> rcat((size_t)R1 + (size_t)logc);
+    memcpy(rcat.data(), Rr1, sizeof(hobbit_F) * (size_t)R1); memcpy(rcat.data() + R1, Rr2, sizeof(hobbit_F) * (size_t)logc);
+    F y1;
+    HB_TRY(hobbit_eval_vector(ctx, reinterpret_cast<hobbit_F *>(e->d_M), trs * cols, rcat.data(), reinterpret_cast<hobbit_F *>(&y1)));
+    *mF(&o->scal[2]) = y1;
+    HB_TRY(prove_fft_matrix_seeded(ctx, reinterpret_cast<const hobbit_F *>(e->d_aggr), trs, half, rcat.data(), &rcat[rcat.size() - 1], Q5, Rr5, o->vr + 6, o->fin + 3));   // P5 (:266)
+    { const HF *q5 = cF(Q5); o->checks[0] = feq(fadd(fadd(q5[0], q5[1]), fadd(q5[2], q5[2])), y1); }      // src/sumcheck.cpp:3016-3019
+    // P5.randomness[0] = its logc challenges | r1 = r[logc .. logc + log2 trs); pop_back (:268); shockwave_prove(C_f, .) (:269)
+    std::vector<hobbit_F> rx((size_t)logc + (size_t)logt);
+    memcpy(rx.data(), Rr5, sizeof(hobbit_F) * (size_t)logc); memcpy(rx.data() + logc, rcat.data() + logc, sizeof(hobbit_F) * (size_t)logt);
+    rx.pop_back();
+    if (o->rx) memcpy(o->rx, rx.data(), sizeof(hobbit_F) * rx.size());
+    HB_TRY(hobbit_shockwave_prove(ctx, reinterpret_cast<const hobbit_F *>(e->d_aggr), reinterpret_cast<const hobbit_F *>(e->d_encf), e->d_lvf, B, 32, rx.data(), (int)rx.size(), o->sp_f));
+    return sc.finish();
+}
+static int elastic_open_begin_lin(hobbit_ctx *ctx, size_t N, size_t B, int trs, const hobbit_F *h_x, int queries, hobbit_elastic_open **out);
+int hobbit_elastic_open_begin_lin(hobbit_ctx *ctx, size_t N, size_t B, int trs, const hobbit_F *h_x, int queries, hobbit_elastic_open **out) {
+    if (!out) return HOBBIT_EINVAL;
+    *out = nullptr;
+    return elastic_open_begin_lin(ctx, N, B, trs, h_x, queries, out);
 }
 int hobbit_elastic_open_begin(hobbit_ctx *ctx, size_t N, size_t B, int trs, const hobbit_F *h_x, int queries, hobbit_elastic_open **out) {
     if (!out) return HOBBIT_EINVAL;
@@ -1523,7 +1665,7 @@ int hobbit_elastic_open_begin(hobbit_ctx *ctx, size_t N, size_t B, int trs, cons
     if (N % B || ilog2_exact(N / B) < 0 || queries <= 0 || !h_x) return ctx->fail(HOBBIT_EINVAL, "elastic_open: N/B must be a power of two");
     hobbit_elastic_open *e = new hobbit_elastic_open();
     e->ctx = ctx; e->N = N; e->B = B; e->K = N / B; e->trs = trs; e->queries = queries; e->cols = 4096; e->rows2 = (uint32_t)(2 * trs);
-    e->n_aggr = e->n_reply = 0; e->committed = false;
+    e->n_aggr = e->n_reply = 0; e->committed = false; e->lin = false;
     e->d_aggr = e->d_T = e->d_G = e->d_reply = e->d_encf = nullptr; e->d_lvf = nullptr; e->d_ucols = nullptr; e->d_pick = nullptr; e->d_nz = nullptr;
     host_eq_table(cF(h_x), ilog2_exact(e->K), e->beta);                                                     // precompute_beta(x1, beta) (:638-643)
     e->rv0 = fadd(fmake((uint64_t)random()), fmake((uint64_t)rand()));                                      // r_v[0] = generate_randomness(1)[0] (:645)
@@ -1551,15 +1693,37 @@ int hobbit_elastic_open_begin(hobbit_ctx *ctx, size_t N, size_t B, int trs, cons
     *out = e;
     return 0;
 }
+void hobbit_elastic_open_dims(const hobbit_elastic_open *e, int *ncols, int *nrem, size_t *np) {
+    if (ncols) *ncols = (int)e->ucols.size();
+    if (nrem) *nrem = e->lin ? (int)e->rem.size() : 0;
+    if (np) *np = e->lin ? e->np : 0;
+}
 int hobbit_elastic_open_aggregate_push(hobbit_ctx *ctx, hobbit_elastic_open *e, const hobbit_F *d_chunk) {
     if (e->n_aggr >= e->K || e->committed) return ctx->fail(HOBBIT_ESTATE, "elastic_open: more aggregate chunks than N/B");
     HB_TRY(launch_axpy(ctx, e->d_aggr, cF(d_chunk), e->beta[e->n_aggr], e->B));                             // aggregated_vector[j] += beta1[i]*buff[j] (:330-333)
     e->n_aggr++;
     return 0;
 }
+// rows of a B-element vector (trs rows of B/trs) RS-encoded to twice their length
+static int elastic_row_codes(hobbit_ctx *ctx, const F *d_v, size_t B, size_t trs, F *d_out) {
+    const size_t half = B / trs; const int logc = ilog2_exact(2 * half);
+    if (logc <= 12) return fft_rows(ctx, d_v, half, (uint32_t)half, d_out, 2 * half, 1, logc, false, 1, (uint32_t)trs, 0, 0);
+    return fft_long(ctx, d_v, half, half, d_out, logc, false, (uint32_t)trs);
+}
 int hobbit_elastic_open_aggregate_finish(hobbit_ctx *ctx, hobbit_elastic_open *e) {
     if (e->n_aggr != e->K) return ctx->fail(HOBBIT_ESTATE, "elastic_open: aggregate pass incomplete");
-    HB_TRY(hobbit_shockwave_commit(ctx, reinterpret_cast<hobbit_F *>(e->d_aggr), e->B, 32, reinterpret_cast<hobbit_F *>(e->d_encf), e->d_lvf));   // C_f (:343-346)
+    HB_TRY(hobbit_shockwave_commit(ctx, reinterpret_cast<hobbit_F *>(e->d_aggr), e->B, 32, reinterpret_cast<hobbit_F *>(e->d_encf), e->d_lvf));   // C_f (:343-346, :349)
+    if (e->lin) {
+        // aggregate()'s linear_time branch (:350-411): aggregated_tensor = the aggregate's rows RS-encoded; aux_commit = the expander codewords of
+        // the queried columns that have a parity-row query; C_c = shockwave_commit(pad(aux_commit), 32)
+        const uint32_t nr = (uint32_t)e->rem.size();
+        if (ctx->code.n != e->trs) { long long l; HB_TRY(hobbit_graph_finalize(ctx, e->trs, &l)); }
+        HB_TRY(elastic_row_codes(ctx, e->d_aggr, e->B, (size_t)e->trs, e->d_M));
+        HB_TRY(launch_zero(ctx, e->d_aux, e->np * sizeof(F)));
+        HB_TRY(launch_gather_cols(ctx, e->d_M, e->cols, (uint32_t)e->trs, e->d_rem, nr, e->d_aux, e->rows2));
+        HB_TRY(launch_encode(ctx, e->d_aux, e->rows2, e->d_aux, e->rows2, e->trs, nr, 0));
+        HB_TRY(hobbit_shockwave_commit(ctx, reinterpret_cast<hobbit_F *>(e->d_aux), e->np, 32, reinterpret_cast<hobbit_F *>(e->d_encc), e->d_lvc));
+    }
     e->committed = true;
     return 0;
 }
@@ -1567,6 +1731,17 @@ int hobbit_elastic_open_reply_push(hobbit_ctx *ctx, hobbit_elastic_open *e, cons
     if (e->n_reply >= e->K) return ctx->fail(HOBBIT_ESTATE, "elastic_open: more reply chunks than N/B");
     const size_t i = e->n_reply, half = e->B / (size_t)e->trs; const uint32_t nc = (uint32_t)e->ucols.size();
     HB_TRY(launch_any_nonzero(ctx, cF(d_chunk), e->B, e->d_nz + i));                                        // an all-zero chunk appends nothing (:510-517)
+    if (e->lin) {
+        // update_reply_spielman (:431-485): rows RS-encoded, every distinct queried column expander-encoded into its row of d_G (the message half
+        // is the column itself); d_pick holds, per reply slot, where the reference AS BUILT reads from (elastic_open_begin_lin)
+        if (ctx->code.n != e->trs) { long long l; HB_TRY(hobbit_graph_finalize(ctx, e->trs, &l)); }
+        HB_TRY(elastic_row_codes(ctx, cF(d_chunk), e->B, (size_t)e->trs, e->d_T));
+        HB_TRY(launch_gather_cols(ctx, e->d_T, e->cols, (uint32_t)e->trs, e->d_ucols, nc, e->d_G, e->rows2));
+        HB_TRY(launch_encode(ctx, e->d_G, e->rows2, e->d_G, e->rows2, e->trs, nc, 0));
+        HB_TRY(launch_gather_strided(ctx, e->d_G, e->d_pick, (size_t)e->queries, 1, 1, 0, e->d_reply + i * (size_t)e->queries));
+        e->n_reply++;
+        return 0;
+    }
     // update_reply (:59-111): rows to twice their length, then each queried column (trs entries, zero-padded) to 2*trs, its queried row kept
     HB_TRY(fft_rows(ctx, cF(d_chunk), half, (uint32_t)half, e->d_T, e->cols, 1, 12, false, 1, (uint32_t)e->trs, 0, 0));
     HB_TRY(launch_gather_cols(ctx, e->d_T, e->cols, (uint32_t)e->trs, e->d_ucols, nc, e->d_G, e->rows2));
@@ -1598,6 +1773,7 @@ int hobbit_elastic_open_finish(hobbit_ctx *ctx, hobbit_elastic_open *e, const ui
         for (size_t q = 0; q < nq; q++) pos[q] = (uint64_t)(e->qr[q] / 4) * cols + e->qc[q];
         HB_TRY(paths_common(ctx, d_commit_levels, 4 * B, pos.data(), nq, o->paths));
     }
+    if (e->lin) return spielman_stream_dev(ctx, e, o);
     return rs_prover_dev(ctx, e->d_aggr, B, trs, e->qc, e->qr, e->ucols, e->d_ucols, e->d_encf, e->d_lvf, o);
 }
 

@@ -287,8 +287,7 @@ int hobbit_open_from_aggregate(hobbit_ctx *ctx, const hobbit_F *d_aggr, size_t M
  *   finish           : replies, Merkle paths (open_tree_blake(Commitment_MT, I[i], 2B/trs), :684-687; d_commit_levels = the
  *                      (8B-1) x 32 B tree hobbit_elastic_finish wrote, or NULL), then recursive_prover_RS
  *                      (src/PC_utils.cpp:396-512): P0, P2 = prove_fft_matrix, P3, P5 = prove_fft_matrix, shockwave_prove(C_f, r_x).
- * Only trs = B/2^11 (4096-point row codes) with linear_time = false is built: option 2's update_reply_spielman (:431-485) reads
- * past a vector in the reference (rows >= tensor_row_size index a tensor_row_size-long copy, :465-478) and has no defined result.
+ * This entry point is option 1: trs = B/2^11 (4096-point row codes), linear_time = false.  Option 2: hobbit_elastic_open_begin_lin below.
  * The MT_commit_Blake over every reply (:677-680) and verify_claim_opt_blake are verifier-side accounting whose results are
  * discarded; they are not run.
  * All hobbit_elastic_open_out pointers are host buffers (NULL = not wanted, except qpoly/r/vr/fin/checks):
@@ -302,8 +301,34 @@ typedef struct {
     uint32_t *cols, *rows; hobbit_F *rv0; hobbit_F *reply; int *reply_len; uint8_t *paths; uint8_t *cf_root; int *ncols;
     hobbit_F *qpoly, *r, *vr, *fin; int *checks; hobbit_F *rx;
     hobbit_shockwave_out *sp_f;
+    /* read only by an opening begun with hobbit_elastic_open_begin_lin (below); option-1 callers may pass the shorter struct that ends at sp_f */
+    uint8_t *cc_root; int *nrem; hobbit_F *scal; hobbit_shockwave_out *sp_c;
 } hobbit_elastic_open_out;
 int hobbit_elastic_open_begin(hobbit_ctx *ctx, size_t N, size_t B, int trs, const hobbit_F *h_x, int queries, hobbit_elastic_open **out);
+/* Elastic_PC open, RS x expander (linear_time == true; test_Elastic_PC option 2, src/Elastic_PC.cpp:762-784: tensor_row_size = B / 2^14, 5900
+ * queries, expander_init_store(tensor_row_size) -- the graphs of that size must have been uploaded to ctx).  Same three passes, same push / finish
+ * / free entry points as above:
+ *   begin_lin        : beta, r_v[0], the queries (:638-655); the distinct queried columns and, of those, the "remaining" ones that have a
+ *                      queried parity row (row >= tensor_row_size; :357-391)
+ *   aggregate_finish : C_f; aggregated_tensor (rows RS-encoded); aux_commit = expander codewords of the remaining columns; C_c =
+ *                      shockwave_commit(pad(aux_commit), 32)                                                                      (:348-411)
+ *   reply_push       : update_reply_spielman (:431-485) AS BUILT: a column WITHOUT a queried parity row is expander-encoded; for a column WITH one
+ *                      the reference copies the un-encoded column over the first tensor_row_size entries of its 2*tensor_row_size buffer and
+ *                      then reads the queried parity row from what the buffer still holds -- the parity of the last column that was encoded in
+ *                      this chunk (zeros before any was).  The real reference returns these bytes deterministically
+ *                      (oracle/check_elastic_open2_determinism.py; fixture tests/golden/elastic_open2.npz).
+ *                      Reply row k belongs to the k-th query in (sorted column, then query order), as the reference appends them (:476-478).
+ *   finish           : replies, paths (query order), recursive_prover_Spielman_stream (src/PC_utils.cpp:168-270): P1 = prove_linear_code over
+ *                      sum_i s^i aux_commit[i], P2, P3 (aux_commit against repeated squares of s2 at positions 0 .. queries-1),
+ *                      shockwave_prove(C_c, P3.r), y1, P5 = prove_fft_matrix (seeded with the last entry of an r one entry longer than it
+ *                      uses), shockwave_prove(C_f, r_x).
+ * Output: qpoly / r : P1, P2, P3, P5 back to back, rounds log2(2trs), log2(2B/trs), log2(np), log2(2B/trs) with np = nrem * 2trs rounded up
+ *   to a power of two; vr 4 x 2 F; fin 4 F; checks[1]: prove_fft_matrix's exit(-1) sum check; rx: log2(B) F; scal = s[0], s2, y1 (required);
+ *   sp_c, sp_f (required); cc_root 32 B; nrem; ncols; reply = queries x reply_len. */
+int hobbit_elastic_open_begin_lin(hobbit_ctx *ctx, size_t N, size_t B, int trs, const hobbit_F *h_x, int queries, hobbit_elastic_open **out);
+/* what the begin call derived from its query draws: distinct queried columns, remaining columns (0 for option 1) and np = the padded length of
+ * aux_commit = the size of the polynomial C_c commits to (what sp_c's buffers must be sized for; 0 for option 1) */
+void hobbit_elastic_open_dims(const hobbit_elastic_open *e, int *ncols, int *nrem, size_t *np);
 int hobbit_elastic_open_aggregate_push(hobbit_ctx *ctx, hobbit_elastic_open *e, const hobbit_F *d_chunk);
 int hobbit_elastic_open_aggregate_finish(hobbit_ctx *ctx, hobbit_elastic_open *e);
 int hobbit_elastic_open_reply_push(hobbit_ctx *ctx, hobbit_elastic_open *e, const hobbit_F *d_chunk);

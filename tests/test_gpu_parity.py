@@ -1261,6 +1261,63 @@ def test_elastic_open_vs_oracle(hb, oracle, logN, logB):
         assert np.array_equal(got["sp_f"][k], want["sp_f"][k]), k
 
 
+# ---- Elastic_PC open, option 2 (RS x expander, linear_time) ------------------------------------------------------------------
+@pytest.mark.parametrize("N,B", golden_cases.ELASTIC_OPEN2_CASES)
+def test_elastic_open2_passes_vs_golden(hb, N, B):
+    """aggregate()'s linear_time branch (aggregate, C_f, aux_commit -> C_c) and compute_aggregation_reply / update_reply_spielman of
+    Elastic_PC::open option 2 against what the REAL reference's functions returned AS BUILT (tests/golden/elastic_open2.npz; B = 2^20 is
+    test_OurPC.sh's own shape): the queries, both inner roots (functions of the whole aggregate and of every remaining column's expander
+    codeword), the number of remaining columns, the replies in the reference's order -- including the stale-parity reads."""
+    import ctypes
+    g = gold("elastic_open2"); key = "eo2_%d_%d_" % (N, B)
+    x, I = golden_cases.elastic_open2_inputs(N, B)
+    hb.rng_reset(); hb.expander_init_store(B >> 14)
+    ctypes.CDLL(None).srandom(902)
+    res = hb.elastic_open2(N, B, x, 5900)
+    assert np.array_equal(dg(res["I"].astype(np.uint64)), g[key + "I_dg"])
+    assert np.array_equal(res["cf_root"], g[key + "cf_root"])
+    assert np.array_equal(res["cc_root"], g[key + "cc_root"])
+    assert int(res["nr"][0]) == int(g[key + "nr"][0])
+    assert res["reply"].shape == (5900, N // B, 2)
+    assert np.array_equal(dg(res["reply"]), g[key + "reply_dg"])
+    assert res["checks"].tolist() == [1]
+
+
+@pytest.mark.parametrize("logN,logB,kind", [(20, 16, 0), (22, 18, 1), (23, 20, 1), (24, 20, 0)])
+def test_elastic_open2_vs_oracle(hb, oracle, logN, logB, kind):
+    """The whole prover side of Elastic_PC::open option 2 on test_Elastic_PC(N, 2)'s sequence (graphs, commit, x = generate_randomness(log N),
+    open): queries, replies, Merkle paths of the commitment, aux_commit's commitment, the four sumcheck transcripts of
+    recursive_prover_Spielman_stream and both shockwave_prove calls with their WHIR proofs, bit-exact against the oracle (whose two stream passes
+    are pinned by the real reference: elastic_open2.npz); prove_fft_matrix's exit(-1) check holds on both.  kind 1: a stream whose chunks all
+    differ (the reference's default stream repeats one chunk), so that a chunk-order or reply-order mistake cannot hide."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    N, B = 1 << logN, 1 << logB
+    oracle.rng_reset(); lv = oracle.elastic_commit(N, B, 2)
+    x = oracle.generate_randomness(logN)
+    oracle.stream_config(kind, 4242)
+    try:
+        libc.srandom(77); want = oracle.elastic_open2(N, B, x, 5900, lv)
+    finally:
+        oracle.stream_config(0, 0)
+    hb.rng_reset()
+    got_lv, dlv = hb.elastic_commit(N, B, 2, keep_levels=True)
+    T = 4 * B
+    assert np.array_equal(got_lv[:T - 1], lv[:T - 1]) and np.array_equal(got_lv[T:], lv[T:])
+    chunks = (lambda i: splitmix_field(B, 4242 + i)) if kind else None
+    libc.srandom(77); got = hb.elastic_open2(N, B, x, 5900, commit_levels=dlv, chunks=chunks)
+    assert want["checks"].tolist() == [1] and got["checks"].tolist() == [1]
+    assert int(got["nr"][0]) == int(want["nr"][0]) and int(got["reply_len"][0]) == N // B
+    for k in ("I", "rv0", "cf_root", "cc_root", "reply", "scal", "poly", "r", "vr", "fin", "rx"):
+        assert np.array_equal(got[k], want[k]), k
+    assert np.array_equal(got["paths"], want["paths"])
+    for sp in ("sp_c", "sp_f"):
+        has_whir = int(want[sp]["iters"][0]) > 0
+        assert want[sp]["wchecks"].tolist() == ([1, 1] if has_whir else [0, 0])
+        for k in SP_KEYS:
+            assert np.array_equal(got[sp][k], want[sp][k]), (sp, k)
+
+
 @pytest.mark.parametrize("logN,K", [(18, 32), (20, 16), (22, 32), (24, 32), (23, 2)])
 def test_open_standard_rs_vs_oracle(hb, oracle, logN, K):
     """Our_PC with linear_time == false on test_PC(N, 1, K)'s sequence (src/Our_PC.cpp:764-777: poly = generate_randomness(N), tensor_row_size = 128,
