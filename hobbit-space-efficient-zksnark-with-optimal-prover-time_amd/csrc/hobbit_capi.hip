@@ -1563,7 +1563,6 @@ static int elastic_open_begin_lin(hobbit_ctx *ctx, size_t N, size_t B, int trs, 
     for (size_t c = 0; c < nc; c++) if (flag[c]) e->rem.push_back(e->ucols[c]);
     const size_t nr = e->rem.size();
     e->np = 1; while (e->np < nr * e->rows2) e->np <<= 1;
-    if (e->np < 128) e->np = 128;
     // the parity a reply slot reads: its own column's when the column was encoded, else that of the last encoded column before it (row nc = zeros)
     std::vector<uint32_t> par(nc); { uint32_t last = (uint32_t)nc; for (size_t c = 0; c < nc; c++) { if (!flag[c]) last = (uint32_t)c; par[c] = last; } }
     // reply row `counter` is the counter-th query in (sorted column, then query order) (:476-478 over column_map)

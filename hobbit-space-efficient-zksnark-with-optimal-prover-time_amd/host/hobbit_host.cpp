@@ -606,15 +606,69 @@ void read_stream(stream_descriptor &fd, vector<F> &v, int size) {   // src/witne
     for (int i = 0; i < size; i++) v[i] = F((i % 1024) + 1);
 }
 #endif
+// src/Elastic_PC.cpp:625-726 under linear_time (RS x expander; test_Elastic_PC option 2): 5900 queries, aggregate()'s expander branch,
+// update_reply_spielman as the reference is built (include/hobbit_hip.h: hobbit_elastic_open_begin_lin), recursive_prover_Spielman_stream
+static void open_linear_time(stream_descriptor fd, vector<F> x, vector<vector<_hash>> &Commitment_MT, double &vt, double &ps) {
+    PhaseTimer pt__("open");
+    const int queries = 5900; aggregation_queries = queries;
+    const size_t B = BUFFER_SPACE, K = fd.size / B; const int trs = tensor_row_size;
+    const size_t cols = 2 * B / (size_t)trs;
+    const int logc = (int)log2((double)cols), R1 = (int)log2((double)(2 * trs)), logt = R1 - 1, depth = (int)log2((double)(4 * B));
+    hobbit_elastic_open *e = nullptr;
+    HCHK(hobbit_elastic_open_begin_lin(hobbit_host_ctx(), fd.size, B, trs, hF(x.data()), queries, &e));
+    hobbit_host_elastic_transcript &t = g_eopen;
+    t.lin = true;
+    hobbit_elastic_open_dims(e, &t.ncols, &t.nrem, &t.np);
+    vector<F> buff(B); DevBuf d(B * sizeof(F));
+    stream_descriptor fd_a = fd, fd_r = fd;                          // aggregate and compute_aggregation_reply each take the descriptor BY VALUE (:316, :487)
+    for (size_t i = 0; i < K; i++) {                                 // aggregate (:327-334)
+        TIMED_READ(read_stream(fd_a, buff, (int)B));
+        TIMED_UP(HCHK(hobbit_memcpy_h2d(g_ctx, d.p, buff.data(), B * sizeof(F))));
+        HCHK(hobbit_elastic_open_aggregate_push(g_ctx, e, (const hobbit_F *)d.p));
+    }
+    HCHK(hobbit_elastic_open_aggregate_finish(g_ctx, e));
+    printf("%d\n", (int)((size_t)t.nrem * 2 * (size_t)trs));         // aggregate() prints the flattened aux_commit's size (:408)
+    for (size_t i = 0; i < K; i++) {                                 // compute_aggregation_reply (:506-531)
+        TIMED_READ(read_stream(fd_r, buff, (int)B));
+        TIMED_UP(HCHK(hobbit_memcpy_h2d(g_ctx, d.p, buff.data(), B * sizeof(F))));
+        HCHK(hobbit_elastic_open_reply_push(g_ctx, e, (const hobbit_F *)d.p));
+    }
+    size_t tot = 0; for (auto &l : Commitment_MT) tot += l.size();
+    DevBuf lv(32 * tot);
+    { size_t off = 0; for (auto &l : Commitment_MT) { HCHK(hobbit_memcpy_h2d(g_ctx, (uint8_t *)lv.p + 32 * off, l.data(), 32 * l.size())); off += l.size(); } }
+    const int R3 = (int)log2((double)t.np);
+    t.rounds = R1 + logc + R3 + logc;
+    t.queries = queries; t.cols.assign(queries, 0); t.rows.assign(queries, 0); t.reply.assign((size_t)queries * K, F(0)); t.paths.assign((size_t)queries * depth * 32, 0);
+    t.qpoly.assign(3 * (size_t)t.rounds, F(0)); t.r.assign(t.rounds, F(0)); t.vr.assign(8, F(0)); t.fin.assign(4, F(0)); t.rx.assign(logc + logt - 1, F(0)); t.scal.assign(3, F(0));
+    SpBuffers bf(t.sp_f, B, 32), bc(t.sp_c, t.np, 32);
+    hobbit_elastic_open_out o{t.cols.data(), t.rows.data(), hF(&t.rv0), hF(t.reply.data()), &t.reply_len, t.paths.data(), t.cf_root, &t.ncols,
+                              hF(t.qpoly.data()), hF(t.r.data()), hF(t.vr.data()), hF(t.fin.data()), t.checks, hF(t.rx.data()), &bf.o,
+                              t.cc_root, &t.nrem, hF(t.scal.data()), &bc.o};
+    HCHK(hobbit_elastic_open_finish(g_ctx, e, tot == 8 * B - 1 ? (const uint8_t *)lv.p : nullptr, &o));
+    hobbit_elastic_open_free(e);
+    if (!t.checks[0]) { printf("Error in fft\n"); exit(-1); }                                                   // src/sumcheck.cpp:3016-3019
+    for (auto *sp : {&t.sp_c, &t.sp_f}) if (sp->iters && !(sp->wchecks[0] && sp->wchecks[1])) { printf("Error in final verification step\n"); exit(-1); }
+    auto t0 = std::chrono::steady_clock::now();
+    double MT_ps = 0.0;
+    vector<size_t> pos(queries);
+    for (int i = 0; i < queries; i++) pos[i] = (size_t)(t.rows[i] / 4) * cols + t.cols[i];
+    path_ps(4 * B, depth, pos, MT_ps);                                                                          // (:684-688)
+    ps += (double)((size_t)queries * (size_t)t.reply_len * sizeof(F)) / 1024.0;                                 // (:701)
+    sumcheck2_ps(R1, ps); sumcheck2_ps(logc, ps); sumcheck2_ps(R3, ps);                                         // P1, P2, P3 (src/PC_utils.cpp:221-248)
+    shockwave_ps(t.sp_c, t.np, 32, ps);                                                                         // (:252)
+    sumcheck2_ps(logc, ps);                                                                                     // P5 (:266)
+    shockwave_ps(t.sp_f, B, 32, ps);                                                                            // (:269)
+    ps += MT_ps;
+    vt += std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::steady_clock::now() - t0).count();
+    for (auto &l : Commitment_MT) { l.clear(); vector<_hash>(l).swap(l); }                                      // (:691-696)
+    Commitment_MT.clear();
+    printf("PC : ps = %lf, vt = %lf\n", ps, vt);
+}
 // src/Elastic_PC.cpp:625-726, !linear_time (RS x RS).  Prover side on the device (hobbit_elastic_open_*: libc draws in the reference's
 // order, the stream re-read twice through read_stream as the reference does); the verifier emulation is reduced to its ps accounting.
 void open(stream_descriptor fd, vector<F> x, vector<vector<_hash>> &Commitment_MT, double &vt, double &ps) {
-    if (linear_time) {
-        // update_reply_spielman (:431-485) indexes a tensor_row_size-long copy of the un-encoded column with rows >= tensor_row_size
-        // (:465-478): a read past the vector in the reference itself -- no defined result to reproduce
-        printf("Error: Elastic_PC::open with linear_time (option 2) is undefined in the reference (update_reply_spielman reads past its vector); not built\n");
-        exit(-1);
-    }
+    if (linear_time) { open_linear_time(fd, x, Commitment_MT, vt, ps); return; }
+    g_eopen.lin = false;
     PhaseTimer pt__("open");
     const int queries = 700; aggregation_queries = queries;
     const size_t B = BUFFER_SPACE, K = fd.size / B; const int trs = tensor_row_size;
@@ -680,13 +734,13 @@ void test_Elastic_PC(size_t N, int option) {                        // src/Elast
     printf("root ");
     for (int i = 0; i < 32; i++) printf("%02x", MT_hashes.back()[0].arr[i]);
     printf("\n");
-    if (option == 2) return;                                         // its open is undefined in the reference (see open())
     double vt = 0.0, ps = 0.0;
     start = std::chrono::steady_clock::now();
     open(commit_data, generate_randomness((int)log2((double)N)), MT_hashes, vt, ps);
     end = std::chrono::steady_clock::now();
     elapsed += std::chrono::duration_cast<std::chrono::duration<double>>(end - start).count();
-    printf("Total prover time : %lf\n", elapsed);
+    if (option == 1) printf("Total prover time : %lf\n", elapsed);                                              // (:759)
+    else std::cout << "Total time: " << elapsed << " seconds" << std::endl;                                      // (:783)
 }
 void test_Elastic_PC_commit(size_t N, int option) {                 // commit phase only (kept for callers that time the commit alone)
     _hash comm; vector<vector<_hash>> MT_hashes;
@@ -1368,6 +1422,27 @@ int hobbit_host_elastic_open(size_t N, size_t B, uint8_t *root_out, uint32_t *co
     memcpy(qpoly, t.qpoly.data(), 16 * 3 * (size_t)t.rounds); memcpy(r, t.r.data(), 16 * (size_t)t.rounds);
     checks[0] = t.checks[0]; checks[1] = t.checks[1]; checks[2] = t.sp_f.wchecks[0] & t.sp_f.wchecks[1];
     *ps_out = ps;
+    return t.rounds;
+}
+// test_Elastic_PC(N, 2) through the mirror from a fresh generator state (graphs, commit, x, open under linear_time); hands back root, queries,
+// replies (the reference's row order), the four transcripts of recursive_prover_Spielman_stream, C_c's root and the proof size
+int hobbit_host_elastic_open2(size_t N, size_t B, uint8_t *root_out, uint32_t *cols_rows, uint64_t *reply, uint64_t *qpoly, uint64_t *r, int *checks, double *ps_out,
+                              int *nrem_out, uint8_t *cc_root_out) {
+    srandom(1);
+    BUFFER_SPACE = B; linear_time = true; tensor_row_size = (int)(B >> 14);
+    expander_init_store(tensor_row_size);
+    _hash comm; vector<vector<_hash>> MT;
+    stream_descriptor fd; fd.name = "test"; fd.size = N;
+    commit(fd, comm, MT);
+    memcpy(root_out, MT.back()[0].arr, 32);
+    double vt = 0, ps = 0;
+    open(fd, generate_randomness((int)log2((double)N)), MT, vt, ps);
+    hobbit_host_elastic_transcript &t = hobbit_host_last_elastic_open();
+    for (int i = 0; i < t.queries; i++) { cols_rows[2 * i] = t.cols[i]; cols_rows[2 * i + 1] = t.rows[i]; }
+    memcpy(reply, t.reply.data(), 16 * (size_t)t.queries * t.reply_len);
+    memcpy(qpoly, t.qpoly.data(), 16 * 3 * (size_t)t.rounds); memcpy(r, t.r.data(), 16 * (size_t)t.rounds);
+    checks[0] = t.checks[0]; checks[1] = t.sp_c.iters ? (t.sp_c.wchecks[0] & t.sp_c.wchecks[1]) : 1; checks[2] = t.sp_f.iters ? (t.sp_f.wchecks[0] & t.sp_f.wchecks[1]) : 1;
+    *ps_out = ps; *nrem_out = t.nrem; memcpy(cc_root_out, t.cc_root, 32);
     return t.rounds;
 }
 // one call through each of the remaining reference-named wrappers; results for the test to compare with the oracle

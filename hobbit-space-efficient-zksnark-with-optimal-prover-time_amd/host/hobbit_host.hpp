@@ -264,6 +264,10 @@ struct hobbit_host_elastic_transcript {
     vector<uint32_t> cols, rows; vector<F> reply, qpoly, r, vr, fin, rx; vector<uint8_t> paths; uint8_t cf_root[32]; F rv0;
     int checks[2] = {0, 0};
     hobbit_host_shockwave_transcript sp_f;
+    /* Elastic_PC::open under linear_time (option 2; recursive_prover_Spielman_stream): remaining columns, padded size of aux_commit, C_c's root,
+     * s[0] / s2 / y1, and shockwave_prove(C_c, .); qpoly / r then hold P1, P2, P3, P5 and checks[0] is prove_fft_matrix's test */
+    bool lin = false; int nrem = 0; size_t np = 0; uint8_t cc_root[32]; vector<F> scal;
+    hobbit_host_shockwave_transcript sp_c;
 };
 hobbit_host_elastic_transcript &hobbit_host_last_elastic_open();
 /* On-wire form of an opening proof.  The reference never serialises a proof (struct proof / mul_tree_proof stay in

@@ -837,6 +837,20 @@ def elastic_open_proof_size(res, N, B, queries=700):
     return ps + _path_ps(4 * B, (4 * B).bit_length() - 1, pos)
 
 
+def elastic_open2_proof_size(res, N, B, queries=5900):
+    """The `ps` (KB) Elastic_PC::open accumulates for option 2 (src/Elastic_PC.cpp:701, 716; src/PC_utils.cpp:221-269), from a transcript"""
+    trs = B >> 14; cols = 2 * B // trs
+    R1 = (2 * trs).bit_length() - 1; logc = cols.bit_length() - 1
+    npad = 1 << (max(int(res["nr"][0]) * 2 * trs, 1) - 1).bit_length()
+    ps = queries * res["reply"].shape[1] * 16.0 / 1024.0
+    ps += _sc_ps(R1) + _sc_ps(logc) + _sc_ps(npad.bit_length() - 1)
+    ps += _shockwave_ps(res["sp_c"], npad, 32)
+    ps += _sc_ps(logc)
+    ps += _shockwave_ps(res["sp_f"], B, 32)
+    pos = (res["I"][:, 1].astype(np.int64) // 4) * cols + res["I"][:, 0].astype(np.int64)
+    return ps + _path_ps(4 * B, (4 * B).bit_length() - 1, pos)
+
+
 def gate_standard_inputs(n, seed):
     """consistent gates: selector s in {0,1}; O = L + R where s = 1, L * R where s = 0 (so the claimed sum 0 holds)"""
     P = (1 << 61) - 1

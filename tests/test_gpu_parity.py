@@ -1466,6 +1466,33 @@ def test_host_mirror_test_elastic_pc(oracle):
     assert ps.value == elastic_open_proof_size(want, N, B)
 
 
+def test_host_mirror_test_elastic_pc_option2(oracle):
+    """test_Elastic_PC(2^22, 2) with BUFFER_SPACE = 2^18 through the C++ mirror (expander_init_store, commit(stream_descriptor),
+    open(stream_descriptor) under linear_time, the reference's signatures): root, queries, replies, C_c's root, the sumcheck transcripts of
+    recursive_prover_Spielman_stream and the proof size against the oracle run on the same libc sequence"""
+    import ctypes
+    from __graft_entry__ import PKG, build_host
+    from oracle.pyoracle import elastic_open2_proof_size
+    build_host()
+    lib = ctypes.CDLL(os.path.join(PKG, "libhobbit_host.so"))
+    N, B = 1 << 22, 1 << 18
+    oracle.rng_reset(); lv = oracle.elastic_commit(N, B, 2)
+    x = oracle.generate_randomness(22)
+    want = oracle.elastic_open2(N, B, x, 5900, lv)
+    root = np.zeros(32, np.uint8); I = np.zeros((5900, 2), np.uint32); reply = np.zeros((5900, N // B, 2), np.uint64)
+    q = np.zeros((96, 3, 2), np.uint64); r = np.zeros((96, 2), np.uint64); chk = np.zeros(3, np.int32); ps = ctypes.c_double(); nrem = ctypes.c_int()
+    ccr = np.zeros(32, np.uint8)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.hobbit_host_elastic_open2.argtypes = [ctypes.c_size_t, ctypes.c_size_t] + [ctypes.c_void_p] * 9
+    rounds = lib.hobbit_host_elastic_open2(N, B, P(root), P(I), P(reply), P(q), P(r), P(chk), ctypes.byref(ps), ctypes.byref(nrem), P(ccr))
+    lib.hobbit_host_close()
+    assert np.array_equal(root, lv[-1]) and chk.tolist() == [1, 1, 1]
+    assert rounds == want["poly"].shape[0] and nrem.value == int(want["nr"][0])
+    assert np.array_equal(I, want["I"]) and np.array_equal(reply, want["reply"]) and np.array_equal(ccr, want["cc_root"])
+    assert np.array_equal(q[:rounds], want["poly"]) and np.array_equal(r[:rounds], want["r"])
+    assert ps.value == elastic_open2_proof_size(want, N, B)
+
+
 # ---- streaming provers (BASELINE config 4's math phases) ---------------------------------------------------------------------
 def test_stream_product_layers_vs_golden(hb):
     """read_mul_tree_layer / read_mul_tree_data on the reference's default stream against the REAL reference (tests/golden/streamdrv.npz)"""
