@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "hobbit_commitment_gather", "hobbit_commitment_path", "hobbit_commitment_paths",
     "hobbit_elastic_begin", "hobbit_elastic_push", "hobbit_elastic_push_inner", "hobbit_elastic_finish", "hobbit_elastic_free",
     "hobbit_elastic_open_begin", "hobbit_elastic_open_aggregate_push", "hobbit_elastic_open_aggregate_finish", "hobbit_elastic_open_reply_push",
-    "hobbit_elastic_open_finish", "hobbit_elastic_open_free", "hobbit_elastic_open_begin_lin", "hobbit_elastic_open_dims", "hobbit_generate_randomness",
+    "hobbit_elastic_open_finish", "hobbit_elastic_open_free", "hobbit_elastic_open_begin_lin", "hobbit_elastic_open_dims", "hobbit_transcript_record", "hobbit_transcript_count", "hobbit_transcript_read", "hobbit_generate_randomness",
     "hobbit_read_mul_tree_layer", "hobbit_read_mul_tree_data", "hobbit_generate_claims_opt", "hobbit_sumcheck3_stream_batch", "hobbit_mul_tree_stream_shallow",
     "hobbit_gate_consistency_stream", "hobbit_set_lookups", "hobbit_gate_consistency_lookups_stream", "hobbit_open_standard_rs", "hobbit_leaf_chain_relay", "hobbit_verify_path_host", "hobbit_fingerprint_map", "hobbit_leaf_chain", "hobbit_axpy_aggregate", "hobbit_stream_fold",
     "hobbit_tensorcode_chunks", "hobbit_inner_digests", "hobbit_chain_digests", "hobbit_blake3_64_host",
@@ -102,6 +102,7 @@ def load_library(path=LIB_PATH):
         "hobbit_elastic_open_begin": [V, S, S, I, V, I, V], "hobbit_elastic_open_aggregate_push": [V, V, V], "hobbit_elastic_open_aggregate_finish": [V, V],
         "hobbit_elastic_open_reply_push": [V, V, V], "hobbit_elastic_open_finish": [V, V, V, V], "hobbit_elastic_open_free": [V],
         "hobbit_elastic_open_begin_lin": [V, S, S, I, V, I, V], "hobbit_elastic_open_dims": [V, V, V, V],
+        "hobbit_transcript_record": [I], "hobbit_transcript_read": [V, S],
         "hobbit_generate_randomness": [S, V],
         "hobbit_read_mul_tree_layer": [V, V, V, S, I, V], "hobbit_read_mul_tree_data": [V, V, V, S, I, I, I, V],
         "hobbit_generate_claims_opt": [V, V, V, S, S, V, I, I, I, I, V], "hobbit_sumcheck3_stream_batch": [V, V, V, S, S, V, I, I, I, I, V, I, V],
@@ -113,6 +114,7 @@ def load_library(path=LIB_PATH):
     }
     for name, args in protos.items():
         getattr(lib, name).argtypes = args
+    lib.hobbit_transcript_count.restype = c_sz; lib.hobbit_transcript_read.restype = c_sz; lib.hobbit_transcript_record.restype = None
     return lib
 
 

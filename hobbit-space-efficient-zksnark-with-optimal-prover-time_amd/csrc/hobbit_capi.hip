@@ -213,6 +213,8 @@ static int fft_long(hobbit_ctx *ctx, const F *src, size_t src_ld, size_t src_len
     return 0;
 }
 
+namespace hobbit { TranscriptRec &transcript_rec() { static thread_local TranscriptRec t; return t; } }
+
 extern "C" {
 
 const char *hobbit_version(void) { return "hobbit-hip 0.1 (gfx950)"; }
@@ -333,6 +335,15 @@ int hobbit_profile_names(hobbit_ctx *ctx, char *buf, size_t buflen) {
     memcpy(buf, s.c_str(), s.size() + 1); return 0;
 }
 
+// ---- transcript recorder (per calling thread) -------------------------------------------------------
+void hobbit_transcript_record(int on) { TranscriptRec &t = transcript_rec(); if (on) t.w.clear(); t.on = on != 0; }
+size_t hobbit_transcript_count(void) { return transcript_rec().w.size() / 6; }
+size_t hobbit_transcript_read(uint64_t *out, size_t max_records) {
+    TranscriptRec &t = transcript_rec();
+    const size_t n = std::min(max_records, t.w.size() / 6);
+    if (n) memcpy(out, t.w.data(), n * 6 * sizeof(uint64_t));
+    return n;
+}
 // ---- host-side field helpers ------------------------------------------------------------------
 void hobbit_mimc(const hobbit_F *x, const hobbit_F *k, hobbit_F *out) { *mF(out) = mimc_hash(*cF(x), *cF(k)); }
 void hobbit_f_mul_host(const hobbit_F *a, const hobbit_F *b, hobbit_F *o, size_t n) { for (size_t i = 0; i < n; i++) mF(o)[i] = fmul(cF(a)[i], cF(b)[i]); }

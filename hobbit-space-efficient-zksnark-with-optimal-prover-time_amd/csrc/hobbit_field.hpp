@@ -11,6 +11,7 @@
 // products (Karatsuba) folded with two Mersenne reductions = 12 v_mad_u64_u32 + ~60 VALU.  A
 // product with a 32-bit real scalar (the expander weights, src/expanders.h:37) is 4 v_mad_u64_u32.
 #pragma once
+#include <vector>
 #include <stdint.h>
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -90,6 +91,10 @@ HB_HD F mimc_hash_plain(const F &x, const F &k) {
     }
     return fadd(h, k);
 }
+// Transcript recorder (test support, include/hobbit_hip.h hobbit_transcript_*): while it is on for the calling thread every transcript hash
+// the library computes on that thread appends (x, k, result), 6 words -- the complete Fiat-Shamir transcript of whatever prover runs, in order.
+struct TranscriptRec { bool on = false; std::vector<uint64_t> w; };
+TranscriptRec &transcript_rec();                                                                    // hobbit_capi.hip (thread_local)
 #if !defined(__HIP_DEVICE_COMPILE__)
 // The host runs ~520 of these per open, one after the other, each on the critical path of a sumcheck round (the GPU waits for the
 // challenge).  Same function with lazy reductions: values ride as any residue below 2^62 + 8, the square uses
@@ -101,7 +106,7 @@ static inline uint64_t lz_red(u128 x) {                                         
     const uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
     return (lo & P61) + (((hi << 3) | (lo >> 61)) & P61) + (hi >> 58);
 }
-inline F mimc_hash(const F &x, const F &k) {
+inline F mimc_hash_lazy(const F &x, const F &k) {
     uint64_t hr = 0, hi_ = 0;                                                                      // h, lazy
     const uint64_t kr = k.re, ki = k.im;
     for (int i = 0; i < 161; i++) {
@@ -116,6 +121,12 @@ inline F mimc_hash(const F &x, const F &k) {
     }
     const uint64_t r = lz_fold(lz_fold(hr + kr)), m = lz_fold(lz_fold(hi_ + ki));                  // <= p + small
     return fmake(r >= P61 ? r - P61 : r, m >= P61 ? m - P61 : m);
+}
+inline F mimc_hash(const F &x, const F &k) {
+    const F o = mimc_hash_lazy(x, k);
+    TranscriptRec &t = transcript_rec();
+    if (t.on) { const uint64_t rec[6] = {x.re, x.im, k.re, k.im, o.re, o.im}; t.w.insert(t.w.end(), rec, rec + 6); }
+    return o;
 }
 #else
 HB_HD F mimc_hash(const F &x, const F &k) { return mimc_hash_plain(x, k); }

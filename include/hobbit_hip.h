@@ -66,6 +66,15 @@ int hobbit_profile_names(hobbit_ctx *ctx, char *buf, size_t buflen); /* ';'-sepa
 
 /* ---- field / transcript (host-side helpers; src/fieldElement.cpp, src/mimc.cpp:95-107) ---- */
 void hobbit_mimc(const hobbit_F *x, const hobbit_F *k, hobbit_F *out);           /* mimc_hash */
+/* Transcript recorder (test support).  Every Fiat-Shamir hash of the path is mimc_hash (src/mimc.cpp:95-107) computed on the host; while
+ * recording is on for the CALLING THREAD, each one this library computes on that thread -- inside any prover entry point and through
+ * hobbit_mimc -- appends the record (x, k, result) = 6 x u64.  The sequence is the complete transcript of the provers that ran, in order;
+ * tests compare its sha256 with the sequence a call-through recorder in front of the real reference's mimc_hash captured on the same streams
+ * (oracle/ref_recorder.cpp, tests/golden/transcripts.json).  record(1) clears and starts, record(0) stops; read copies up to max_records.
+ * Entry points that use a second host thread (hobbit_open_standard's shockwave_prove(C_c)) record that thread's hashes on that thread. */
+void hobbit_transcript_record(int on);
+size_t hobbit_transcript_count(void);
+size_t hobbit_transcript_read(uint64_t *out, size_t max_records);
 void hobbit_f_mul_host(const hobbit_F *a, const hobbit_F *b, hobbit_F *out, size_t n);
 void hobbit_f_inv_host(const hobbit_F *a, hobbit_F *out, size_t n);
 /* generate_randomness (src/utils.cpp:873-883), host side, on the process-wide libc generator: every 100 elements c = random(),

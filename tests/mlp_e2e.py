@@ -37,8 +37,13 @@ def main():
         if not os.path.exists(so):
             subprocess.check_call(["gcc", "-O1", "-g", "-fPIC", "-shared", "-o", so, os.path.join(ROOT, "tests", "aux", "segv_bt.c"), "-ldl"])
         bt = ctypes.CDLL(so, mode=RTLD_GLOBAL | RTLD_LAZY); bt.segv_bt_install()
-    load(os.path.join(PKG, "libhobbit_hip.so"))
-    h_mir = load(os.path.join(PKG, "libhobbit_host_refmode.so"))          # first in the lookup order
+    record = bool(os.environ.get("HOBBIT_E2E_TRANSCRIPT"))
+    h_hip = load(os.path.join(PKG, "libhobbit_hip.so"))
+    if record:
+        # transcript run: Elastic_PC::open is stood in for exactly as in the reference-side recording (tests/ref_transcript.py, oracle/ref_recorder.cpp),
+        # so that both transcripts end where the reference's run has to end (its open needs SHA3); the library records its own transcript hashes
+        load(os.path.join(ROOT, "oracle", "_ref", "libref_openstub.so"))
+    h_mir = load(os.path.join(PKG, "libhobbit_host_refmode.so"))          # first in the lookup order (after the open stand-in of a transcript run)
     h_ref = load(os.path.join(ROOT, "oracle", "_ref", os.environ.get("HOBBIT_E2E_REFLIB", "libhobbit_ref.so")))
     # the mirror's gate prover reads the trace through a hook: the reference's read_trace
     hook = dlsym(h_mir, b"hobbit_read_trace_hook")
@@ -53,8 +58,23 @@ def main():
     args = [b"pigeon"] + [a.encode() for a in sys.argv[1:]]
     argv = (ctypes.c_char_p * (len(args) + 1))(*args, None)
     sys.stdout.flush()
+    if record:
+        ctypes.CFUNCTYPE(None, ctypes.c_int)(dlsym(h_hip, b"hobbit_transcript_record"))(1)
     rc = ref_main(len(args), argv)
     libc.fflush(None)
+    if record:
+        import json
+        import numpy as np
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from ref_transcript import summarize
+        ctypes.CFUNCTYPE(None, ctypes.c_int)(dlsym(h_hip, b"hobbit_transcript_record"))(0)
+        n = ctypes.CFUNCTYPE(ctypes.c_size_t)(dlsym(h_hip, b"hobbit_transcript_count"))()
+        rec = np.zeros((n, 6), np.uint64)
+        ctypes.CFUNCTYPE(ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t)(dlsym(h_hip, b"hobbit_transcript_read"))(rec.ctypes.data, n)
+        out = summarize(rec); out["rc"] = rc; out["args"] = sys.argv[1:]
+        print("TRANSCRIPT " + json.dumps(out)); sys.stdout.flush()
+        if os.environ.get("HOBBIT_TRANSCRIPT_DUMP"):
+            np.save(os.environ["HOBBIT_TRANSCRIPT_DUMP"], rec)
     os._exit(rc)                                   # the reference leaves its Seval thread detached and blocked
 
 

@@ -380,8 +380,9 @@ def test_sumcheck2_2e20_vs_oracle(hb, oracle):
 
 
 def test_sumcheck2_2e24_claim_consistency(hb, oracle):
-    """C2 size (2^24): too slow for the oracle inside a test, so check the protocol's own
-    invariants (what the reference's inline self-checks verify): q_0(0)+q_0(1) = <v1,v2>,
+    """C2 at its stated size (2^24), bit-exact against the REAL reference's generate_2product_sumcheck_proof on the same inputs
+    (tests/golden/sumcheck2_2e24.npz: every round polynomial, challenge, vr and the final value; oracle/gen_sumcheck_2e24.py ran
+    oracle/_ref once), plus the protocol's own invariants (what the reference's inline self-checks verify): q_0(0)+q_0(1) = <v1,v2>,
     q_{i+1}(0)+q_{i+1}(1) = q_i(r_i), and q_last(r_last) = vr[0]*vr[1]."""
     n = 1 << 24
     d1 = hb.fill_splitmix(n, 1)
@@ -389,6 +390,9 @@ def test_sumcheck2_2e24_claim_consistency(hb, oracle):
     d2 = hb.precompute_beta(r, keep_on_device=True)
     pr = np.array([33, 0], np.uint64)
     res = hb.generate_2product_sumcheck_proof((d1, n), (d2, n), pr)
+    g = gold("sumcheck2_2e24")
+    for k in ("poly", "r", "vr", "fin"):
+        assert np.array_equal(res[k], g[k]), k
 
     def ev(q, x):   # ((a x) + b) x + c
         t = oracle.f_add(oracle.f_mul(q[0:1], x), q[1:2])

@@ -92,3 +92,38 @@ def test_prove_circuit_standard_end_to_end():
     m = re.search(r"Pt : ([0-9.]+), Vt : ([0-9.]+), Ps : ([0-9.]+)", out)
     assert m, out[-2000:]
     assert float(m.group(3)) > 0
+
+
+def _transcript_cases():
+    import json
+    path = os.path.join(ROOT, "tests", "golden", "transcripts.json")
+    if not os.path.exists(path):
+        return []
+    return [(k, v) for k, v in json.load(open(path)).items() if isinstance(v, dict)]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_openstub.so")), reason="oracle/_ref/libref_openstub.so is not built")
+@pytest.mark.parametrize("name,want", _transcript_cases(), ids=[k for k, _ in _transcript_cases()])
+def test_transcript_matches_reference(name, want):
+    """The orchestration of the streaming provers against the REAL reference, message by message.  tests/golden/transcripts.json holds, per
+    command, what a call-through recorder in front of the real reference's mimc_hash captured while the reference's OWN commit,
+    prove_multiplication_tree_stream_shallow (twice for the lookup circuits) and prove_gate_consistency / prove_gate_consistency_lookups ran on
+    the reference's own Seval streams (oracle/gen_transcripts.py, tests/ref_transcript.py, oracle/ref_recorder.cpp): every Fiat-Shamir hash --
+    (input, key, result), i.e. every round polynomial coefficient, every claim that is hashed and every challenge, in order.  Here the same
+    command runs with the device-backed mirror answering those functions and the library's own recorder on (hobbit_transcript_record): the
+    number of hashes, the sha256 of the whole sequence, of every 4096-record block and the `Ps` the run prints must be identical.  Both runs
+    end at the first Elastic_PC::open (it needs SHA3 in the reference; the open has its own tests and the `Ps : 559` fingerprint)."""
+    import json
+    env = dict(os.environ, HOBBIT_E2E_TRANSCRIPT="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mlp_e2e.py")] + want["cmd"].split(), capture_output=True, text=True, timeout=600, env=env)
+    out = p.stdout + p.stderr
+    assert p.returncode == 0, out[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("TRANSCRIPT ")]
+    assert lines, out[-2000:]
+    got = json.loads(lines[-1][11:])
+    assert got["count"] == want["count"], (got["count"], want["count"])
+    first_bad = next((i for i, (a, b) in enumerate(zip(got["blocks"], want["blocks"])) if a != b), None)
+    assert first_bad is None, "transcripts diverge in block %d (records %d..)" % (first_bad, first_bad * 4096)
+    assert got["sha256"] == want["sha256"] and got["first"] == want["first"] and got["last"] == want["last"]
+    m = re.search(r"Ps : ([0-9.]+) KB", out)
+    assert m and float(m.group(1)) == want["ps_truncated_run"], out[-500:]
