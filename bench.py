@@ -31,15 +31,17 @@ def fft_butterflies(s):
     return (s // 2) * (s.bit_length() - 1)
 
 
-def commit_op_counts(N, K, edges):
+def commit_op_counts(N, K, edges, nz=1.0):
     """SURVEY.md 8(d): per chunk mul = trs*FFT(4096) + cols*E(trs); add = 2*trs*FFT(4096) + cols*E(trs);
-    BLAKE3 compressions 2M per chunk + (M-1) for the tree."""
+    BLAKE3 compressions per chunk and leaf: one for the 64 bytes of the four tensor entries unless all four rows lie past the codeword
+    length (the constant H(0^64), not recomputed: share nz of the leaves has a non-zero row), one for the chain; + (M-1) for the tree.
+    nz = 1 gives the reference's nominal 2M per chunk."""
     M = N // K
     trs = N // (K << 11)
     cols = 2 * M // trs
     mul = K * (trs * fft_butterflies(cols) + cols * edges)
     add = K * (2 * trs * fft_butterflies(cols) + cols * edges)
-    comp = K * 2 * M + (M - 1)
+    comp = int(K * M * (1 + nz)) + (M - 1)
     return mul, add, comp
 
 
@@ -204,7 +206,8 @@ def main():
     hb.rng_reset()
     code_len = hb.expander_init_store(trs)   # graphs drawn on the host with libc, reference order; returns the codeword length
     edges = sum(int(L) * int(d) for (L, R, d, nbr, w) in hb._graph_levels.values())
-    mul, add, comp = commit_op_counts(N, K, edges)
+    mul, add, comp = commit_op_counts(N, K, edges, nonzero_group_fraction(trs, code_len))        # executed compressions (the roofline block uses the same share)
+    comp_nominal = commit_op_counts(N, K, edges)[2]
 
     def barrier():
         if dist is not None:
@@ -342,7 +345,7 @@ def main():
             "step_ms_outliers": [x for x in step_ms if x > 1.25 * float(np.median(step_ms))],
             "f_mul_per_s": mul * (1 if sharded else world) / (wall_max / args.steps),
             "blake3_compressions_per_s": comp * (1 if sharded else world) / (wall_max / args.steps),
-            "op_counts": {"f_mul": mul, "f_add": add, "blake3_compress": comp, "expander_edges": edges, "open_f_mul": omul, "open_f_add": oadd},
+            "op_counts": {"f_mul": mul, "f_add": add, "blake3_compress": comp, "blake3_compress_nominal": comp_nominal, "expander_edges": edges, "open_f_mul": omul, "open_f_add": oadd},
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items())},
             "kernels_ms_note": "k_fft4096 and k_transpose run on two streams, overlapped (chunk group g's transpose beside group g+1's FFT): their durations sum to more than their wall-clock span; kernels_ms_extra_profiled_step / launches_extra_profiled_step come from one extra untimed step with every launch bracketed, which runs the open on ONE thread and stream (the timed steps run shockwave_prove(C_c) on a helper context from a second thread and the inner commitments on a third stream)",
             "kernels_ms_extra_profiled_step": {k: v[0] for k, v in sorted(prof_full.items())},

@@ -519,10 +519,7 @@ int hobbit_eval_vector(hobbit_ctx *ctx, const hobbit_F *d_v, size_t n, const hob
 }
 
 // ---- tensor code / commit ---------------------------------------------------------------------
-// d_dig (nullable; honoured on the large RS x expander path only, *dig_done says whether): the inner digests of the commitment's leaves,
-// K x cols x trs/2 x 32 B, written by the encode passes into the row-FFT scratch (workspace2), which is dead once the transpose has run
-static int tensorcode_chunks(hobbit_ctx *ctx, const F *d_msg, size_t M, int K, int trs, int lin, F *d_out, uint8_t **d_dig = nullptr) {
-    if (d_dig) *d_dig = nullptr;
+static int tensorcode_chunks(hobbit_ctx *ctx, const F *d_msg, size_t M, int K, int trs, int lin, F *d_out) {
     if (trs <= 0 || M % (size_t)trs) return ctx->fail(HOBBIT_EINVAL, "tensorcode: trs must divide M");
     size_t half = M / trs, cols = 2 * half, rows2 = 2 * (size_t)trs;
     int logc = ilog2_exact(cols), logr = ilog2_exact(rows2);
@@ -554,16 +551,18 @@ static int tensorcode_chunks(hobbit_ctx *ctx, const F *d_msg, size_t M, int K, i
     // transposed layout directly (one launch less, the scattered stores stay in L2).
     if ((size_t)K * trs * cols * sizeof(F) >= ((size_t)64 << 20)) {
         F *rm; HB_TRY(ctx->workspace2((size_t)K * trs * cols * sizeof(F), (void **)&rm));
-        const char *es_env = getenv("HOBBIT_ENC_STRIDED"); const bool enc_strided = es_env && es_env[0] == '1';
         // Two-stream pipeline over chunk groups (default on; HOBBIT_COMMIT_PIPE=0 turns it off, =G asks for G groups): group g's layout
         // change (HBM-bound, next to no VALU work) runs on the side stream while group g+1's row FFT (VALU-bound, one pass over the
         // data) runs on the main one.  Same kernels, same bytes, bit-identical tensor; DESIGN.md section 4 has the A/B.
         const char *pp_env = getenv("HOBBIT_COMMIT_PIPE");
         int pipe = pp_env ? atoi(pp_env) : (K % 8 == 0 ? 8 : K % 4 == 0 ? 4 : K % 2 == 0 ? 2 : 0);
-        if (pipe > 64) pipe = 64;
-        if (pipe > 1 && K % pipe == 0 && !enc_strided) {
+        if (pipe > 56) pipe = 56;                                    // side_ev[0 .. pipe) are this loop's; 60-63 belong to open_impl, 64/65 to the brackets below
+        if (pipe > 1 && K % pipe == 0) {
             HB_TRY(ctx->side_init());
             const int per = K / pipe; hipStream_t mainS = ctx->stream;
+            // every exit from this block -- also an error inside the group loop -- leaves the side stream joined: the caller may free or re-use
+            // d_out / the scratch right away
+            struct SideJoin { hobbit_ctx *c; hipStream_t m; bool done = false; ~SideJoin() { c->stream = m; if (!done) hipStreamSynchronize(c->side); } } join{ctx, mainS};
             HB_CHECK(ctx, hipEventRecord(ctx->side_ev[64], mainS)); HB_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->side_ev[64], 0));   // d_out / rm are free for the side stream
             for (int g = 0; g < pipe; g++) {
                 const size_t c0 = (size_t)g * per;
@@ -575,19 +574,10 @@ static int tensorcode_chunks(hobbit_ctx *ctx, const F *d_msg, size_t M, int K, i
                 if (rc) return rc;
             }
             HB_CHECK(ctx, hipEventRecord(ctx->side_ev[65], ctx->side)); HB_CHECK(ctx, hipStreamWaitEvent(mainS, ctx->side_ev[65], 0));
+            join.done = true;
         } else {
             HB_TRY(fft_rows(ctx, d_msg, half, (uint32_t)half, rm, cols, 1, logc, false, (uint32_t)K, (uint32_t)trs, M, (size_t)trs * cols));
-            if (lin && enc_strided && trs > 13 && ctx->code.n == trs && ((size_t)K * cols) % 64 == 0) {
-                // EXPERIMENT (off by default, measured slower: DESIGN.md 4): no transpose pass, the encode reads its message as a strided
-                // column of the row-major FFT output (8 adjacent columns on one XCD) and writes message + parity contiguously
-                return launch_encode_strided(ctx, rm, 0, (uint32_t)cols, (uint32_t)cols, (size_t)trs * cols, d_out, rows2, trs, (size_t)K * cols, 1, nullptr);
-            }
             HB_TRY(launch_transpose(ctx, rm, (size_t)trs * cols, (uint32_t)trs, (uint32_t)cols, d_out, cols * rows2, rows2, (uint32_t)K));
-        }
-        const char *dg_env = getenv("HOBBIT_ENC_DIGESTS");
-        if (lin && d_dig && trs > 13 && trs % 4 == 0 && ctx->code.n == trs && dg_env && dg_env[0] == '1') {     // EXPERIMENT, off by default (measured slower: DESIGN.md 4)
-            *d_dig = reinterpret_cast<uint8_t *>(rm);                   // K*M digests of 32 B = the scratch's K*trs*cols elements of 16 B
-            return launch_encode_strided(ctx, d_out, rows2, 1, 0, 0, d_out, rows2, trs, (size_t)K * cols, 0, *d_dig);
         }
     } else
         HB_TRY(fft_rows(ctx, d_msg, half, (uint32_t)half, d_out, 1, rows2, logc, false, (uint32_t)K, (uint32_t)trs, M, cols * rows2));
@@ -634,12 +624,10 @@ int hobbit_commit_standard(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, in
             }
         }
     }
-    uint8_t *dig = nullptr;
-    int r = tensorcode_chunks(ctx, cF(d_poly), M, K, trs, linear_time, c->d_tensor, &dig);
-    // leaf chain over the K chunks (src/Our_PC.cpp:155-167), then the tree (src/Our_PC.cpp:169)
-    if (!r && dig) r = launch_leaf_chain_dig(ctx, dig, M * 32, K, (uint32_t)cols, (uint32_t)(trs / 2), c->d_levels);
+    int r = tensorcode_chunks(ctx, cF(d_poly), M, K, trs, linear_time, c->d_tensor);
+    // leaf chain over the K chunks (src/Our_PC.cpp:155-167), then the tree (src/Our_PC.cpp:169);
     // rows >= the codeword length are zero in every chunk of an RS x expander tensor (RS x RS fills all 2*trs rows)
-    else if (!r) r = launch_leaf_chain(ctx, c->d_tensor, cols * rows2, K, (uint32_t)cols, (uint32_t)(trs / 2), c->d_levels,
+    if (!r) r = launch_leaf_chain(ctx, c->d_tensor, cols * rows2, K, (uint32_t)cols, (uint32_t)(trs / 2), c->d_levels,
                                        linear_time && ctx->code.n == trs ? (uint32_t)ctx->code.len : (uint32_t)rows2);
     if (!r) r = launch_merkle_levels(ctx, c->d_levels, M, 1);
     if (r) { hobbit_commitment_free(c); return r; }
@@ -2313,8 +2301,22 @@ struct OpenTrace {
 };
 // With a commitment `c`: the aggregate is computed from d_poly (N = M K coefficients).  With c == NULL (multi-GPU open): d_poly is the
 // M-element aggregate itself, summed by the caller from per-rank partials; dims = {K, trs}; replies and paths are the caller's business.
+static int open_impl_body(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const int *dims, const hobbit_F *h_x, int queries, hobbit_open_out *o,
+                          bool full);
 static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const int *dims, const hobbit_F *h_x, int queries, hobbit_open_out *o,
                      bool full) {
+    const int rc = open_impl_body(ctx, d_poly, N, c, dims, h_x, queries, o, full);
+    if (rc) {
+        // an error return may leave work queued on the helper contexts' streams (inner commitments, query answers, their staged read-backs
+        // into THIS context's arena): drain them before the caller -- or the next call's StageScope -- re-uses those buffers
+        for (hobbit_ctx *h : {ctx->helper, ctx->helper2}) if (h) hipStreamSynchronize(h->stream);
+        if (ctx->side) hipStreamSynchronize(ctx->side);
+        hipStreamSynchronize(ctx->stream);
+    }
+    return rc;
+}
+static int open_impl_body(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const int *dims, const hobbit_F *h_x, int queries, hobbit_open_out *o,
+                          bool full) {
     if ((!c && !dims) || !o || queries <= 0 || (full && (!o->sp_c || !o->sp_f))) return ctx->fail(HOBBIT_EINVAL, "open: bad arguments");
     if (!c && (o->reply || o->paths)) return ctx->fail(HOBBIT_EINVAL, "open_from_aggregate: replies and paths come from the tensor shards, not from here");
     OpenTrace tr(ctx);

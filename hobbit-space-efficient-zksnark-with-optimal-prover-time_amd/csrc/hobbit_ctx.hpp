@@ -65,7 +65,9 @@ struct hobbit_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
-    // second stream + events: the commit's layout change (HBM-bound) of one chunk group runs beside the next group's row FFT (VALU-bound)
+    // second stream + events: the commit's layout change (HBM-bound) of one chunk group runs beside the next group's row FFT (VALU-bound).
+    // Event slots: [0, 56) the commit pipeline's chunk groups (tensorcode_chunks clamps its group count to 56), 60-63 open_impl's cross-stream
+    // fences, 64/65 the pipeline's opening / closing brackets.
     hipStream_t side = nullptr; hipEvent_t side_ev[66] = {};
     int side_init() {
         if (side) return 0;

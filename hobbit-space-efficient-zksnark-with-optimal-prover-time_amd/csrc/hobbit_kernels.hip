@@ -5,10 +5,17 @@
 // accesses; the FFT and the expander encode keep a whole row / codeword in LDS (64 KB / <=110 KB
 // of the CU's 160 KB) and are bound by the v_mad_u64_u32 rate.
 #include "hobbit_kernels.hpp"
+#include <atomic>
 #include "hobbit_blake3.hpp"
 #include <vector>
 
 namespace hobbit {
+// The dynamic-LDS limit is an attribute of the function ON ONE DEVICE: latched per device (bit = device ordinal), not per process -- a host that
+// creates contexts on several devices from one process must set it on each (torchrun's one device per process never noticed).
+static inline void set_lds_limit_once(hobbit_ctx *ctx, const void *kernel, int bytes, std::atomic<uint64_t> &done) {
+    const uint64_t bit = 1ull << (ctx->device & 63);
+    if (!(done.load(std::memory_order_relaxed) & bit)) { hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); done.fetch_or(bit); }
+}
 
 // ============================================================================================
 // small utilities
@@ -169,8 +176,8 @@ k_fft_cols(const F *__restrict__ y, size_t gs, int logr, F *__restrict__ out, co
 int launch_fft_cols(hobbit_ctx *ctx, const F *y, size_t gs, int logr, F *out, const F *tw2, const F *twr, uint32_t batch) {
     if (logr < 2 || logr > 8) return ctx->fail(HOBBIT_EINVAL, "fft_cols: R must be in [4, 256]");
     const size_t lds = (size_t)16 * (fft_row_slots(1u << logr) + 1) * 16;
-    static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute((const void *)k_fft_cols, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 289 * 16); attr_set = true; }
+    static std::atomic<uint64_t> attr_set{0};
+    set_lds_limit_once(ctx, (const void *)k_fft_cols, 16 * 289 * 16, attr_set);
     HB_LAUNCH(ctx, "k_fft_cols", k_fft_cols, dim3(4096 / 16, batch), dim3(512), lds, y, gs, logr, out, tw2, twr);
     return 0;
 }
@@ -178,8 +185,8 @@ int launch_fft_cols(hobbit_ctx *ctx, const F *y, size_t gs, int logr, F *out, co
 int launch_fft_rows(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_len, F *dst, size_t dst_ld, size_t dst_es,
                     int logn, const F *tw, F scale, int do_scale, uint32_t groups, uint32_t rows_per_group, size_t src_gs, size_t dst_gs) {
     if (logn < 1 || logn > 12) return ctx->fail(HOBBIT_EINVAL, "fft: logn must be in [1,12] for the LDS-resident kernel");
-    static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute((const void *)k_fft_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 81920); attr_set = true; }
+    static std::atomic<uint64_t> attr_set{0};
+    set_lds_limit_once(ctx, (const void *)k_fft_rows, 81920, attr_set);
     const size_t total = (size_t)groups * rows_per_group;
     if (total == 0) return 0;
     if (total >> 32) return ctx->fail(HOBBIT_EINVAL, "fft: too many rows");
@@ -805,38 +812,23 @@ __device__ __forceinline__ F shfl_xor_F(const F &a, int m) {
 // CU) and pass B = everything else (46 KB window, 3 per CU) so that one workgroup's global
 // load/store overlaps another's gather loop.
 struct EncPass { uint32_t base, ld_lo, ld_hi, s_lo, s_hi, st_lo, st_hi, direct_out; };
-struct EncSrc { uint32_t stride, cols, remap; size_t gs; };      // stride <= 1: contiguous messages at ld_src
-// digest output of a pass: groups [g_lo, g_hi) of 4 consecutive codeword entries (all inside the pass's LDS window after its last step;
-// entries >= len are zero), written to out[(block * per_col + g) * 32]; groups [g_hi, g_fill) are entirely zero: the constant H(0^64)
-struct EncDig { uint8_t *out; uint32_t g_lo, g_hi, g_fill, per_col; uint32_t zero[8]; };
-
-// DIG: the workgroup also hashes the 4-row groups of the part of the codeword it holds in LDS -- inner digests H(t[4j..4j+3][col])
-// of the commitment's leaves (src/merkle_tree.cpp:70-75) -- into dig[(column * groups_per_col + j) * 32].  The encode's waves wait on
-// LDS gathers and barriers for most of their cycles, the hash is pure VALU work: done here it fills issue slots that are idle anyway,
-// and the leaf chain afterwards reads 32-byte digests instead of re-reading the 64 bytes of tensor behind each of them.
-template <bool SMALLW, bool DIG>
+template <bool SMALLW>
 __global__ void __launch_bounds__(1024)
 k_encode(const F *__restrict__ src, size_t ld_src, F *__restrict__ dst, size_t ld_dst, uint32_t len, EncPass ps,
          const EncStep *__restrict__ steps, const uint32_t *__restrict__ slice_ptr,
          const uint32_t *__restrict__ slice_width, const uint32_t *__restrict__ slice_out, const uint2 *__restrict__ e32,
-         const uint32_t *__restrict__ eidx, const F *__restrict__ ew, EncSrc es, EncDig dg) {
+         const uint32_t *__restrict__ eidx, const F *__restrict__ ew) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     F *cw = reinterpret_cast<F *>(lds_raw) - ps.base;          // cw[i] addresses codeword index i
-    // Strided source (es.stride > 1): the message is column `c` of a row-major matrix (the row FFT's output), element i at
-    // in[i * stride]; a 128-byte line then holds the same row of 8 adjacent columns, so the block -> column map keeps 8 adjacent
-    // columns on blocks b, b+8, ..., b+56 -- dealt to ONE XCD back to back (MI355X_MICROARCH.md, workgroup dispatch) -- and the
-    // other seven find the line in that XCD's L2.  A speed choice only: any placement gives the same result.
-    uint32_t b = blockIdx.x;
-    if (es.stride > 1 && es.remap) { const uint32_t x = b & 7, q = b >> 3; b = ((q >> 3) << 6) + (x << 3) + (q & 7); }
-    const F *in = es.stride > 1 ? src + (size_t)(b / es.cols) * es.gs + (b % es.cols) : src + (size_t)b * ld_src;
-    const size_t istr = es.stride > 1 ? es.stride : 1;
+    const uint32_t b = blockIdx.x;
+    const F *in = src + (size_t)b * ld_src;
     F *out = dst + (size_t)b * ld_dst;
     // window load: eight global loads per thread in flight before the first LDS store (one at a time cost a full memory round
     // trip per element: 7 400 of pass A's 27 000 cycles per column, measured with s_memtime stamps)
     for (uint32_t b0 = ps.ld_lo; b0 < ps.ld_hi; b0 += 8 * blockDim.x) {
         F v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const uint32_t i = b0 + u * blockDim.x + threadIdx.x; if (i < ps.ld_hi) v[u] = ldF(in + (size_t)i * istr); }
+        for (int u = 0; u < 8; u++) { const uint32_t i = b0 + u * blockDim.x + threadIdx.x; if (i < ps.ld_hi) v[u] = ldF(in + i); }
 #pragma unroll
         for (int u = 0; u < 8; u++) { const uint32_t i = b0 + u * blockDim.x + threadIdx.x; if (i < ps.ld_hi) stF(&cw[i], v[u]); }
     }
@@ -926,39 +918,17 @@ k_encode(const F *__restrict__ src, size_t ld_src, F *__restrict__ dst, size_t l
         }
         __syncthreads();
     }
-    if (DIG) {
-        uint8_t *dout = dg.out + (size_t)b * dg.per_col * 32;
-        for (uint32_t g = dg.g_lo + threadIdx.x; g < dg.g_hi; g += blockDim.x) {
-            uint32_t m[16], h[8];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t i = 4 * g + q;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (i < len) v = *reinterpret_cast<const uint4 *>(&cw[i]);
-                m[4 * q] = v.x; m[4 * q + 1] = v.y; m[4 * q + 2] = v.z; m[4 * q + 3] = v.w;
-            }
-            blake3_compress64(m, h);
-            store8w(dout + 32 * (size_t)g, h);
-        }
-        for (uint32_t g = dg.g_hi + threadIdx.x; g < dg.g_fill; g += blockDim.x) store8w(dout + 32 * (size_t)g, dg.zero);
-    }
     for (uint32_t i = ps.st_lo + threadIdx.x; i < ps.st_hi; i += blockDim.x) stF(out + i, i < len ? ldF(&cw[i]) : fmake(0));
 }
 
-template <bool SMALLW, bool DIG>
-static int launch_encode_pass(hobbit_ctx *ctx, const char *name, const F *src, size_t ld_src, F *dst, size_t ld_dst, size_t batch, EncPass ps,
-                              uint32_t lds_elems, uint32_t block, EncSrc es, EncDig dg) {
-    DeviceCode &c = ctx->code;
-    hipFuncSetAttribute((const void *)k_encode<SMALLW, DIG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    HB_LAUNCH(ctx, name, (k_encode<SMALLW, DIG>), dim3((unsigned)batch), dim3(block), (size_t)lds_elems * 16, src, ld_src, dst, ld_dst, (uint32_t)c.len, ps,
-              c.d_steps, c.d_slice_ptr, c.d_slice_width, c.d_slice_out, c.d_edges32, c.d_eidx, c.d_ew, es, dg);
-    return 0;
-}
 template <bool SMALLW>
 static int launch_encode_pass(hobbit_ctx *ctx, const char *name, const F *src, size_t ld_src, F *dst, size_t ld_dst, size_t batch, EncPass ps,
-                              uint32_t lds_elems, uint32_t block, EncSrc es = EncSrc{1, 0, 0, 0}, const EncDig *dg = nullptr) {
-    if (dg && dg->out) return launch_encode_pass<SMALLW, true>(ctx, name, src, ld_src, dst, ld_dst, batch, ps, lds_elems, block, es, *dg);
-    return launch_encode_pass<SMALLW, false>(ctx, name, src, ld_src, dst, ld_dst, batch, ps, lds_elems, block, es, EncDig{});
+                              uint32_t lds_elems, uint32_t block) {
+    DeviceCode &c = ctx->code;
+    hipFuncSetAttribute((const void *)k_encode<SMALLW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    HB_LAUNCH(ctx, name, (k_encode<SMALLW>), dim3((unsigned)batch), dim3(block), (size_t)lds_elems * 16, src, ld_src, dst, ld_dst, (uint32_t)c.len, ps,
+              c.d_steps, c.d_slice_ptr, c.d_slice_width, c.d_slice_out, c.d_edges32, c.d_eidx, c.d_ew);
+    return 0;
 }
 static uint32_t block_for(const DeviceCode &c, uint32_t s_lo, uint32_t s_hi, uint32_t max_waves) {
     uint32_t widest = 1;
@@ -967,35 +937,17 @@ static uint32_t block_for(const DeviceCode &c, uint32_t s_lo, uint32_t s_hi, uin
 }
 
 int launch_encode(hobbit_ctx *ctx, const F *src, size_t ld_src, F *dst, size_t ld_dst, long long n, size_t batch, int write_msg) {
-    return launch_encode_strided(ctx, src, ld_src, 1, 0, 0, dst, ld_dst, n, batch, write_msg, nullptr);
-}
-// src_stride > 1: message b is column (b % src_cols) of row-major matrix (b / src_cols) (matrices src_gs apart, element stride
-// src_stride); the message is then always written to dst as well (it is not there yet).
-// d_dig != NULL (n a multiple of 4): the inner digests of the 2n/4 four-row groups of every codeword are written to
-// d_dig[(b * (n/2) + j) * 32] by the passes that hold those rows in LDS (see k_encode<.., DIG>).
-int launch_encode_strided(hobbit_ctx *ctx, const F *src, size_t ld_src, uint32_t src_stride, uint32_t src_cols, size_t src_gs, F *dst, size_t ld_dst, long long n,
-                          size_t batch, int write_msg, uint8_t *d_dig) {
     DeviceCode &c = ctx->code;
     if (c.n != n) return ctx->fail(HOBBIT_ESTATE, "encode: graphs for this n are not finalized (hobbit_graph_finalize)");
     if (batch == 0) return 0;
     if ((size_t)c.len * 16 > 160 * 1024) return ctx->fail(HOBBIT_EINVAL, "encode: codeword does not fit in 160 KB of LDS (n <= 4096 supported)");
     const uint32_t nn = (uint32_t)n, nsteps = (uint32_t)c.steps.size();
-    EncSrc es{src_stride, src_cols, (uint32_t)(src_stride > 1 && batch % 64 == 0 ? 1 : 0), src_gs};
-    if (src_stride > 1) { write_msg = 1; if (!src_cols || batch % src_cols) return ctx->fail(HOBBIT_EINVAL, "encode: strided source needs batch to be a multiple of the matrix width"); }
     const bool split = nsteps >= 2 && (size_t)c.len * 16 > 80 * 1024;     // cannot co-schedule two workgroups per CU otherwise
-    if (d_dig && nn % 4) return ctx->fail(HOBBIT_EINVAL, "encode: digests need n to be a multiple of 4");
-    EncDig dgA{d_dig, 0, 0, 0, nn / 2, {0}}, dgB = dgA;
-    if (d_dig) {
-        uint32_t z[16] = {0}; blake3_compress64(z, dgA.zero); memcpy(dgB.zero, dgA.zero, sizeof dgA.zero);
-        const uint32_t g_len = ((uint32_t)c.len + 3) / 4;                  // groups with at least one non-zero entry
-        if (!split) { dgA.g_lo = 0; dgA.g_hi = g_len; dgA.g_fill = nn / 2; }
-        else { dgA.g_lo = 0; dgA.g_hi = nn / 4; dgA.g_fill = nn / 4; dgB.g_lo = nn / 4; dgB.g_hi = g_len; dgB.g_fill = nn / 2; }
-    }
     if (!split) {
         EncPass ps = {0, 0, nn, 0, nsteps, write_msg ? 0u : nn, 2 * nn, 0};
         uint32_t block = block_for(c, 0, nsteps, 16);
-        return c.small_weights ? launch_encode_pass<true>(ctx, "k_encode", src, ld_src, dst, ld_dst, batch, ps, (uint32_t)c.len, block, es, &dgA)
-                               : launch_encode_pass<false>(ctx, "k_encode_fullw", src, ld_src, dst, ld_dst, batch, ps, (uint32_t)c.len, block, es, &dgA);
+        return c.small_weights ? launch_encode_pass<true>(ctx, "k_encode", src, ld_src, dst, ld_dst, batch, ps, (uint32_t)c.len, block)
+                               : launch_encode_pass<false>(ctx, "k_encode_fullw", src, ld_src, dst, ld_dst, batch, ps, (uint32_t)c.len, block);
     }
     // pass A: x_1 = C_0 x_0, outputs straight to the column in global memory
     const uint32_t r0 = c.steps[0].out_len;
@@ -1003,11 +955,11 @@ int launch_encode_strided(hobbit_ctx *ctx, const F *src, size_t ld_src, uint32_t
     // pass B: the remaining steps on the window [n, len)
     EncPass pb = {nn, nn, nn + r0, 1, nsteps, nn + r0, 2 * nn, 0};
     if (c.small_weights) {
-        HB_TRY(launch_encode_pass<true>(ctx, "k_encode_A", src, ld_src, dst, ld_dst, batch, pa, nn, block_for(c, 0, 1, 16), es, &dgA));
-        return launch_encode_pass<true>(ctx, "k_encode_B", dst, ld_dst, dst, ld_dst, batch, pb, (uint32_t)c.len - nn, block_for(c, 1, nsteps, 8), EncSrc{1, 0, 0, 0}, &dgB);
+        HB_TRY(launch_encode_pass<true>(ctx, "k_encode_A", src, ld_src, dst, ld_dst, batch, pa, nn, block_for(c, 0, 1, 16)));
+        return launch_encode_pass<true>(ctx, "k_encode_B", dst, ld_dst, dst, ld_dst, batch, pb, (uint32_t)c.len - nn, block_for(c, 1, nsteps, 8));
     }
-    HB_TRY(launch_encode_pass<false>(ctx, "k_encode_fullw_A", src, ld_src, dst, ld_dst, batch, pa, nn, block_for(c, 0, 1, 8), es, &dgA));
-    return launch_encode_pass<false>(ctx, "k_encode_fullw_B", dst, ld_dst, dst, ld_dst, batch, pb, (uint32_t)c.len - nn, block_for(c, 1, nsteps, 8), EncSrc{1, 0, 0, 0}, &dgB);
+    HB_TRY(launch_encode_pass<false>(ctx, "k_encode_fullw_A", src, ld_src, dst, ld_dst, batch, pa, nn, block_for(c, 0, 1, 8)));
+    return launch_encode_pass<false>(ctx, "k_encode_fullw_B", dst, ld_dst, dst, ld_dst, batch, pb, (uint32_t)c.len - nn, block_for(c, 1, nsteps, 8));
 }
 
 // ============================================================================================
@@ -1474,33 +1426,6 @@ int launch_merkle_levels(hobbit_ctx *ctx, uint8_t *levels, size_t n, int quirk) 
     }
     return 0;
 }
-// The same chain from inner digests already computed by the encode passes (k_encode<.., DIG>): dig[(i*cols*half_trs + c*half_trs + j)*32].
-// One compression per leaf and chunk instead of two, 32 bytes read instead of 64.
-__global__ void __launch_bounds__(256)
-k_leaf_chain_dig(const uint8_t *__restrict__ dig, size_t chunk_stride_bytes, int K, uint32_t cols, uint32_t half_trs, uint8_t *__restrict__ leaves) {
-    const size_t total = (size_t)cols * half_trs;
-    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-        uint32_t st[8], m[16];
-#pragma unroll
-        for (int q = 0; q < 8; q++) st[q] = 0;
-        const uint8_t *p = dig + 32 * g;
-        uint32_t nx[8];
-        load8w(p, nx);
-        for (int i = 0; i < K; i++) {
-#pragma unroll
-            for (int q = 0; q < 8; q++) { m[q] = nx[q]; m[8 + q] = st[q]; }
-            if (i + 1 < K) load8w(p + (size_t)(i + 1) * chunk_stride_bytes, nx);      // next chunk's digest in flight during the compression
-            blake3_compress64(m, st);
-        }
-        const uint32_t c = (uint32_t)(g / half_trs), j = (uint32_t)(g % half_trs);
-        store8w(leaves + 32 * ((size_t)j * cols + c), st);
-    }
-}
-int launch_leaf_chain_dig(hobbit_ctx *ctx, const uint8_t *dig, size_t chunk_stride_bytes, int K, uint32_t cols, uint32_t half_trs, uint8_t *leaves) {
-    size_t total = (size_t)cols * half_trs;
-    HB_LAUNCH(ctx, "k_leaf_chain_dig", k_leaf_chain_dig, dim3(grid_for(total, 256, 1 << 20)), dim3(256), 0, dig, chunk_stride_bytes, K, cols, half_trs, leaves);
-    return 0;
-}
 // zero_rows_from: first row index that is zero in EVERY chunk (the expander codeword length; 2*half_trs = none)
 int launch_leaf_chain(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, int K, uint32_t cols, uint32_t half_trs, uint8_t *leaves, uint32_t zero_rows_from) {
     size_t total = (size_t)cols * half_trs;
@@ -1579,8 +1504,8 @@ int launch_eq_table(hobbit_ctx *ctx, const HF *h_r, int k, F *d_out) {
     F *cur = (launches % 2 == 0) ? d_out : tmp;
     EqHead hd;
     for (int i = 0; i < 12; i++) hd.b[i] = i < h ? h_r[k - 1 - i] : fmake(0);
-    static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute((const void *)k_eq_head, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_set = true; }
+    static std::atomic<uint64_t> attr_set{0};
+    set_lds_limit_once(ctx, (const void *)k_eq_head, 65536, attr_set);
     HB_LAUNCH(ctx, "k_eq_head", k_eq_head, dim3(1), dim3(256), ((size_t)16 << h), hd, h, cur);
     for (int i = h; i < k;) {
         F *nxt = cur == d_out ? tmp : d_out;

@@ -16,9 +16,6 @@ int launch_elastic_inner(hobbit_ctx *ctx, const F *t0, const F *t1, const F *t2,
 int launch_elastic_finish(hobbit_ctx *ctx, const uint8_t *state, uint32_t rows2, uint32_t cols, uint8_t *leaves);
 int launch_transpose(hobbit_ctx *ctx, const F *in, size_t in_gs, uint32_t rows, uint32_t cols, F *out, size_t out_gs, size_t ld_out, uint32_t groups);
 int launch_encode(hobbit_ctx *ctx, const F *src, size_t ld_src, F *dst, size_t ld_dst, long long n, size_t batch, int write_msg);
-int launch_encode_strided(hobbit_ctx *ctx, const F *src, size_t ld_src, uint32_t src_stride, uint32_t src_cols, size_t src_gs, F *dst, size_t ld_dst, long long n,
-                          size_t batch, int write_msg, uint8_t *d_dig);
-int launch_leaf_chain_dig(hobbit_ctx *ctx, const uint8_t *dig, size_t chunk_stride_bytes, int K, uint32_t cols, uint32_t half_trs, uint8_t *leaves);
 int launch_blake3_64(hobbit_ctx *ctx, const uint8_t *in, uint8_t *out, size_t n);
 int launch_hash_md(hobbit_ctx *ctx, const F *xyzw, const uint8_t *prev, uint8_t *out, size_t n);
 int launch_merkle_levels(hobbit_ctx *ctx, uint8_t *levels, size_t n, int quirk);

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <set>
 
 int tensor_row_size = 128;        /* src/main.cpp:31 */
 size_t BUFFER_SPACE = 0;          /* src/main.cpp:38 */
@@ -1168,7 +1169,17 @@ bool de_sp(const uint8_t *buf, size_t n, hobbit_host_shockwave_transcript &t) {
     return ok && r.ok;
 }
 void header(Wr &w, uint32_t kind, uint32_t nsec) { w.raw("HBPF", 4); w.u32(1); w.u32(kind); w.u32(nsec); }
-bool check_header(Rd &r, uint32_t kind) { char m[4]; if (!r.raw(m, 4) || memcmp(m, "HBPF", 4)) return false; if (r.u32() != 1 || r.u32() != kind) return false; r.u32(); return r.ok; }
+bool check_header(Rd &r, uint32_t kind, uint32_t &nsec) { char m[4]; if (!r.raw(m, 4) || memcmp(m, "HBPF", 4)) return false; if (r.u32() != 1 || r.u32() != kind) return false; nsec = r.u32(); return r.ok; }
+// a well-formed proof has every required section exactly once and as many sections as its header announces (unknown tags count, and are skipped)
+struct Sections {
+    std::set<uint32_t> seen; uint32_t n = 0; bool dup = false;
+    void note(uint32_t tag) { n++; if (!seen.insert(tag).second) dup = true; }
+    bool complete(std::initializer_list<uint32_t> required, uint32_t announced) const {
+        if (dup || n != announced) return false;
+        for (uint32_t t : required) if (!seen.count(t)) return false;
+        return true;
+    }
+};
 }  // namespace
 std::vector<uint8_t> hobbit_host_serialize_open(const hobbit_host_open_transcript &t) {
     Wr w; header(w, 1, 12);
@@ -1178,9 +1189,10 @@ std::vector<uint8_t> hobbit_host_serialize_open(const hobbit_host_open_transcrip
     return w.b;
 }
 bool hobbit_host_deserialize_open(const uint8_t *buf, size_t n, hobbit_host_open_transcript &t) {
-    Rd r(buf, n); if (!check_header(r, 1)) return false;
+    uint32_t nsec = 0; Sections sec;
+    Rd r(buf, n); if (!check_header(r, 1, nsec)) return false;
     uint32_t tag; const uint8_t *pay; size_t len; bool ok = true;
-    while (ok && r.next(tag, pay, len)) switch (tag) {
+    while (ok && r.next(tag, pay, len)) switch (sec.note(tag), tag) {
         case T_COLS: ok = take(pay, len, t.cols); break; case T_ROWS: ok = take(pay, len, t.rows); break; case T_REPLY: ok = take(pay, len, t.reply); break;
         case T_PATHS: ok = take(pay, len, t.paths); break; case T_QPOLY: ok = take(pay, len, t.qpoly); break; case T_R: ok = take(pay, len, t.r); break; case T_VR: ok = take(pay, len, t.vr); break;
         case T_FIN: ok = take(pay, len, t.fin); break; case T_SCAL: ok = take(pay, len, t.scalars); break; case T_ROOTS: ok = len == 64; if (ok) memcpy(t.roots, pay, 64); break;
@@ -1188,11 +1200,13 @@ bool hobbit_host_deserialize_open(const uint8_t *buf, size_t n, hobbit_host_open
         default: break;
     }
     if (ok && r.ok) { t.queries = (int)t.cols.size(); t.rounds = (int)t.r.size(); }
-    return ok && r.ok && t.cols.size() == t.rows.size();
+    return ok && r.ok && t.cols.size() == t.rows.size() &&
+           sec.complete({T_COLS, T_ROWS, T_REPLY, T_PATHS, T_QPOLY, T_R, T_VR, T_FIN, T_SCAL, T_ROOTS, T_SPC, T_SPF}, nsec);
 }
 std::vector<uint8_t> hobbit_host_serialize_rs_open(const hobbit_host_elastic_transcript &t) {
-    Wr w; header(w, 2, 12);
+    Wr w; header(w, 2, 13);
     const size_t nr = (size_t)t.rounds;
+    { const int32_t nc = t.ncols; w.sec(T_NCOLS, &nc, 4); }
     w.vec(T_COLS, t.cols); w.vec(T_ROWS, t.rows);
     w.sec(T_REPLY, t.reply.data(), (size_t)t.queries * (size_t)t.reply_len * sizeof(F)); w.vec(T_PATHS, t.paths);
     w.sec(T_QPOLY, t.qpoly.data(), 3 * nr * sizeof(F)); w.sec(T_R, t.r.data(), nr * sizeof(F)); w.vec(T_VR, t.vr); w.vec(T_FIN, t.fin);
@@ -1201,9 +1215,11 @@ std::vector<uint8_t> hobbit_host_serialize_rs_open(const hobbit_host_elastic_tra
     return w.b;
 }
 bool hobbit_host_deserialize_rs_open(const uint8_t *buf, size_t n, hobbit_host_elastic_transcript &t) {
-    Rd r(buf, n); if (!check_header(r, 2)) return false;
+    uint32_t nsec = 0; Sections sec;
+    Rd r(buf, n); if (!check_header(r, 2, nsec)) return false;
     uint32_t tag; const uint8_t *pay; size_t len; bool ok = true;
-    while (ok && r.next(tag, pay, len)) switch (tag) {
+    while (ok && r.next(tag, pay, len)) switch (sec.note(tag), tag) {
+        case T_NCOLS: ok = len == 4; if (ok) { int32_t nc; memcpy(&nc, pay, 4); t.ncols = nc; } break;
         case T_COLS: ok = take(pay, len, t.cols); break; case T_ROWS: ok = take(pay, len, t.rows); break; case T_REPLY: ok = take(pay, len, t.reply); break;
         case T_PATHS: ok = take(pay, len, t.paths); break; case T_QPOLY: ok = take(pay, len, t.qpoly); break; case T_R: ok = take(pay, len, t.r); break; case T_VR: ok = take(pay, len, t.vr); break;
         case T_FIN: ok = take(pay, len, t.fin); break; case T_RV0: ok = len == sizeof(F); if (ok) memcpy((void *)&t.rv0, pay, len); break;
@@ -1211,7 +1227,8 @@ bool hobbit_host_deserialize_rs_open(const uint8_t *buf, size_t n, hobbit_host_e
         default: break;
     }
     if (ok && r.ok) { t.queries = (int)t.cols.size(); t.rounds = (int)t.r.size(); t.reply_len = t.queries ? (int)(t.reply.size() / (size_t)t.queries) : 0; }
-    return ok && r.ok && t.cols.size() == t.rows.size();
+    return ok && r.ok && t.cols.size() == t.rows.size() &&
+           sec.complete({T_NCOLS, T_COLS, T_ROWS, T_REPLY, T_PATHS, T_QPOLY, T_R, T_VR, T_FIN, T_RV0, T_CFROOT, T_RX, T_SPF}, nsec);
 }
 
 // ---- driver (src/Our_PC.cpp:757-826, option 4, commit phase) ---------------------------------------
@@ -1383,6 +1400,17 @@ long hobbit_host_wire_roundtrip(int kind) {
     std::vector<uint8_t> c = a; c[0] ^= 1;
     hobbit_host_open_transcript t1; hobbit_host_elastic_transcript t2;
     if (kind == 1 ? hobbit_host_deserialize_open(c.data(), c.size(), t1) : hobbit_host_deserialize_rs_open(c.data(), c.size(), t2)) return -4;     // wrong magic
+    auto parses = [&](const std::vector<uint8_t> &v) { return kind == 1 ? hobbit_host_deserialize_open(v.data(), v.size(), t1) : hobbit_host_deserialize_rs_open(v.data(), v.size(), t2); };
+    // header: "HBPF" | version | kind | section count (16 bytes); a section: u32 tag | u64 bytes | payload
+    uint64_t l0; memcpy(&l0, a.data() + 16 + 4, 8);
+    const size_t first_end = 16 + 12 + (size_t)l0;
+    auto set_count = [](std::vector<uint8_t> &v, int delta) { uint32_t n; memcpy(&n, v.data() + 12, 4); n = (uint32_t)((int)n + delta); memcpy(v.data() + 12, &n, 4); };
+    {   std::vector<uint8_t> d = a; d.insert(d.end(), a.begin() + 16, a.begin() + first_end); set_count(d, +1);      // a section twice, announced
+        if (parses(d)) return -5; }
+    {   std::vector<uint8_t> d(a.begin(), a.begin() + 16); d.insert(d.end(), a.begin() + first_end, a.end()); set_count(d, -1);   // a required section missing, count consistent
+        if (parses(d)) return -6; }
+    {   std::vector<uint8_t> d = a; set_count(d, +1);                                                                       // header announces more sections than follow
+        if (parses(d)) return -7; }
     return (long)a.size();
 }
 int hobbit_host_sumcheck2(const uint64_t *v1, const uint64_t *v2, size_t n, const uint64_t *prev, uint64_t *qpoly, uint64_t *r, uint64_t *vr, uint64_t *fin) {

@@ -58,6 +58,20 @@ class ShardPlan:
         return rank * self.m_local, (rank + 1) * self.m_local
 
 
+def _generation(ops):
+    """An ops object that keeps the commitment's tensor shard / tree in RETAINED buffers (HipOps: no allocation per commit) holds ONE live
+    commitment: the next commit overwrites them.  Such an object counts its commits (`generation`); a commit result carries the count it was
+    made under and sharded_open refuses a stale one instead of silently serving paths and replies of a later commitment against this root."""
+    return getattr(ops, "generation", None)
+
+
+def _check_live(ops, commit_res):
+    g = getattr(ops, "generation", None)
+    if g is not None and commit_res.get("gen") is not None and commit_res["gen"] != g:
+        raise RuntimeError("sharded_open: this commitment's retained tensor shard and tree were overwritten by a later commit on the same ops object "
+                           "(commitment generation %r, current %r): an ops object holds one live commitment" % (commit_res["gen"], g))
+
+
 def sharded_commit(ops, dist, plan, rank, local_chunks):
     """local_chunks: this rank's chunk messages in `ops`' native form.  Returns a dict with this
     rank's leaf range, its subtree levels (flat: m_local leaves ... subtree root), the top levels
@@ -100,7 +114,7 @@ def sharded_commit(ops, dist, plan, rank, local_chunks):
     else:
         roots = [my_root]
     top = ops.tree_top(ops.to_host("roots", torch.cat(roots)).copy())   # flat [2G-1, 32] (numpy, host)
-    return dict(leaf_range=(lo, hi), subtree=subtree, top=top, root=top[-1])
+    return dict(leaf_range=(lo, hi), subtree=subtree, top=top, root=top[-1], gen=_generation(ops))
 
 
 def sharded_commit_relay(ops, dist, plan, rank, local_chunks, blocks=16):
@@ -144,7 +158,7 @@ def sharded_commit_relay(ops, dist, plan, rank, local_chunks, blocks=16):
     if G > 1:
         dist.broadcast(root, last)
         ops.after_collective()
-    return dict(root=ops.to_host("root", root).copy(), owner=last, levels=levels)
+    return dict(root=ops.to_host("root", root).copy(), owner=last, levels=levels, gen=_generation(ops))
 
 
 class ElasticPlan:
@@ -186,6 +200,7 @@ def sharded_open(ops, dist, plan, rank, commit_res, x, queries=5900):
     `x`: (log2 N, 2) uint64 host array; commit_res: what sharded_commit returned on this rank.  Returns the transcript (as
     Hobbit.open_standard / open_from_aggregate) with "reply" (queries, K, 2) and "paths" (queries, log2 M, 32) filled in."""
     import torch
+    _check_live(ops, commit_res)
     G = plan.world
     own = plan.chunks_of(rank)
     logK = plan.K.bit_length() - 1
@@ -295,6 +310,7 @@ class HipOps:
     def __init__(self, hb, torch_device):
         self.hb = hb
         self.device = torch_device
+        self.generation = 0            # commits made through this object; its retained tensor shard and tree belong to the latest one only
 
     def empty_digests(self, K, m_local):
         import torch
@@ -338,6 +354,8 @@ class HipOps:
         import torch
         ptr, n_own = local_chunks
         hb = self.hb
+        if li == 0:
+            self.generation += 1
         if li == 0 and (getattr(self, "_tensor", None) is None or self._tensor.ptr is None or self._tensor.nbytes != 16 * 4 * plan.M * n_own):
             self._tensor = hb.alloc(16 * 4 * plan.M * n_own)   # retained: the commitment's tensor shard (re-used by the next commit of the same shape:
                                                                # allocating and freeing 16 GiB / G per commit stalls the device queue for seconds now and then)
@@ -385,6 +403,7 @@ class HipOps:
         """tensor codes of all local chunks into the retained shard, one library call"""
         ptr, n_own = local_chunks
         hb = self.hb
+        self.generation += 1
         if getattr(self, "_tensor", None) is None or self._tensor.ptr is None or self._tensor.nbytes != 16 * 4 * plan.M * n_own:
             self._tensor = hb.alloc(16 * 4 * plan.M * n_own)
         hb._chk(hb.lib.hobbit_tensorcode_chunks(hb.ctx, ptr, plan.M, n_own, plan.trs, 1, self._tensor.ptr))

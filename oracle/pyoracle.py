@@ -15,7 +15,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ORACLE_SO = os.path.join(HERE, "libhobbit_oracle.so")
+ORACLE_SO = os.environ.get("HOBBIT_ORACLE_SO") or os.path.join(HERE, "libhobbit_oracle.so")     # (make -C oracle asan-test points this at the sanitizer build)
 REF_SO = os.path.join(HERE, "_ref", "libhobbit_ref.so")
 P = (1 << 61) - 1
 

@@ -690,25 +690,50 @@ def test_relay_commit_hip_ops(hb, oracle):
     d = hb.to_device(poly)
     res = mod.parallel.sharded_commit_relay(mod.parallel.HipOps(hb, dev), None, plan, 0, (d.ptr, K))
     assert np.array_equal(res["levels"].cpu().numpy(), want) and np.array_equal(res["root"], want[-1])
-    G = 4
-    plan4 = mod.parallel.ShardPlan(N, K, trs, G, contiguous=True)
-    M = plan4.M; per = M // 8
-    state = None
-    for r in range(G):
-        ops = mod.parallel.HipOps(hb, dev)
-        loc = np.concatenate([poly[i * M:(i + 1) * M] for i in plan4.chunks_of(r)])
-        dl = hb.to_device(loc)
-        ops.encode_local((dl.ptr, K // G), plan4)
-        out = ops.empty_state(M) if r < G - 1 else None
-        lv = ops.empty_state(2 * M) if r == G - 1 else None
-        for b in range(8):
-            ops.chain_block(plan4, b * per, per, state[b * per:(b + 1) * per] if state is not None else None, out[b * per:(b + 1) * per] if out is not None else None, lv)
-        state = out
-    assert np.array_equal(ops.tree_full(lv, M).cpu().numpy(), want)
-    pos = np.array([0, 5, M - 1, M // 2 + 3], np.uint64)
-    got = ops.tree_paths(lv, pos, M)
-    for k, p in enumerate(pos):
-        assert np.array_equal(got[k], oracle.open_tree_blake(want, M, int(p), 0, 0))
+    # emulated worlds: 4 ranks x 8 blocks, and 8 ranks x 16 blocks -- the shape the driver's SCALE run launches (bench.py --gpus 8: K/G = 4 chunks
+    # per rank, sharded_commit_relay's default 16 blocks)
+    for G, blocks in ((4, 8), (8, 16)):
+        planG = mod.parallel.ShardPlan(N, K, trs, G, contiguous=True)
+        M = planG.M; per = M // blocks
+        state = None
+        for r in range(G):
+            ops = mod.parallel.HipOps(hb, dev)
+            loc = np.concatenate([poly[i * M:(i + 1) * M] for i in planG.chunks_of(r)])
+            dl = hb.to_device(loc)
+            ops.encode_local((dl.ptr, K // G), planG)
+            out = ops.empty_state(M) if r < G - 1 else None
+            lv = ops.empty_state(2 * M) if r == G - 1 else None
+            for b in range(blocks):
+                ops.chain_block(planG, b * per, per, state[b * per:(b + 1) * per] if state is not None else None, out[b * per:(b + 1) * per] if out is not None else None, lv)
+            state = out
+        assert np.array_equal(ops.tree_full(lv, M).cpu().numpy(), want), G
+        pos = np.array([0, 5, M - 1, M // 2 + 3], np.uint64)
+        got = ops.tree_paths(lv, pos, M)
+        for k, p in enumerate(pos):
+            assert np.array_equal(got[k], oracle.open_tree_blake(want, M, int(p), 0, 0))
+
+
+def test_sharded_commit_result_goes_stale(hb, oracle):
+    """A HipOps object keeps the tensor shard and the tree in retained buffers: a second commit overwrites them, and sharded_open must refuse
+    the first commit's result instead of serving the second commitment's replies and paths against the first root."""
+    import torch
+    from __graft_entry__ import load_package
+    mod = load_package()
+    N, K = 1 << 18, 32
+    trs = N // (K << 11)
+    oracle.rng_reset(); poly = oracle.generate_randomness(N); oracle.expander_init_store(trs)
+    hb.upload_graphs(trs, graphs_from(oracle, trs))
+    dev = torch.device("cuda", 0)
+    plan = mod.parallel.ShardPlan(N, K, trs, 1, contiguous=True)
+    ops = mod.parallel.HipOps(hb, dev)
+    d = hb.to_device(poly); d2 = hb.to_device(poly[::-1].copy())
+    ops.set_local_chunks((d.ptr, K))
+    res_a = mod.parallel.sharded_commit_relay(ops, None, plan, 0, (d.ptr, K))
+    res_b = mod.parallel.sharded_commit_relay(ops, None, plan, 0, (d2.ptr, K))
+    assert res_a["gen"] + 1 == res_b["gen"] and not np.array_equal(res_a["root"], res_b["root"])
+    x = oracle.generate_randomness(18)
+    with pytest.raises(RuntimeError, match="one live commitment"):
+        mod.parallel.sharded_open(ops, None, plan, 0, res_a, x, 64)
 
 def test_sharded_open_hip_ops_world1(hb, oracle):
     """The per-rank GPU operations of the multi-GPU open (local aggregate, field sum of partials, open from the aggregate, replies
@@ -1742,3 +1767,88 @@ def test_host_mirror_remaining_wrappers(oracle):
     lib.hobbit_host_close()
     libc.srandom(11); want3 = oracle.mul_tree_stream_shallow(1 << 20, 1 << 13, 8, 1 << 17, np.array([32, 0], np.uint64), 2, px, naive=False)
     assert m == 8 and np.array_equal(o3, want3["output"]) and all(st["checks"].tolist() == [1, 1, 1] for st in want3["steps"])
+
+
+# ---- host pointers of the C ABI are 8-byte aligned, not 16 (regression for the one crash of round 2) ----------------------------
+class _MisalignedNumpy:
+    """stands in for `np` inside the binding module: every uint64 / int64 buffer it hands out starts at an address = 8 (mod 16) -- what a
+    C caller's `new hobbit_F[n]`, a std::vector<F> or a struct member may legitimately be (hobbit_F is two uint64_t: alignment 8)"""
+
+    def __init__(self):
+        self.count = 0
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    def _mis(self, shape, dtype):
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) if not isinstance(shape, int) else shape
+        raw = np.zeros(n * dt.itemsize + 32, np.uint8)
+        off = (8 - raw.ctypes.data) % 16
+        v = raw[off:off + n * dt.itemsize].view(dt).reshape(shape)
+        assert v.ctypes.data % 16 == 8 or n == 0
+        self.count += 1
+        return v
+
+    def zeros(self, shape, dtype=float, **kw):
+        return self._mis(shape, dtype) if np.dtype(dtype).itemsize == 8 else np.zeros(shape, dtype, **kw)
+
+    def ascontiguousarray(self, a, dtype=None):
+        b = np.ascontiguousarray(a, dtype)
+        if b.dtype.itemsize == 8 and b.size and b.ctypes.data % 16 == 0:
+            v = self._mis(b.shape, b.dtype); v[...] = b
+            return v
+        return b
+
+
+def test_abi_host_pointers_8_mod_16(hb, oracle):
+    """Every host-pointer argument of include/hobbit_hip.h is `hobbit_F *` / `uint64_t *` = 8-byte aligned.  Round 2's one crash was a
+    16-byte-aligned vector load (movaps) on such a buffer inside hobbit_elastic_open_finish; the fix reads host field elements through an
+    8-byte-aligned view (csrc/hobbit_field.hpp HF).  Here every field-element buffer the binding hands to the library -- inputs and outputs,
+    also the nested shockwave / WHIR output structs -- starts at an address = 8 (mod 16), across the openings, the sumchecks, the multiplication
+    tree, the code-membership provers and the streaming drivers; results must equal the aligned run's."""
+    import ctypes
+    import sys
+    mod = sys.modules["hobbit_amd"]
+    libc = ctypes.CDLL(None)
+    N, K = 1 << 18, 32
+    trs = N // (K << 11)
+    oracle.rng_reset(); poly = oracle.generate_randomness(N); oracle.expander_init_store(trs)
+    hb.upload_graphs(trs, graphs_from(oracle, trs))
+    x = splitmix_field(18, 3)
+    v1 = splitmix_field(1 << 12, 1); v2 = splitmix_field(1 << 12, 2); v3 = splitmix_field(1 << 12, 3); pr = np.array([33, 0], np.uint64)
+    tree_in = splitmix_field(4 * 64, 9).reshape(4, 64, 2)
+
+    def run_all():
+        out = {}
+        c = hb.commit_standard(poly, K, trs, 1)
+        libc.srandom(5); out["open"] = hb.open_standard(poly, c, x, 5900)
+        c.free()
+        out["sc2"] = hb.generate_2product_sumcheck_proof(v1, v2, pr)
+        out["sc3"] = hb.generate_3product_sumcheck_proof(v1, v2, v3, pr) if hasattr(hb, "generate_3product_sumcheck_proof") else {}
+        libc.srandom(6); out["tree"] = hb.mul_tree(tree_in, np.array([17, 5], np.uint64))
+        out["beta"] = {"b": hb.precompute_beta(splitmix_field(10, 4))}
+        out["eval"] = {"e": hb.evaluate_vector(v1, splitmix_field(12, 5))}
+        libc.srandom(7); out["eo1"] = hb.elastic_open(1 << 18, 1 << 14, x, 700)
+        hb.rng_reset(); hb.expander_init_store(4)
+        libc.srandom(8); out["eo2"] = hb.elastic_open2(1 << 20, 1 << 16, splitmix_field(20, 6), 5900)
+        hb.upload_graphs(trs, graphs_from(oracle, trs))
+        return out
+
+    def flat(d, pre=""):
+        for k, v in d.items():
+            if isinstance(v, dict):
+                yield from flat(v, pre + k + ".")
+            elif isinstance(v, np.ndarray):
+                yield pre + k, v
+    want = dict(flat(run_all()))
+    shim = _MisalignedNumpy()
+    mod.np = shim
+    try:
+        got = dict(flat(run_all()))
+    finally:
+        mod.np = np
+    assert shim.count > 100, "the shim did not see the binding's buffers"
+    assert set(got) == set(want)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
