@@ -350,13 +350,21 @@ class Hobbit:
         self._chk(self.lib.hobbit_graph_finalize(self.ctx, c_ll(n), ctypes.byref(ln)))
         return ln.value
 
-    def encode_monolithic(self, src):
-        """src: (batch, n, 2) or (n, 2) -> (batch, 2n, 2)"""
+    def encode_monolithic(self, src, in_place=False):
+        """src: (batch, n, 2) or (n, 2) -> (batch, 2n, 2).  in_place: the messages are laid out at the head of their 2n-element codewords and
+        encoded there, as the commit does (the form the persistent deep-code kernels serve)."""
         s = Fh(src)
         single = s.ndim == 2
         if single:
             s = s[None]
         batch, n = s.shape[0], s.shape[1]
+        if in_place:
+            buf = np.zeros((batch, 2 * n, 2), np.uint64); buf[:, :n] = s
+            buf[:, n:] = np.uint64(0x0123456789ABCDEF)                 # whatever the buffer held before must not matter
+            dd = self.to_device(buf)
+            self._chk(self.lib.hobbit_encode_batch(self.ctx, c_vp(dd.ptr), c_vp(dd.ptr), c_ll(n), c_sz(batch), c_sz(2 * n), c_sz(2 * n)))
+            out = self.to_host(dd, (batch, 2 * n, 2), np.uint64)
+            return out[0] if single else out
         ds = self.to_device(s); dd = self.alloc(batch * 2 * n * 16)
         self._chk(self.lib.hobbit_encode_batch(self.ctx, c_vp(ds.ptr), c_vp(dd.ptr), c_ll(n), c_sz(batch), c_sz(n), c_sz(2 * n)))
         out = self.to_host(dd, (batch, 2 * n, 2), np.uint64)

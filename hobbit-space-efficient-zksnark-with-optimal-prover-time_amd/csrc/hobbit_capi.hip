@@ -12,10 +12,11 @@
 
 using namespace hobbit;
 
-// (HF = F with the C ABI's 8-byte alignment, hobbit_field.hpp: host buffers are dereferenced through it; device pointers pass through
-// to the launchers unchanged)
-static inline const HF *cF(const hobbit_F *p) { return reinterpret_cast<const HF *>(p); }
-static inline HF *mF(hobbit_F *p) { return reinterpret_cast<HF *>(p); }
+// A hobbit_F pointer of the ABI is either a DEVICE pointer (handed on to the launchers as F *: 16-byte aligned by hobbit_malloc) or a HOST
+// pointer (8-byte aligned: dereferenced only through HF, hobbit_field.hpp).  cF / mF give a thin pointer wrapper that converts to F * for
+// the first use and indexes / dereferences as HF for the second -- host code never sees an F lvalue at an 8-byte-aligned address.
+static inline CHP cF(const hobbit_F *p) { return CHP(reinterpret_cast<const HF *>(p)); }
+static inline MHP mF(hobbit_F *p) { return MHP(reinterpret_cast<HF *>(p)); }
 static_assert(sizeof(hobbit_F) == sizeof(F), "ABI field element must be 16 bytes");
 
 struct hobbit_commitment {
@@ -127,6 +128,8 @@ static int fft_rows(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_l
                     uint32_t groups, uint32_t rows_per_group, size_t src_gs, size_t dst_gs);
 
 static void free_code(DeviceCode &c) {
+    for (FatStep *f : {&c.fatA, &c.fatD}) { if (f->d_wt) hipFree(f->d_wt); if (f->d_ot) hipFree(f->d_ot); if (f->d_oidx) hipFree(f->d_oidx); if (f->d_w) hipFree(f->d_w); }
+    { MidCode &m = c.mid; if (m.d_wt) hipFree(m.d_wt); if (m.d_ot) hipFree(m.d_ot); if (m.d_oidx) hipFree(m.d_oidx); if (m.d_w) hipFree(m.d_w); }
     if (c.d_steps) hipFree(c.d_steps);
     if (c.d_slice_ptr) hipFree(c.d_slice_ptr);
     if (c.d_slice_width) hipFree(c.d_slice_width);
@@ -365,10 +368,97 @@ int hobbit_graph_upload(hobbit_ctx *ctx, int dep, int kind, long long L, long lo
     if (dep < 0 || dep >= 100 || (kind != 0 && kind != 1) || L <= 0 || R <= 0 || degree <= 0) return ctx->fail(HOBBIT_EINVAL, "graph_upload: bad dims");
     HostGraph g; g.L = L; g.R = R; g.degree = degree;
     g.nbr.assign(nbr, nbr + L * degree);
-    g.w.assign(cF(w), cF(w) + L * degree);
+    g.w.resize((size_t)(L * degree)); for (size_t i = 0; i < g.w.size(); i++) g.w[i] = cF(w)[i];
     for (long long t : g.nbr) if (t < 0 || t >= R) return ctx->fail(HOBBIT_EINVAL, "graph_upload: neighbour out of range");
     ctx->graphs[{dep, kind}] = std::move(g);
     return 0;
+}
+// fat form of one step (hobbit_ctx.hpp FatStep); returns false (and leaves f.ok false) when a degree exceeds the kernel's caps
+static bool build_fat_step(const HostGraph &g, uint32_t in_off, uint32_t out_off, uint32_t nout, uint32_t ncons, const uint32_t *cap, FatStep &f) {
+    const size_t R = (size_t)g.R, lanes = (size_t)ncons * 64;
+    if (R > nout * lanes || (size_t)g.L * 16 > 65536) return false;
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> rows(R);
+    for (long long i = 0; i < g.L; i++)
+        for (int j = 0; j < g.degree; j++) rows[g.nbr[i * g.degree + j]].push_back({(uint32_t)i, (uint32_t)g.w[i * g.degree + j].re});
+    std::vector<uint32_t> order(R);
+    for (size_t t = 0; t < R; t++) order[t] = (uint32_t)t;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rows[a].size() > rows[b].size(); });
+    uint32_t base[4] = {0, 0, 0, 0}, tot = 0;
+    for (uint32_t j = 0; j < nout; j++) { base[j] = tot; tot += cap[j]; }
+    std::vector<uint32_t> wt((size_t)tot * lanes, 0), ot((size_t)(tot / 2) * lanes, 0), oidx((size_t)nout * lanes, 0xFFFFFFFFu), wid((size_t)ncons * nout, 0);
+    for (uint32_t j = 0; j < nout; j++)
+        for (size_t l = 0; l < lanes; l++) {
+            const size_t i = (j % 2 == 0) ? (size_t)j * lanes + l : (size_t)(j + 1) * lanes - 1 - l;      // serpentine: heavy with light
+            if (i >= R) continue;
+            const auto &row = rows[order[i]];
+            if (row.size() > cap[j]) return false;
+            oidx[(size_t)j * lanes + l] = order[i];
+            uint32_t &w = wid[(l / 64) * nout + j];
+            w = std::max(w, (uint32_t)((row.size() + 3) / 4 * 4));
+            for (size_t k = 0; k < row.size(); k++) {
+                const size_t slot = base[j] + k;
+                wt[slot * lanes + l] = row[k].second;
+                ot[(slot / 2) * lanes + l] |= (row[k].first * 16u) << (16 * (slot & 1));
+            }
+        }
+    f.nout = nout; f.ncons = ncons; for (uint32_t j = 0; j < 3; j++) f.cap[j] = j < nout ? cap[j] : 0;
+    f.in_off = in_off; f.in_len = (uint32_t)g.L; f.out_off = out_off; f.out_len = (uint32_t)R;
+    f.slots_used = 0; for (uint32_t v : wid) f.slots_used += v;
+    auto up = [&](uint32_t **d, const std::vector<uint32_t> &h) { return hipMalloc((void **)d, h.size() * 4) == hipSuccess && hipMemcpy(*d, h.data(), h.size() * 4, hipMemcpyHostToDevice) == hipSuccess; };
+    f.ok = up(&f.d_wt, wt) && up(&f.d_ot, ot) && up(&f.d_oidx, oidx) && up(&f.d_w, wid);
+    return f.ok;
+}
+// the narrow middle steps in lane-group form (hobbit_ctx.hpp MidCode); false when the shapes do not fit what k_enc_mid was compiled for
+struct MidPlanStep { const HostGraph *g; long long in_off, out_off; };
+static bool build_mid(const std::vector<MidPlanStep> &steps, uint32_t win_off, uint32_t in_len, MidCode &m) {
+    const uint32_t ns = (uint32_t)steps.size();
+    if (ns == 0 || ns > MID_MAX_STEPS) return false;
+    const size_t lanes = (size_t)MID_WAVES * 64;
+    uint32_t base[MID_MAX_STEPS + 1] = {0};
+    for (uint32_t s = 0; s < ns; s++) base[s + 1] = base[s] + MID_CAP[s];
+    const uint32_t tot = base[ns];
+    std::vector<uint32_t> wt((size_t)tot * lanes, 0), ot((size_t)(tot / 2) * lanes, 0), oidx((size_t)ns * lanes, 0xFFFFFFFFu), wid((size_t)MID_WAVES * ns, 0);
+    uint32_t win_end = 0;
+    for (uint32_t s = 0; s < ns; s++) {
+        const HostGraph &g = *steps[s].g; const size_t R = (size_t)g.R;
+        if (steps[s].in_off < win_off || (steps[s].in_off - win_off + g.L) * 16 > 65536) return false;
+        std::vector<std::vector<std::pair<uint32_t, uint32_t>>> rows(R);
+        size_t maxdeg = 0;
+        for (long long i = 0; i < g.L; i++)
+            for (int j = 0; j < g.degree; j++) rows[g.nbr[i * g.degree + j]].push_back({(uint32_t)i, (uint32_t)g.w[i * g.degree + j].re});
+        for (auto &r : rows) maxdeg = std::max(maxdeg, r.size());
+        // lanes per output: as many as the workgroup has for this step, but no more than leaves every lane at least ~2 records of the widest row; the lanes of an
+        // output sit in one wave
+        uint32_t lg = 0;
+        while (lg < 5 && (R << (lg + 1)) <= lanes && ((size_t)2 << (lg + 1)) <= maxdeg) lg++;
+        while ((maxdeg + ((size_t)1 << lg) - 1) >> lg > MID_CAP[s]) { if (lg == 5 || (R << (lg + 1)) > lanes) return false; lg++; }
+        const uint32_t G = 1u << lg;
+        m.lg[s] = lg; m.R[s] = (uint32_t)R; m.out_rel[s] = (uint32_t)(steps[s].out_off - win_off);
+        win_end = std::max(win_end, (uint32_t)(steps[s].out_off - win_off + R));
+        std::vector<uint32_t> order(R);
+        for (size_t t = 0; t < R; t++) order[t] = (uint32_t)t;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rows[a].size() > rows[b].size(); });
+        const uint32_t in_rel = (uint32_t)(steps[s].in_off - win_off);
+        for (size_t i = 0; i < R; i++) {
+            const auto &row = rows[order[i]];
+            for (uint32_t q = 0; q < G; q++) {
+                const size_t l = i * G + q;
+                if (q == 0) oidx[(size_t)s * lanes + l] = order[i];
+                uint32_t cnt = 0;
+                for (size_t k = q; k < row.size(); k += G, cnt++) {
+                    const size_t slot = base[s] + cnt;
+                    wt[slot * lanes + l] = row[k].second;
+                    ot[(slot / 2) * lanes + l] |= ((in_rel + row[k].first) * 16u) << (16 * (slot & 1));
+                }
+                uint32_t &w = wid[(l / 64) * ns + s];
+                w = std::max(w, (cnt + 1) / 2 * 2);
+            }
+        }
+    }
+    m.nsteps = ns; m.win_off = win_off; m.in_len = in_len; m.win_len = win_end; m.st_lo = in_len;
+    auto up = [&](uint32_t **d, const std::vector<uint32_t> &h) { return hipMalloc((void **)d, h.size() * 4) == hipSuccess && hipMemcpy(*d, h.data(), h.size() * 4, hipMemcpyHostToDevice) == hipSuccess; };
+    m.ok = up(&m.d_wt, wt) && up(&m.d_ot, ot) && up(&m.d_oidx, oidx) && up(&m.d_w, wid);
+    return m.ok;
 }
 int hobbit_graph_finalize(hobbit_ctx *ctx, long long n, long long *len_out) {
     hipStreamSynchronize(ctx->stream);
@@ -443,12 +533,23 @@ int hobbit_graph_finalize(hobbit_ctx *ctx, long long n, long long *len_out) {
     HB_TRY(up((void **)&c.d_slice_out, slice_out.data(), slice_out.size() * 4));
     if (c.small_weights) HB_TRY(up((void **)&c.d_edges32, e32.data(), e32.size() * sizeof(uint2)));
     else { HB_TRY(up((void **)&c.d_eidx, eidx.data(), eidx.size() * 4)); HB_TRY(up((void **)&c.d_ew, ew.data(), ew.size() * sizeof(F))); }
+    // deep codes (n = 4096: the codeword does not leave room for two workgroups per CU): first and last step also in fat form
+    if (c.small_weights && c.steps.size() >= 4 && (size_t)c.len * 16 > 80 * 1024) {
+        const uint32_t capA[3] = {FAT_A_CAP0, FAT_A_CAP1, 0}, capD[3] = {FAT_D_CAP0, FAT_D_CAP1, FAT_D_CAP2};
+        build_fat_step(*plan.front().g, (uint32_t)plan.front().in_off, (uint32_t)plan.front().out_off, FAT_A_NOUT, FAT_A_CONS, capA, c.fatA);
+        build_fat_step(*plan.back().g, (uint32_t)plan.back().in_off, (uint32_t)plan.back().out_off, FAT_D_NOUT, FAT_D_CONS, capD, c.fatD);
+        std::vector<MidPlanStep> ms;
+        for (size_t i = 1; i + 1 < plan.size(); i++) ms.push_back({plan[i].g, plan[i].in_off, plan[i].out_off});
+        build_mid(ms, (uint32_t)plan[1].in_off, (uint32_t)plan[1].g->L, c.mid);
+    }
     if (len_out) *len_out = c.len;
     return 0;
 }
 int hobbit_encode_batch(hobbit_ctx *ctx, const hobbit_F *d_src, hobbit_F *d_dst, long long n, size_t batch, size_t ld_src, size_t ld_dst) {
     if (n <= 0 || ld_src < (size_t)n || ld_dst < (size_t)(2 * n)) return ctx->fail(HOBBIT_EINVAL, "encode_batch: bad n / leading dimensions");
-    return launch_encode(ctx, cF(d_src), ld_src, mF(d_dst), ld_dst, n, batch, 1);
+    // in place (the messages already sit at the head of their codewords): nothing to copy, and the deep-code kernels apply
+    const bool in_place = (const void *)d_src == (const void *)d_dst && ld_src == ld_dst;
+    return launch_encode(ctx, cF(d_src), ld_src, mF(d_dst), ld_dst, n, batch, in_place ? 0 : 1);
 }
 
 // ---- FFT --------------------------------------------------------------------------------------
@@ -1203,7 +1304,7 @@ int hobbit_prepare_matrix_cols(hobbit_ctx *ctx, const hobbit_F *d_M, size_t rows
     F *a = ws, *b = ws + (rows / 2) * cols;
     const F *src = cF(d_M); F *dst = a; size_t r = rows;
     for (int t = 0; t < k; t++) {
-        F *o = (t == k - 1 && (r / 2) == 1) ? mF(d_out) : dst;
+        F *o = (t == k - 1 && (r / 2) == 1) ? static_cast<F *>(mF(d_out)) : dst;
         HB_TRY(launch_fold_rows(ctx, src, o, r / 2, cols, cF(h_r)[t]));
         src = o; dst = dst == a ? b : a; r /= 2;
     }
@@ -1422,7 +1523,7 @@ static int mul_tree_impl(hobbit_ctx *ctx, const hobbit_F *d_input, size_t vector
             HB_TRY(hobbit_eq_table(ctx, reinterpret_cast<hobbit_F *>(r.data()), rl, reinterpret_cast<hobbit_F *>(beta)));
             HB_TRY(hobbit_sumcheck3(ctx, reinterpret_cast<hobbit_F *>(in1 + lo[i]), reinterpret_cast<hobbit_F *>(in2 + lo[i]), reinterpret_cast<hobbit_F *>(beta), n,
                                     reinterpret_cast<hobbit_F *>(&previous_r), h_cpoly + qo, h_r + ro, h_vr + 3 * layers, h_fin + layers));
-            const HF *q0 = cF(h_cpoly + qo);
+            CHP q0 = cF(h_cpoly + qo);
             F claim = fadd(fadd(fadd(q0[0], q0[1]), fadd(q0[2], q0[3])), q0[3]);        // P.c_poly[0].eval(1) + eval(0)
             if (!feq(claim, sum)) printf("error %d\n", i);                              // the reference's own (non-fatal) check, :151,:203
             for (int t = 0; t < rl; t++) r[t] = cF(h_r + ro)[t];
@@ -1452,7 +1553,7 @@ struct hobbit_elastic_open {
     size_t bytes2[5];
 };
 // precompute_beta (src/utils.cpp:251-296) on the host for a handful of variables
-static void host_eq_table(const HF *r, int k, std::vector<F> &out) {
+static void host_eq_table(CHP r, int k, std::vector<F> &out) {
     out.assign((size_t)1 << k, fmake(0)); out[0] = fmake(1);
     for (int i = 0; i < k; i++) for (size_t j = ((size_t)1 << i); j-- > 0;) { F t = fmul(r[k - 1 - i], out[j]); out[2 * j + 1] = t; out[2 * j] = fsub(out[j], t); }
 }
@@ -1497,7 +1598,7 @@ static int rs_prover_dev(hobbit_ctx *ctx, const F *d_aggr, size_t B, size_t trs,
     HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(out3), reinterpret_cast<hobbit_F *>(bt), np2 * rows2, &p323, Q, Rr, o->vr, o->fin));          // P0 (:474)
     const hobbit_F *r0 = Rr; Q += 3 * R0; Rr += R0;
     HB_TRY(hobbit_prove_fft_matrix(ctx, reinterpret_cast<hobbit_F *>(sel), np2, trs, r0, Q, Rr, o->vr + 2, o->fin + 1));                                       // P2 (:480)
-    { const HF *q2 = cF(Q); o->checks[0] = feq(fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])), cF(o->vr)[0]); }                                                   // src/sumcheck.cpp:3016-3019
+    { CHP q2 = cF(Q); o->checks[0] = feq(fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])), cF(o->vr)[0]); }                                                   // src/sumcheck.cpp:3016-3019
     const hobbit_F *r2 = Rr; Q += 3 * logr; Rr += logr;
     // r_point: P2.randomness[0] (its logr sumcheck challenges, then r1 = P0.r[logr..]) from index log2(trs) on (:482-485)
     std::vector<F> rpt; rpt.push_back(cF(r2)[logt]);
@@ -1514,7 +1615,7 @@ static int rs_prover_dev(hobbit_ctx *ctx, const F *d_aggr, size_t B, size_t trs,
     HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(out1), reinterpret_cast<hobbit_F *>(b2), trs * cols, &p323, Q, Rr, o->vr + 4, o->fin + 2));     // P3 (:498)
     const hobbit_F *r3 = Rr; Q += 3 * (logt + logc); Rr += logt + logc;
     HB_TRY(hobbit_prove_fft_matrix(ctx, reinterpret_cast<const hobbit_F *>(d_aggr), trs, half, r3, Q, Rr, o->vr + 6, o->fin + 3));                               // P5 (:503)
-    { const HF *q5 = cF(Q); o->checks[1] = feq(fadd(fadd(q5[0], q5[1]), fadd(q5[2], q5[2])), cF(o->vr)[4]); }
+    { CHP q5 = cF(Q); o->checks[1] = feq(fadd(fadd(q5[0], q5[1]), fadd(q5[2], q5[2])), cF(o->vr)[4]); }
     // r_x = P5.randomness[0]: its sumcheck challenges, then r1 = P3.r[logc .. logc + log2 trs) (src/sumcheck.cpp:3021-3023)
     std::vector<hobbit_F> rx((size_t)logc + (size_t)logt);
     memcpy(rx.data(), Rr, sizeof(hobbit_F) * (size_t)logc); memcpy(rx.data() + logc, r3 + logc, sizeof(hobbit_F) * (size_t)logt);
@@ -1640,7 +1741,7 @@ static int spielman_stream_dev(hobbit_ctx *ctx, hobbit_elastic_open *e, hobbit_e
     HB_TRY(hobbit_eval_vector(ctx, reinterpret_cast<hobbit_F *>(e->d_M), trs * cols, rcat.data(), reinterpret_cast<hobbit_F *>(&y1)));
     *mF(&o->scal[2]) = y1;
     HB_TRY(prove_fft_matrix_seeded(ctx, reinterpret_cast<const hobbit_F *>(e->d_aggr), trs, half, rcat.data(), &rcat[rcat.size() - 1], Q5, Rr5, o->vr + 6, o->fin + 3));   // P5 (:266)
-    { const HF *q5 = cF(Q5); o->checks[0] = feq(fadd(fadd(q5[0], q5[1]), fadd(q5[2], q5[2])), y1); }      // src/sumcheck.cpp:3016-3019
+    { CHP q5 = cF(Q5); o->checks[0] = feq(fadd(fadd(q5[0], q5[1]), fadd(q5[2], q5[2])), y1); }      // src/sumcheck.cpp:3016-3019
     // P5.randomness[0] = its logc challenges | r1 = r[logc .. logc + log2 trs); pop_back (:268); shockwave_prove(C_f, .) (:269)
     std::vector<hobbit_F> rx((size_t)logc + (size_t)logt);
     memcpy(rx.data(), Rr5, sizeof(hobbit_F) * (size_t)logc); memcpy(rx.data() + logc, rcat.data() + logc, sizeof(hobbit_F) * (size_t)logt);
@@ -1820,7 +1921,7 @@ static int src_next(hobbit_ctx *ctx, const StreamSrc &s, size_t n, const F **d) 
 }
 static int src_reset(hobbit_ctx *ctx, const StreamSrc &s) { const F *d; return src_next(ctx, s, 0, &d); }   // reset_stream (src/witness_stream.cpp:228-234)
 // evaluate_vector (src/utils.cpp:789-802) on a handful of host values
-static F host_eval_vector(std::vector<F> v, const HF *r, int k) {
+static F host_eval_vector(std::vector<F> v, CHP r, int k) {
     for (int i = 0; i < k; i++) { size_t L = v.size() / 2; for (size_t j = 0; j < L; j++) v[j] = fadd(v[2 * j], fmul(r[i], fsub(v[2 * j + 1], v[2 * j]))); v.resize(L); }
     return v[0];
 }
@@ -1867,7 +1968,7 @@ struct StreamPlan {
     int batches, logB; size_t size, nch, tot, vtot;
     size_t sz[16], off[16], vlen[16], voff[16]; int n_init[16]; std::vector<F> rb[16];
 };
-static int stream_plan(hobbit_ctx *ctx, StreamPlan &P, size_t fd_size, size_t B, const HF *h_r, int rlen, int rstride, int batches, int distance, int layer_id) {
+static int stream_plan(hobbit_ctx *ctx, StreamPlan &P, size_t fd_size, size_t B, CHP h_r, int rlen, int rstride, int batches, int distance, int layer_id) {
     if (batches < 1 || batches > 16 || distance < 1 || layer_id < 0) return ctx->fail(HOBBIT_EINVAL, "streaming sumcheck: bad batches / distance / layer");
     P.batches = batches; P.size = fd_size >> layer_id; P.logB = ilog2_exact(B);
     if (P.logB < 1 || ilog2_exact(P.size) < 0 || P.size < 4 * B) return ctx->fail(HOBBIT_EINVAL, "streaming sumcheck: needs power-of-two sizes with size >= 4*BUFFER_SPACE");
@@ -1971,7 +2072,7 @@ int hobbit_sumcheck3_stream_batch(hobbit_ctx *ctx, hobbit_chunk_source source, v
     std::vector<size_t> lens(batches); for (int i = 0; i < batches; i++) lens[i] = P.sz[i];
     HB_TRY(hobbit_batch_3product_sumcheck(ctx, reinterpret_cast<hobbit_F *>(f1), reinterpret_cast<hobbit_F *>(f2), reinterpret_cast<hobbit_F *>(f3), lens.data(), batches,
                                           reinterpret_cast<hobbit_F *>(a.data()), o->cpoly1, o->r1, o->vr1));
-    { const HF *q0 = cF(o->cpoly1); o->checks[1] = feq(fadd(fadd(fadd(q0[0], q0[1]), fadd(q0[2], q0[3])), q0[3]), Kf); }
+    { CHP q0 = cF(o->cpoly1); o->checks[1] = feq(fadd(fadd(fadd(q0[0], q0[1]), fadd(q0[2], q0[3])), q0[3]), Kf); }
     // Partial_Evals pass (:1303-1340): beta[k] over P1's first log2(sizes[k]) challenges
     for (int k = 0; k < batches; k++) HB_TRY(hobbit_eq_table(ctx, o->r1, ilog2_exact(P.sz[k]), reinterpret_cast<hobbit_F *>(b3 + P.off[k])));
     for (size_t i = 0; i < P.nch; i++) {
@@ -1999,14 +2100,14 @@ int hobbit_sumcheck3_stream_batch(hobbit_ctx *ctx, hobbit_chunk_source source, v
     hobbit_F zero = {0, 0};                                                             // previous_r = the local `rand`, never updated: F(0) (:1207, 1351)
     HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(dR), reinterpret_cast<hobbit_F *>(dR + nR), nR, &zero, o->qpoly2, o->r2, o->vr2, o->fin2));
     {   // "Error in sumcheck 2" (:1356-1365)
-        F sum = fmake(0); const HF *vr1 = cF(o->vr1), *q2 = cF(o->qpoly2);
+        F sum = fmake(0); CHP vr1 = cF(o->vr1), q2 = cF(o->qpoly2);
         for (int i = 0; i < batches; i++) { sum = fadd(sum, fmul(bb[2 * i], vr1[3 * i])); sum = fadd(sum, fmul(bb[2 * i + 1], vr1[3 * i + 1])); }
         o->checks[2] = feq(fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])), sum);
     }
     const int lR = ilog2_exact(nR);
     const F pad = fmake((uint64_t)random());                                            // (:1368)
     for (int i = 0; i < batches; i++) {
-        HF *row = mF(o->new_r) + (size_t)i * o->new_r_ld; int n = 0;
+        MHP row = mF(o->new_r) + (size_t)i * o->new_r_ld; int n = 0;
         if (1 + P.n_init[i] + lR > o->new_r_ld) return ctx->fail(HOBBIT_EINVAL, "sumcheck3_stream_batch: new_r_ld too small");
         row[n++] = pad;
         for (int j = 0; j < P.n_init[i]; j++) row[n++] = cF(o->r1)[j];
@@ -2162,7 +2263,7 @@ int hobbit_gate_consistency_stream(hobbit_ctx *ctx, hobbit_trace_source source, 
     HB_TRY(hobbit_memcpy_h2d(ctx, dR + n_chunks, pe.data(), n_chunks * sizeof(F)));
     HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(dR), reinterpret_cast<hobbit_F *>(dR + n_chunks), n_chunks, reinterpret_cast<hobbit_F *>(&rnd), o->q2, o->r2, o->vr2, o->fin2));
     {   // "Error in gate consistency 3" (:966-972); fin6 = add, beta, L, R, O, mul
-        const HF *f6 = cF(o->fin6), *q2 = cF(o->q2);
+        CHP f6 = cF(o->fin6), q2 = cF(o->q2);
         F sm = fadd(fadd(fmul(f6[2], b[0]), fmul(f6[3], b[1])), fadd(fmul(f6[4], b[2]), fmul(b[3], f6[0])));
         sm = fadd(sm, fadd(fmul(b[4], f6[5]), fmul(b[5], f6[1])));
         o->checks[2] = feq(fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])), sm);
@@ -2275,7 +2376,7 @@ int hobbit_gate_consistency_lookups_stream(hobbit_ctx *ctx, hobbit_trace_source 
     HB_TRY(hobbit_memcpy_h2d(ctx, dR + n_chunks, pe.data(), n_chunks * sizeof(F)));
     HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(dR), reinterpret_cast<hobbit_F *>(dR + n_chunks), n_chunks, reinterpret_cast<hobbit_F *>(&rnd), o->q2, o->r2, o->vr2, o->fin2));
     {   // "Error in gate consistency 3" (:783-789)
-        const HF *f9 = cF(o->fin9), *q2 = cF(o->q2);
+        CHP f9 = cF(o->fin9), q2 = cF(o->q2);
         F sm = fadd(fadd(fmul(f9[TL], b[0]), fmul(f9[TR], b[1])), fmul(f9[TO], b[2]));
         sm = fadd(sm, fmul(b[3], f9[AL])); sm = fadd(sm, fmul(b[4], f9[AR])); sm = fadd(sm, fmul(b[5], f9[MU]));
         sm = fadd(sm, fmul(b[6], f9[LK])); sm = fadd(sm, fmul(b[7], f9[LO]));
@@ -2502,7 +2603,7 @@ static int open_impl_body(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, con
         HB_TRY(chain_d(ctx));
         tr.mark("buff2, P3");
     }
-    { const HF *q2 = cF(Q2); F c2 = fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])); o->checks[0] = feq(c2, cF(o->vr)[1]); }       // "Error recursion 1" (:323-326)
+    { CHP q2 = cF(Q2); F c2 = fadd(fadd(q2[0], q2[1]), fadd(q2[2], q2[2])); o->checks[0] = feq(c2, cF(o->vr)[1]); }       // "Error recursion 1" (:323-326)
     Q = Q3 + 3 * R3; Rr = Rr3 + R3;
     // a, beta(P2.r | P1.r) + a * beta(P3.r) (:342-349); P4 against [M' | C] (:362); "Error recursion 2" (:364-367)
     std::vector<hobbit_F> rcat(R3);
@@ -2510,7 +2611,7 @@ static int open_impl_body(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, con
     HB_TRY(launch_eq_pair_axpy(ctx, cF(rcat.data()), cF(r_p3), R3, a, d_bb, d_b));      // d_b = beta(r) + a * beta(P3.r), d_bb: scratch
     hobbit_F p312 = {312, 0};
     HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(d_b), reinterpret_cast<hobbit_F *>(BIG), big, &p312, Q, Rr, o->vr + 6, o->fin + 3));
-    const hobbit_F *r_p4 = Rr; const HF *q4 = cF(Q);
+    const hobbit_F *r_p4 = Rr; CHP q4 = cF(Q);
     { F c4 = fadd(fadd(q4[0], q4[1]), fadd(q4[2], q4[2])); F want = fadd(fmul(a, cF(o->vr)[4]), cF(o->vr)[3]); o->checks[1] = feq(c4, want); }
     Q += 3 * R3; Rr += R3;
     tr.mark("betas, P4");
@@ -2549,7 +2650,7 @@ static int open_impl_body(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, con
     HB_TRY(hobbit_eval_vector(ctx, reinterpret_cast<hobbit_F *>(Mp), (size_t)trs * cols, r_p4, reinterpret_cast<hobbit_F *>(&y1)));
     o->scalars[4] = *reinterpret_cast<hobbit_F *>(&y1);
     HB_TRY(hobbit_prove_fft_matrix(ctx, reinterpret_cast<hobbit_F *>(d_aggr), (size_t)trs, cols / 2, r_p4, Q, Rr, o->vr + 8, o->fin + 4));
-    { const HF *q5 = cF(Q); F c5 = fadd(fadd(q5[0], q5[1]), fadd(q5[2], q5[2])); o->checks[2] = feq(c5, y1); }
+    { CHP q5 = cF(Q); F c5 = fadd(fadd(q5[0], q5[1]), fadd(q5[2], q5[2])); o->checks[2] = feq(c5, y1); }
     tr.mark("y1, P5");   // src/sumcheck.cpp:3016-3019
     if (!full) return sc.finish();
     if (!sp_threaded) {

@@ -42,6 +42,34 @@ struct HostGraph {          // one uploaded level (src/expanders.h:7-16)
     std::vector<F> w;
 };
 
+// One WIDE SpMV step in "fat" form for the persistent encode kernels (hobbit_kernels.hip, k_enc_fat): a workgroup stays on its CU for the
+// whole launch and walks the columns; every lane of its `ncons` consumer waves owns `nout` outputs of the step for good, and the edge
+// records of those outputs -- 32-bit weight, 16-bit byte offset of the input inside the step's window -- live in REGISTERS, loaded once per
+// launch (position j of a lane has cap[j] register slots; a wave uses the first w[wave][j] of them, a multiple of 4; unused slots have
+// weight 0).  Outputs are dealt to lanes in order of in-degree, serpentine over the positions, so that a lane's heavy output is paired
+// with a light one.  Built by hobbit_graph_finalize when the step's degrees fit the caps the kernel was compiled for.
+struct FatStep {
+    bool ok = false;
+    uint32_t nout = 0, ncons = 0, cap[3] = {0, 0, 0};
+    uint32_t in_off = 0, in_len = 0, out_off = 0, out_len = 0;
+    uint32_t *d_wt = nullptr, *d_ot = nullptr, *d_oidx = nullptr, *d_w = nullptr;
+    size_t slots_used = 0;                   // sum over waves and positions of the widths (x 64 = padded edge count)
+};
+static constexpr uint32_t FAT_A_NOUT = 2, FAT_A_CONS = 7, FAT_A_CAP0 = 72, FAT_A_CAP1 = 48;          // C_0 of n = 4096: 864 outputs, in-degree 42.7 +- 6.5
+static constexpr uint32_t FAT_D_NOUT = 3, FAT_D_CONS = 8, FAT_D_CAP0 = 32, FAT_D_CAP1 = 16, FAT_D_CAP2 = 16;   // D_0: 1463 outputs, in-degree 12.2 +- 3.5
+
+// The NARROW dependent steps between the first and the last one (C_1 .. D_1 of n = 4096: 182, 38, 8, 19, 66, 309 outputs) for the persistent
+// kernel k_enc_mid: one workgroup of MID_WAVES waves per CU walks the columns; step s gives each of its outputs to 2^lg[s] adjacent lanes of one
+// wave, which split its in-edges round-robin, keep their share of the records in registers (cap[s] slots per lane) and combine by shuffles.
+static constexpr uint32_t MID_WAVES = 16, MID_MAX_STEPS = 6;
+static constexpr uint32_t MID_CAP[MID_MAX_STEPS] = {16, 4, 8, 8, 4, 16};       // C_1 (4 lanes per output), C_2 (16), C_3 (8), D_3 (2), D_2 (8), D_1 (2)
+struct MidCode {
+    bool ok = false;
+    uint32_t nsteps = 0, win_off = 0, win_len = 0, in_len = 0, st_lo = 0;     // window [win_off, win_off + win_len) of the codeword; the first in_len come from memory, [st_lo, win_len) go back
+    uint32_t lg[MID_MAX_STEPS] = {}, R[MID_MAX_STEPS] = {}, out_rel[MID_MAX_STEPS] = {};
+    uint32_t *d_wt = nullptr, *d_ot = nullptr, *d_oidx = nullptr, *d_w = nullptr;
+};
+
 struct DeviceCode {         // finalized code for one message length n
     long long n = 0, len = 0;
     bool small_weights = true;               // all weights real and < 2^32
@@ -51,6 +79,8 @@ struct DeviceCode {         // finalized code for one message length n
     uint2 *d_edges32 = nullptr;              // {idx, w32}          (small_weights)
     uint32_t *d_eidx = nullptr; F *d_ew = nullptr;   // general weights
     size_t n_edges_padded = 0, n_edges = 0;
+    FatStep fatA, fatD;                      // first and last step in fat form (deep codes only: n = 4096)
+    MidCode mid;                             // the steps between them
     // H^T in CSR (evaluate_parity_matrix), built on first use
     uint32_t *d_pm_rowptr = nullptr, *d_pm_idx = nullptr; F *d_pm_w = nullptr; size_t pm_rows = 0;
 };

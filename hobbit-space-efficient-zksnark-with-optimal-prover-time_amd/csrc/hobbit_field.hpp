@@ -12,6 +12,7 @@
 // product with a 32-bit real scalar (the expander weights, src/expanders.h:37) is 4 v_mad_u64_u32.
 #pragma once
 #include <vector>
+#include <cstddef>
 #include <stdint.h>
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -29,8 +30,50 @@ struct __attribute__((aligned(16))) F {
     uint64_t re, im;
 };
 // Host view of the same element: the C ABI's hobbit_F (and the reference's virgo::fieldElement) is 8-byte aligned, so every access
-// through a HOST pointer that came in over the boundary goes through this typedef (unaligned 16-byte moves instead of movaps/movdqa).
-typedef F HF __attribute__((aligned(8)));
+// through a HOST pointer that came in over the boundary goes through this type.  It is a DISTINCT type, not an under-aligned typedef of F:
+// with a typedef an HF lvalue still binds directly to `const F &` (fadd(cF(p)[i], ..), vector<F>::push_back(cF(p)[i]), v[t] = cF(p)[t]) and
+// the callee is then free to load it with a 16-byte ALIGNED move -- round 2's crash, and round 3's (tests/test_gpu_parity.py::
+// test_abi_host_pointers_8_mod_16 found vector<F>::push_back of such an lvalue in recursive_prover_RS).  Here every use goes through the
+// conversion below: two 8-byte loads / stores, whatever the address.
+struct HF {
+    uint64_t re, im;
+    HB_HD operator F() const { F r; r.re = re; r.im = im; return r; }
+    HB_HD HF &operator=(const F &v) { re = v.re; im = v.im; return *this; }
+};
+static_assert(sizeof(HF) == 16 && alignof(HF) == 8, "HF must mirror hobbit_F");
+// Pointer to host field elements (or to device ones, when it is only handed on): constructed from F * (library-owned, 16-byte aligned
+// arrays) and from HF * (caller-owned, 8-byte aligned) alike; indexing and dereferencing always go through HF.  The parameter type of every
+// internal function that reads or writes host field elements.
+struct MHP;
+struct CHP {
+    const HF *p;
+    CHP() : p(nullptr) {}
+    CHP(std::nullptr_t) : p(nullptr) {}
+    CHP(const HF *q) : p(q) {}
+    CHP(const F *q) : p(reinterpret_cast<const HF *>(q)) {}
+    inline CHP(const MHP &m);
+    operator const F *() const { return reinterpret_cast<const F *>(p); }
+    explicit operator bool() const { return p != nullptr; }
+    const HF &operator[](size_t i) const { return p[i]; }
+    const HF &operator*() const { return *p; }
+    CHP operator+(ptrdiff_t k) const { return CHP(p + k); }
+    const void *raw() const { return p; }
+};
+struct MHP {
+    HF *p;
+    MHP() : p(nullptr) {}
+    MHP(std::nullptr_t) : p(nullptr) {}
+    MHP(HF *q) : p(q) {}
+    MHP(F *q) : p(reinterpret_cast<HF *>(q)) {}
+    operator F *() const { return reinterpret_cast<F *>(p); }
+    operator const F *() const { return reinterpret_cast<const F *>(p); }
+    explicit operator bool() const { return p != nullptr; }
+    HF &operator[](size_t i) const { return p[i]; }
+    HF &operator*() const { return *p; }
+    MHP operator+(ptrdiff_t k) const { return MHP(p + k); }
+    void *raw() const { return p; }
+};
+inline CHP::CHP(const MHP &m) : p(m.p) {}
 
 HB_HD F fmake(uint64_t re, uint64_t im = 0) { F r; r.re = re; r.im = im; return r; }
 HB_HD bool fis0(const F &a) { return (a.re | a.im) == 0; }

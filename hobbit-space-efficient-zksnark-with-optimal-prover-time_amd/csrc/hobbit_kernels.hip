@@ -792,6 +792,15 @@ struct Acc96 { uint64_t lo; uint32_t hi; };
 __device__ __forceinline__ void acc96_mad(Acc96 &a, uint32_t w, uint32_t x) {
     asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc" : "+v"(a.lo), "+v"(a.hi) : "v"(w), "v"(x) : "vcc");
 }
+// the four sums of one edge (re.lo, re.hi, im.lo, im.hi) in ONE asm statement: between separate statements hipcc pads every vcc hand-over with an s_nop
+__device__ __forceinline__ void acc96_mad4(Acc96 &a, Acc96 &b, Acc96 &c, Acc96 &d, uint32_t w, const uint4 &x) {
+    asm("v_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+        "v_mad_u64_u32 %2, vcc, %8, %10, %2\n\tv_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+        "v_mad_u64_u32 %4, vcc, %8, %11, %4\n\tv_addc_co_u32_e32 %5, vcc, 0, %5, vcc\n\t"
+        "v_mad_u64_u32 %6, vcc, %8, %12, %6\n\tv_addc_co_u32_e32 %7, vcc, 0, %7, vcc"
+        : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi), "+v"(d.lo), "+v"(d.hi)
+        : "v"(w), "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w) : "vcc");
+}
 __device__ __forceinline__ uint64_t acc_fold(const Acc96 &lo, const Acc96 &hi) {
     // value = lo + hi * 2^32 < 2^(96+33)... bounded by (#edges) * 2^93 < 2^124 for any in-degree < 2^31
     const u128 v = (((u128)lo.hi << 64) | lo.lo) + ((((u128)hi.hi << 64) | hi.lo) << 32);
@@ -936,6 +945,204 @@ static uint32_t block_for(const DeviceCode &c, uint32_t s_lo, uint32_t s_hi, uin
     return (widest >= max_waves ? max_waves : widest) * 64;
 }
 
+// ============================================================================================
+// Wide SpMV steps of a deep code (n = 4096), persistent and register-resident (hobbit_ctx.hpp FatStep).
+// One workgroup of NW fat waves per CU for the whole launch.  A lane owns NOUT outputs of the step for good and keeps their edge records --
+// 32-bit weight, 16-bit LDS byte offset -- in registers: the inner loop is one address add (SDWA word select), one ds_read_b128 and the
+// 4 v_mad_u64_u32 + 4 v_addc of the unreduced 96-bit sums per edge; after the prologue no edge record, slice descriptor or index comes from
+// memory.  The step's input window of the NEXT column streams into the second of two LDS buffers by LDS-DMA (global_load_lds_dwordx4, 1 KiB
+// per wave-instruction, no registers) while the waves work on the current one; every wave issues its share of the pieces right after the
+// one barrier per column that hands the buffers over.  The outputs of column c are stored one iteration late, behind that barrier, so that
+// the `vmcnt(0)` which retires a wave's DMA pieces never waits for a store it has just issued.
+// (The one-workgroup-per-column k_encode re-reads 8 bytes of record per edge and column through L2 -- 40 GB per commit at 2^28 -- and its
+// window load, barriers and slice loop do not overlap: DESIGN.md section 4.)
+// ============================================================================================
+template <int NOUT, int CAP0, int CAP1, int CAP2, int NW, int NLOAD>
+__global__ void __launch_bounds__((NW + NLOAD) * 64)
+k_enc_fat(F *__restrict__ tensor, size_t ld, uint32_t ncols, uint32_t in_off, uint32_t in_len, uint32_t out_off, uint32_t z_lo, uint32_t z_hi,
+          const uint32_t *__restrict__ wt, const uint32_t *__restrict__ ot, const uint32_t *__restrict__ oidx, const uint32_t *__restrict__ wid) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr int LANES = NW * 64, TOT = CAP0 + CAP1 + CAP2;
+    constexpr int CAP[3] = {CAP0, CAP1, CAP2}, BASE[3] = {0, CAP0, CAP0 + CAP1};
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t pieces = (in_len + 63) >> 6, win_bytes = pieces << 10;             // whole 1-KiB DMA pieces
+    // NLOAD > 0: the last NLOAD waves only load (a wave's DMA pieces cost it ~100+ cycles each under load: with dedicated loaders the consumers
+    // never stall on them -- 2.5 vs 3.3 ms for C_0 at 2^28); NLOAD = 0: every wave issues its share right after the barrier
+    constexpr int NISS = NLOAD > 0 ? NLOAD : NW;
+    const bool loader = NLOAD > 0 && wave >= NW;
+    const uint32_t first_piece = NLOAD > 0 ? wave - NW : wave;
+    auto issue = [&](uint32_t c, uint32_t buf) {                                         // this wave's pieces of column c's window -> buffer buf
+        const F *colp = tensor + (size_t)c * ld + in_off;
+        for (uint32_t p = first_piece; p < pieces; p += NISS) {
+            uint32_t i = (p << 6) + lane; i = i < in_len ? i : in_len - 1;             // (the pad lanes of the last piece re-read the last element)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(colp + i),
+                                             (__attribute__((address_space(3))) void *)(lds_raw + buf * win_bytes + (p << 10)), 16, 0, 0);
+        }
+    };
+    if (NLOAD > 0) {
+        if (loader) {
+            uint32_t c = blockIdx.x, it = 0;
+            if (c < ncols) issue(c, 0);
+            for (; c < ncols; c += gridDim.x, it++) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // this column's window has landed
+                __builtin_amdgcn_s_barrier();                                              // ... and the consumers are done with the other buffer
+                const uint32_t cn = c + gridDim.x;
+                if (cn < ncols) issue(cn, (it + 1) & 1);
+            }
+            return;
+        }
+    } else if (blockIdx.x < ncols) issue(blockIdx.x, 0);
+    // edge records into registers, once
+    uint32_t w[TOT], o[TOT / 2], oi[NOUT], W[NOUT];
+#pragma unroll
+    for (int k = 0; k < TOT; k++) w[k] = wt[(size_t)k * LANES + threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < TOT / 2; k++) o[k] = ot[(size_t)k * LANES + threadIdx.x];
+#pragma unroll
+    for (int j = 0; j < NOUT; j++) { oi[j] = oidx[(size_t)j * LANES + threadIdx.x]; W[j] = __builtin_amdgcn_readfirstlane(wid[wave * NOUT + j]); }
+    F held[NOUT];                                                                        // the previous column's outputs, stored behind the next barrier
+    F *hcol = nullptr;
+    uint32_t it = 0;
+    for (uint32_t c = blockIdx.x; c < ncols; c += gridDim.x, it++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                 // my pieces of this column's window have landed
+        __builtin_amdgcn_s_barrier();                                                      // ... everyone's have, and everyone is done with the other buffer
+        if (hcol) {
+#pragma unroll
+            for (int j = 0; j < NOUT; j++) if (oi[j] != 0xFFFFFFFFu) stF(hcol + out_off + oi[j], held[j]);
+            for (uint32_t i = z_lo + threadIdx.x; i < z_hi; i += LANES) stF(hcol + i, fmake(0));
+        }
+        if (NLOAD == 0) { const uint32_t cn = c + gridDim.x; if (cn < ncols) issue(cn, (it + 1) & 1); }
+        const unsigned char *win = lds_raw + (it & 1) * win_bytes;
+#pragma unroll
+        for (int j = 0; j < NOUT; j++) {
+            Acc96 rl = {0, 0}, rh = {0, 0}, il = {0, 0}, ih = {0, 0};
+#pragma unroll
+            for (int g = 0; g < CAP[j]; g += 4) {
+                if ((uint32_t)g < W[j]) {                                                  // wave-uniform
+                    uint4 x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int k = BASE[j] + g + u;
+                        const uint32_t off = (k & 1) ? (o[k >> 1] >> 16) : (o[k >> 1] & 0xFFFFu);
+                        x[u] = *reinterpret_cast<const uint4 *>(win + off);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) acc96_mad4(rl, rh, il, ih, w[BASE[j] + g + u], x[u]);
+                }
+            }
+            held[j] = fmake(acc_fold(rl, rh), acc_fold(il, ih));
+        }
+        hcol = tensor + (size_t)c * ld;
+    }
+    if (hcol) {
+#pragma unroll
+        for (int j = 0; j < NOUT; j++) if (oi[j] != 0xFFFFFFFFu) stF(hcol + out_off + oi[j], held[j]);
+        for (uint32_t i = z_lo + threadIdx.x; i < z_hi; i += LANES) stF(hcol + i, fmake(0));
+    }
+}
+template <int NOUT, int CAP0, int CAP1, int CAP2, int NW, int NLOAD>
+static int launch_enc_fat(hobbit_ctx *ctx, const char *name, const FatStep &f, F *tensor, size_t ld, size_t ncols, uint32_t z_lo, uint32_t z_hi, uint32_t wgs) {
+    const size_t lds = (size_t)2 * ((f.in_len + 63) / 64) * 1024;
+    auto kern = k_enc_fat<NOUT, CAP0, CAP1, CAP2, NW, NLOAD>;
+    hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const size_t grid = std::min(ncols, (size_t)wgs);
+    HB_LAUNCH(ctx, name, kern, dim3((unsigned)grid), dim3((NW + NLOAD) * 64), lds, tensor, ld, (uint32_t)ncols, f.in_off, f.in_len, f.out_off, z_lo, z_hi,
+              f.d_wt, f.d_ot, f.d_oidx, f.d_w);
+    return 0;
+}
+
+// The narrow dependent steps between the first and the last one (hobbit_ctx.hpp MidCode), persistent: one workgroup of MID_WAVES waves per CU
+// walks the columns.  Each step hands an output to 2^lg adjacent lanes that split its in-edges, hold their share of the records in registers,
+// accumulate unreduced, fold once and combine by shuffles; one barrier per step.  x_1 of the next column arrives by LDS-DMA into the other
+// window buffer meanwhile, and the finished [x_2 .. z_1] of this column leaves one iteration late (held in a register per lane), so that the
+// vmcnt(0) which retires the DMA never waits for a store just issued.  (The one-workgroup-per-column k_encode spends 2.6 ms on these 21 % of
+// the edges at 2^28: descriptor -> record -> gather -> fold -> barrier chains of ~4 K cycles per step and column.)
+struct MidArgs { uint32_t nsteps, win_off, win_len, in_len, st_lo, lg[MID_MAX_STEPS], R[MID_MAX_STEPS], out_rel[MID_MAX_STEPS]; };
+__global__ void __launch_bounds__(MID_WAVES * 64)
+k_enc_mid(F *__restrict__ tensor, size_t ld, uint32_t ncols, MidArgs a, const uint32_t *__restrict__ wt, const uint32_t *__restrict__ ot,
+          const uint32_t *__restrict__ oidx, const uint32_t *__restrict__ wid) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr int NW = MID_WAVES, LANES = NW * 64, NS = MID_MAX_STEPS;
+    constexpr int CAP[NS] = {(int)MID_CAP[0], (int)MID_CAP[1], (int)MID_CAP[2], (int)MID_CAP[3], (int)MID_CAP[4], (int)MID_CAP[5]};
+    constexpr int BASE[NS] = {0, CAP[0], CAP[0] + CAP[1], CAP[0] + CAP[1] + CAP[2], CAP[0] + CAP[1] + CAP[2] + CAP[3], CAP[0] + CAP[1] + CAP[2] + CAP[3] + CAP[4]};
+    constexpr int TOT = BASE[5] + CAP[5];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t pieces = (a.in_len + 63) >> 6, win_bytes = ((a.win_len + 63) >> 6) << 10;
+    auto issue = [&](uint32_t c, uint32_t buf) {
+        const F *colp = tensor + (size_t)c * ld + a.win_off;
+        for (uint32_t p = wave; p < pieces; p += NW) {
+            uint32_t i = (p << 6) + lane; i = i < a.in_len ? i : a.in_len - 1;          // (pad lanes land on slots the first step overwrites later)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(colp + i),
+                                             (__attribute__((address_space(3))) void *)(lds_raw + buf * win_bytes + (p << 10)), 16, 0, 0);
+        }
+    };
+    if (blockIdx.x < ncols) issue(blockIdx.x, 0);
+    uint32_t w[TOT], o[TOT / 2], oi[NS], W[NS];
+#pragma unroll
+    for (int k = 0; k < TOT; k++) w[k] = wt[(size_t)k * LANES + threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < TOT / 2; k++) o[k] = ot[(size_t)k * LANES + threadIdx.x];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        oi[s] = (uint32_t)s < a.nsteps ? oidx[(size_t)s * LANES + threadIdx.x] : 0xFFFFFFFFu;
+        W[s] = (uint32_t)s < a.nsteps ? __builtin_amdgcn_readfirstlane(wid[wave * a.nsteps + s]) : 0u;
+    }
+    F held = fmake(0); F *hcol = nullptr;
+    const uint32_t my_st = a.st_lo + threadIdx.x;                                        // the window element this lane carries back to memory
+    uint32_t it = 0;
+    for (uint32_t c = blockIdx.x; c < ncols; c += gridDim.x, it++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (hcol && my_st < a.win_len) stF(hcol + a.win_off + my_st, held);
+        const uint32_t cn = c + gridDim.x;
+        if (cn < ncols) issue(cn, (it + 1) & 1);
+        unsigned char *win = lds_raw + (it & 1) * win_bytes;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            if ((uint32_t)s < a.nsteps) {
+                Acc96 rl = {0, 0}, rh = {0, 0}, il = {0, 0}, ih = {0, 0};
+#pragma unroll
+                for (int g = 0; g < CAP[s]; g += 2) {
+                    if ((uint32_t)g < W[s]) {
+                        uint4 x[2];
+#pragma unroll
+                        for (int u = 0; u < 2; u++) {
+                            const int k = BASE[s] + g + u;
+                            const uint32_t off = (k & 1) ? (o[k >> 1] >> 16) : (o[k >> 1] & 0xFFFFu);
+                            x[u] = *reinterpret_cast<const uint4 *>(win + off);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; u++) acc96_mad4(rl, rh, il, ih, w[BASE[s] + g + u], x[u]);
+                    }
+                }
+                F v = fmake(acc_fold(rl, rh), acc_fold(il, ih));
+                const uint32_t lg = a.lg[s];
+                if (lg > 0) v = fadd(v, shfl_xor_F(v, 1));
+                if (lg > 1) v = fadd(v, shfl_xor_F(v, 2));
+                if (lg > 2) v = fadd(v, shfl_xor_F(v, 4));
+                if (lg > 3) v = fadd(v, shfl_xor_F(v, 8));
+                if (lg > 4) v = fadd(v, shfl_xor_F(v, 16));
+                if (oi[s] != 0xFFFFFFFFu) stF(reinterpret_cast<F *>(win) + a.out_rel[s] + oi[s], v);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        if (my_st < a.win_len) held = ldF(reinterpret_cast<const F *>(win) + my_st);
+        hcol = tensor + (size_t)c * ld;
+    }
+    if (hcol && my_st < a.win_len) stF(hcol + a.win_off + my_st, held);
+}
+static int launch_enc_mid(hobbit_ctx *ctx, const MidCode &m, F *tensor, size_t ld, size_t ncols, uint32_t wgs) {
+    if (m.win_len - m.st_lo > MID_WAVES * 64) return ctx->fail(HOBBIT_EINVAL, "encode: middle window longer than the workgroup");
+    MidArgs a{}; a.nsteps = m.nsteps; a.win_off = m.win_off; a.win_len = m.win_len; a.in_len = m.in_len; a.st_lo = m.st_lo;
+    for (uint32_t s = 0; s < MID_MAX_STEPS; s++) { a.lg[s] = m.lg[s]; a.R[s] = m.R[s]; a.out_rel[s] = m.out_rel[s]; }
+    const size_t lds = (size_t)2 * ((m.win_len + 63) / 64) * 1024;
+    hipFuncSetAttribute((const void *)k_enc_mid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const size_t grid = std::min(ncols, (size_t)wgs);
+    HB_LAUNCH(ctx, "k_enc_mid", k_enc_mid, dim3((unsigned)grid), dim3(MID_WAVES * 64), lds, tensor, ld, (uint32_t)ncols, a, m.d_wt, m.d_ot, m.d_oidx, m.d_w);
+    return 0;
+}
+
 int launch_encode(hobbit_ctx *ctx, const F *src, size_t ld_src, F *dst, size_t ld_dst, long long n, size_t batch, int write_msg) {
     DeviceCode &c = ctx->code;
     if (c.n != n) return ctx->fail(HOBBIT_ESTATE, "encode: graphs for this n are not finalized (hobbit_graph_finalize)");
@@ -954,6 +1161,39 @@ int launch_encode(hobbit_ctx *ctx, const F *src, size_t ld_src, F *dst, size_t l
     EncPass pa = {0, 0, nn, 0, 1, write_msg ? 0u : nn, write_msg ? nn : nn, 1};
     // pass B: the remaining steps on the window [n, len)
     EncPass pb = {nn, nn, nn + r0, 1, nsteps, nn + r0, 2 * nn, 0};
+    // persistent register-resident first step (in place only: the message is where the codeword goes)
+    const char *fat_env = getenv("HOBBIT_ENC_FAT"); const int fat = fat_env ? atoi(fat_env) : 3;       // bit 0: C_0 fat; bit 1: D_0 fat (+ the middle steps as their own pass); bit 2: middle steps by k_enc_mid (measured slower: DESIGN.md 4)
+    if (c.small_weights && (fat & 1) && c.fatA.ok && src == dst && ld_src == ld_dst && !write_msg) {
+        const char *wg_env = getenv("HOBBIT_ENC_FAT_WGS");
+        const uint32_t wgs = wg_env ? (uint32_t)atoi(wg_env) : 256u;
+        HB_TRY((launch_enc_fat<FAT_A_NOUT, FAT_A_CAP0, FAT_A_CAP1, 0, FAT_A_CONS, 1>(ctx, "k_enc_fat_A", c.fatA, dst, ld_dst, batch, 0, 0, wgs)));
+        if ((fat & 2) && c.fatD.ok && nsteps >= 4) {
+            // the narrow dependent steps C_1 .. D_1 on the 24 KB window [x_1 .. z_1], then D_0 in fat form (it also writes the zero tail)
+            const EncStep &last = c.steps[nsteps - 1];
+            EncPass pm = {nn, nn, nn + r0, 1, nsteps - 1, nn + r0, last.out_off, 0};
+            if ((fat & 4) && c.mid.ok) {
+                const char *wm_env = getenv("HOBBIT_ENC_MID_WGS");
+                HB_TRY(launch_enc_mid(ctx, c.mid, dst, ld_dst, batch, wm_env ? (uint32_t)atoi(wm_env) : 512u));
+            } else
+                HB_TRY(launch_encode_pass<true>(ctx, "k_encode_M", dst, ld_dst, dst, ld_dst, batch, pm, last.out_off - nn, block_for(c, 1, nsteps - 1, 8)));
+            const char *wd_env = getenv("HOBBIT_ENC_FAT_WGS_D");
+            return launch_enc_fat<FAT_D_NOUT, FAT_D_CAP0, FAT_D_CAP1, FAT_D_CAP2, FAT_D_CONS, 1>(ctx, "k_enc_fat_D", c.fatD, dst, ld_dst, batch, (uint32_t)c.len, 2 * nn,
+                                                                                                     wd_env ? (uint32_t)atoi(wd_env) : 256u);
+        }
+        return launch_encode_pass<true>(ctx, "k_encode_B", dst, ld_dst, dst, ld_dst, batch, pb, (uint32_t)c.len - nn, block_for(c, 1, nsteps, 8));
+    }
+    const char *s3_env = getenv("HOBBIT_ENC_SPLIT3"); const int split3 = s3_env ? atoi(s3_env) : 0;      // (read per call: scripts/ab_commit.py alternates it in one process)
+    if (c.small_weights && split3 && nsteps >= 4) {
+        // EXPERIMENT: pass B as two launches -- the narrow dependent steps C_1 .. D_1 on the 24 KB window [x_1 .. z_1] (six workgroups per CU), then
+        // D_0 alone: it reads that window back and streams its outputs and the zero tail to global memory
+        const EncStep &last = c.steps[nsteps - 1];
+        const uint32_t w_end = last.in_off + (uint32_t)(last.out_off - last.in_off);      // = out_off of D_0 = end of cw_1
+        EncPass pm = {nn, nn, nn + r0, 1, nsteps - 1, nn + r0, w_end, 0};
+        EncPass pd = {nn, nn, w_end, nsteps - 1, nsteps, (uint32_t)c.len, 2 * nn, 1};
+        HB_TRY(launch_encode_pass<true>(ctx, "k_encode_A", src, ld_src, dst, ld_dst, batch, pa, nn, block_for(c, 0, 1, 16)));
+        HB_TRY(launch_encode_pass<true>(ctx, "k_encode_M", dst, ld_dst, dst, ld_dst, batch, pm, w_end - nn, block_for(c, 1, nsteps - 1, 8)));
+        return launch_encode_pass<true>(ctx, "k_encode_D", dst, ld_dst, dst, ld_dst, batch, pd, w_end - nn, block_for(c, nsteps - 1, nsteps, 8));
+    }
     if (c.small_weights) {
         HB_TRY(launch_encode_pass<true>(ctx, "k_encode_A", src, ld_src, dst, ld_dst, batch, pa, nn, block_for(c, 0, 1, 16)));
         return launch_encode_pass<true>(ctx, "k_encode_B", dst, ld_dst, dst, ld_dst, batch, pb, (uint32_t)c.len - nn, block_for(c, 1, nsteps, 8));
@@ -1494,7 +1734,7 @@ __global__ void k_eq_final_axpy(const F *__restrict__ o1, const F *__restrict__ 
         stF(out + 2 * j + 1, fadd(t1, fmul(a, t2)));
     }
 }
-int launch_eq_table(hobbit_ctx *ctx, const HF *h_r, int k, F *d_out) {
+int launch_eq_table(hobbit_ctx *ctx, CHP h_r, int k, F *d_out) {
     // head in one workgroup, then ping-pong between d_out (final) and workspace so that the last step lands in d_out
     size_t n = (size_t)1 << k;
     F *tmp = nullptr;
@@ -1517,7 +1757,7 @@ int launch_eq_table(hobbit_ctx *ctx, const HF *h_r, int k, F *d_out) {
     return 0;
 }
 // d_out[0..2^k) = eq(r1) + a * eq(r2); d_half: scratch of 2^k elements (the two half-size tables)
-int launch_eq_pair_axpy(hobbit_ctx *ctx, const HF *h_r1, const HF *h_r2, int k, F a, F *d_half, F *d_out) {
+int launch_eq_pair_axpy(hobbit_ctx *ctx, CHP h_r1, CHP h_r2, int k, F a, F *d_half, F *d_out) {
     if (k < 1) return ctx->fail(HOBBIT_EINVAL, "eq_pair_axpy: k must be >= 1");
     const size_t m = (size_t)1 << (k - 1);
     HB_TRY(launch_eq_table(ctx, h_r1 + 1, k - 1, d_half));             // levels 0..k-2 use r[k-1] .. r[1]; the last level uses r[0]
@@ -1542,7 +1782,7 @@ __global__ void k_aggregate_arg(const F *__restrict__ poly, size_t M, int K, Agg
         stF(aggr + j, acc);
     }
 }
-int launch_aggregate(hobbit_ctx *ctx, const F *poly, size_t M, int K, const HF *h_beta, F *aggr) {
+int launch_aggregate(hobbit_ctx *ctx, const F *poly, size_t M, int K, CHP h_beta, F *aggr) {
     if (K <= 64) {
         AggCoef cf;
         for (int i = 0; i < 64; i++) cf.b[i] = i < K ? h_beta[i] : fmake(0);
@@ -1639,7 +1879,7 @@ __global__ void __launch_bounds__(256) k_phi_head(F *__restrict__ g, int n, int 
     }
     for (uint32_t j = threadIdx.x; j < (1u << h); j += 256) stF(g + j, ldF(&s[j]));
 }
-int launch_phi_head(hobbit_ctx *ctx, F *g, int n, int h, const HF *h_rx, F scale, const F *pm) {
+int launch_phi_head(hobbit_ctx *ctx, F *g, int n, int h, CHP h_rx, F scale, const F *pm) {
     if (h < 1 || h > 11 || h >= n) return ctx->fail(HOBBIT_EINVAL, "phi_head: 1 <= h <= min(11, n - 1)");
     EqHead rx;
     for (int i = 1; i <= 12; i++) rx.b[i - 1] = i <= h ? h_rx[n - i] : fmake(0);
@@ -1888,7 +2128,7 @@ __global__ void __launch_bounds__(256) k_sc_reduce_post(const F *__restrict__ pa
 
 // host tail of the 2-product sumcheck: tables a,b of size sz (not yet folded with `rnd` when
 // pending_fold), continuing at round `round` exactly as src/sumcheck.cpp:2401-2452
-static void sc2_host_tail(std::vector<F> &a, std::vector<F> &b, F &rnd, bool pending_fold, int round, int rounds, HF *h_qpoly, HF *h_r) {
+static void sc2_host_tail(std::vector<F> &a, std::vector<F> &b, F &rnd, bool pending_fold, int round, int rounds, MHP h_qpoly, MHP h_r) {
     size_t sz = a.size();
     auto fold = [&](std::vector<F> &v) { for (size_t j = 0; j < sz / 2; j++) v[j] = fadd(v[2 * j], fmul(rnd, fsub(v[2 * j + 1], v[2 * j]))); };
     if (pending_fold) { fold(a); fold(b); sz /= 2; }
@@ -1950,7 +2190,7 @@ __global__ void __launch_bounds__(256) k_err_terms(ErrArgs a, size_t n, F *__res
 }
 // runs one error-term reduction; h_K receives the NC sums (not accumulated)
 template <int KIND, int NC>
-static int run_err(hobbit_ctx *ctx, const char *name, const ErrArgs &a, size_t n, HF *h_K) {
+static int run_err(hobbit_ctx *ctx, const char *name, const ErrArgs &a, size_t n, MHP h_K) {
     const int MAXB = 1024;
     F *ws; HB_TRY(ctx->workspace(((size_t)MAXB * NC + NC + 4) * sizeof(F), (void **)&ws));
     F *part = ws, *coef = ws + (size_t)MAXB * NC;
@@ -1963,7 +2203,7 @@ static int run_err(hobbit_ctx *ctx, const char *name, const ErrArgs &a, size_t n
     for (int q = 0; q < NC; q++) h_K[q] = pin[q];
     return 0;
 }
-int launch_err_terms(hobbit_ctx *ctx, int kind, const F *const *tables, const int32_t *gate, size_t n, HF *h_K) {
+int launch_err_terms(hobbit_ctx *ctx, int kind, const F *const *tables, const int32_t *gate, size_t n, MHP h_K) {
     ErrArgs a; for (int i = 0; i < 8; i++) a.t[i] = tables[i]; a.gate = gate; a.lk = ctx->has_lookups ? 1 : 0; a.lr0 = ctx->lookup_rand[0]; a.lr1 = ctx->lookup_rand[1];
     if (!n) { int nc = kind == 2 ? 2 : kind == 4 ? 4 : 3; for (int q = 0; q < nc; q++) h_K[q] = fmake(0); return 0; }
     switch (kind) {
@@ -2222,18 +2462,18 @@ __global__ void __launch_bounds__(256) k_scatter_counted(const uint64_t *__restr
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) stF(out + idx[i], ldF(val + i));
 }
 
-static int sumcheck2_impl(hobbit_ctx *ctx, const F *v1, const F *v2, const uint64_t *sp_idx, const F *sp_val, size_t sp_m, size_t n, F prev_r, HF *h_qpoly, HF *h_r,
-                          HF *h_vr, HF *h_final);
-int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev_r, HF *h_qpoly, HF *h_r, HF *h_vr, HF *h_final) {
+static int sumcheck2_impl(hobbit_ctx *ctx, const F *v1, const F *v2, const uint64_t *sp_idx, const F *sp_val, size_t sp_m, size_t n, F prev_r, MHP h_qpoly, MHP h_r,
+                          MHP h_vr, MHP h_final);
+int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev_r, MHP h_qpoly, MHP h_r, MHP h_vr, MHP h_final) {
     return sumcheck2_impl(ctx, v1, v2, nullptr, nullptr, 0, n, prev_r, h_qpoly, h_r, h_vr, h_final);
 }
 // v2 given as sp_m sorted, distinct (index, value) pairs on the device (every other entry zero)
-int launch_sumcheck2_sparse(hobbit_ctx *ctx, const F *v1, const uint64_t *d_idx, const F *d_val, size_t m, size_t n, F prev_r, HF *h_qpoly, HF *h_r, HF *h_vr, HF *h_final) {
+int launch_sumcheck2_sparse(hobbit_ctx *ctx, const F *v1, const uint64_t *d_idx, const F *d_val, size_t m, size_t n, F prev_r, MHP h_qpoly, MHP h_r, MHP h_vr, MHP h_final) {
     if (!m || m > ((size_t)1 << 20)) return ctx->fail(HOBBIT_EINVAL, "sumcheck2_sparse: between 1 and 2^20 non-zeros");
     return sumcheck2_impl(ctx, v1, nullptr, d_idx, d_val, m, n, prev_r, h_qpoly, h_r, h_vr, h_final);
 }
-static int sumcheck2_impl(hobbit_ctx *ctx, const F *v1, const F *v2, const uint64_t *sp_idx, const F *sp_val, size_t sp_m, size_t n, F prev_r, HF *h_qpoly, HF *h_r,
-                          HF *h_vr, HF *h_final) {
+static int sumcheck2_impl(hobbit_ctx *ctx, const F *v1, const F *v2, const uint64_t *sp_idx, const F *sp_val, size_t sp_m, size_t n, F prev_r, MHP h_qpoly, MHP h_r,
+                          MHP h_vr, MHP h_final) {
     int rounds = 0; while (((size_t)1 << rounds) < n) rounds++;
     if (((size_t)1 << rounds) != n || n < 2) return ctx->fail(HOBBIT_EINVAL, "sumcheck2: n must be a power of two >= 2");
     const int MAXB = 1024;
@@ -2397,7 +2637,7 @@ struct GateStd {
         quad_acc(c + 9, b[1], d[1], b[4], d[4]);
     }
     // combine the twelve sums into the quartic (a..e)  (:899-903)
-    static void combine(const F *c, const HF *a, F *p) {
+    static void combine(const F *c, CHP a, F *p) {
         p[0] = fmul(a[2], c[4]);
         p[1] = fadd(fmul(a[2], c[5]), c[0]);
         p[2] = fadd(fadd(fmul(a[2], c[6]), c[1]), fmul(a[3], c[9]));
@@ -2419,7 +2659,7 @@ struct GateLkp {
         quartic_acc(c + 12, b[7], d[7], b[8], d[8], b[2], d[2], b[3], d[3]);
         quad_acc(c + 17, b[8], d[8], b[4], d[4]);
     }
-    static void combine(const F *c, const HF *a, F *p) {                       // (:689-704)
+    static void combine(const F *c, CHP a, F *p) {                       // (:689-704)
         F C[4];
         for (int k = 0; k < 4; k++) C[k] = fadd(fadd(fmul(a[0], c[k]), fmul(a[1], c[4 + k])), fmul(a[4], c[8 + k]));
         p[0] = fmul(a[2], c[12]);
@@ -2463,7 +2703,7 @@ __global__ void __launch_bounds__(256) k_gate_fold_poly(GateTabsT<G::NT> t, size
 }
 // one transcript step: combine the sums into the quartic (a..e), hash, check against the running sum, evaluate
 template <class G>
-static bool gate_round_host(const F *c, const HF *a, F &rnd, F &sum, HF *poly_out, HF *r_out) {
+static bool gate_round_host(const F *c, CHP a, F &rnd, F &sum, MHP poly_out, MHP r_out) {
     F p[5];
     G::combine(c, a, p);
     for (int q = 0; q < 5; q++) { rnd = mimc_hash(p[q], rnd); poly_out[q] = p[q]; }
@@ -2475,7 +2715,7 @@ static bool gate_round_host(const F *c, const HF *a, F &rnd, F &sum, HF *poly_ou
 }
 // inputs are preserved (the reference folds in place and afterwards only reads element 0 of each table: h_final)
 template <class G>
-static int gate_sumcheck_impl(hobbit_ctx *ctx, const F *const *tabs, size_t n, const HF *h_a, HF *h_rand, HF *h_sum, HF *h_poly, HF *h_r, HF *h_final, int *h_check) {
+static int gate_sumcheck_impl(hobbit_ctx *ctx, const F *const *tabs, size_t n, CHP h_a, MHP h_rand, MHP h_sum, MHP h_poly, MHP h_r, MHP h_final, int *h_check) {
     constexpr int NT = G::NT, NS = G::NS;
     int rounds = 0; while (((size_t)1 << rounds) < n) rounds++;
     if (((size_t)1 << rounds) != n || n < 2) return ctx->fail(HOBBIT_EINVAL, "gate_sumcheck: n must be a power of two >= 2");
@@ -2530,11 +2770,11 @@ static int gate_sumcheck_impl(hobbit_ctx *ctx, const F *const *tabs, size_t n, c
     *h_rand = rnd; *h_sum = sum; *h_check = ok ? 1 : 0;
     return 0;
 }
-int launch_gate_sumcheck(hobbit_ctx *ctx, const F *const tabs[6], size_t n, const HF *h_a, HF *h_rand, HF *h_sum, HF *h_poly, HF *h_r, HF *h_final, int *h_check) {
+int launch_gate_sumcheck(hobbit_ctx *ctx, const F *const tabs[6], size_t n, CHP h_a, MHP h_rand, MHP h_sum, MHP h_poly, MHP h_r, MHP h_final, int *h_check) {
     return gate_sumcheck_impl<GateStd>(ctx, tabs, n, h_a, h_rand, h_sum, h_poly, h_r, h_final, h_check);
 }
 // tabs: add_L, add_R, L, R, O, lkp, lkp_O, mul, beta; h_a: 5 coefficients; h_final: the nine folded values in that order
-int launch_gate_lkp_sumcheck(hobbit_ctx *ctx, const F *const tabs[9], size_t n, const HF *h_a, HF *h_rand, HF *h_sum, HF *h_poly, HF *h_r, HF *h_final, int *h_check) {
+int launch_gate_lkp_sumcheck(hobbit_ctx *ctx, const F *const tabs[9], size_t n, CHP h_a, MHP h_rand, MHP h_sum, MHP h_poly, MHP h_r, MHP h_final, int *h_check) {
     return gate_sumcheck_impl<GateLkp>(ctx, tabs, n, h_a, h_rand, h_sum, h_poly, h_r, h_final, h_check);
 }
 
@@ -2601,7 +2841,7 @@ int launch_mul_layer(hobbit_ctx *ctx, const F *x, size_t n_out, F *in1, F *in2, 
 }
 
 // host rounds of the 3-product sumcheck on tables of size sz (src/sumcheck.cpp:1981-2037)
-static void sc3_host_tail(std::vector<F> &a, std::vector<F> &b, std::vector<F> &c3, F &rnd, int round, int rounds, HF *h_cpoly, HF *h_r) {
+static void sc3_host_tail(std::vector<F> &a, std::vector<F> &b, std::vector<F> &c3, F &rnd, int round, int rounds, MHP h_cpoly, MHP h_r) {
     size_t sz = a.size();
     for (int i = round; i < rounds; i++) {
         F pa = fmake(0), pb = fmake(0), pc = fmake(0), pd = fmake(0);
@@ -2619,7 +2859,7 @@ static void sc3_host_tail(std::vector<F> &a, std::vector<F> &b, std::vector<F> &
         sz /= 2;
     }
 }
-int launch_sumcheck3(hobbit_ctx *ctx, const F *v1, const F *v2, const F *v3, size_t n, F prev_r, HF *h_cpoly, HF *h_r, HF *h_vr, HF *h_final) {
+int launch_sumcheck3(hobbit_ctx *ctx, const F *v1, const F *v2, const F *v3, size_t n, F prev_r, MHP h_cpoly, MHP h_r, MHP h_vr, MHP h_final) {
     int rounds = 0; while (((size_t)1 << rounds) < n) rounds++;
     if (((size_t)1 << rounds) != n || n < 2) return ctx->fail(HOBBIT_EINVAL, "sumcheck3: n must be a power of two >= 2");
     const int MAXB = 1024;

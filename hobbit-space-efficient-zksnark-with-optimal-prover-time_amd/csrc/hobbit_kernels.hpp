@@ -27,15 +27,15 @@ int launch_leaf_chain(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, int
 int launch_inner_digests(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, int nchunks, uint32_t cols, uint32_t half_trs, uint8_t *out);
 int launch_chain_digests(hobbit_ctx *ctx, const uint8_t *digests, size_t stride_bytes, int K, size_t m, uint8_t *leaves);
 int launch_merkle_paths(hobbit_ctx *ctx, const uint8_t *levels, size_t n, const uint64_t *d_pos, size_t nq, int depth, uint8_t *d_paths);
-int launch_eq_table(hobbit_ctx *ctx, const HF *h_r, int k, F *d_out);
-int launch_aggregate(hobbit_ctx *ctx, const F *poly, size_t M, int K, const HF *h_beta, F *aggr);
+int launch_eq_table(hobbit_ctx *ctx, CHP h_r, int k, F *d_out);
+int launch_aggregate(hobbit_ctx *ctx, const F *poly, size_t M, int K, CHP h_beta, F *aggr);
 int launch_gather(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, uint32_t rows2, int K, const uint32_t *d_rows, const uint32_t *d_cols,
                   size_t nq, F *d_reply);
 int launch_tensor_row(hobbit_ctx *ctx, const F *chunk, uint32_t rows2, uint32_t cols, uint32_t row, F *d_out);
 int launch_eval_fold(hobbit_ctx *ctx, const F *v, F *o, size_t L, F r);
 int launch_csr_gather(hobbit_ctx *ctx, const uint32_t *rowptr, const uint32_t *idx, const F *w, const F *x, F *y, size_t rows);
 int launch_phi_step(hobbit_ctx *ctx, F *g, size_t half, int m, F rx, const F *pm, int last_only);
-int launch_phi_head(hobbit_ctx *ctx, F *g, int n, int h, const HF *h_rx, F scale, const F *pm);
+int launch_phi_head(hobbit_ctx *ctx, F *g, int n, int h, CHP h_rx, F scale, const F *pm);
 int launch_fold_rows(hobbit_ctx *ctx, const F *in, F *out, size_t out_rows, size_t cols, F r);
 int launch_transpose_ld(hobbit_ctx *ctx, const F *in, size_t in_gs, size_t in_ld, uint32_t rows, uint32_t cols, F *out, size_t out_gs, size_t ld_out,
                         uint32_t groups);
@@ -44,10 +44,10 @@ int launch_vecmat(hobbit_ctx *ctx, const F *Mx, size_t rows, size_t cols, const 
 int launch_gather_strided(hobbit_ctx *ctx, const F *src, const uint64_t *d_idx, size_t nq, uint32_t m, size_t bmul, size_t stride, F *out);
 int launch_dot(hobbit_ctx *ctx, const F *a, const F *b, size_t n, F *part, F *out);
 int launch_change_form_tail(hobbit_ctx *ctx, F *data, size_t n, uint32_t T);
-int launch_eq_pair_axpy(hobbit_ctx *ctx, const HF *h_r1, const HF *h_r2, int k, F a, F *d_half, F *d_out);
+int launch_eq_pair_axpy(hobbit_ctx *ctx, CHP h_r1, CHP h_r2, int k, F a, F *d_half, F *d_out);
 int launch_scatter(hobbit_ctx *ctx, const uint64_t *idx, const F *val, size_t n, F *out);
 int launch_axpy(hobbit_ctx *ctx, F *y, const F *x, F a, size_t n);
-int launch_err_terms(hobbit_ctx *ctx, int kind, const F *const *tables, const int32_t *gate, size_t n, HF *h_K);
+int launch_err_terms(hobbit_ctx *ctx, int kind, const F *const *tables, const int32_t *gate, size_t n, MHP h_K);
 int launch_axpy_i32(hobbit_ctx *ctx, F *y, const int32_t *sel, F a, int one_minus, size_t n);
 int launch_sc3_poly(hobbit_ctx *ctx, const F *s1, const F *s2, const F *s3, size_t L, F *part, F *coef);
 int launch_fold3(hobbit_ctx *ctx, const F *s1, const F *s2, const F *s3, F *d1, F *d2, F *d3, size_t L, F r);
@@ -63,13 +63,13 @@ int launch_whir_round(hobbit_ctx *ctx, F *poly, F *beta, size_t L, F a, F *part,
 int launch_eq_step_batched(hobbit_ctx *ctx, const F *old, F *nw, size_t m, size_t ld, const F *z, int v, int level, int reps);
 int launch_eq_head_batched(hobbit_ctx *ctx, F *out, size_t ld, const F *z, int v, int h, int reps);
 int launch_fill_F(hobbit_ctx *ctx, F *p, size_t stride, size_t n, F v);
-int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev_r, HF *h_qpoly, HF *h_r, HF *h_vr, HF *h_final);
-int launch_sumcheck2_sparse(hobbit_ctx *ctx, const F *v1, const uint64_t *d_idx, const F *d_val, size_t m, size_t n, F prev_r, HF *h_qpoly, HF *h_r, HF *h_vr, HF *h_final);
-int launch_gate_lkp_sumcheck(hobbit_ctx *ctx, const F *const tabs[9], size_t n, const HF *h_a, HF *h_rand, HF *h_sum, HF *h_poly, HF *h_r, HF *h_final, int *h_check);
+int launch_sumcheck2(hobbit_ctx *ctx, const F *v1, const F *v2, size_t n, F prev_r, MHP h_qpoly, MHP h_r, MHP h_vr, MHP h_final);
+int launch_sumcheck2_sparse(hobbit_ctx *ctx, const F *v1, const uint64_t *d_idx, const F *d_val, size_t m, size_t n, F prev_r, MHP h_qpoly, MHP h_r, MHP h_vr, MHP h_final);
+int launch_gate_lkp_sumcheck(hobbit_ctx *ctx, const F *const tabs[9], size_t n, CHP h_a, MHP h_rand, MHP h_sum, MHP h_poly, MHP h_r, MHP h_final, int *h_check);
 int launch_lkp_prepare(hobbit_ctx *ctx, const int32_t *S, const F *L, const F *R, const F *O, int32_t *s2, int32_t *s3, F *blo, size_t n);
 int launch_lkp_sel_fold(hobbit_ctx *ctx, const int32_t *S, F rnd, F *aL, F *aR, F *lkp, F *mul, size_t n);
-int launch_gate_sumcheck(hobbit_ctx *ctx, const F *const tabs[6], size_t n, const HF *h_a, HF *h_rand, HF *h_sum, HF *h_poly, HF *h_r, HF *h_final, int *h_check);
-int launch_sumcheck3(hobbit_ctx *ctx, const F *v1, const F *v2, const F *v3, size_t n, F prev_r, HF *h_cpoly, HF *h_r, HF *h_vr, HF *h_final);
+int launch_gate_sumcheck(hobbit_ctx *ctx, const F *const tabs[6], size_t n, CHP h_a, MHP h_rand, MHP h_sum, MHP h_poly, MHP h_r, MHP h_final, int *h_check);
+int launch_sumcheck3(hobbit_ctx *ctx, const F *v1, const F *v2, const F *v3, size_t n, F prev_r, MHP h_cpoly, MHP h_r, MHP h_vr, MHP h_final);
 int launch_any_nonzero(hobbit_ctx *ctx, const F *v, size_t n, int *d_flag);
 int launch_gather_cols(hobbit_ctx *ctx, const F *T, size_t ld, uint32_t nrows, const uint32_t *d_cols, uint32_t ncols, F *G, size_t ldG);
 int launch_spread_cols(hobbit_ctx *ctx, const uint32_t *d_cols, const F *d_vals, uint32_t ncols, uint32_t nrows, size_t ld, F *out);

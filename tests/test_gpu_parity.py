@@ -244,6 +244,28 @@ def test_encode_batch_linearity_4096(hb, oracle):
     assert np.array_equal(y[0], oracle.encode_monolithic(x[0])[0])
 
 
+@pytest.mark.parametrize("batch", [1, 255, 700])
+def test_encode_in_place_4096_persistent_kernels(hb, oracle, batch, monkeypatch):
+    """n = 4096 in place -- the commit's form, served by the persistent register-resident kernels (k_enc_fat for C_0 and D_0, LDS-DMA
+    double-buffered windows): fewer columns than workgroups, one short of a full round, and several rounds with a ragged last one; against
+    the oracle on sampled columns and against the one-workgroup-per-column kernels (HOBBIT_ENC_FAT=0) and every mix of the two on all of them."""
+    oracle.rng_reset(); oracle.expander_init_store(4096)
+    hb.upload_graphs(4096, graphs_from(oracle, 4096))
+    x = splitmix_field(batch * 4096, 77 + batch).reshape(batch, 4096, 2)
+    got = {}
+    for mode in ("0", "1", "3", "7"):
+        monkeypatch.setenv("HOBBIT_ENC_FAT", mode)
+        got[mode] = hb.encode_monolithic(x, in_place=True)
+    monkeypatch.delenv("HOBBIT_ENC_FAT")
+    got["default"] = hb.encode_monolithic(x, in_place=True)
+    for mode in got:
+        assert np.array_equal(got[mode], got["0"]), mode
+    assert np.array_equal(got["0"], hb.encode_monolithic(x))                          # the out-of-place form
+    for b in sorted({0, batch // 2, batch - 1}):
+        want, ln = oracle.encode_monolithic(x[b])
+        assert ln == 7045 and np.array_equal(got["default"][b][:ln], want[:ln]) and not got["default"][b][ln:].any()
+
+
 # ---- tensor code / commit ------------------------------------------------------------------
 def test_tensorcode_vs_golden(hb):
     g = gold("tensorcode")
