@@ -488,6 +488,7 @@ int hobbit_graph_finalize(hobbit_ctx *ctx, long long n, long long *len_out) {
     for (int d = D - 1; d >= 0; d--) plan.push_back({&ctx->graphs[{d, 1}], off[d + 1], off[d + 1] + cwlen[d + 1]});
     c.small_weights = true;
     for (auto &p : plan) for (auto &w : p.g->w) if (w.im != 0 || w.re >> 32) { c.small_weights = false; break; }
+    const char *wm_env = getenv("HOBBIT_ENC_WIDE_MIN"); const uint32_t wide_min = wm_env ? (uint32_t)atoi(wm_env) : ENC_WIDE_MIN;
     std::vector<uint32_t> slice_ptr, slice_width, slice_out, eidx; std::vector<uint2> e32; std::vector<F> ew;
     size_t pos = 0;
     for (auto &p : plan) {
@@ -496,7 +497,7 @@ int hobbit_graph_finalize(hobbit_ctx *ctx, long long n, long long *len_out) {
         for (long long i = 0; i < g.L; i++)
             for (int j = 0; j < g.degree; j++) rows[g.nbr[i * g.degree + j]].push_back({(uint32_t)i, g.w[i * g.degree + j]});
         EncStep s; s.in_off = (uint32_t)p.in_off; s.out_off = (uint32_t)p.out_off; s.out_len = (uint32_t)g.R;
-        const uint32_t sw = (uint32_t)g.R >= ENC_WIDE_MIN ? 64u : ENC_SW, split = 64 / sw;
+        const uint32_t sw = (uint32_t)g.R >= wide_min ? 64u : ENC_SW, split = 64 / sw;
         // records per output are padded to the lane-group count, and for the wide steps to whole unrolled groups (no remainder loop)
         const uint32_t pad = sw == 64 ? ENC_UNROLL : split;
         s.sw = sw; s.out_base = (uint32_t)slice_out.size();

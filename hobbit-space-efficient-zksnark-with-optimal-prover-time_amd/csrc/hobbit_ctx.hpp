@@ -33,7 +33,9 @@ struct EncStep {
                            // ENC_SW (lane groups share an output) for the narrow ones, where a slice per wave would leave waves idle
     uint32_t out_base;     // index of this step's first entry in slice_out (sw entries per slice)
 };
-static constexpr uint32_t ENC_WIDE_MIN = 512;          // steps with at least this many outputs use sw = 64
+static constexpr uint32_t ENC_WIDE_MIN = 128;          // steps with at least this many outputs use sw = 64 (one fold per lane and no cross-lane
+                                                       // combine: the narrow form's per-slice fold + shuffles cost more than its shorter rows save --
+                                                       // middle pass at 2^28: 2.61 ms at 512, 2.36 at 256, 2.28 at 128, 2.46 at 32)
 
 struct HostGraph {          // one uploaded level (src/expanders.h:7-16)
     long long L = 0, R = 0;
@@ -56,7 +58,7 @@ struct FatStep {
     size_t slots_used = 0;                   // sum over waves and positions of the widths (x 64 = padded edge count)
 };
 static constexpr uint32_t FAT_A_NOUT = 2, FAT_A_CONS = 7, FAT_A_CAP0 = 72, FAT_A_CAP1 = 48;          // C_0 of n = 4096: 864 outputs, in-degree 42.7 +- 6.5
-static constexpr uint32_t FAT_D_NOUT = 3, FAT_D_CONS = 8, FAT_D_CAP0 = 32, FAT_D_CAP1 = 16, FAT_D_CAP2 = 16;   // D_0: 1463 outputs, in-degree 12.2 +- 3.5
+static constexpr uint32_t FAT_D_NOUT = 3, FAT_D_CONS = 8, FAT_D_CAP0 = 28, FAT_D_CAP1 = 16, FAT_D_CAP2 = 12;   // D_0: 1463 outputs, in-degree 12.2 +- 3.5
 
 // The NARROW dependent steps between the first and the last one (C_1 .. D_1 of n = 4096: 182, 38, 8, 19, 66, 309 outputs) for the persistent
 // kernel k_enc_mid: one workgroup of MID_WAVES waves per CU walks the columns; step s gives each of its outputs to 2^lg[s] adjacent lanes of one

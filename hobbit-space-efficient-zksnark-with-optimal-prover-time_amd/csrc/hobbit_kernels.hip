@@ -802,9 +802,13 @@ __device__ __forceinline__ void acc96_mad4(Acc96 &a, Acc96 &b, Acc96 &c, Acc96 &
         : "v"(w), "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w) : "vcc");
 }
 __device__ __forceinline__ uint64_t acc_fold(const Acc96 &lo, const Acc96 &hi) {
-    // value = lo + hi * 2^32 < 2^(96+33)... bounded by (#edges) * 2^93 < 2^124 for any in-degree < 2^31
-    const u128 v = (((u128)lo.hi << 64) | lo.lo) + ((((u128)hi.hi << 64) | hi.lo) << 32);
-    return red124(v);
+    // value = lo + hi 2^32 with lo, hi 96-bit sums (any in-degree < 2^29).  No 128-bit arithmetic: 2^64 = 8 and 2^61 = 1 (mod p), so a 96-bit
+    // sum {l, h} folds to fold61(l) + 8h < 2^61 + 2^36, and for the high sum b = b0 + 2^29 b1: b 2^32 = (b0 << 32) + b1.
+    const uint64_t a = ((lo.lo & P61) + (lo.lo >> 61)) + ((uint64_t)lo.hi << 3);
+    const uint64_t b = ((hi.lo & P61) + (hi.lo >> 61)) + ((uint64_t)hi.hi << 3);
+    const uint64_t t = a + ((b & 0x1FFFFFFFull) << 32) + (b >> 29);                     // < 2^63
+    const uint64_t r = (t & P61) + (t >> 61);                                            // <= p + 3
+    return r >= P61 ? r - P61 : r;
 }
 __device__ __forceinline__ F shfl_xor_F(const F &a, int m) {
     F r;
