@@ -177,6 +177,7 @@ def main():
                          "commit+opencore stops before the two shockwave_prove calls")
     ap.add_argument("--queries", type=int, default=5900)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the reference-shaped driver leg (host/test_pc <logN> 4 <K>: host vector in, PCIe inclusive)")
     ap.add_argument("--cpu-logn", type=int, default=24, help="size of the CPU-baseline sample (2^24: about 17 s of single-thread reference time)")
     args = ap.parse_args()
     if args.mode is None:
@@ -372,10 +373,34 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_logn, K)
             if do_open:
                 out["cpu_baseline_open_port"] = cpu_open_port(args.cpu_logn, K, args.queries, full_open)
+        if not args.no_dropin and world == 1 and do_open and full_open:
+            out["dropin"] = dropin_leg(args.logn, K)
         print(json.dumps(out))
     hb.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def dropin_leg(logn, K):
+    """The drop-in number (never `value`): the reference-shaped driver `host/test_pc <logN> 4 <K>` -- the reference's commented-out
+    `./pigeon <logN> 4 <K>` hook (src/main.cpp:1176) over the C++ mirror -- run once as its own process, outside the timed region: test_PC
+    draws the polynomial into a std::vector on the host, commit_standard(vector<F> &, ...) streams it over PCIe under the commit's kernels
+    (hobbit_commit_standard_host) and hands back every Merkle level as the reference's signature demands, open_standard follows.  Reported:
+    the driver's own `Commit time` / `Total time` prints and the proof size it prints (the reference's stdout fingerprint)."""
+    import re, subprocess, time
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hobbit-space-efficient-zksnark-with-optimal-prover-time_amd", "host", "test_pc")
+    if not os.path.exists(exe):
+        return {"error": "host/test_pc not built"}
+    out = {"driver": "host/test_pc %d 4 %d" % (logn, K), "includes": "host vector -> device over PCIe (pageable source, 64 MiB pinned pieces, pipelined with the row FFTs), "
+           "first-use HIP context and allocations, all Merkle levels copied back to the host (the reference's MT_hashes), proof-size accounting"}
+    for tag, env in (("pipelined_upload", {}), ("blocking_upload", {"HOBBIT_HOST_BLOCKING_UPLOAD": "1"})):
+        t0 = time.time()
+        p = subprocess.run([exe, str(logn), "4", str(K)], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+        m1 = re.search(r"Commit time: ([0-9.eE+-]+) seconds", p.stdout); m2 = re.search(r"Total time: ([0-9.eE+-]+) seconds", p.stdout)
+        last = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else ""
+        out[tag] = {"rc": p.returncode, "commit_s": float(m1.group(1)) if m1 else None, "total_s": float(m2.group(1)) if m2 else None,
+                    "proof_kb": float(last.split(",")[0]) if "," in last else None, "process_wall_s": time.time() - t0}
+    return out
 
 
 def cpu_baseline(logn, K):

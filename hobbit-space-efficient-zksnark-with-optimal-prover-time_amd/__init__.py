@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "hobbit_graph_reset", "hobbit_graph_upload", "hobbit_graph_finalize", "hobbit_encode_batch", "hobbit_fft_batch",
     "hobbit_blake3_64", "hobbit_hash_md", "hobbit_mt_commit_blake", "hobbit_merkle_levels", "hobbit_merkle_path", "hobbit_merkle_paths",
     "hobbit_eq_table", "hobbit_eval_vector", "hobbit_tensorcode",
-    "hobbit_commit_standard", "hobbit_commitment_free", "hobbit_commitment_num_leaves", "hobbit_commitment_levels_dev",
+    "hobbit_commit_standard", "hobbit_commit_standard_host", "hobbit_commitment_free", "hobbit_commitment_num_leaves", "hobbit_commitment_levels_dev",
     "hobbit_commitment_tensor_dev", "hobbit_commitment_levels", "hobbit_commitment_root", "hobbit_commitment_tensor_row",
     "hobbit_commitment_gather", "hobbit_commitment_path", "hobbit_commitment_paths",
     "hobbit_elastic_begin", "hobbit_elastic_push", "hobbit_elastic_push_inner", "hobbit_elastic_finish", "hobbit_elastic_free",
@@ -80,7 +80,7 @@ def load_library(path=LIB_PATH):
         "hobbit_blake3_64": [V, V, V, S], "hobbit_hash_md": [V, V, V, V, S], "hobbit_mt_commit_blake": [V, V, S, V],
         "hobbit_merkle_levels": [V, V, S, I], "hobbit_merkle_path": [V, V, S, S, V], "hobbit_merkle_paths": [V, V, S, V, S, V],
         "hobbit_eq_table": [V, V, I, V], "hobbit_eval_vector": [V, V, S, V, V], "hobbit_tensorcode": [V, V, S, I, I, V],
-        "hobbit_commit_standard": [V, V, S, I, I, I, V], "hobbit_commitment_free": [V], "hobbit_commitment_num_leaves": [V],
+        "hobbit_commit_standard": [V, V, S, I, I, I, V], "hobbit_commit_standard_host": [V, V, V, S, I, I, I, V], "hobbit_commitment_free": [V], "hobbit_commitment_num_leaves": [V],
         "hobbit_commitment_levels_dev": [V], "hobbit_commitment_tensor_dev": [V], "hobbit_commitment_levels": [V, V, V],
         "hobbit_commitment_root": [V, V, V], "hobbit_commitment_tensor_row": [V, V, I, I, V], "hobbit_commitment_gather": [V, V, V, V, S, V],
         "hobbit_commitment_path": [V, V, S, S, V], "hobbit_commitment_paths": [V, V, V, V, S, V], "hobbit_aggregate": [V, V, S, V, I, V],
@@ -448,6 +448,16 @@ class Hobbit:
         self._chk(self.lib.hobbit_commit_standard(self.ctx, c_vp(ptr), c_sz(N), c_int(K), c_int(trs), c_int(lin), ctypes.byref(h)))
         self.sync()
         return Commitment(self, h, N, K, trs)
+
+    def commit_standard_host(self, poly, K, trs, lin=1):
+        """commit_standard on a polynomial in (pageable) host memory, streamed to the device chunk group by chunk group under the commit's own
+        kernels (hobbit_commit_standard_host).  Returns (Commitment, DeviceBuffer holding the uploaded polynomial)."""
+        p = Fh(poly).reshape(-1, 2); N = p.shape[0]
+        d = self.alloc(16 * N)
+        h = c_vp()
+        self._chk(self.lib.hobbit_commit_standard_host(self.ctx, _hp(p), c_vp(d.ptr), c_sz(N), c_int(K), c_int(trs), c_int(lin), ctypes.byref(h)))
+        self.sync()
+        return Commitment(self, h, N, K, trs), d
 
     def open_from_aggregate(self, aggr, K, trs, queries=5900):
         """open_standard's prover side from a given aggregate vector (host array or (DeviceBuffer/ptr, M)); multi-GPU open"""

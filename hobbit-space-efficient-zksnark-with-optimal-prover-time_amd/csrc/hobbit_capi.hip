@@ -281,6 +281,12 @@ void hobbit_ctx_destroy(hobbit_ctx *ctx) {
     if (ctx->spare_tensor) hipFree(ctx->spare_tensor);
     if (ctx->spare_levels) hipFree(ctx->spare_levels);
     hipEventDestroy(ctx->t0); hipEventDestroy(ctx->t1);
+    if (ctx->up_stream) {
+        hipStreamSynchronize(ctx->up_stream);
+        for (int i = 0; i < 2; i++) { if (ctx->up_pin[i]) hipHostFree(ctx->up_pin[i]); if (ctx->up_done[i]) hipEventDestroy(ctx->up_done[i]); }
+        for (auto &e : ctx->up_ready) if (e) hipEventDestroy(e);
+        hipStreamDestroy(ctx->up_stream);
+    }
     if (ctx->side) { hipStreamSynchronize(ctx->side); for (auto &e : ctx->side_ev) if (e) hipEventDestroy(e); hipStreamDestroy(ctx->side); }
     if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -310,10 +316,50 @@ int hobbit_free(hobbit_ctx *ctx, void *d_ptr) {
     if (it != ctx->pooled.end()) { const size_t bytes = it->second; ctx->pooled.erase(it); ctx->pool_put(bytes, d_ptr); return 0; }
     HB_TRY(ctx->sync()); HB_CHECK(ctx, hipFree(d_ptr)); return 0;
 }
+// Large transfers between the device and PAGEABLE host memory go through the context's two pinned 64 MiB staging pieces, the host side of
+// each piece copied by a few threads while the other piece is on the bus: a plain hipMemcpy of 512 MB of Merkle levels into a std::vector ran at
+// 4 GB/s (124 ms of the mirror's 277 ms commit at 2^28).  Both calls return when the data has arrived, like the plain ones.
+static void par_memcpy(void *dst, const void *src, size_t n) {
+    const int T = 8; std::thread th[T]; const size_t per = (n + T - 1) / T / 4096 * 4096 + 4096;
+    for (int t = 0; t < T; t++) { const size_t lo = std::min(n, (size_t)t * per), hi = std::min(n, lo + per); th[t] = std::thread([=] { if (hi > lo) memcpy((char *)dst + lo, (const char *)src + lo, hi - lo); }); }
+    for (int t = 0; t < T; t++) th[t].join();
+}
+static const size_t HB_STAGED_COPY_MIN = (size_t)32 << 20;
 int hobbit_memcpy_h2d(hobbit_ctx *ctx, void *d, const void *h, size_t bytes) {
+    if (bytes >= HB_STAGED_COPY_MIN && ctx->up_init() == 0) {
+        HB_TRY(ctx->sync());                                            // ordered after what the context's stream has queued
+        int piece = 0;
+        for (size_t off = 0; off < bytes; off += hobbit_ctx::UP_PIECE, piece++) {
+            const size_t n = std::min(hobbit_ctx::UP_PIECE, bytes - off); const int b = piece & 1;
+            if (piece >= 2) HB_CHECK(ctx, hipEventSynchronize(ctx->up_done[b]));
+            par_memcpy(ctx->up_pin[b], (const char *)h + off, n);
+            HB_CHECK(ctx, hipMemcpyAsync((char *)d + off, ctx->up_pin[b], n, hipMemcpyHostToDevice, ctx->up_stream));
+            HB_CHECK(ctx, hipEventRecord(ctx->up_done[b], ctx->up_stream));
+        }
+        HB_CHECK(ctx, hipStreamSynchronize(ctx->up_stream));
+        return 0;
+    }
     HB_CHECK(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream)); HB_TRY(ctx->sync()); return 0;
 }
 int hobbit_memcpy_d2h(hobbit_ctx *ctx, void *h, const void *d, size_t bytes) {
+    if (bytes >= HB_STAGED_COPY_MIN && ctx->up_init() == 0) {
+        HB_TRY(ctx->sync());
+        const size_t np = (bytes + hobbit_ctx::UP_PIECE - 1) / hobbit_ctx::UP_PIECE;
+        auto issue = [&](size_t p) -> int {
+            const size_t off = p * hobbit_ctx::UP_PIECE, n = std::min(hobbit_ctx::UP_PIECE, bytes - off); const int b = (int)(p & 1);
+            HB_CHECK(ctx, hipMemcpyAsync(ctx->up_pin[b], (const char *)d + off, n, hipMemcpyDeviceToHost, ctx->up_stream));
+            HB_CHECK(ctx, hipEventRecord(ctx->up_done[b], ctx->up_stream));
+            return 0;
+        };
+        HB_TRY(issue(0));
+        for (size_t p = 0; p < np; p++) {
+            if (p + 1 < np) HB_TRY(issue(p + 1));                       // the next piece crosses the bus while this one is copied out
+            const size_t off = p * hobbit_ctx::UP_PIECE, n = std::min(hobbit_ctx::UP_PIECE, bytes - off);
+            HB_CHECK(ctx, hipEventSynchronize(ctx->up_done[p & 1]));
+            par_memcpy((char *)h + off, ctx->up_pin[p & 1], n);
+        }
+        return 0;
+    }
     HB_CHECK(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream)); HB_TRY(ctx->sync()); return 0;
 }
 int hobbit_memset(hobbit_ctx *ctx, void *d, int value, size_t bytes) { HB_CHECK(ctx, hipMemsetAsync(d, value, bytes, ctx->stream)); return 0; }
@@ -621,13 +667,39 @@ int hobbit_eval_vector(hobbit_ctx *ctx, const hobbit_F *d_v, size_t n, const hob
 }
 
 // ---- tensor code / commit ---------------------------------------------------------------------
-static int tensorcode_chunks(hobbit_ctx *ctx, const F *d_msg, size_t M, int K, int trs, int lin, F *d_out) {
+// Streams a caller's (pageable) host polynomial to the device in `groups` equal parts, each in 64 MiB pieces through two pinned staging buffers:
+// piece p + 1 is copied into its buffer by a few host threads while piece p crosses PCIe; group g's last piece records ready[g] on the copy
+// stream.  The commit's row-FFT loop waits for ready[g] and, once group g's kernels are queued, starts group g + 1 -- so the upload of one
+// chunk group overlaps the device work of the previous one (hobbit_commit_standard_host).
+struct Uploader {
+    hobbit_ctx *ctx; const unsigned char *h; unsigned char *d; size_t group_bytes; int groups, started = 0, piece_no = 0;
+    int start(int g) {
+        if (g != started || g >= groups) return 0;
+        started++;
+        const unsigned char *src = h + (size_t)g * group_bytes; unsigned char *dst = d + (size_t)g * group_bytes;
+        for (size_t off = 0; off < group_bytes; off += hobbit_ctx::UP_PIECE, piece_no++) {
+            const size_t n = std::min(hobbit_ctx::UP_PIECE, group_bytes - off); const int b = piece_no & 1;
+            if (piece_no >= 2 && hipEventSynchronize(ctx->up_done[b]) != hipSuccess) return ctx->fail(HOBBIT_EHIP, "upload: staging buffer wait failed");
+            unsigned char *pin = (unsigned char *)ctx->up_pin[b];
+            par_memcpy(pin, src + off, n);
+            HB_CHECK(ctx, hipMemcpyAsync(dst + off, pin, n, hipMemcpyHostToDevice, ctx->up_stream));
+            HB_CHECK(ctx, hipEventRecord(ctx->up_done[b], ctx->up_stream));
+        }
+        HB_CHECK(ctx, hipEventRecord(ctx->up_ready[g], ctx->up_stream));
+        return 0;
+    }
+    int wait(int g, hipStream_t s) { HB_TRY(start(g)); HB_CHECK(ctx, hipStreamWaitEvent(s, ctx->up_ready[g], 0)); return 0; }
+    int all(hipStream_t s) { for (int g = 0; g < groups; g++) HB_TRY(wait(g, s)); return 0; }
+};
+static int tensorcode_chunks(hobbit_ctx *ctx, const F *d_msg, size_t M, int K, int trs, int lin, F *d_out, Uploader *up = nullptr) {
     if (trs <= 0 || M % (size_t)trs) return ctx->fail(HOBBIT_EINVAL, "tensorcode: trs must divide M");
     size_t half = M / trs, cols = 2 * half, rows2 = 2 * (size_t)trs;
     int logc = ilog2_exact(cols), logr = ilog2_exact(rows2);
     if (logc < 1 || logc > 24) return ctx->fail(HOBBIT_EINVAL, "tensorcode: row length 2M/trs must be a power of two <= 2^24");
     if (logr < 1) return ctx->fail(HOBBIT_EINVAL, "tensorcode: trs must be a power of two");
     // rows: RS encode = zero-padded FFT (src/PC_utils.cpp:75-84,105-107)
+    const bool piped_shape = logc <= 12 && (size_t)K * trs * cols * sizeof(F) >= ((size_t)64 << 20);
+    if (up && !piped_shape) { up->groups = 1; up->group_bytes = (size_t)K * M * sizeof(F); HB_TRY(up->all(ctx->stream)); up = nullptr; }
     if (logc > 15) {
         // very long rows (test_PC option 1 at 2^27 and beyond: tensor_row_size stays 128): one chunk at a time through the long transform
         F *rm; HB_TRY(ctx->workspace3((size_t)trs * cols * sizeof(F), (void **)&rm));
@@ -666,18 +738,22 @@ static int tensorcode_chunks(hobbit_ctx *ctx, const F *d_msg, size_t M, int K, i
             // d_out / the scratch right away
             struct SideJoin { hobbit_ctx *c; hipStream_t m; bool done = false; ~SideJoin() { c->stream = m; if (!done) hipStreamSynchronize(c->side); } } join{ctx, mainS};
             HB_CHECK(ctx, hipEventRecord(ctx->side_ev[64], mainS)); HB_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->side_ev[64], 0));   // d_out / rm are free for the side stream
+            if (up) { up->groups = pipe; up->group_bytes = (size_t)per * M * sizeof(F); }
             for (int g = 0; g < pipe; g++) {
                 const size_t c0 = (size_t)g * per;
+                if (up) HB_TRY(up->wait(g, mainS));
                 HB_TRY(fft_rows(ctx, d_msg + c0 * M, half, (uint32_t)half, rm + c0 * trs * cols, cols, 1, logc, false, (uint32_t)per, (uint32_t)trs, M, (size_t)trs * cols));
                 HB_CHECK(ctx, hipEventRecord(ctx->side_ev[g], mainS)); HB_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->side_ev[g], 0));
                 ctx->stream = ctx->side;
                 const int rc = launch_transpose(ctx, rm + c0 * trs * cols, (size_t)trs * cols, (uint32_t)trs, (uint32_t)cols, d_out + c0 * cols * rows2, cols * rows2, rows2, (uint32_t)per);
                 ctx->stream = mainS;
                 if (rc) return rc;
+                if (up) HB_TRY(up->start(g + 1));                 // (host copy + PCIe of the next group, beside this group's kernels)
             }
             HB_CHECK(ctx, hipEventRecord(ctx->side_ev[65], ctx->side)); HB_CHECK(ctx, hipStreamWaitEvent(mainS, ctx->side_ev[65], 0));
             join.done = true;
         } else {
+            if (up) { up->groups = 1; up->group_bytes = (size_t)K * M * sizeof(F); HB_TRY(up->all(ctx->stream)); }
             HB_TRY(fft_rows(ctx, d_msg, half, (uint32_t)half, rm, cols, 1, logc, false, (uint32_t)K, (uint32_t)trs, M, (size_t)trs * cols));
             HB_TRY(launch_transpose(ctx, rm, (size_t)trs * cols, (uint32_t)trs, (uint32_t)cols, d_out, cols * rows2, rows2, (uint32_t)K));
         }
@@ -696,7 +772,19 @@ int hobbit_tensorcode(hobbit_ctx *ctx, const hobbit_F *d_msg, size_t M, int trs,
     return tensorcode_chunks(ctx, cF(d_msg), M, 1, trs, linear_time, mF(d_out));
 }
 
+static int commit_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, int K, int trs, int linear_time, hobbit_commitment **out, Uploader *up);
 int hobbit_commit_standard(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, int K, int trs, int linear_time, hobbit_commitment **out) {
+    return commit_impl(ctx, d_poly, N, K, trs, linear_time, out, nullptr);
+}
+int hobbit_commit_standard_host(hobbit_ctx *ctx, const hobbit_F *h_poly, hobbit_F *d_poly, size_t N, int K, int trs, int linear_time, hobbit_commitment **out) {
+    if (!h_poly || !d_poly) return ctx->fail(HOBBIT_EINVAL, "commit_standard_host: null polynomial");
+    HB_TRY(ctx->up_init());
+    Uploader up{ctx, reinterpret_cast<const unsigned char *>(h_poly), reinterpret_cast<unsigned char *>(d_poly), 0, 0};
+    const int rc = commit_impl(ctx, d_poly, N, K, trs, linear_time, out, &up);
+    if (rc) hipStreamSynchronize(ctx->up_stream);                 // nothing of the caller's buffer is still being read on an error return
+    return rc;
+}
+static int commit_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, int K, int trs, int linear_time, hobbit_commitment **out, Uploader *up) {
     if (!out) return HOBBIT_EINVAL;
     *out = nullptr;
     if (K <= 0 || N % (size_t)K) return ctx->fail(HOBBIT_EINVAL, "commit_standard: K must divide N");
@@ -726,7 +814,7 @@ int hobbit_commit_standard(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, in
             }
         }
     }
-    int r = tensorcode_chunks(ctx, cF(d_poly), M, K, trs, linear_time, c->d_tensor);
+    int r = tensorcode_chunks(ctx, cF(d_poly), M, K, trs, linear_time, c->d_tensor, up);
     // leaf chain over the K chunks (src/Our_PC.cpp:155-167), then the tree (src/Our_PC.cpp:169);
     // rows >= the codeword length are zero in every chunk of an RS x expander tensor (RS x RS fills all 2*trs rows)
     if (!r) r = launch_leaf_chain(ctx, c->d_tensor, cols * rows2, K, (uint32_t)cols, (uint32_t)(trs / 2), c->d_levels,

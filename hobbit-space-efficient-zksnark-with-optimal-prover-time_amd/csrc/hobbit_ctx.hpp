@@ -101,6 +101,19 @@ struct hobbit_ctx {
     // Event slots: [0, 56) the commit pipeline's chunk groups (tensorcode_chunks clamps its group count to 56), 60-63 open_impl's cross-stream
     // fences, 64/65 the pipeline's opening / closing brackets.
     hipStream_t side = nullptr; hipEvent_t side_ev[66] = {};
+    // host -> device streaming of a caller's pageable polynomial (hobbit_commit_standard_host): copy stream, two pinned staging pieces, events
+    hipStream_t up_stream = nullptr; void *up_pin[2] = {nullptr, nullptr}; hipEvent_t up_done[2] = {}; hipEvent_t up_ready[64] = {};
+    static constexpr size_t UP_PIECE = (size_t)64 << 20;
+    int up_init() {
+        if (up_stream) return 0;
+        if (hipStreamCreateWithFlags(&up_stream, hipStreamNonBlocking) != hipSuccess) { err = "upload stream create failed"; return HOBBIT_EHIP; }
+        for (int i = 0; i < 2; i++) {
+            if (hipHostMalloc(&up_pin[i], UP_PIECE, hipHostMallocDefault) != hipSuccess) { err = "upload staging hipHostMalloc failed"; return HOBBIT_ENOMEM; }
+            if (hipEventCreateWithFlags(&up_done[i], hipEventDisableTiming) != hipSuccess) { err = "upload event create failed"; return HOBBIT_EHIP; }
+        }
+        for (auto &e : up_ready) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { err = "upload event create failed"; return HOBBIT_EHIP; }
+        return 0;
+    }
     int side_init() {
         if (side) return 0;
         if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { err = "side stream create failed"; return HOBBIT_EHIP; }

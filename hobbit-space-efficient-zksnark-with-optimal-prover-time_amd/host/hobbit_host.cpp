@@ -257,22 +257,30 @@ void hobbit_host_materialize_tensor(vector<vector<vector<F>>> &_tensor) {
 void commit_standard(vector<F> &poly, _hash &comm, vector<vector<_hash>> &MT_hashes, vector<vector<vector<F>>> &_tensor, int K) {   // src/Our_PC.cpp:146-171
     (void)comm;                                                     // the reference never writes it either
     size_t N = poly.size(), M = N / K;
+    const double t_in = now_s();
+    auto lap = [&](const char *what) { if (g_timing) printf("[hobbit] commit_standard: %-34s at %9.3f ms\n", what, 1e3 * (now_s() - t_in)); };
     // the previous commitment (with the device copy of its polynomial) moves to the one-deep stash; what was there is released
     hobbit_host_ctx();
+    lap("context ready");
     free_prev();
     if (g_commit) { swap_with_prev(); g_commit = nullptr; g_poly_dev = nullptr; g_poly_n = 0; }
     // the device copy of poly is kept: open_standard receives the same vector and would otherwise pay the PCIe upload again
     HCHK(hobbit_malloc(hobbit_host_ctx(), N * sizeof(F), &g_poly_dev)); g_poly_n = N;
-    HCHK(hobbit_memcpy_h2d(g_ctx, g_poly_dev, poly.data(), N * sizeof(F)));
-    HCHK(hobbit_commit_standard(g_ctx, (const hobbit_F *)g_poly_dev, N, K, tensor_row_size, linear_time ? 1 : 0, &g_commit));
+    if (getenv("HOBBIT_HOST_BLOCKING_UPLOAD")) {                    // the round-2 form, for A/B: one blocking copy of the whole vector, then the commit
+        HCHK(hobbit_memcpy_h2d(g_ctx, g_poly_dev, poly.data(), N * sizeof(F)));
+        HCHK(hobbit_commit_standard(g_ctx, (const hobbit_F *)g_poly_dev, N, K, tensor_row_size, linear_time ? 1 : 0, &g_commit));
+    } else                                                          // chunk group g + 1 crosses PCIe while group g's row FFT / layout change run
+        HCHK(hobbit_commit_standard_host(g_ctx, hF(poly.data()), (hobbit_F *)g_poly_dev, N, K, tensor_row_size, linear_time ? 1 : 0, &g_commit));
     HCHK(hobbit_sync(g_ctx));
+    lap("upload + commit kernels done");
     g_commit_K = K; g_commit_trs = tensor_row_size; g_commit_cols = 2 * M / tensor_row_size;
-    vector<uint8_t> flat(32 * (2 * M - 1));
-    HCHK(hobbit_commitment_levels(g_ctx, g_commit, flat.data()));
+    // MT_hashes (the reference's return value: every level of the tree, 64 B per leaf): each level straight into its own vector
     size_t levels = (size_t)log2((double)M) + 1, off = 0;
     MT_hashes.resize(levels);
-    for (size_t l = 0, sz = M; l < levels; l++, sz /= 2) { MT_hashes[l].resize(sz); memcpy(MT_hashes[l].data(), flat.data() + 32 * off, 32 * sz); off += sz; }
+    const uint8_t *d_lv = (const uint8_t *)hobbit_commitment_levels_dev(g_commit);
+    for (size_t l = 0, sz = M; l < levels; l++, sz /= 2) { MT_hashes[l].resize(sz); HCHK(hobbit_memcpy_d2h(g_ctx, MT_hashes[l].data(), d_lv + 32 * off, 32 * sz)); off += sz; }
     memcpy(g_commit_root, MT_hashes.back()[0].arr, 32);
+    lap("MT_hashes read back");
     _tensor.clear(); _tensor.resize(K);
     const char *mat = getenv("HOBBIT_MATERIALIZE_TENSOR");
     if ((mat && atoi(mat)) || (size_t)4 * N * sizeof(F) <= ((size_t)256 << 20)) hobbit_host_materialize_tensor(_tensor);

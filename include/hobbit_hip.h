@@ -134,6 +134,11 @@ int hobbit_tensorcode(hobbit_ctx *ctx, const hobbit_F *d_msg, size_t M, int trs,
  * codeword-major) and Merkle levels. */
 int hobbit_commit_standard(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, int K, int trs, int linear_time,
                            hobbit_commitment **out);
+/* The same for a polynomial that still lives in (pageable) HOST memory -- what the reference's commit_standard(vector<F> &poly, ...) is handed
+ * (src/Our_PC.cpp:146).  h_poly is streamed into d_poly (N F of device memory, which the caller keeps for the opening) chunk group by chunk
+ * group through two pinned 64 MiB staging buffers owned by the context, and the row FFT of group g starts as soon as group g has landed while
+ * group g + 1 is on its way: the upload costs max(PCIe + host copy, device work) instead of their sum.  Same commitment, bit for bit. */
+int hobbit_commit_standard_host(hobbit_ctx *ctx, const hobbit_F *h_poly, hobbit_F *d_poly, size_t N, int K, int trs, int linear_time, hobbit_commitment **out);
 void hobbit_commitment_free(hobbit_commitment *c);
 size_t hobbit_commitment_num_leaves(const hobbit_commitment *c);
 const uint8_t *hobbit_commitment_levels_dev(const hobbit_commitment *c);   /* flat levels, device */

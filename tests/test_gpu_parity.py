@@ -266,6 +266,24 @@ def test_encode_in_place_4096_persistent_kernels(hb, oracle, batch, monkeypatch)
         assert ln == 7045 and np.array_equal(got["default"][b][:ln], want[:ln]) and not got["default"][b][ln:].any()
 
 
+@pytest.mark.parametrize("logN,K,lin", [(18, 32, 1), (22, 32, 1), (24, 32, 1), (24, 16, 0), (23, 2, 0)])
+def test_commit_standard_host_streaming_upload(hb, logN, K, lin):
+    """hobbit_commit_standard_host: the polynomial comes from pageable host memory in 64 MiB pieces through two pinned buffers, chunk group g + 1
+    in flight while group g's row FFT runs (the reference-shaped commit_standard(vector<F> &) of the mirror uses it).  Same tree, same tensor,
+    and the device copy it leaves behind is the polynomial: small tensors (no pipeline), the piped shape, RS x RS, long rows."""
+    N = 1 << logN
+    trs = N // (K << 11) if lin else 128
+    poly = splitmix_field(N, 300 + logN)
+    if lin:
+        hb.rng_reset(); hb.expander_init_store(trs)
+    c0 = hb.commit_standard(poly, K, trs, lin)
+    c1, d = hb.commit_standard_host(poly, K, trs, lin)
+    assert np.array_equal(c1.levels(), c0.levels())
+    assert np.array_equal(c1.tensor_row(K - 1, 2 * trs - 1), c0.tensor_row(K - 1, 2 * trs - 1)) and np.array_equal(c1.tensor_row(0, 1), c0.tensor_row(0, 1))
+    assert np.array_equal(hb.to_host(d, (N, 2), np.uint64), poly)
+    c0.free(); c1.free()
+
+
 # ---- tensor code / commit ------------------------------------------------------------------
 def test_tensorcode_vs_golden(hb):
     g = gold("tensorcode")
