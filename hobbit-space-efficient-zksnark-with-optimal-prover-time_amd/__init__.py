@@ -17,7 +17,7 @@ import sys
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libhobbit_hip.so")
+LIB_PATH = os.environ.get("HOBBIT_HIP_LIB") or os.path.join(PKG_DIR, "libhobbit_hip.so")      # (HOBBIT_HIP_LIB: A/B runs of two builds in one gpurun call)
 P = (1 << 61) - 1
 
 c_sz = ctypes.c_size_t

@@ -108,12 +108,44 @@ HB_HD F fsub(const F &a, const F &b) { return fmake(subp(a.re, b.re), subp(a.im,
 HB_HD F fneg(const F &a) { return fmake(a.re ? P61 - a.re : 0, a.im ? P61 - a.im : 0); }
 // (a+bi)(c+di) = (ac - bd) + ((a+b)(c+d) - ac - bd) i, all three products kept 128-bit wide and
 // folded once per component.  C = p*2^61 >= (p-1)^2 keeps ac + C - bd non-negative.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HOBBIT_FMUL_U128)
+// Device form: no 128-bit value anywhere.  Split x = x0 + 2^31 x1 (x0 < 2^31, x1 <= 2^31 - 1).  With 2^61 = 1 and 2^62 = 2 (mod p)
+//     x y = x0 y0 + 2 x1 y1 + 2^31 (x0 y1 + x1 y0),
+// and a complex product is a sum of two such products per component (the real part takes -a.im as 2p - a.im), so each component is
+//     L = sum of four 32 x 32 products (< 2^64: v_mad_u64_u32 chains that never carry),  M = sum of four (< 2^64 likewise),
+//     L + 2^31 M = L + ((M mod 2^30) << 31) + (M >> 30)      (2^61 = 1 again),      one fold61 -> [0, p + 7].
+// 16 + 2 v_mad_u64_u32 and ~30 32-bit operations instead of 12 multiply-adds and ~70 operations of 128-bit glue (two 128-bit
+// subtractions with an offset, two canonical reductions of 124-bit values).  Inputs: every component <= p + 7 (canonical, or the lazy range
+// of the FFT octets).  Host-checked against 128-bit arithmetic on 10^7 products with the bounds at their edges.
+HB_HD uint64_t limb_mad(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
+HB_HD uint64_t limb_finish(uint64_t L, uint64_t M) {
+    const uint64_t t = limb_mad((uint32_t)M & 0x3FFFFFFFu, 0x80000000u, L) + (M >> 30);
+    return (t & P61) + (t >> 61);
+}
+HB_HD F fmul_lazy(const F &a, const F &b) {                  // components <= p + 7 in and out
+    const uint64_t nai = 2 * P61 - a.im;
+    const uint32_t ar0 = (uint32_t)a.re & 0x7FFFFFFFu, ar1 = (uint32_t)(a.re >> 31), ai0 = (uint32_t)a.im & 0x7FFFFFFFu, ai1 = (uint32_t)(a.im >> 31);
+    const uint32_t na0 = (uint32_t)nai & 0x7FFFFFFFu, na1 = (uint32_t)(nai >> 31);
+    const uint32_t br0 = (uint32_t)b.re & 0x7FFFFFFFu, br1 = (uint32_t)(b.re >> 31), bi0 = (uint32_t)b.im & 0x7FFFFFFFu, bi1 = (uint32_t)(b.im >> 31);
+    const uint32_t br1d = br1 << 1, bi1d = bi1 << 1;
+    const uint64_t Lr = limb_mad(na1, bi1d, limb_mad(na0, bi0, limb_mad(ar1, br1d, limb_mad(ar0, br0, 0))));
+    const uint64_t Mr = limb_mad(na1, bi0, limb_mad(na0, bi1, limb_mad(ar1, br0, limb_mad(ar0, br1, 0))));
+    const uint64_t Li = limb_mad(ai1, br1d, limb_mad(ai0, br0, limb_mad(ar1, bi1d, limb_mad(ar0, bi0, 0))));
+    const uint64_t Mi = limb_mad(ai1, br0, limb_mad(ai0, br1, limb_mad(ar1, bi0, limb_mad(ar0, bi1, 0))));
+    return fmake(limb_finish(Lr, Mr), limb_finish(Li, Mi));
+}
+HB_HD F fmul(const F &a, const F &b) {
+    const F r = fmul_lazy(a, b);
+    return fmake(r.re >= P61 ? r.re - P61 : r.re, r.im >= P61 ? r.im - P61 : r.im);
+}
+#else
 HB_HD F fmul(const F &a, const F &b) {
     u128 ac = (u128)a.re * b.re, bd = (u128)a.im * b.im;
     u128 all = (u128)(a.re + a.im) * (b.re + b.im);        // operands < 2^62
     const u128 C = ((u128)P61) << 61;
     return fmake(red124(ac + C - bd), red124(all - ac - bd));
 }
+#endif
 HB_HD F fsqr(const F &a) { return fmul(a, a); }
 HB_HD F fmul32(const F &a, uint32_t w) { return fmake(mulp32(a.re, w), mulp32(a.im, w)); }
 // multiply by i: (a+bi) i = -b + a i

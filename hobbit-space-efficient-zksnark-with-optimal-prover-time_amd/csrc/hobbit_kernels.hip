@@ -231,12 +231,18 @@ template <int B> __device__ __forceinline__ F fsubl(const F &a, const F &b) {   
 }
 // a * b for a lazy a (components < 2^62 - 2^10) and a canonical twiddle b.  Same Karatsuba form as fmul, with the offset that keeps
 // ac - bd non-negative doubled: C = p 2^62 >= bd, ac + C < 2^124, ad + bc < 2^124.
+#if !defined(HOBBIT_FMUL_U128)
+// (the carry-free limb product of hobbit_field.hpp takes components up to p + 7 -- what ffold leaves -- and its canonical form is what the octet's
+// bounds need for the seven right-hand operands)
+__device__ __forceinline__ F fmul_lz(const F &a, const F &b) { return fmul(a, b); }
+#else
 __device__ __forceinline__ F fmul_lz(const F &a, const F &b) {
     const u128 ac = (u128)a.re * b.re, bd = (u128)a.im * b.im;
     const u128 all = (u128)(a.re + a.im) * (b.re + b.im);
     const u128 C = ((u128)P61) << 62;
     return fmake(red124(ac + C - bd), red124(all - ac - bd));
 }
+#endif
 template <int B> __device__ __forceinline__ F fmul_w4(const F &a, int plus_i) {   // a * (+i) or a * (-i); components <= B p in and out
     return plus_i ? fmake((uint64_t)B * P61 - a.im, a.re) : fmake(a.im, (uint64_t)B * P61 - a.re);
 }
