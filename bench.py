@@ -48,9 +48,10 @@ def commit_op_counts(N, K, edges, nz=1.0):
 # which resource binds each bulk kernel: "valu" kernels report frac_valu (issue cycles the instruction stream needs at the
 # sustained clock / measured time) as the primary fraction; the HBM fraction the contract asks for stays in `frac`
 KERNEL_BOUND = {"k_leaf_chain": "valu", "k_fft4096": "valu", "k_encode_A": "valu", "k_encode_B": "valu", "k_encode": "valu", "k_transpose": "hbm",
+                "k_enc_fat_A": "hbm", "k_enc_fat_D": "hbm", "k_encode_M": "valu",
                 "k_inner_digests": "valu", "k_chain_digests": "valu", "k_leaf_chain_relay": "valu", "k_aggregate": "hbm"}
 SUSTAINED_GHZ, PEAK_GHZ = 1.78, 2.4       # profiles/r01_microbench.txt: clock held under the VALU-heavy kernels; the chip's peak clock
-TRAFFIC_PROFILE = "r02_hbm_traffic_commit_2e28.json"     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (scripts/hbm_traffic.py)
+TRAFFIC_PROFILE = "r03_hbm_traffic_commit_2e28.json"     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (scripts/hbm_traffic.py)
 
 ROOFLINE_NOTES = {
     "k_leaf_chain": "VALU-issue bound, not HBM bound: BLAKE3 compress = 2023 SIMD-cycles per wave-compression with v_alignbit/v_add3 at half rate "
@@ -151,6 +152,11 @@ def algorithmic_bytes(N, K, world=1, sharded=False, nz=1.0):
         "k_encode": f * (32 * N + 32 * N),              # single-pass encode: read message half, write parity half
         "k_encode_A": f * (32 * N + 32 * N * r0),       # read message half, write x_1 = C_0 x_0
         "k_encode_B": f * (32 * N * r0 + 32 * N * (1 - r0)),   # read x_1, write the rest of the parity half
+        # deep codes (trs = 4096), round 3: C_0 by the persistent register-resident kernel (same bytes as pass A); the narrow middle steps read x_1
+        # and write [x_2 .. z_1] (622 of the 4096 parity rows at trs = 4096); D_0 reads [x_1 .. z_1] back and writes z_0 and the zero tail
+        "k_enc_fat_A": f * (32 * N + 32 * N * r0),
+        "k_encode_M": f * (32 * N * r0 + 32 * N * (622.0 / 4096.0)),
+        "k_enc_fat_D": f * (32 * N * (1486.0 / 4096.0) + 32 * N * ((4096.0 - 1486.0) / 4096.0)),
         "k_leaf_chain": 64 * N * nz + 32 * M,           # read the non-zero rows of the tensor once (rows past the codeword length are zero), write the leaves once
         "k_inner_digests": f * (64 * N + 32 * N),       # read the local tensor shard, write its 32-byte digests
         "k_chain_digests": (32 * M * K + 64 * M) * (1.0 / world if sharded else 1.0),

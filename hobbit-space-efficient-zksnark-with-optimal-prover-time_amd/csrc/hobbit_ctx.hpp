@@ -248,7 +248,7 @@ struct hobbit_ctx {
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev_get() { if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; } hipEvent_t e; hipEventCreate(&e); return e; }
     static bool prof_bulk(const char *n) {
-        return !strncmp(n, "k_leaf_chain", 12) || !strncmp(n, "k_fft4096", 9) || !strncmp(n, "k_encode", 8) || !strcmp(n, "k_transpose") ||
+        return !strncmp(n, "k_leaf_chain", 12) || !strncmp(n, "k_fft4096", 9) || !strncmp(n, "k_encode", 8) || !strncmp(n, "k_enc_", 6) || !strcmp(n, "k_transpose") ||
                !strncmp(n, "k_inner_digests", 15) || !strncmp(n, "k_chain_digests", 15) || !strcmp(n, "k_aggregate");
     }
     bool prof_cur = false;

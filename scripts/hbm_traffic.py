@@ -3,14 +3,18 @@ into HBM bytes per launch and kernel.  gfx950 corrections per the guide: counter
 wide coalesced reads, so it is doubled.  usage: hbm_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> <command...>"""
 import collections, csv, json, sys
 
+deep = True     # at trs = 4096 (the 2^28 workload) the 512-thread pass is the middle pass M of round 3's three-launch encode (HOBBIT_ENC_FAT=3, the default)
 def load(path, counter):
     acc = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("hobbit::", "").split("<")[0]
-        if name.startswith("k_encode"):                       # passes A and B are one template: tell them apart by their workgroup size
-            name = "k_encode_A" if int(r["Workgroup_Size"]) > 512 else "k_encode_B"
+        full = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("hobbit::", "")
+        name = full.split("<")[0]
+        if name == "k_enc_fat":                               # one template: C_0 has two outputs per lane, D_0 three
+            name = "k_enc_fat_A" if full.split("<")[1].startswith("2") else "k_enc_fat_D"
+        elif name.startswith("k_encode"):                     # the one-workgroup-per-column passes are one template: tell them apart by their workgroup size
+            name = "k_encode_A" if int(r["Workgroup_Size"]) > 512 else ("k_encode_M" if deep else "k_encode_B")
         a = acc[name]; a[0] += float(r["Counter_Value"]); a[1] += 1
     return acc
 
