@@ -128,7 +128,7 @@ static int fft_rows(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_l
                     uint32_t groups, uint32_t rows_per_group, size_t src_gs, size_t dst_gs);
 
 static void free_code(DeviceCode &c) {
-    for (FatStep *f : {&c.fatA, &c.fatD}) { if (f->d_wt) hipFree(f->d_wt); if (f->d_ot) hipFree(f->d_ot); if (f->d_oidx) hipFree(f->d_oidx); if (f->d_w) hipFree(f->d_w); }
+    for (FatStep *f : {&c.fatA, &c.fatC1, &c.fatD}) { if (f->d_wt) hipFree(f->d_wt); if (f->d_ot) hipFree(f->d_ot); if (f->d_oidx) hipFree(f->d_oidx); if (f->d_w) hipFree(f->d_w); }
     { MidCode &m = c.mid; if (m.d_wt) hipFree(m.d_wt); if (m.d_ot) hipFree(m.d_ot); if (m.d_oidx) hipFree(m.d_oidx); if (m.d_w) hipFree(m.d_w); }
     if (c.d_steps) hipFree(c.d_steps);
     if (c.d_slice_ptr) hipFree(c.d_slice_ptr);
@@ -585,6 +585,8 @@ int hobbit_graph_finalize(hobbit_ctx *ctx, long long n, long long *len_out) {
         const uint32_t capA[3] = {FAT_A_CAP0, FAT_A_CAP1, 0}, capD[3] = {FAT_D_CAP0, FAT_D_CAP1, FAT_D_CAP2};
         build_fat_step(*plan.front().g, (uint32_t)plan.front().in_off, (uint32_t)plan.front().out_off, FAT_A_NOUT, FAT_A_CONS, capA, c.fatA);
         build_fat_step(*plan.back().g, (uint32_t)plan.back().in_off, (uint32_t)plan.back().out_off, FAT_D_NOUT, FAT_D_CONS, capD, c.fatD);
+        const uint32_t capC1[3] = {FAT_C1_CAP0, 0, 0};
+        build_fat_step(*plan[1].g, (uint32_t)plan[1].in_off, (uint32_t)plan[1].out_off, FAT_C1_NOUT, FAT_C1_CONS, capC1, c.fatC1);
         std::vector<MidPlanStep> ms;
         for (size_t i = 1; i + 1 < plan.size(); i++) ms.push_back({plan[i].g, plan[i].in_off, plan[i].out_off});
         build_mid(ms, (uint32_t)plan[1].in_off, (uint32_t)plan[1].g->L, c.mid);

@@ -58,6 +58,7 @@ struct FatStep {
     size_t slots_used = 0;                   // sum over waves and positions of the widths (x 64 = padded edge count)
 };
 static constexpr uint32_t FAT_A_NOUT = 2, FAT_A_CONS = 7, FAT_A_CAP0 = 72, FAT_A_CAP1 = 48;          // C_0 of n = 4096: 864 outputs, in-degree 42.7 +- 6.5
+static constexpr uint32_t FAT_C1_NOUT = 1, FAT_C1_CONS = 3, FAT_C1_CAP0 = 64;                        // C_1: 182 outputs, in-degree 42.7 (max ~62): three waves, a few workgroups per CU
 static constexpr uint32_t FAT_D_NOUT = 3, FAT_D_CONS = 8, FAT_D_CAP0 = 28, FAT_D_CAP1 = 16, FAT_D_CAP2 = 12;   // D_0: 1463 outputs, in-degree 12.2 +- 3.5
 
 // The NARROW dependent steps between the first and the last one (C_1 .. D_1 of n = 4096: 182, 38, 8, 19, 66, 309 outputs) for the persistent
@@ -81,7 +82,7 @@ struct DeviceCode {         // finalized code for one message length n
     uint2 *d_edges32 = nullptr;              // {idx, w32}          (small_weights)
     uint32_t *d_eidx = nullptr; F *d_ew = nullptr;   // general weights
     size_t n_edges_padded = 0, n_edges = 0;
-    FatStep fatA, fatD;                      // first and last step in fat form (deep codes only: n = 4096)
+    FatStep fatA, fatC1, fatD;               // first, second and last step in fat form (deep codes only: n = 4096)
     MidCode mid;                             // the steps between them
     // H^T in CSR (evaluate_parity_matrix), built on first use
     uint32_t *d_pm_rowptr = nullptr, *d_pm_idx = nullptr; F *d_pm_w = nullptr; size_t pm_rows = 0;

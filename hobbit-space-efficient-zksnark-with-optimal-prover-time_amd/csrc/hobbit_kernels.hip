@@ -1181,7 +1181,22 @@ int launch_encode(hobbit_ctx *ctx, const F *src, size_t ld_src, F *dst, size_t l
             // the narrow dependent steps C_1 .. D_1 on the 24 KB window [x_1 .. z_1], then D_0 in fat form (it also writes the zero tail)
             const EncStep &last = c.steps[nsteps - 1];
             EncPass pm = {nn, nn, nn + r0, 1, nsteps - 1, nn + r0, last.out_off, 0};
-            if ((fat & 4) && c.mid.ok) {
+            const char *m2_env = getenv("HOBBIT_ENC_M2"); const int m2 = m2_env ? atoi(m2_env) : 2;
+            if (m2 > 0 && nsteps >= 5) {
+                // the middle as two launches (HOBBIT_ENC_M2=0: one, k_encode_M): C_1 alone -- 21 % of the edges on a 14 KB window: fat form, three workgroups per CU --
+                // then the five short steps behind it with a two-wave workgroup per column on the 10 KB window [x_2 .. z_1] (sixteen of them per CU
+                // hide the dependent step chains).  2^28: 2.44 ms as one launch, 0.93 + 1.05 split, 0.63 + 1.05 with C_1 fat
+                const uint32_t r1 = c.steps[1].out_len, x2 = nn + r0;
+                EncPass p1 = {nn, nn, nn + r0, 1, 2, x2, x2, 1};
+                const char *c1_env = getenv("HOBBIT_ENC_FAT_C1");
+                if (c.fatC1.ok && !(c1_env && c1_env[0] == '0')) {
+                    const char *wc_env = getenv("HOBBIT_ENC_FAT_WGS_C1");
+                    HB_TRY((launch_enc_fat<FAT_C1_NOUT, FAT_C1_CAP0, 0, 0, FAT_C1_CONS, 1>(ctx, "k_enc_fat_C1", c.fatC1, dst, ld_dst, batch, 0, 0, wc_env ? (uint32_t)atoi(wc_env) : 768u)));
+                } else
+                    HB_TRY(launch_encode_pass<true>(ctx, "k_encode_C1", dst, ld_dst, dst, ld_dst, batch, p1, r0, block_for(c, 1, 2, 8)));
+                EncPass p2 = {x2, x2, x2 + r1, 2, nsteps - 1, x2 + r1, last.out_off, 0};
+                HB_TRY(launch_encode_pass<true>(ctx, "k_encode_M2", dst, ld_dst, dst, ld_dst, batch, p2, last.out_off - x2, block_for(c, 2, nsteps - 1, (uint32_t)m2)));
+            } else if ((fat & 4) && c.mid.ok) {
                 const char *wm_env = getenv("HOBBIT_ENC_MID_WGS");
                 HB_TRY(launch_enc_mid(ctx, c.mid, dst, ld_dst, batch, wm_env ? (uint32_t)atoi(wm_env) : 512u));
             } else

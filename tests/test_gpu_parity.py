@@ -257,6 +257,10 @@ def test_encode_in_place_4096_persistent_kernels(hb, oracle, batch, monkeypatch)
         monkeypatch.setenv("HOBBIT_ENC_FAT", mode)
         got[mode] = hb.encode_monolithic(x, in_place=True)
     monkeypatch.delenv("HOBBIT_ENC_FAT")
+    for m2, c1 in (("0", "1"), ("1", "1"), ("2", "0"), ("4", "1")):                   # the middle steps: one launch / C_1 + narrow remainder, C_1 generic or fat
+        monkeypatch.setenv("HOBBIT_ENC_M2", m2); monkeypatch.setenv("HOBBIT_ENC_FAT_C1", c1)
+        got["m2_%s_%s" % (m2, c1)] = hb.encode_monolithic(x, in_place=True)
+    monkeypatch.delenv("HOBBIT_ENC_M2"); monkeypatch.delenv("HOBBIT_ENC_FAT_C1")
     got["default"] = hb.encode_monolithic(x, in_place=True)
     for mode in got:
         assert np.array_equal(got[mode], got["0"]), mode
