@@ -7,6 +7,7 @@
 #include <cstring>
 #include <map>
 #include <thread>
+#include <functional>
 #include "hobbit_kernels.hpp"
 #include "hobbit_blake3.hpp"
 
@@ -432,19 +433,79 @@ static bool build_fat_step(const HostGraph &g, uint32_t in_off, uint32_t out_off
     uint32_t base[4] = {0, 0, 0, 0}, tot = 0;
     for (uint32_t j = 0; j < nout; j++) { base[j] = tot; tot += cap[j]; }
     std::vector<uint32_t> wt((size_t)tot * lanes, 0), ot((size_t)(tot / 2) * lanes, 0), oidx((size_t)nout * lanes, 0xFFFFFFFFu), wid((size_t)ncons * nout, 0);
+    const char *bs_env = getenv("HOBBIT_ENC_BANK_SCHED"); const bool bank_sched = !(bs_env && bs_env[0] == '0');
+    // which output each (position, lane) owns, and the widths
+    std::vector<int64_t> own((size_t)nout * lanes, -1);
     for (uint32_t j = 0; j < nout; j++)
         for (size_t l = 0; l < lanes; l++) {
             const size_t i = (j % 2 == 0) ? (size_t)j * lanes + l : (size_t)(j + 1) * lanes - 1 - l;      // serpentine: heavy with light
             if (i >= R) continue;
             const auto &row = rows[order[i]];
             if (row.size() > cap[j]) return false;
-            oidx[(size_t)j * lanes + l] = order[i];
+            own[(size_t)j * lanes + l] = order[i]; oidx[(size_t)j * lanes + l] = order[i];
             uint32_t &w = wid[(l / 64) * nout + j];
             w = std::max(w, (uint32_t)((row.size() + 3) / 4 * 4));
-            for (size_t k = 0; k < row.size(); k++) {
-                const size_t slot = base[j] + k;
-                wt[slot * lanes + l] = row[k].second;
-                ot[(slot / 2) * lanes + l] |= (row[k].first * 16u) << (16 * (slot & 1));
+        }
+    // Slot order.  A lane's records are its own, so their order is free -- and the kernels turned out to be bound by LDS bank conflicts (SQ counters, round 3:
+    // 65 % of the LDS-array cycles of k_enc_fat are conflict cycles with the edges in graph order).  A ds_read_b128 is served in four fixed groups of 16 lanes;
+    // a 16-byte element covers one of 16 bank quads (index mod 16).  Per wave, position and group, slot after slot: a maximum matching of lanes to the quads
+    // of their remaining edges (most constrained lanes first) -- a matched lane reads conflict-free, an unmatched one spends a padding slot if its row
+    // is shorter than the wave's width, else takes any edge; padding slots point at a quad nobody else uses.
+    static const int GROUPS[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                      {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59}, {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+    auto put = [&](uint32_t j, size_t l, uint32_t k, uint32_t idx, uint32_t w32) {
+        const size_t slot = base[j] + k;
+        wt[slot * lanes + l] = w32;
+        ot[(slot / 2) * lanes + l] |= (idx * 16u) << (16 * (slot & 1));
+    };
+    for (uint32_t j = 0; j < nout; j++)
+        for (uint32_t wv = 0; wv < ncons; wv++) {
+            const uint32_t W = wid[wv * nout + j];
+            for (int gi = 0; gi < 4; gi++) {
+                std::vector<std::pair<uint32_t, uint32_t>> rem[16]; int slack[16];
+                for (int q = 0; q < 16; q++) {
+                    const size_t l = (size_t)wv * 64 + GROUPS[gi][q];
+                    const int64_t t = own[(size_t)j * lanes + l];
+                    if (t >= 0) rem[q] = rows[(size_t)t];
+                    slack[q] = (int)W - (int)rem[q].size();
+                }
+                if (!bank_sched) {                                                                // graph order (A/B)
+                    for (int q = 0; q < 16; q++) { for (uint32_t k = 0; k < rem[q].size(); k++) put(j, (size_t)wv * 64 + GROUPS[gi][q], k, rem[q][k].first, rem[q][k].second); rem[q].clear(); }
+                    continue;
+                }
+                for (uint32_t k = 0; k < W; k++) {
+                    int lane_of[16], quad_of[16]; for (int q = 0; q < 16; q++) { lane_of[q] = -1; quad_of[q] = -1; }
+                    int ord[16]; for (int q = 0; q < 16; q++) ord[q] = q;
+                    std::stable_sort(ord, ord + 16, [&](int a, int b) { return slack[a] < slack[b]; });
+                    std::function<bool(int, bool *)> aug = [&](int q, bool *seen) -> bool {
+                        for (auto &e : rem[q]) { const int r = e.first & 15; if (seen[r]) continue; seen[r] = true;
+                            if (lane_of[r] < 0 || aug(lane_of[r], seen)) { lane_of[r] = q; quad_of[q] = r; return true; } }
+                        return false;
+                    };
+                    for (int oq = 0; oq < 16; oq++) { const int q = ord[oq]; if (rem[q].empty()) continue; bool seen[16] = {false}; aug(q, seen); }
+                    bool used[16] = {false};
+                    for (int q = 0; q < 16; q++) if (quad_of[q] >= 0) used[quad_of[q]] = true;
+                    for (int q = 0; q < 16; q++) {
+                        const size_t l = (size_t)wv * 64 + GROUPS[gi][q];
+                        if (rem[q].empty()) continue;
+                        int pick = -1;
+                        if (quad_of[q] >= 0) { for (size_t e = 0; e < rem[q].size(); e++) if ((int)(rem[q][e].first & 15) == quad_of[q]) { pick = (int)e; break; } }
+                        else if (slack[q] > 0) { slack[q]--; continue; }                       // wait: a padding slot now (filled below), a real edge later
+                        else pick = 0;                                                            // no room to wait: a conflict
+                        put(j, l, k, rem[q][pick].first, rem[q][pick].second);
+                        rem[q].erase(rem[q].begin() + pick);
+                    }
+                    // padding slots of this position (weight 0): a quad nobody reads
+                    for (int q = 0; q < 16; q++) {
+                        const size_t l = (size_t)wv * 64 + GROUPS[gi][q];
+                        const size_t slot = base[j] + k;
+                        if (wt[slot * lanes + l] != 0 || ((ot[(slot / 2) * lanes + l] >> (16 * (slot & 1))) & 0xFFFFu) != 0) continue;     // (a real edge with weight 0 and index 0 is re-pointed harmlessly: 0 * x)
+                        int r = 0; while (r < 15 && used[r]) r++;
+                        used[r] = true;
+                        if ((uint32_t)r < (uint32_t)g.L) ot[(slot / 2) * lanes + l] |= ((uint32_t)r * 16u) << (16 * (slot & 1));
+                    }
+                }
+                for (int q = 0; q < 16; q++) if (!rem[q].empty()) return false;                  // (cannot happen: every lane places one edge per slot once its slack is spent)
             }
         }
     f.nout = nout; f.ncons = ncons; for (uint32_t j = 0; j < 3; j++) f.cap[j] = j < nout ? cap[j] : 0;

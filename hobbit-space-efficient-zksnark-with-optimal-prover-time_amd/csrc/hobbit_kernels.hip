@@ -967,7 +967,7 @@ static uint32_t block_for(const DeviceCode &c, uint32_t s_lo, uint32_t s_hi, uin
 // (The one-workgroup-per-column k_encode re-reads 8 bytes of record per edge and column through L2 -- 40 GB per commit at 2^28 -- and its
 // window load, barriers and slice loop do not overlap: DESIGN.md section 4.)
 // ============================================================================================
-template <int NOUT, int CAP0, int CAP1, int CAP2, int NW, int NLOAD>
+template <int NOUT, int CAP0, int CAP1, int CAP2, int NW, int NLOAD, int CP>
 __global__ void __launch_bounds__((NW + NLOAD) * 64)
 k_enc_fat(F *__restrict__ tensor, size_t ld, uint32_t ncols, uint32_t in_off, uint32_t in_len, uint32_t out_off, uint32_t z_lo, uint32_t z_hi,
           const uint32_t *__restrict__ wt, const uint32_t *__restrict__ ot, const uint32_t *__restrict__ oidx, const uint32_t *__restrict__ wid) {
@@ -978,12 +978,15 @@ k_enc_fat(F *__restrict__ tensor, size_t ld, uint32_t ncols, uint32_t in_off, ui
     const uint32_t pieces = (in_len + 63) >> 6, win_bytes = pieces << 10;             // whole 1-KiB DMA pieces
     // NLOAD > 0: the last NLOAD waves only load (a wave's DMA pieces cost it ~100+ cycles each under load: with dedicated loaders the consumers
     // never stall on them -- 2.5 vs 3.3 ms for C_0 at 2^28); NLOAD = 0: every wave issues its share right after the barrier
+    // CP > 0 (with NLOAD > 0): every consumer wave also issues CP pieces per column right after the barrier, the loaders the rest -- one wave can keep
+    // at most 63 vector-memory instructions in flight and its pieces cost it ~100+ cycles each, so a single loader caps the window stream
     constexpr int NISS = NLOAD > 0 ? NLOAD : NW;
     const bool loader = NLOAD > 0 && wave >= NW;
-    const uint32_t first_piece = NLOAD > 0 ? wave - NW : wave;
+    const uint32_t first_piece = NLOAD > 0 ? (loader ? NW * CP + (wave - NW) : wave * CP) : wave;
+    const uint32_t end_piece = (NLOAD > 0 && !loader) ? wave * CP + CP : 0xFFFFFFFFu, step_piece = (NLOAD > 0 && !loader) ? 1u : (uint32_t)NISS;
     auto issue = [&](uint32_t c, uint32_t buf) {                                         // this wave's pieces of column c's window -> buffer buf
         const F *colp = tensor + (size_t)c * ld + in_off;
-        for (uint32_t p = first_piece; p < pieces; p += NISS) {
+        for (uint32_t p = first_piece; p < pieces && p < end_piece; p += step_piece) {
             uint32_t i = (p << 6) + lane; i = i < in_len ? i : in_len - 1;             // (the pad lanes of the last piece re-read the last element)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(colp + i),
                                              (__attribute__((address_space(3))) void *)(lds_raw + buf * win_bytes + (p << 10)), 16, 0, 0);
@@ -1001,7 +1004,8 @@ k_enc_fat(F *__restrict__ tensor, size_t ld, uint32_t ncols, uint32_t in_off, ui
             }
             return;
         }
-    } else if (blockIdx.x < ncols) issue(blockIdx.x, 0);
+    }
+    if ((NLOAD == 0 || CP > 0) && blockIdx.x < ncols) issue(blockIdx.x, 0);
     // edge records into registers, once
     uint32_t w[TOT], o[TOT / 2], oi[NOUT], W[NOUT];
 #pragma unroll
@@ -1021,7 +1025,7 @@ k_enc_fat(F *__restrict__ tensor, size_t ld, uint32_t ncols, uint32_t in_off, ui
             for (int j = 0; j < NOUT; j++) if (oi[j] != 0xFFFFFFFFu) stF(hcol + out_off + oi[j], held[j]);
             for (uint32_t i = z_lo + threadIdx.x; i < z_hi; i += LANES) stF(hcol + i, fmake(0));
         }
-        if (NLOAD == 0) { const uint32_t cn = c + gridDim.x; if (cn < ncols) issue(cn, (it + 1) & 1); }
+        if (NLOAD == 0 || CP > 0) { const uint32_t cn = c + gridDim.x; if (cn < ncols) issue(cn, (it + 1) & 1); }
         const unsigned char *win = lds_raw + (it & 1) * win_bytes;
 #pragma unroll
         for (int j = 0; j < NOUT; j++) {
@@ -1050,10 +1054,10 @@ k_enc_fat(F *__restrict__ tensor, size_t ld, uint32_t ncols, uint32_t in_off, ui
         for (uint32_t i = z_lo + threadIdx.x; i < z_hi; i += LANES) stF(hcol + i, fmake(0));
     }
 }
-template <int NOUT, int CAP0, int CAP1, int CAP2, int NW, int NLOAD>
+template <int NOUT, int CAP0, int CAP1, int CAP2, int NW, int NLOAD, int CP = 0>
 static int launch_enc_fat(hobbit_ctx *ctx, const char *name, const FatStep &f, F *tensor, size_t ld, size_t ncols, uint32_t z_lo, uint32_t z_hi, uint32_t wgs) {
     const size_t lds = (size_t)2 * ((f.in_len + 63) / 64) * 1024;
-    auto kern = k_enc_fat<NOUT, CAP0, CAP1, CAP2, NW, NLOAD>;
+    auto kern = k_enc_fat<NOUT, CAP0, CAP1, CAP2, NW, NLOAD, CP>;
     hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const size_t grid = std::min(ncols, (size_t)wgs);
     HB_LAUNCH(ctx, name, kern, dim3((unsigned)grid), dim3((NW + NLOAD) * 64), lds, tensor, ld, (uint32_t)ncols, f.in_off, f.in_len, f.out_off, z_lo, z_hi,
@@ -1176,6 +1180,7 @@ int launch_encode(hobbit_ctx *ctx, const F *src, size_t ld_src, F *dst, size_t l
     if (c.small_weights && (fat & 1) && c.fatA.ok && src == dst && ld_src == ld_dst && !write_msg) {
         const char *wg_env = getenv("HOBBIT_ENC_FAT_WGS");
         const uint32_t wgs = wg_env ? (uint32_t)atoi(wg_env) : 256u;
+        // (CP = 2 / 4 / 6 pieces per consumer wave beside the loader were measured: 3.06 / 3.15 / 3.27 ms against 2.65 with the loader alone, same call)
         HB_TRY((launch_enc_fat<FAT_A_NOUT, FAT_A_CAP0, FAT_A_CAP1, 0, FAT_A_CONS, 1>(ctx, "k_enc_fat_A", c.fatA, dst, ld_dst, batch, 0, 0, wgs)));
         if ((fat & 2) && c.fatD.ok && nsteps >= 4) {
             // the narrow dependent steps C_1 .. D_1 on the 24 KB window [x_1 .. z_1], then D_0 in fat form (it also writes the zero tail)
