@@ -245,7 +245,6 @@ extern size_t circuit_size;
 extern void (*hobbit_read_trace_hook)(stream_descriptor &fd, vector<F> &buff_L, vector<F> &buff_R, vector<F> &buff_O, vector<int> &buff_S);
 extern void (*hobbit_read_memory_hook)(stream_descriptor &fd, vector<F> &buff_addr, vector<F> &buff_value, vector<F> &buff_access);
 void reset_stream(stream_descriptor &fd);                      /* src/witness_stream.cpp:228-234 */
-void prove_circuit_standard();
 /* src/sumcheck.h:90-91, src/sumcheck.cpp:796 / :503: the streaming gate-consistency provers.  The trace is read through
  * hobbit_read_trace_hook (BUFFER_SPACE gates per call); has_lookups / lookup_rand: src/main.cpp:70 / :67 (prove_gate_consistency_lookups
  * reads lookup_rand[0..1] and needs has_lookups set, as compute{3,4}p_error_terms do in the reference). */

@@ -595,58 +595,6 @@ def test_host_mirror_test_pc_option1(oracle):
     assert queries * K * 16 / 1024.0 < ps.value
 
 
-def test_host_mirror_prove_circuit_standard(oracle):
-    """prove_circuit_standard (src/main.cpp:985-1087) through the C++ mirror with synthetic read_trace / read_memory hooks: the circuit
-    polynomial's RS x RS commitment (tensor_row_size = 128) and the witness's RS x expander commitment alive at the same time, the
-    multiplication tree over the memory fingerprints, the gate sumcheck, then both openings -- every libc draw in the reference's order
-    (a, b; the expander graphs between the two commitments; the evaluation points).  Checked against the oracle's pieces run in the same
-    order: both roots, the tree's products and final evaluation, and the complete challenge sequences of the two openings (functions of
-    every earlier message)."""
-    import ctypes
-    from __graft_entry__ import PKG, build_host
-    from oracle.pyoracle import gate_standard_inputs
-    build_host()
-    lib = ctypes.CDLL(os.path.join(PKG, "libhobbit_host.so"))
-    libc = ctypes.CDLL(None); libc.random.restype = ctypes.c_long
-    cs, B, seed = 1 << 16, 1 << 13, 4242
-    L, R, O, add = gate_standard_inputs(cs, 31)
-    S = add[:, 0].astype(np.int32)
-    addr, value, access = [splitmix_field(8 * cs, 600 + i) for i in range(3)]
-    roots = np.zeros((2, 32), np.uint8); mul_out = np.zeros((9, 2), np.uint64)
-    rw = np.zeros((128, 2), np.uint64); rc = np.zeros((128, 2), np.uint64); rounds = np.zeros(2, np.int32); ps = ctypes.c_double(0)
-    Pv = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    lib.hobbit_host_prove_circuit_standard.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint] + [ctypes.c_void_p] * 13
-    assert lib.hobbit_host_prove_circuit_standard(cs, B, seed, Pv(L), Pv(R), Pv(O), Pv(S), Pv(addr), Pv(value), Pv(access), Pv(roots), Pv(mul_out), Pv(rw), Pv(rc),
-                                                  Pv(rounds), ctypes.byref(ps)) == 0
-    lib.hobbit_host_close()
-    # the same sequence with the oracle
-    libc.srandom(seed)
-    a = np.array([[libc.random(), 0]], np.uint64); b = np.array([[libc.random(), 0]], np.uint64)
-    cpoly = np.zeros((16 * cs, 2), np.uint64)
-    cpoly[:cs, 0] = S.astype(np.uint64)
-    cpoly[cs:cs + 8 * cs:2] = addr[:4 * cs]; cpoly[cs + 1:cs + 8 * cs:2] = access[:4 * cs]
-    lv_c, _ = oracle.commit_standard(cpoly, 32, 128, 0)
-    trs = 4 * cs // (32 << 11)
-    oracle.expander_init_store(trs)
-    wit = np.zeros((4 * cs, 2), np.uint64)
-    wit[0:3 * cs:3] = L; wit[1:3 * cs:3] = R; wit[2:3 * cs:3] = O; wit[3 * cs:] = value[-cs:]
-    lv_w, _ = oracle.commit_standard(wit, 32, trs, 1)
-    assert np.array_equal(roots[0], lv_c[-1]) and np.array_equal(roots[1], lv_w[-1])
-    one = np.zeros_like(addr); one[:, 0] = 1
-    mt_in = oracle.f_add(oracle.f_add(oracle.f_add(addr, oracle.f_mul(np.repeat(a, 8 * cs, 0), value)), oracle.f_mul(np.repeat(b, 8 * cs, 0), access)), one).reshape(8, cs, 2)
-    mt = oracle.mul_tree(mt_in, np.array([322, 0], np.uint64), None)
-    assert np.array_equal(mul_out[8], mt["final_eval"])
-    assert np.array_equal(mul_out[:8], np.stack([oracle.field_prod(mt_in[i]) for i in range(8)]))
-    oracle.generate_randomness(16)                                     # the gate sumcheck's point (prove_gate_consistency_standard draws nothing itself)
-    x1 = oracle.generate_randomness(18)
-    want_w = oracle.open_standard(wit, 32, trs, x1, 5900)
-    x2 = oracle.generate_randomness(20)
-    want_c = oracle.open_standard_rs(cpoly, 32, 128, x2, 790)
-    assert rounds[0] == want_w["r"].shape[0] and np.array_equal(rw[:rounds[0]], want_w["r"])
-    assert rounds[1] == want_c["r"].shape[0] and np.array_equal(rc[:rounds[1]], want_c["r"])
-    assert ps.value > 0
-
-
 @pytest.mark.parametrize("lookups", [0, 1])
 def test_host_mirror_gate_consistency_stream(oracle, lookups):
     """prove_gate_consistency / prove_gate_consistency_lookups with the reference's signatures (stream_descriptor, r, vt, ps) through the C++
