@@ -117,5 +117,17 @@ for logN in (26, 30):
         assert r["checks"].tolist() == [1, 1]
     out["C5_elastic_open_2e%d_B2e20_opt1_s" % logN] = timed(c5_open, reps=2, warm=1)
     del lvd
+# C5 open (option 2, RS x expander: test_OurPC.sh's `./pigeon N 20 2`): 5900 queries, aux_commit, recursive_prover_Spielman_stream
+for logN in (26, 30):
+    N5 = 1 << logN
+    hb.rng_reset()
+    lvh, lvd = hb.elastic_commit(N5, 1 << 20, 2, chunk=chunk, keep_levels=True)      # (draws and uploads the graphs for trs = 64)
+    x5 = splitmix_field(logN, 6)
+    rs = hb.to_device(hb.read_stream(1 << 20))
+    def c5_open2():
+        r = hb.elastic_open2(N5, 1 << 20, x5, 5900, commit_levels=lvd, chunks=lambda i: rs)
+        assert r["checks"].tolist() == [1]
+    out["C5_elastic_open_2e%d_B2e20_opt2_s" % logN] = timed(c5_open2, reps=2, warm=1)
+    del lvd
 print(json.dumps(out))
 hb.close()
