@@ -48,7 +48,7 @@ def commit_op_counts(N, K, edges, nz=1.0):
 # which resource binds each bulk kernel: "valu" kernels report frac_valu (issue cycles the instruction stream needs at the
 # sustained clock / measured time) as the primary fraction; the HBM fraction the contract asks for stays in `frac`
 KERNEL_BOUND = {"k_leaf_chain": "valu", "k_fft4096": "valu", "k_encode_A": "valu", "k_encode_B": "valu", "k_encode": "valu", "k_transpose": "hbm",
-                "k_enc_fat_A": "hbm", "k_enc_fat_D": "hbm", "k_encode_M": "valu",
+                "k_enc_fat_A": "hbm", "k_enc_fat_D": "hbm", "k_encode_M": "valu", "k_enc_fat_C1": "hbm", "k_encode_M2": "valu",
                 "k_inner_digests": "valu", "k_chain_digests": "valu", "k_leaf_chain_relay": "valu", "k_aggregate": "hbm"}
 SUSTAINED_GHZ, PEAK_GHZ = 1.78, 2.4       # profiles/r01_microbench.txt: clock held under the VALU-heavy kernels; the chip's peak clock
 TRAFFIC_PROFILE = "r03_hbm_traffic_commit_2e28.json"     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (scripts/hbm_traffic.py)
@@ -156,6 +156,10 @@ def algorithmic_bytes(N, K, world=1, sharded=False, nz=1.0):
         # and write [x_2 .. z_1] (622 of the 4096 parity rows at trs = 4096); D_0 reads [x_1 .. z_1] back and writes z_0 and the zero tail
         "k_enc_fat_A": f * (32 * N + 32 * N * r0),
         "k_encode_M": f * (32 * N * r0 + 32 * N * (622.0 / 4096.0)),
+        # the default splits the middle in two (HOBBIT_ENC_M2=2): C_1 alone in the fat form reads x_1 (864 rows) and writes x_2 (182 rows); the
+        # remaining narrow steps read x_2 and write [x_3 .. z_1] (440 rows)
+        "k_enc_fat_C1": f * (32 * N * r0 + 32 * N * (182.0 / 4096.0)),
+        "k_encode_M2": f * (32 * N * (182.0 / 4096.0) + 32 * N * (440.0 / 4096.0)),
         "k_enc_fat_D": f * (32 * N * (1486.0 / 4096.0) + 32 * N * ((4096.0 - 1486.0) / 4096.0)),
         "k_leaf_chain": 64 * N * nz + 32 * M,           # read the non-zero rows of the tensor once (rows past the codeword length are zero), write the leaves once
         "k_inner_digests": f * (64 * N + 32 * N),       # read the local tensor shard, write its 32-byte digests
@@ -357,7 +361,7 @@ def main():
             "kernels_ms_note": "k_fft4096 and k_transpose run on two streams, overlapped (chunk group g's transpose beside group g+1's FFT): their durations sum to more than their wall-clock span; kernels_ms_extra_profiled_step / launches_extra_profiled_step come from one extra untimed step with every launch bracketed, which runs the open on ONE thread and stream (the timed steps run shockwave_prove(C_c) on a helper context from a second thread and the inner commitments on a third stream)",
             "kernels_ms_extra_profiled_step": {k: v[0] for k, v in sorted(prof_full.items())},
             "launches_extra_profiled_step": {"total": int(sum(v[1] for v in prof_full.values())),
-                                             "open": int(sum(v[1] for k, v in prof_full.items() if not (k.startswith("k_leaf_chain") or k in ("k_fft4096", "k_transpose", "k_encode_A", "k_encode_B", "k_encode", "k_merkle_level", "k_merkle_top"))))},
+                                             "open": int(sum(v[1] for k, v in prof_full.items() if not (k.startswith(("k_leaf_chain", "k_enc")) or k in ("k_fft4096", "k_transpose", "k_merkle_level", "k_merkle_top"))))},
             "roofline": {"bound": KERNEL_BOUND.get(dom, "hbm"), "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(dom, args.logn, K)[0], "traffic_source": measured_traffic(dom, args.logn, K)[1],
                          "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": dom_ms, "note": ROOFLINE_NOTES.get(dom, "")},

@@ -11,10 +11,11 @@ def load(path, counter):
             continue
         full = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("hobbit::", "")
         name = full.split("<")[0]
-        if name == "k_enc_fat":                               # one template: C_0 has two outputs per lane, D_0 three
-            name = "k_enc_fat_A" if full.split("<")[1].startswith("2") else "k_enc_fat_D"
+        if name == "k_enc_fat":                               # one template: C_0 has two outputs per lane, C_1 one, D_0 three
+            name = "k_enc_fat_" + {"2": "A", "1": "C1", "3": "D"}.get(full.split("<")[1][:1], "?")
         elif name.startswith("k_encode"):                     # the one-workgroup-per-column passes are one template: tell them apart by their workgroup size
-            name = "k_encode_A" if int(r["Workgroup_Size"]) > 512 else ("k_encode_M" if deep else "k_encode_B")
+            wgs = int(r["Workgroup_Size"])
+            name = "k_encode_A" if wgs > 512 else "k_encode_M2" if wgs <= 128 else ("k_encode_M" if deep else "k_encode_B")
         a = acc[name]; a[0] += float(r["Counter_Value"]); a[1] += 1
     return acc
 
