@@ -381,6 +381,7 @@ def main():
             out["roofline"]["frac_valu_of_peak_clock"] = cyc / (dom_ms * 1e-3 * PEAK_GHZ * 1e9)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_logn, K)
+            out["cpu_baseline_all_cores"] = cpu_all_cores(K)
             if do_open:
                 out["cpu_baseline_open_port"] = cpu_open_port(args.cpu_logn, K, args.queries, full_open)
         if not args.no_dropin and world == 1 and do_open and full_open:
@@ -435,6 +436,39 @@ def cpu_baseline(logn, K):
     return {"value": (mul + add) / secs, "unit": "field-ops/s", "cores": 1, "kind": kind, "seconds": secs,
             "sample": "commit_standard (commit phase only: the reference's open_standard ends in SHA3 from a prebuilt library that is not linked) on "
                       "test_PC(2^%d,4,%d) inputs (trs=%d): the bench workload at 1/%d of its size, single thread" % (logn, K, trs, 1 << (28 - logn))}
+
+
+def host_threads():
+    """Threads this process may really use: its affinity mask, cut to the cgroup's CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_all_cores(K):
+    """the same commit on all host cores -- the oracle's restatement with the rows / columns / leaves of each chunk dealt to
+    threads (oracle/hobbit_oracle.c orc_commit_standard_mt; levels identical to the single-thread restatement, tests/test_oracle_selfcheck.py).
+    The reference itself is single-threaded, so this leg is always a "port"."""
+    from oracle import pyoracle
+    orc = pyoracle.Oracle()
+    T = host_threads()
+    logn = 26 if T >= 8 else 24              # ~10-30 s of CPU work either way
+    n = 1 << logn
+    trs = n // (K << 11)
+    secs = orc.time_commit_standard_mt(n, K, T)
+    edges, dep, m = 0, 0, trs
+    while m > 13:
+        edges += orc.graph(dep, 0)["L"] * 9 + orc.graph(dep, 1)["L"] * 12
+        m = int(0.211 * m); dep += 1
+    mul, add, comp = commit_op_counts(n, K, edges)
+    return {"value": (mul + add) / secs, "unit": "field-ops/s", "cores": T, "kind": "port", "seconds": secs,
+            "sample": "commit_standard (commit phase only) on test_PC(2^%d,4,%d) inputs (trs=%d): the bench workload at 1/%d of its size, the oracle's "
+                      "restatement on %d threads (rows, columns and leaves of each chunk dealt in ranges)" % (logn, K, trs, 1 << (28 - logn), T)}
 
 
 def cpu_open_port(logn, K, queries, full=True):

@@ -2068,3 +2068,88 @@ double orc_time_commit_standard(size_t N, int K) {
     free(poly); free(lv);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* The same commit_standard on T threads (the "all host cores" CPU leg).    */
+/* Chunk after chunk as above; inside a chunk the rows (FFT), then the columns (encode), then   */
+/* the leaves (hash chain step) are dealt to the threads in contiguous ranges, with a barrier   */
+/* between the three loops.  Same arithmetic in the same order per element: same levels.        */
+/* ------------------------------------------------------------------------------------------ */
+#include <pthread.h>
+typedef struct { const oF *poly; size_t M, cols, rows; int K, trs, lin, T, id; oF *t; uint8_t *levels; oF *tensor_out; pthread_barrier_t *bar; } mt_arg;
+static void *mt_worker(void *p) {
+    mt_arg *a = (mt_arg *)p;
+    const size_t trs = (size_t)a->trs, cols = a->cols, rows = a->rows, half = a->M / trs;
+    const int logc = (int)log2((double)cols), logr = (int)log2((double)rows);
+    oF *buf = (oF *)malloc(sizeof(oF) * rows), *buf2 = (oF *)malloc(sizeof(oF) * rows);
+    for (int i = 0; i < a->K; i++) {
+        const oF *msg = a->poly + (size_t)i * a->M;
+        size_t lo = trs * (size_t)a->id / (size_t)a->T, hi = trs * (size_t)(a->id + 1) / (size_t)a->T;
+        for (size_t r = lo; r < hi; r++) {                                   /* message rows: copy, zero-pad, row FFT */
+            memcpy(a->t + r * cols, msg + r * half, sizeof(oF) * half);
+            memset(a->t + r * cols + half, 0, sizeof(oF) * (cols - half));
+            orc_fft_cached(a->t + r * cols, logc, 0);
+        }
+        pthread_barrier_wait(a->bar);
+        lo = cols * (size_t)a->id / (size_t)a->T; hi = cols * (size_t)(a->id + 1) / (size_t)a->T;
+        for (size_t c = lo; c < hi; c++) {
+            if (!a->lin) {
+                for (size_t j = 0; j < rows; j++) buf[j] = j < trs ? a->t[j * cols + c] : fint(0);
+                orc_fft_cached(buf, logr, 0);
+                for (size_t j = 0; j < rows; j++) a->t[j * cols + c] = buf[j];
+            } else {
+                for (size_t j = 0; j < trs; j++) buf[j] = a->t[j * cols + c];
+                orc_encode_monolithic(buf, buf2, (long long)trs);
+                for (size_t j = 0; j < rows; j++) a->t[j * cols + c] = buf2[j];
+            }
+        }
+        pthread_barrier_wait(a->bar);
+        if (a->tensor_out && a->id == 0) memcpy(a->tensor_out + (size_t)i * rows * cols, a->t, sizeof(oF) * rows * cols);
+        const size_t nl = trs / 2 * cols;
+        lo = nl * (size_t)a->id / (size_t)a->T; hi = nl * (size_t)(a->id + 1) / (size_t)a->T;
+        for (size_t g = lo; g < hi; g++) {
+            const size_t j = g / cols, k = g % cols;
+            oF x[4] = {a->t[(4 * j) * cols + k], a->t[(4 * j + 1) * cols + k], a->t[(4 * j + 2) * cols + k], a->t[(4 * j + 3) * cols + k]};
+            uint8_t *leaf = a->levels + 32 * g;
+            hash_md(x, leaf, leaf);
+        }
+        pthread_barrier_wait(a->bar);
+    }
+    free(buf); free(buf2);
+    return NULL;
+}
+size_t orc_commit_standard_mt(const oF *poly, size_t N, int K, int trs, int lin, int T, uint8_t *levels_out, oF *tensor_out) {
+    size_t M = N / (size_t)K, cols = 2 * M / (size_t)trs, rows = 2 * (size_t)trs;
+    if (T < 1) T = 1;
+    if ((size_t)T > (size_t)trs) T = trs;
+    oF *t = (oF *)malloc(sizeof(oF) * rows * cols);
+    memset(levels_out, 0, 32 * M);
+    /* the twiddle cache is keyed on the length only (quirk above) and is not thread-safe to fill: with RS x RS the two lengths would
+       thrash it, so that mode runs on one thread; RS x expander uses one length, filled here before the workers start */
+    if (!lin) T = 1;
+    { oF *one = (oF *)calloc(cols, sizeof(oF)); orc_fft_cached(one, (int)log2((double)cols), 0); free(one); }
+    pthread_barrier_t bar; pthread_barrier_init(&bar, NULL, (unsigned)T);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)T); mt_arg *args = (mt_arg *)malloc(sizeof(mt_arg) * (size_t)T);
+    for (int i = 0; i < T; i++) {
+        args[i] = (mt_arg){poly, M, cols, rows, K, trs, lin, T, i, t, levels_out, tensor_out, &bar};
+        pthread_create(&th[i], NULL, mt_worker, &args[i]);
+    }
+    for (int i = 0; i < T; i++) pthread_join(th[i], NULL);
+    pthread_barrier_destroy(&bar); free(th); free(args); free(t);
+    return create_tree(levels_out, M);
+}
+double orc_time_commit_standard_mt(size_t N, int K, int T) {
+    srandom(1);
+    oF *poly = (oF *)malloc(sizeof(oF) * N);
+    orc_generate_randomness((int)N, poly);
+    int trs = (int)(N / ((size_t)K << 11));
+    orc_expander_init_store(trs);
+    size_t M = N / (size_t)K;
+    uint8_t *lv = (uint8_t *)malloc(64 * M);
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    orc_commit_standard_mt(poly, N, K, trs, 1, T, lv, NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    free(poly); free(lv);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

@@ -158,6 +158,9 @@ size_t orc_elastic_commit_model(size_t N, size_t B, int opt, uint8_t *levels_out
 
 /* cpu_baseline helper: generate test_PC's inputs and time commit_standard (seconds) */
 double orc_time_commit_standard(size_t N, int K);
+/* the same commit on T threads (rows / columns / leaves dealt in ranges inside each chunk); identical levels */
+size_t orc_commit_standard_mt(const oF *poly, size_t N, int K, int trs, int lin, int T, uint8_t *levels_out, oF *tensor_out);
+double orc_time_commit_standard_mt(size_t N, int K, int T);
 
 #ifdef __cplusplus
 }

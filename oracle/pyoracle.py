@@ -396,6 +396,16 @@ class Oracle(_Base):
         cnt = f(_p(p), c_sz(N), ctypes.c_int(K), ctypes.c_int(trs), ctypes.c_int(lin), _p(lv), _p(t) if want_tensor else None)
         return lv[:cnt], t
 
+    def commit_standard_mt(self, poly, K, trs, lin, threads, want_tensor=False):
+        """commit_standard on `threads` threads (BASELINE.md 3.2(b)'s all-cores CPU leg): identical levels"""
+        p = F(poly).reshape(-1, 2)
+        N = p.shape[0]; M = N // K
+        lv = np.zeros((2 * M, 32), np.uint8)
+        t = np.zeros((K, 2 * trs, 2 * M // trs, 2), np.uint64) if want_tensor else None
+        f = self.lib.orc_commit_standard_mt; f.restype = c_sz
+        cnt = f(_p(p), c_sz(N), ctypes.c_int(K), ctypes.c_int(trs), ctypes.c_int(lin), ctypes.c_int(threads), _p(lv), _p(t) if want_tensor else None)
+        return lv[:cnt], t
+
     def open_tree_blake(self, levels, n_leaves, col, row, columns):
         lv = np.ascontiguousarray(levels, dtype=np.uint8)
         path = np.zeros((64, 32), np.uint8)
@@ -770,6 +780,10 @@ class Oracle(_Base):
     def time_commit_standard(self, N, K):
         f = self.lib.orc_time_commit_standard; f.restype = ctypes.c_double
         return f(c_sz(N), ctypes.c_int(K))
+
+    def time_commit_standard_mt(self, N, K, threads):
+        f = self.lib.orc_time_commit_standard_mt; f.restype = ctypes.c_double
+        return f(c_sz(N), ctypes.c_int(K), ctypes.c_int(threads))
 
 
 def _path_ps(n_leaves, depth, pos):

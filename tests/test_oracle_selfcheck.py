@@ -135,3 +135,14 @@ def test_gate_consistency_lookups_stream_selfchecks(oracle):
     assert oracle.gate_consistency_lookups_stream(L, R, O2, S, B, r, lr)["checks"][0] == 0
     O3 = O.copy(); O3[il, 0] ^= np.uint64(1)
     assert oracle.gate_consistency_lookups_stream(L, R, O3, S, B, r, lr)["checks"].tolist() == [1, 1, 1, 1, 1]
+
+
+@pytest.mark.parametrize("logn,K,trs,lin", [(16, 4, 16, 1), (18, 8, 64, 1), (16, 4, 16, 0), (20, 32, 16, 1)])
+def test_commit_standard_threaded_restatement_is_identical(oracle, logn, K, trs, lin):
+    """bench.py's all-cores CPU leg times orc_commit_standard_mt: every tree level and the tensor must equal the
+    single-thread restatement's (which the golden fixtures and oracle/_ref pin) for any thread count, including ones that do not divide the ranges"""
+    oracle.rng_reset(); poly = oracle.generate_randomness(1 << logn); oracle.expander_init_store(trs)
+    lv, t = oracle.commit_standard(poly, K, trs, lin, want_tensor=True)
+    for threads in (1, 3, 8):
+        lv_mt, t_mt = oracle.commit_standard_mt(poly, K, trs, lin, threads, want_tensor=True)
+        assert np.array_equal(lv, lv_mt) and np.array_equal(t, t_mt), threads
