@@ -252,7 +252,7 @@ def main():
                 ops_.set_local_chunks((d_local.ptr, len(own)))
                 open_last["res"] = mod.parallel.sharded_open(ops_, dist, plan, rank, last["res"], x_open, args.queries)
             return                        # (the tensor shard stays with ops_ and is re-used by the next step)
-        c = hb.commit_standard((d_poly, N), K, trs, 1)
+        c = hb.commit_standard((d_poly, N), K, trs, 1, sync=not do_open)        # with an opening behind it: queued, not waited for
         if do_open:
             open_last["res"] = hb.open_core((d_poly, N), c, x_open, args.queries, full=full_open)
         c.free()                          # parks the 16.5 GiB of buffers for the next step

@@ -53,6 +53,17 @@ ABI_SYMBOLS = [
 ]
 
 
+
+class _OpenOut(ctypes.Structure):
+    """hobbit_open_out (include/hobbit_hip.h)"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("cols", "rows", "reply", "paths", "qpoly", "r", "vr", "fin", "scalars", "checks", "roots", "sp_c", "sp_f")]
+
+
+class _ShockwaveOut(ctypes.Structure):
+    """hobbit_shockwave_out (include/hobbit_hip.h); field order = Hobbit._SP_NAMES"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("I", "q1", "r1", "vr1", "fin1", "q2", "r2", "vr2", "fin2", "wq", "wa", "wroots", "wscal", "wchecks", "whir_root", "iters",
+                                              "reply", "paths", "qidx", "qreply", "qpaths", "final_pb", "qn")]
+
 class HobbitError(RuntimeError):
     pass
 
@@ -434,8 +445,10 @@ class Hobbit:
         t = self.to_host(o, (cols, 2 * trs, 2), np.uint64)      # codeword-major on the device
         return np.ascontiguousarray(t.transpose(1, 0, 2))
 
-    def commit_standard(self, poly, K, trs, lin=1):
-        """poly: host array (N,2) or a DeviceBuffer/int pointer with N given as tuple (ptr, N)"""
+    def commit_standard(self, poly, K, trs, lin=1, sync=True):
+        """poly: host array (N,2) or a DeviceBuffer/int pointer with N given as tuple (ptr, N).  sync=False returns once the commit is queued
+        (the C call itself is asynchronous): whatever is queued next on this context -- an opening -- starts the moment the tree is done, without
+        the host round trip in between; every accessor of the commitment synchronises as needed."""
         if isinstance(poly, tuple):
             ptr, N = poly
             ptr = ptr.ptr if isinstance(ptr, DeviceBuffer) else int(ptr)
@@ -446,7 +459,8 @@ class Hobbit:
             keep = self.to_device(p); ptr = keep.ptr
         h = c_vp()
         self._chk(self.lib.hobbit_commit_standard(self.ctx, c_vp(ptr), c_sz(N), c_int(K), c_int(trs), c_int(lin), ctypes.byref(h)))
-        self.sync()
+        if sync or keep is not None:
+            self.sync()
         return Commitment(self, h, N, K, trs)
 
     def commit_standard_host(self, poly, K, trs, lin=1):
@@ -481,10 +495,7 @@ class Hobbit:
         R1 = (2 * c.trs).bit_length() - 1; logc = c.cols.bit_length() - 1
         rounds = R1 + logc + 2 * (R1 + logc) + logc
         depth = c.M.bit_length() - 1
-        names = ("cols", "rows", "reply", "paths", "qpoly", "r", "vr", "fin", "scalars", "checks", "roots", "sp_c", "sp_f")
-
-        class Out(ctypes.Structure):
-            _fields_ = [(n, c_vp) for n in names]
+        Out = _OpenOut                    # (class creation costs ~0.1 ms: the ctypes mirrors of the two hot output structs are made once)
         res = dict(cols=np.zeros(queries, np.uint32), rows=np.zeros(queries, np.uint32), reply=None if _from_aggregate else np.zeros((queries, c.K, 2), np.uint64),
                    paths=np.zeros((queries, depth, 32), np.uint8) if want_paths else None, poly=np.zeros((rounds, 3, 2), np.uint64),
                    r=np.zeros((rounds, 2), np.uint64), vr=np.zeros((5, 2, 2), np.uint64), fin=np.zeros((5, 2), np.uint64),
@@ -522,10 +533,7 @@ class Hobbit:
                    wscal=np.zeros((2, 2), np.uint64), wchecks=np.zeros(2, np.int32), whir_root=np.zeros(32, np.uint8), iters=np.zeros(1, np.int32),
                    reply=np.zeros((240, k, 2), np.uint64), paths=np.zeros((240, lgW, 32), np.uint8))
         out.update(self._wq_buffers())
-
-        class Out(ctypes.Structure):
-            _fields_ = [(n, c_vp) for n in self._SP_NAMES]
-        return out, Out(*[out[n].ctypes.data for n in self._SP_NAMES])
+        return out, _ShockwaveOut(*[out[n].ctypes.data for n in self._SP_NAMES])
 
     @staticmethod
     def _sp_trim(out, N, k):

@@ -2542,11 +2542,14 @@ int hobbit_gate_consistency_lookups_stream(hobbit_ctx *ctx, hobbit_trace_source 
 // shockwave_commit / shockwave_prove.  Host: libc draws in the reference's order, the transcript,
 // challenge powers; device: everything that touches a table.
 struct OpenTrace {
-    bool on; hobbit_ctx *ctx; std::chrono::steady_clock::time_point t0; const char *last;
-    OpenTrace(hobbit_ctx *c) : on(getenv("HOBBIT_TRACE") != nullptr), ctx(c), t0(std::chrono::steady_clock::now()), last("start") {}
+    // HOBBIT_TRACE=1: stage times with the stream drained at every mark (everything on one thread and stream); HOBBIT_TRACE=host: the host
+    // thread's own time between marks, nothing drained, the production threads and streams
+    bool on, drain; hobbit_ctx *ctx; std::chrono::steady_clock::time_point t0; const char *last;
+    OpenTrace(hobbit_ctx *c) : on(getenv("HOBBIT_TRACE") != nullptr), drain(on && strcmp(getenv("HOBBIT_TRACE"), "host") != 0), ctx(c),
+                               t0(std::chrono::steady_clock::now()), last("start") {}
     void mark(const char *name) {
         if (!on) return;
-        hipStreamSynchronize(ctx->stream);
+        if (drain) hipStreamSynchronize(ctx->stream);
         auto t1 = std::chrono::steady_clock::now();
         fprintf(stderr, "[hobbit open] %-28s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(t1 - t0).count());
         t0 = t1;
@@ -2570,7 +2573,7 @@ static int open_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const ho
 }
 static int open_impl_body(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const int *dims, const hobbit_F *h_x, int queries, hobbit_open_out *o,
                           bool full) {
-    if ((!c && !dims) || !o || queries <= 0 || (full && (!o->sp_c || !o->sp_f))) return ctx->fail(HOBBIT_EINVAL, "open: bad arguments");
+    if ((!c && !dims) || !o || queries <= 0 || queries >= (1 << 20) || (full && (!o->sp_c || !o->sp_f))) return ctx->fail(HOBBIT_EINVAL, "open: bad arguments");
     if (!c && (o->reply || o->paths)) return ctx->fail(HOBBIT_EINVAL, "open_from_aggregate: replies and paths come from the tensor shards, not from here");
     OpenTrace tr(ctx);
     tr.mark("entry (stream drain)");
@@ -2636,7 +2639,7 @@ static int open_impl_body(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, con
     // P5 -> shockwave_prove(C_f).  Each of these chains is a sequence of small dependent launches and host round trips that leaves the
     // GPU mostly idle on its own.  DESIGN.md section 4 has the A/B of every step.
     const char *ot_env = getenv("HOBBIT_OPEN_THREADS");
-    const bool par = full && o->sp_c && !(ot_env && ot_env[0] == '0') && ctx->prof_on != 1 && !tr.on;
+    const bool par = full && o->sp_c && !(ot_env && ot_env[0] == '0') && ctx->prof_on != 1 && !tr.drain;
     if (par) {
         for (hobbit_ctx **h : {&ctx->helper, &ctx->helper2}) if (!*h) {
             if (hobbit_ctx_create(ctx->device, h) != 0) return ctx->fail(HOBBIT_EHIP, "open: helper context creation failed");
@@ -2677,12 +2680,18 @@ static int open_impl_body(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, con
     const F a = fmake((uint64_t)random()); o->scalars[3] = *reinterpret_cast<const hobbit_F *>(&a);
     if (o->cols) memcpy(o->cols, qc.data(), 4 * (size_t)queries);
     if (o->rows) memcpy(o->rows, qr.data(), 4 * (size_t)queries);
+    tr.mark("libc draws");
     // B: the query answers feed nothing below.  With the inner commitments on helper2's stream they are queued behind them there (the
     // staging arena stays this context's; scratch is lent from helper2), off the chain P1 -> ... -> shockwave_prove(C_f).
     const char *qs_env = getenv("HOBBIT_OPEN_QUERIES_SIDE");
     const bool queries_side = commits_side && c && !(qs_env && qs_env[0] == '0');
+    // The answers are 7 MB (replies + Merkle paths): handing them from the pinned staging arena to the caller's buffers at the closing
+    // synchronisation cost 0.7 ms of single-threaded memcpy at the very end of the critical path.  They are final long before that, so a
+    // short-lived thread waits for their event and copies them out while the main chain runs.
+    std::thread q_thread; struct QJoiner { std::thread &t; ~QJoiner() { if (t.joinable()) t.join(); } } q_join{q_thread};
     if (queries_side) {
         hobbit_ctx *hc = ctx->helper2; hipStream_t mainS = ctx->stream;
+        const size_t n_def0 = ctx->deferred.size();
         const size_t lend = (size_t)queries * ((size_t)K * sizeof(F) + 8 + 32 * 40) + 4096;
         void *lp; if (hc->workspace2(lend, &lp) != 0) return ctx->fail(HOBBIT_ENOMEM, hc->err);      // (in stream order behind the commitments' last use of it)
         ctx->stream = hc->stream; ctx->ws_lent = lp; ctx->ws_lent_bytes = lend;
@@ -2692,10 +2701,23 @@ static int open_impl_body(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, con
         ctx->stream = mainS; ctx->ws_lent = nullptr; ctx->ws_lent_bytes = 0;
         if (rc) return rc;
         HB_CHECK(ctx, hipEventRecord(ctx->side_ev[60], hc->stream));
+        const char *qe_env = getenv("HOBBIT_OPEN_QUERIES_EAGER");
+        if (!(qe_env && qe_env[0] == '0') && ctx->deferred.size() > n_def0) {
+            std::vector<hobbit_ctx::Deferred> qdef(ctx->deferred.begin() + (long)n_def0, ctx->deferred.end());
+            try {
+                q_thread = std::thread([qdef, ev = ctx->side_ev[60], dev = ctx->device] {
+                    hipSetDevice(dev);
+                    if (hipEventSynchronize(ev) != hipSuccess) return;          // (the closing synchronisation reports the error)
+                    for (const auto &d : qdef) memcpy(d.dst, d.src, d.bytes);
+                });
+                ctx->deferred.resize(n_def0);                                   // the thread owns these hand-overs now
+            } catch (const std::exception &) { /* no thread: the closing hand-over copies them as before */ }
+        }
     } else {
         if (c && o->reply) HB_TRY(hobbit_commitment_gather(ctx, c, qr.data(), qc.data(), (size_t)queries, o->reply));     // replies (:291-305)
         if (c && o->paths) HB_TRY(hobbit_commitment_paths(ctx, c, qc.data(), qr.data(), (size_t)queries, o->paths));      // Merkle paths (:645-647)
     }
+    tr.mark("queries: gather + paths queued");
     for (size_t i = 1; i < cols; i++) sv[i] = fmul(sv[i - 1], sv[0]);                                                   // s powers (:293-297)
     HB_TRY(h2d_staged(ctx, d_s, sv.data(), cols * sizeof(F)));
     // buff2: s2 powers at the queried positions, last write wins (:331-336).  P3 takes it as a sorted (index, value) list -- 5900 non-zeros
@@ -2704,10 +2726,14 @@ static int open_impl_body(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, con
     F *const tmpv = d_b1 + rows2; uint64_t *const tmpi = reinterpret_cast<uint64_t *>(tmpv + queries + 1);      // arena tail
     size_t nnz = 0;
     {
-        std::map<uint64_t, F> last; F pw = s2;
-        for (int q = 0; q < queries; q++) { last[Iv[q]] = pw; pw = fmul(pw, s2); }
-        std::vector<uint64_t> idx; std::vector<F> val;
-        for (auto &kv : last) { idx.push_back(kv.first); val.push_back(kv.second); }
+        // (position, draw number) sorted as one key: the last draw of a position is the one whose power stays (a std::map here cost 0.6 ms of host time)
+        std::vector<uint64_t> key((size_t)queries); std::vector<F> pws((size_t)queries);
+        F pw = s2;
+        for (int q = 0; q < queries; q++) { key[q] = (Iv[q] << 20) | (uint64_t)q; pws[q] = pw; pw = fmul(pw, s2); }
+        std::sort(key.begin(), key.end());
+        std::vector<uint64_t> idx; std::vector<F> val; idx.reserve((size_t)queries); val.reserve((size_t)queries);
+        for (int q = 0; q < queries; q++)
+            if (q + 1 == queries || (key[q + 1] >> 20) != (key[q] >> 20)) { idx.push_back(key[q] >> 20); val.push_back(pws[key[q] & 0xFFFFF]); }
         nnz = idx.size();
         HB_TRY(h2d_staged(ctx, tmpv, val.data(), val.size() * sizeof(F)));
         HB_TRY(h2d_staged(ctx, tmpi, idx.data(), idx.size() * 8));
