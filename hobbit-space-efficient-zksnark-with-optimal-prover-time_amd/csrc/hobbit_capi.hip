@@ -721,10 +721,17 @@ int hobbit_eval_vector(hobbit_ctx *ctx, const hobbit_F *d_v, size_t n, const hob
     F *a = ws, *b = ws + n / 2;
     const F *src = cF(d_v);
     F *dst = a;
-    for (int i = 0; i < lg; i++) {
-        size_t L = n >> (i + 1);
-        HB_TRY(launch_eval_fold(ctx, src, dst, L, cF(h_r)[i]));
+    // two levels per launch while the table is large, the last (up to 12) levels in one workgroup: 7 launches instead of 24 at n = 2^24
+    int i = 0;
+    while (lg - i > 12 || (lg - i > 1 && ((size_t)n >> i) > 4096)) {
+        if (lg - i >= 2) { HB_TRY(launch_eval_fold2(ctx, src, dst, n >> (i + 2), cF(h_r)[i], cF(h_r)[i + 1])); i += 2; }
+        else { HB_TRY(launch_eval_fold(ctx, src, dst, n >> (i + 1), cF(h_r)[i])); i += 1; }
         src = dst; dst = dst == a ? b : a;
+    }
+    if (i < lg) {
+        std::vector<F> rt((size_t)(lg - i)); for (int q = i; q < lg; q++) rt[(size_t)(q - i)] = cF(h_r)[q];
+        HB_TRY(launch_eval_tail(ctx, src, dst, n >> i, lg - i, rt.data()));
+        src = dst;
     }
     return hobbit_memcpy_d2h(ctx, h_out, src, sizeof(F));
 }
@@ -1253,12 +1260,29 @@ static int shockwave_plan(size_t N, int k, ShockPlan &P) {
     P.committed = w > 256;
     return P.committed ? whir_plan(w, P.whir) : 0;
 }
+struct OpenTrace {
+    // HOBBIT_TRACE=1: stage times with the stream drained at every mark (everything on one thread and stream); HOBBIT_TRACE=host: the host
+    // thread's own time between marks, nothing drained, the production threads and streams
+    bool on, drain; hobbit_ctx *ctx; std::chrono::steady_clock::time_point t0; const char *last; uint64_t w0;
+    OpenTrace(hobbit_ctx *c) : on(getenv("HOBBIT_TRACE") != nullptr), drain(on && strcmp(getenv("HOBBIT_TRACE"), "host") != 0), ctx(c),
+                               t0(std::chrono::steady_clock::now()), last("start"), w0(c->wait_ns) {}
+    void mark(const char *name) {
+        if (!on) return;
+        if (drain) hipStreamSynchronize(ctx->stream);
+        auto t1 = std::chrono::steady_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count(), waited = 1e-6 * (double)(ctx->wait_ns - w0);
+        if (drain) fprintf(stderr, "[hobbit open] %-28s %8.3f ms\n", name, ms);
+        else fprintf(stderr, "[hobbit open] %-28s %8.3f ms  (waiting for the device %.3f, host work %.3f)\n", name, ms, waited, ms - waited);
+        t0 = t1; w0 = ctx->wait_ns;
+    }
+};
 static int shockwave_prove_run(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobbit_F *d_enc, const uint8_t *d_levels, size_t N, int k, const hobbit_F *h_x, int xlen,
                                hobbit_shockwave_out *o, const ShockPlan &plan) {
     const int lk = ilog2_exact((size_t)k);
     if (lk < 0 || k > 64 || N % (size_t)k || xlen < lk || !o) return ctx->fail(HOBBIT_EINVAL, "shockwave_prove: bad k / N / x");
     const size_t w = N / k, W = 2 * w;
     StageScope sc(ctx);
+    OpenTrace tr(ctx); const bool helper_ctx = ctx->helper == nullptr && ctx->helper2 == nullptr; if (helper_ctx && !tr.drain) tr.on = false;   // (host mode: the main context's call only)
     std::vector<F> beta1((size_t)k); beta1[0] = fmake(1);
     for (int i = 0; i < lk; i++) for (size_t j = ((size_t)1 << i); j-- > 0;) { F t = fmul(cF(h_x)[xlen - lk + (lk - 1 - i)], beta1[j]); beta1[2 * j + 1] = t; beta1[2 * j] = fsub(beta1[j], t); }
     // workspace4 layout: [0, nested) belongs to the nested whir_commit / whir_prove calls (they carve from the start and never ask
@@ -1294,9 +1318,12 @@ static int shockwave_prove_run(hobbit_ctx *ctx, const hobbit_F *d_matrix, const 
         HB_TRY(launch_merkle_paths(ctx, d_levels, W, didx, 240, depth, d_pth));
         HB_TRY(d2h_staged(ctx, o->paths, d_pth, 240 * (size_t)depth * 32));
     }
+    tr.mark("  sp: aggregate, whir_commit, queries");
     hobbit_F p33 = {33, 0};
     HB_TRY(hobbit_sumcheck2(ctx, reinterpret_cast<hobbit_F *>(at), reinterpret_cast<hobbit_F *>(b1v), W, &p33, o->q1, o->r1, o->vr1, o->fin1));         // (:477)
+    tr.mark("  sp: sumcheck");
     HB_TRY(hobbit_prove_fft(ctx, reinterpret_cast<hobbit_F *>(aggr), w, o->r1, o->q2, o->r2, o->vr2, o->fin2));                                            // (:478)
+    tr.mark("  sp: prove_fft");
     int iters = 0;
     // (:479) aggr.size()/2 > 256 is evaluated after prove_fft doubled aggr in place (src/sumcheck.cpp:2984-2985): the original width w
     if (committed) {
@@ -1305,7 +1332,9 @@ static int shockwave_prove_run(hobbit_ctx *ctx, const hobbit_F *d_matrix, const 
         HB_TRY(whir_prove_run(ctx, reinterpret_cast<hobbit_F *>(aggr), w, reinterpret_cast<hobbit_F *>(wcom), wlv, o->r2, &wo, plan.whir));                    // (:480-481)
     }
     if (o->iters) *o->iters = iters;
+    tr.mark("  sp: whir_prove");
     HB_TRY(ctx->sync());
+    tr.mark("  sp: closing drain");
     return sc.finish();
 }
 int hobbit_shockwave_prove(hobbit_ctx *ctx, const hobbit_F *d_matrix, const hobbit_F *d_enc, const uint8_t *d_levels, size_t N, int k, const hobbit_F *h_x, int xlen,
@@ -2541,20 +2570,6 @@ int hobbit_gate_consistency_lookups_stream(hobbit_ctx *ctx, hobbit_trace_source 
 // open_standard (src/Our_PC.cpp:604-661) + recursive_prover_Spielman (src/PC_utils.cpp:271-385) minus
 // shockwave_commit / shockwave_prove.  Host: libc draws in the reference's order, the transcript,
 // challenge powers; device: everything that touches a table.
-struct OpenTrace {
-    // HOBBIT_TRACE=1: stage times with the stream drained at every mark (everything on one thread and stream); HOBBIT_TRACE=host: the host
-    // thread's own time between marks, nothing drained, the production threads and streams
-    bool on, drain; hobbit_ctx *ctx; std::chrono::steady_clock::time_point t0; const char *last;
-    OpenTrace(hobbit_ctx *c) : on(getenv("HOBBIT_TRACE") != nullptr), drain(on && strcmp(getenv("HOBBIT_TRACE"), "host") != 0), ctx(c),
-                               t0(std::chrono::steady_clock::now()), last("start") {}
-    void mark(const char *name) {
-        if (!on) return;
-        if (drain) hipStreamSynchronize(ctx->stream);
-        auto t1 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[hobbit open] %-28s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(t1 - t0).count());
-        t0 = t1;
-    }
-};
 // With a commitment `c`: the aggregate is computed from d_poly (N = M K coefficients).  With c == NULL (multi-GPU open): d_poly is the
 // M-element aggregate itself, summed by the caller from per-rank partials; dims = {K, trs}; replies and paths are the caller's business.
 static int open_impl_body(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, const hobbit_commitment *c, const int *dims, const hobbit_F *h_x, int queries, hobbit_open_out *o,
@@ -2823,10 +2838,12 @@ static int open_impl_body(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, con
             });
         } catch (const std::exception &e) { return ctx->fail(HOBBIT_ESTATE, std::string("open: cannot start the helper thread: ") + e.what()); }
     }
+    tr.mark("  plan C_c, drain, helper thread started");
     // y1 = evaluate_vector(M', P4.r minus its last entry) (:372-373); P5 = prove_fft_matrix(initial tensor, r, y1) (:383)
     F y1;
     HB_TRY(hobbit_eval_vector(ctx, reinterpret_cast<hobbit_F *>(Mp), (size_t)trs * cols, r_p4, reinterpret_cast<hobbit_F *>(&y1)));
     o->scalars[4] = *reinterpret_cast<hobbit_F *>(&y1);
+    tr.mark("  y1 = evaluate_vector");
     HB_TRY(hobbit_prove_fft_matrix(ctx, reinterpret_cast<hobbit_F *>(d_aggr), (size_t)trs, cols / 2, r_p4, Q, Rr, o->vr + 8, o->fin + 4));
     { CHP q5 = cF(Q); F c5 = fadd(fadd(q5[0], q5[1]), fadd(q5[2], q5[2])); o->checks[2] = feq(c5, y1); }
     tr.mark("y1, P5");   // src/sumcheck.cpp:3016-3019

@@ -294,10 +294,19 @@ struct hobbit_ctx {
     // sleeping, 39.18 / 39.44 ms polling.  (The other configs of scripts/bench_configs.py do not move; what looked like a regression of
     // the 2^24 sumcheck there was the order of the runs -- the first process on a fresh box is the fast one whichever mode it uses.)
     int sync_mode = -1;
+    // time this context's host thread spent waiting for the device (stream drains, mailbox spins): HOBBIT_TRACE=host prints it per stage,
+    // the rest of a stage's time is host work the GPU may be waiting for
+    uint64_t wait_ns = 0;
+    struct WaitClock {
+        hobbit_ctx *c; std::chrono::steady_clock::time_point t0;
+        explicit WaitClock(hobbit_ctx *ctx) : c(ctx), t0(std::chrono::steady_clock::now()) {}
+        ~WaitClock() { c->wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+    };
     int sync() {
         if (sync_mode < 0) { const char *e = getenv("HOBBIT_SYNC"); sync_mode = (e && !strcmp(e, "sleep")) ? 0 : 1; }
+        WaitClock wc(this);
         if (sync_mode == 0) return hip(hipStreamSynchronize(stream), "stream sync");
-        const auto t_start = std::chrono::steady_clock::now();
+        const auto t_start = wc.t0;
         for (uint32_t it = 1;; it++) {
             const hipError_t q = hipStreamQuery(stream);
             if (q == hipSuccess) return 0;
@@ -308,6 +317,7 @@ struct hobbit_ctx {
     int mbox_mode = -1;
     int mbox_wait(uint32_t seq) {
         if (mbox_mode < 0) { const char *e = getenv("HOBBIT_MBOX"); mbox_mode = (e && !strcmp(e, "sync")) ? 0 : 1; }
+        WaitClock wc(this);
         if (mbox_mode == 0) {                    // sleep in the runtime; the post is complete when the kernel is
             int r = hip(hipStreamSynchronize(stream), "mailbox wait");
             if (r) return r;

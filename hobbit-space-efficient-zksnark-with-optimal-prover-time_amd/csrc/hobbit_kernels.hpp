@@ -33,6 +33,8 @@ int launch_gather(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, uint32_
                   size_t nq, F *d_reply);
 int launch_tensor_row(hobbit_ctx *ctx, const F *chunk, uint32_t rows2, uint32_t cols, uint32_t row, F *d_out);
 int launch_eval_fold(hobbit_ctx *ctx, const F *v, F *o, size_t L, F r);
+int launch_eval_fold2(hobbit_ctx *ctx, const F *v, F *o, size_t L, F r0, F r1);
+int launch_eval_tail(hobbit_ctx *ctx, const F *v, F *o, size_t n, int levels, const F *r);
 int launch_csr_gather(hobbit_ctx *ctx, const uint32_t *rowptr, const uint32_t *idx, const F *w, const F *x, F *y, size_t rows);
 int launch_phi_step(hobbit_ctx *ctx, F *g, size_t half, int m, F rx, const F *pm, int last_only);
 int launch_phi_head(hobbit_ctx *ctx, F *g, int n, int h, CHP h_rx, F scale, const F *pm);

@@ -139,6 +139,15 @@ def test_fft_vs_golden(hb):
     assert np.array_equal(hb.evaluate_vector(splitmix_field(1024, 4), splitmix_field(12, 5)), g["eval"])
 
 
+@pytest.mark.gpu
+def test_evaluate_vector_all_fold_paths_vs_oracle(hb, oracle):
+    """evaluate_vector folds two levels per launch above 4096 elements and the last (up to 12) levels in one workgroup: every split of the
+    levels between the two kernels, against the oracle's level-by-level fold (src/utils.cpp:789-802)"""
+    for logn in (1, 2, 5, 11, 12, 13, 14, 15, 17, 20):
+        v = splitmix_field(1 << logn, 40 + logn); r = splitmix_field(logn, 90 + logn)
+        assert np.array_equal(hb.evaluate_vector(v, r), oracle.evaluate_vector(v, r)), logn
+
+
 @pytest.mark.parametrize("logn", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 def test_fft_all_sizes_batched_vs_oracle(hb, oracle, logn):
     """every LDS-resident length (64 ... 2048: the radix-8 kernel with its radix-1/2/4 tail; 4096: its own kernel; below 64: the generic
