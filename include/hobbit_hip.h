@@ -131,7 +131,10 @@ int hobbit_tensorcode(hobbit_ctx *ctx, const hobbit_F *d_msg, size_t M, int trs,
 
 /* ---- Our_PC commit (src/Our_PC.cpp:146-171 commit_standard) -------------------------------- */
 /* poly: N F on the device.  The commitment object owns the device-resident tensor (K chunks,
- * codeword-major) and Merkle levels. */
+ * codeword-major) and Merkle levels.  The call returns once the work is queued on the context's stream (stream semantics, as every
+ * device-side entry point here): the host-returning accessors below and hobbit_sync() wait for it; an opening queued on the same
+ * context simply runs behind it.  The raw device pointers (levels_dev / tensor_dev) are to be used on this context's stream or after
+ * hobbit_sync(). */
 int hobbit_commit_standard(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, int K, int trs, int linear_time,
                            hobbit_commitment **out);
 /* The same for a polynomial that still lives in (pageable) HOST memory -- what the reference's commit_standard(vector<F> &poly, ...) is handed
