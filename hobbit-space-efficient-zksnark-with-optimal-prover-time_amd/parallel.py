@@ -236,17 +236,17 @@ def sharded_open(ops, dist, plan, rank, commit_res, x, queries=5900):
             raise RuntimeError("sharded_open: rank %d drew different queries than rank 0 (the libc generator streams diverged)" % rank)
     # 4. replies
     mine = ops.gather_local(rows, cols, plan)                                        # int64 tensor (queries, n_own, 2)
-    rep = [torch.empty_like(mine) for _ in range(G)]
     if G > 1:
+        rep = [torch.empty_like(mine) for _ in range(G)]
         dist.all_gather(rep, mine)
         ops.after_collective()
     else:
         rep = [mine]
-    reply = np.zeros((queries, plan.K, 2), np.uint64)
+    reply = np.empty((queries, plan.K, 2), np.uint64)
     for h in range(G):
         r_h = ops.to_host("reply", rep[h]).view(np.uint64)          # (consumed before the next to_host("reply"))
-        for li, i in enumerate(plan.chunks_of(h)):
-            reply[:, i] = r_h[:, li]
+        ch = list(plan.chunks_of(h))
+        reply[:, ch] = r_h[:, :len(ch)]                             # one strided copy per rank (a Python loop over the K chunks cost 0.8 ms)
     res["reply"] = reply
     # 5. paths: leaf position (row/4) * cols + col (src/merkle_tree.cpp:309)
     pos = (rows // 4) * plan.cols + cols
@@ -339,6 +339,8 @@ class HipOps:
         which on this runtime stalls for 30-40 ms now and then (the same effect as in _upload; one step in ~40 of the sharded bench).
         The returned array is a view of the retained buffer: valid until the next to_host of the same role."""
         import torch
+        if isinstance(t, np.ndarray):
+            return t
         cache = self.__dict__.setdefault("_down", {})
         pin = cache.get(role)
         if pin is None or pin.shape != t.shape or pin.dtype != t.dtype:
@@ -468,6 +470,8 @@ class HipOps:
     def sum_vectors(self, parts):
         hb = self.hb
         import torch
+        if len(parts) == 1:
+            return parts[0]                                        # one rank: the partial is the aggregate
         acc = parts[0].clone()
         torch.cuda.current_stream(self.device).synchronize()   # the clone ran on torch's stream; the sums run on the library's
         for p in parts[1:]:
@@ -486,6 +490,8 @@ class HipOps:
         r = np.ascontiguousarray(rows, np.uint32); c = np.ascontiguousarray(cols, np.uint32)
         out = np.zeros((len(r), n_own, 2), np.uint64)
         hb._chk(hb.lib.hobbit_tensor_gather(hb.ctx, self._tensor.ptr, plan.M, n_own, plan.trs, r.ctypes.data, c.ctypes.data, len(r), out.ctypes.data))
+        if plan.world == 1:
+            return out.view(np.int64)                              # nobody to gather with: the answers stay on the host (to_host passes arrays through)
         return self._upload("reply", out.view(np.int64))
 
     def subtree_paths(self, subtree, local_pos, plan):

@@ -21,9 +21,10 @@ def wrap(obj, name):
     def g(*a, **k):
         t0 = time.perf_counter(); r = f(*a, **k); torch.cuda.synchronize(); marks.append((name, 1e3 * (time.perf_counter() - t0))); return r
     setattr(obj, name, g)
-for n in ("encode_local", "chain_block", "tree_full", "aggregate_local", "sum_vectors", "open_from_aggregate", "gather_local", "tree_paths"):
+for n in ("encode_local", "chain_block", "tree_full", "aggregate_local", "sum_vectors", "open_from_aggregate", "gather_local", "tree_paths", "to_host", "empty_state"):
     wrap(ops, n)
-for step in range(14):
+import gc; gc.collect(); gc.disable()          # as bench.py does over its timed region
+for step in range(int(sys.argv[1]) if len(sys.argv) > 1 else 14):
     marks.clear()
     t0 = time.perf_counter()
     res = par.sharded_commit_relay(ops, None, plan, 0, (d.ptr, K))
