@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "hobbit_prove_fft_matrix",
     "hobbit_whir_prove", "hobbit_shockwave_prove",
     "hobbit_batch_3product_sumcheck", "hobbit_mul_tree", "hobbit_shockwave_commit", "hobbit_change_form", "hobbit_whir_commit",
-    "hobbit_open_core", "hobbit_open_standard", "hobbit_open_from_aggregate", "hobbit_tensor_gather", "hobbit_gate_sumcheck", "hobbit_compute2p_error_terms", "hobbit_compute3p_error_terms", "hobbit_compute4p_error_terms", "hobbit_fold_axpy",
+    "hobbit_open_core", "hobbit_open_standard", "hobbit_open_from_aggregate", "hobbit_tensor_gather", "hobbit_u64_bias_fold", "hobbit_gate_sumcheck", "hobbit_compute2p_error_terms", "hobbit_compute3p_error_terms", "hobbit_compute4p_error_terms", "hobbit_fold_axpy",
     "hobbit_fold_axpy_i32", "hobbit_batch_prod",
     "hobbit_aggregate", "hobbit_sumcheck2", "hobbit_sumcheck3", "hobbit_fill_splitmix",
 ]
@@ -101,7 +101,7 @@ def load_library(path=LIB_PATH):
         "hobbit_prove_linear_code": [V, V, S, L, V, V, V, V, V], "hobbit_prove_fft": [V, V, S, V, V, V, V, V],
         "hobbit_prove_fft_matrix": [V, V, S, S, V, V, V, V, V],
         "hobbit_gate_sumcheck": [V, V, V, V, V, V, V, S, V, V, V, V, V, V, V],
-        "hobbit_open_core": [V, V, S, V, V, I, V], "hobbit_open_standard": [V, V, S, V, V, I, V], "hobbit_open_from_aggregate": [V, V, S, I, I, I, V], "hobbit_tensor_gather": [V, V, S, I, I, V, V, S, V],
+        "hobbit_open_core": [V, V, S, V, V, I, V], "hobbit_open_standard": [V, V, S, V, V, I, V], "hobbit_open_from_aggregate": [V, V, S, I, I, I, V], "hobbit_tensor_gather": [V, V, S, I, I, V, V, S, V], "hobbit_u64_bias_fold": [V, V, S, ctypes.c_uint64, I],
         "hobbit_whir_prove": [V, V, S, V, V, V, V], "hobbit_shockwave_prove": [V, V, V, V, S, I, V, I, V],
         "hobbit_shockwave_commit": [V, V, S, I, V, V], "hobbit_change_form": [V, V, I], "hobbit_whir_commit": [V, V, S, V, V],
         "hobbit_batch_3product_sumcheck": [V, V, V, V, V, I, V, V, V, V], "hobbit_mul_tree": [V, V, S, S, V, V, V, V, V, V, V, V, V, V],

@@ -931,6 +931,12 @@ int hobbit_commitment_gather(hobbit_ctx *ctx, const hobbit_commitment *c, const 
     HB_TRY(d2h_staged(ctx, h_reply, d_reply, nq * c->K * sizeof(F)));
     return sc.finish();
 }
+// the multi-GPU open's aggregate exchange: see k_u64_bias_fold
+int hobbit_u64_bias_fold(hobbit_ctx *ctx, void *d_words, size_t n_words, uint64_t bias, int fold) {
+    if (!d_words && n_words) return ctx->fail(HOBBIT_EINVAL, "u64_bias_fold: null buffer");
+    if (!n_words) return 0;
+    return launch_u64_bias_fold(ctx, reinterpret_cast<uint64_t *>(d_words), n_words, bias, fold);
+}
 // the same gather on a raw tensor shard (codeword-major, `nchunks` chunks of 4M F): the multi-GPU open's replies
 int hobbit_tensor_gather(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M, int nchunks, int trs, const uint32_t *h_rows, const uint32_t *h_cols, size_t nq, hobbit_F *h_reply) {
     if (nchunks <= 0 || trs <= 0 || M % (size_t)trs) return ctx->fail(HOBBIT_EINVAL, "tensor_gather: bad shard shape");

@@ -69,6 +69,20 @@ int launch_f_binop(hobbit_ctx *ctx, int op, const F *a, const F *b, F *o, size_t
     HB_LAUNCH(ctx, "k_f_binop", k_f_binop, dim3(grid_for(n, 256)), dim3(256), 0, op, a, b, o, n);
     return 0;
 }
+// Multi-GPU aggregate exchange (parallel.sharded_open): the per-rank partial aggregates are summed by a plain 64-bit integer all-reduce -- field
+// elements are < 2^61, so up to eight of them add up without leaving 64 bits -- and reduced mod p afterwards.  fold == 0: w += bias (the
+// partials are shifted by -2^60 first, so that a SIGNED 64-bit sum cannot overflow either); fold != 0: w = (w + bias) mod p, canonical.
+__global__ void k_u64_bias_fold(uint64_t *w, size_t n, uint64_t bias, int fold) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t x = w[i] + bias;
+        if (fold) { x = (x & P61) + (x >> 61); x = x >= P61 ? x - P61 : x; }
+        w[i] = x;
+    }
+}
+int launch_u64_bias_fold(hobbit_ctx *ctx, uint64_t *w, size_t n, uint64_t bias, int fold) {
+    HB_LAUNCH(ctx, "k_u64_bias_fold", k_u64_bias_fold, dim3(grid_for(n, 256, 8192)), dim3(256), 0, w, n, bias, fold);
+    return 0;
+}
 int launch_fill_splitmix(hobbit_ctx *ctx, F *o, size_t n, uint64_t seed) {
     HB_LAUNCH(ctx, "k_fill_splitmix", k_fill_splitmix, dim3(grid_for(n, 256)), dim3(256), 0, o, n, seed);
     return 0;

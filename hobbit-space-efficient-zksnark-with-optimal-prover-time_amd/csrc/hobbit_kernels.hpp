@@ -5,6 +5,7 @@
 namespace hobbit {
 int launch_f_binop(hobbit_ctx *ctx, int op, const F *a, const F *b, F *o, size_t n);
 int launch_fill_splitmix(hobbit_ctx *ctx, F *o, size_t n, uint64_t seed);
+int launch_u64_bias_fold(hobbit_ctx *ctx, uint64_t *w, size_t n, uint64_t bias, int fold);
 int launch_fft_rows(hobbit_ctx *ctx, const F *src, size_t src_ld, uint32_t src_len, F *dst, size_t dst_ld, size_t dst_es, int logn,
                     const F *tw, F scale, int do_scale, uint32_t groups, uint32_t rows_per_group, size_t src_gs, size_t dst_gs);
 int launch_fft4096(hobbit_ctx *ctx, const F *src, size_t src_ld, size_t src_es, uint32_t src_len, F *dst, size_t dst_ld, size_t dst_es, const F *tw1,

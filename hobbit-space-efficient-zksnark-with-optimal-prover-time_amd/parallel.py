@@ -190,7 +190,8 @@ class ElasticPlan:
 def sharded_open(ops, dist, plan, rank, commit_res, x, queries=5900):
     """The open of a chunk-sharded commitment (the reference's open_standard, src/Our_PC.cpp:604-661, on one process):
       1. rank g aggregates ITS chunks with their eq-table coefficients: partial_g = sum_{i = g (mod G)} beta[i] * chunk_i;
-      2. ONE all-gather of the partials (M F each) and a local field sum -> every rank holds the aggregate;
+      2. ONE 64-bit integer all-reduce of the partials (M F each; up to 8 ranks: sums of canonical components fit 64 bits) and a local
+         reduction mod p -> every rank holds the aggregate (more than 8 ranks: all-gather + field sums);
       3. every rank runs the rest of the open from the aggregate (tensor code of the aggregate, inner commitments, five sumchecks,
          both shockwave_prove / WHIR proofs): it depends on the aggregate alone, its rounds are sequential and short, so it is
          replicated, not sharded -- and because every rank draws the same libc sequence, every rank holds the same queries;
@@ -207,13 +208,21 @@ def sharded_open(ops, dist, plan, rank, commit_res, x, queries=5900):
     beta = ops.eq_table_host(np.asarray(x)[:logK])                       # (K, 2) uint64, host
     # 1-2. aggregate
     partial = ops.aggregate_local(np.ascontiguousarray(beta[own]), plan)          # int64 tensor (M, 2) on ops.device
-    parts = [torch.empty_like(partial) for _ in range(G)]
-    if G > 1:
+    if G == 1:
+        aggr = partial
+    elif G <= 8:
+        # ONE integer all-reduce instead of an all-gather of G partials and G - 1 field sums: canonical components are < 2^61, so eight of
+        # them add up inside 64 bits; shifted by -2^60 each, the SIGNED sum the collective computes cannot overflow either.  Per rank the
+        # links carry 2 (G-1)/G x 128 MiB instead of (G-1) x 128 MiB (N = 2^28); the sum is brought back into the field locally.
+        ops.bias_words(partial, -(1 << 60))
+        dist.all_reduce(partial, op=dist.ReduceOp.SUM)
+        ops.after_collective()
+        aggr = ops.fold_words(partial, G << 60)
+    else:
+        parts = [torch.empty_like(partial) for _ in range(G)]
         dist.all_gather(parts, partial)
         ops.after_collective()
-    else:
-        parts = [partial]
-    aggr = ops.sum_vectors(parts)
+        aggr = ops.sum_vectors(parts)
     # 3. the rest of the open, replicated.  Its challenges and queries are libc draws, so every rank must hold the same generator state:
     #    rank 0 draws one value, everybody seeds with it (whatever a rank's runtime, RCCL or loader drew from libc before is forgotten)
     if G > 1:
@@ -466,6 +475,19 @@ class HipOps:
         hb._chk(hb.lib.hobbit_aggregate(hb.ctx, ptr, plan.M * n_own, coeffs.ctypes.data, n_own, out.data_ptr()))
         hb.sync()
         return out
+
+    def bias_words(self, t, bias):
+        """every 64-bit word of the int64 tensor t += bias (mod 2^64), on the library's stream; complete on return"""
+        hb = self.hb
+        hb._chk(hb.lib.hobbit_u64_bias_fold(hb.ctx, t.data_ptr(), t.numel(), bias & 0xFFFFFFFFFFFFFFFF, 0))
+        hb.sync()
+
+    def fold_words(self, t, bias):
+        """every word w of t -> (w + bias) mod p, canonical: the integer sum of the ranks' partials back in the field"""
+        hb = self.hb
+        hb._chk(hb.lib.hobbit_u64_bias_fold(hb.ctx, t.data_ptr(), t.numel(), bias & 0xFFFFFFFFFFFFFFFF, 1))
+        hb.sync()
+        return t
 
     def sum_vectors(self, parts):
         hb = self.hb

@@ -221,6 +221,11 @@ int hobbit_tensorcode_chunks(hobbit_ctx *ctx, const hobbit_F *d_msg, size_t M, i
  * (as written by hobbit_tensorcode_chunks) */
 int hobbit_tensor_gather(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M, int nchunks, int trs, const uint32_t *h_rows, const uint32_t *h_cols, size_t nq,
                          hobbit_F *h_reply);
+/* Multi-GPU open (no reference counterpart: the reference is one process): the per-rank partial aggregates of _aggregate (src/Our_PC.cpp:258-272)
+ * are summed across ranks by a 64-bit INTEGER all-reduce -- canonical field components are < 2^61, so eight of them fit -- and brought back into
+ * the field here.  n_words 64-bit words at d_words; fold == 0: w += bias (callers shift by -2^60 before the reduction so that a signed sum
+ * cannot overflow); fold != 0: w = (w + bias) mod 2^61-1, canonical. */
+int hobbit_u64_bias_fold(hobbit_ctx *ctx, void *d_words, size_t n_words, uint64_t bias, int fold);
 /* inner leaf digests H(t[4j..4j+3][c]) (src/merkle_tree.cpp:70-75) of nchunks tensors, in leaf
  * order: d_out[(i*M + j*cols + c)*32] */
 int hobbit_inner_digests(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M, int nchunks, int trs, uint8_t *d_out);

@@ -99,6 +99,16 @@ class OracleOps:
         flat = np.concatenate(self._chunks)
         return torch.from_numpy(self.orc.aggregate(flat, coeffs).view(np.int64))
 
+    def bias_words(self, t, bias):
+        v = t.numpy().view(np.uint64); v += np.uint64(bias & 0xFFFFFFFFFFFFFFFF)
+
+    def fold_words(self, t, bias):
+        P = np.uint64((1 << 61) - 1)
+        v = t.numpy().view(np.uint64); v += np.uint64(bias & 0xFFFFFFFFFFFFFFFF)
+        v[...] = (v & P) + (v >> np.uint64(61))
+        v[v >= P] -= P
+        return t
+
     def sum_vectors(self, parts):
         acc = parts[0].numpy().view(np.uint64)
         for p in parts[1:]:

@@ -776,6 +776,20 @@ def test_sharded_open_hip_ops_world1(hb, oracle):
         parts.append(o2.aggregate_local(np.ascontiguousarray(beta[own]), plan2))
     total = ops.sum_vectors(parts).cpu().numpy().view(np.uint64)
     assert np.array_equal(total, oracle.aggregate(poly, beta))
+    # ... and so does the exchange the open uses up to 8 ranks: partials shifted by -2^60, a plain int64 sum (what the all-reduce computes),
+    # folded back into the field -- here with eight "ranks" of extreme values as well (8 (p - 1) is the largest sum there can be)
+    a, b = parts[0].clone(), parts[1].clone()
+    for t in (a, b):
+        ops.bias_words(t, -(1 << 60))
+    summed = a + b                                          # torch int64 addition: two's complement, as RCCL's sum
+    assert np.array_equal(ops.fold_words(summed, 2 << 60).cpu().numpy().view(np.uint64), oracle.aggregate(poly, beta))
+    P = (1 << 61) - 1
+    edge = np.array([P - 1, 0, 1, P - 1, 12345, P - 2], np.uint64)
+    acc = torch.zeros(len(edge), dtype=torch.int64, device="cuda")
+    for _ in range(8):
+        t = torch.from_numpy(edge.view(np.int64)).to("cuda"); ops.bias_words(t, -(1 << 60)); acc += t
+    want = np.array([(8 * int(v)) % P for v in edge], np.uint64)
+    assert np.array_equal(ops.fold_words(acc, 8 << 60).cpu().numpy().view(np.uint64), want)
 
 
 # ---- Elastic_PC streaming commit + long-row tensor codes ---------------------------------------
