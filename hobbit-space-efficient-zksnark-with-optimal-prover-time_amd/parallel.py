@@ -117,7 +117,14 @@ def sharded_commit(ops, dist, plan, rank, local_chunks):
     return dict(leaf_range=(lo, hi), subtree=subtree, top=top, root=top[-1], gen=_generation(ops))
 
 
-def sharded_commit_relay(ops, dist, plan, rank, local_chunks, blocks=16):
+def relay_blocks(world):
+    """Blocks the M leaf states are cut into for the relay.  A hop moves M*32 bytes over ONE link whatever the world size, so the relay takes
+    about (blocks + world - 1) block transfers: the fill grows with the world size and shrinks with the block count, while every block
+    costs each rank a receive, a launch and a send (~50 us of host time).  16 blocks up to two ranks, 8 per rank beyond, at most 64."""
+    return max(16, min(64, 8 * world))
+
+
+def sharded_commit_relay(ops, dist, plan, rank, local_chunks, blocks=None):
     """Chain-relay commit (module docstring, 1'-3').  plan must be contiguous.  Returns dict(root, owner = the last rank, levels = the
     whole tree flat [2M-1, 32] on the owner (None elsewhere)).  Leaves travel in SLOT order (slot = col * trs/2 + j, the order the
     shard is read in); the last rank writes them out in the reference's leaf order."""
@@ -125,6 +132,8 @@ def sharded_commit_relay(ops, dist, plan, rank, local_chunks, blocks=16):
     assert plan.contiguous, "the relay needs contiguous chunk ownership (ShardPlan(..., contiguous=True))"
     G, M = plan.world, plan.M
     last = G - 1
+    if blocks is None:
+        blocks = relay_blocks(G)
     if G == 1:
         blocks = 1                                             # nothing to relay: one chain launch
     while blocks > 1 and M % blocks:

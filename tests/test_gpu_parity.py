@@ -691,9 +691,10 @@ def test_relay_commit_hip_ops(hb, oracle):
     d = hb.to_device(poly)
     res = mod.parallel.sharded_commit_relay(mod.parallel.HipOps(hb, dev), None, plan, 0, (d.ptr, K))
     assert np.array_equal(res["levels"].cpu().numpy(), want) and np.array_equal(res["root"], want[-1])
-    # emulated worlds: 4 ranks x 8 blocks, and 8 ranks x 16 blocks -- the shape the driver's SCALE run launches (bench.py --gpus 8: K/G = 4 chunks
-    # per rank, sharded_commit_relay's default 16 blocks)
-    for G, blocks in ((4, 8), (8, 16)):
+    # emulated worlds: 4 ranks x 8 blocks, and 8 ranks x relay_blocks(8) = 64 blocks -- the shape the driver's SCALE run launches (bench.py
+    # --gpus 8: K/G = 4 chunks per rank, sharded_commit_relay's default block count)
+    assert mod.parallel.relay_blocks(8) == 64 and mod.parallel.relay_blocks(2) == 16 and mod.parallel.relay_blocks(4) == 32
+    for G, blocks in ((4, 8), (8, mod.parallel.relay_blocks(8))):
         planG = mod.parallel.ShardPlan(N, K, trs, G, contiguous=True)
         M = planG.M; per = M // blocks
         state = None
