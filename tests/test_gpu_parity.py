@@ -3,6 +3,7 @@ BIT-EXACTLY (integer / byte work, no tolerance) with the oracle on the same seed
 the committed golden vectors the real reference produced, and -- at sizes the oracle cannot
 finish in seconds -- through size-independent properties."""
 import os
+import sys
 import numpy as np
 import pytest
 import golden_cases
@@ -11,6 +12,7 @@ from oracle.pyoracle import splitmix_field, P
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -736,6 +738,93 @@ def test_sharded_commit_result_goes_stale(hb, oracle):
     x = oracle.generate_randomness(18)
     with pytest.raises(RuntimeError, match="one live commitment"):
         mod.parallel.sharded_open(ops, None, plan, 0, res_a, x, 64)
+
+def _two_rank_gpu_worker(rank, world, port, N, K, queries, seed, q):
+    """one rank of test_two_process_relay_commit_and_open_on_one_gpu: real HipOps on cuda:0, gloo transport staged through the host"""
+    import ctypes
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle
+    from staged_dist import StagedDist
+    from __graft_entry__ import load_package
+    mod = load_package()
+    orc = pyoracle.Oracle()
+    trs = N // (K << 11)
+    orc.rng_reset(); poly = orc.generate_randomness(N); orc.expander_init_store(trs)
+    x = orc.generate_randomness(N.bit_length() - 1)
+    hb = mod.Hobbit(0)
+    hb.upload_graphs(trs, graphs_from(orc, trs))
+    plan = mod.parallel.ShardPlan(N, K, trs, world, contiguous=True)
+    M = plan.M
+    own = plan.chunks_of(rank)
+    d_local = hb.to_device(np.concatenate([poly[i * M:(i + 1) * M] for i in own]))
+    ops = mod.parallel.HipOps(hb, torch.device("cuda", 0))
+    sd = StagedDist()
+    out = []
+    for it in range(2):                                   # twice: the retained buffers of HipOps are re-used by the second commit
+        res = mod.parallel.sharded_commit_relay(ops, sd, plan, rank, (d_local.ptr, len(own)))
+        ops.set_local_chunks((d_local.ptr, len(own)))
+        ctypes.CDLL(None).srandom(seed)                   # (only rank 0's state matters: it draws the value every rank re-seeds with)
+        o = mod.parallel.sharded_open(ops, sd, plan, rank, res, x, queries)
+        keep = {k: o[k] for k in ("cols", "rows", "reply", "paths", "poly", "r", "vr", "fin", "scalars", "roots", "checks")}
+        keep["sp_c_wq"] = o["sp_c"]["wq"]; keep["sp_f_q1"] = o["sp_f"]["q1"]
+        out.append((res["root"], keep))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+    hb.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_two_process_relay_commit_and_open_on_one_gpu(hb, oracle, world):
+    """parallel.py end to end as two / four real processes with the real per-rank GPU operations (HipOps, both on this one GPU) -- relay commit
+    (16 / 32 blocks handed from rank to rank), the integer all-reduce of the partial aggregates with its shift and fold kernels, the replicated
+    open, replies all-gathered from the two tensor shards, paths broadcast from the tree's owner -- over gloo with the device tensors staged
+    through the host (tests/staged_dist.py: RCCL wants one device per rank).  Equal, twice in a row, to the single-process commit_standard +
+    open_standard on the same inputs and libc stream."""
+    import ctypes
+    import multiprocessing as mp
+    import queue as _q
+    import socket
+    import time as _t
+    N, K, queries, seed = 1 << 20, 32, 700, 4242          # (4 ranks + this process = 5 processes on the card: the box allows 6)
+    trs = N // (K << 11)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_gpu_worker, args=(r, world, port, N, K, queries, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = []
+    deadline = _t.time() + 400
+    while len(got) < world:
+        try:
+            got.append(q.get(timeout=2))
+        except _q.Empty:
+            assert all(p.exitcode in (None, 0) for p in procs), "a rank died: exit codes %s" % [p.exitcode for p in procs]
+            assert _t.time() < deadline, "timeout waiting for the ranks"
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    oracle.rng_reset(); poly = oracle.generate_randomness(N); oracle.expander_init_store(trs)
+    x = oracle.generate_randomness(N.bit_length() - 1)
+    hb.upload_graphs(trs, graphs_from(oracle, trs))
+    c = hb.commit_standard(poly, K, trs, 1)
+    libc = ctypes.CDLL(None); libc.random.restype = ctypes.c_long
+    libc.srandom(seed); libc.srandom(ctypes.c_uint(libc.random() & 0xFFFFFFFF))
+    want = hb.open_standard(poly, c, x, queries, want_paths=True)
+    root = c.root(); c.free()
+    for rank, outs in got:
+        for it, (r, o) in enumerate(outs):
+            assert np.array_equal(r, root), (rank, it)
+            for k in ("cols", "rows", "reply", "paths", "poly", "r", "vr", "fin", "scalars", "roots", "checks"):
+                assert np.array_equal(o[k], want[k]), (rank, it, k)
+            assert np.array_equal(o["sp_c_wq"], want["sp_c"]["wq"]) and np.array_equal(o["sp_f_q1"], want["sp_f"]["q1"]), (rank, it)
+
 
 def test_sharded_open_hip_ops_world1(hb, oracle):
     """The per-rank GPU operations of the multi-GPU open (local aggregate, field sum of partials, open from the aggregate, replies
