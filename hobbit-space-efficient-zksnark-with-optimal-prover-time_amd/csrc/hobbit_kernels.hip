@@ -1374,9 +1374,14 @@ k_leaf_chain(const F *__restrict__ tensor, size_t chunk_stride, int K, uint32_t 
     // Blocks are dealt round-robin over the 8 XCDs, and with 8 blocks per column the all-zero groups of EVERY column would land on one
     // XCD (b % 8 == 7): that XCD would idle while the other seven set the kernel's time (measured: skipping 6 % of the compressions
     // bought 0.5 %).  Rotating the block index inside each run of 8 by the run's number spreads the cheap blocks evenly.
-    size_t bid = blockIdx.x;
-    if ((gridDim.x & 7) == 0) bid = (bid & ~(size_t)7) | ((bid + (bid >> 3)) & 7);
-    for (size_t g0 = bid * (size_t)blockDim.x + threadIdx.x; g0 < per; g0 += (size_t)gridDim.x * blockDim.x) {
+    // The grid is capped (launch_leaf_chain): a block walks several runs of 8, and the pass number joins the rotation, or it would meet the same
+    // position of every column it visits.  (The rotation permutes whole runs of 8 blocks: only when the block count is a multiple of 8.)
+    const bool rot = (gridDim.x & 7) == 0 && (((per + blockDim.x - 1) / blockDim.x) & 7) == 0;
+    uint32_t pass = 0;
+    for (size_t vb = blockIdx.x; vb * (size_t)blockDim.x < per; vb += gridDim.x, pass++) {
+        const size_t bid = rot ? (vb & ~(size_t)7) | ((vb + (vb >> 3) + pass) & 7) : vb;
+        const size_t g0 = bid * (size_t)blockDim.x + threadIdx.x;
+        if (g0 >= per) continue;
         uint32_t st[NL][8];
         const F *p[NL];
         size_t g[NL];
@@ -1423,7 +1428,13 @@ k_leaf_chain(const F *__restrict__ tensor, size_t chunk_stride, int K, uint32_t 
 __global__ void __launch_bounds__(256)
 k_leaf_chain_relay(const F *__restrict__ tensor, size_t chunk_stride, int K, uint32_t cols, uint32_t half_trs, size_t g_begin, size_t g_count,
                    const uint8_t *__restrict__ state_in, uint8_t *__restrict__ state_out, uint8_t *leaves, uint32_t zero_from, ZeroDig zdig, int leaves_inout) {
-    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < g_count; t += (size_t)gridDim.x * blockDim.x) {
+    // capped grid + per-pass rotation of the block order inside each run of 8, as in k_leaf_chain
+    const bool rot = (gridDim.x & 7) == 0 && (((g_count + blockDim.x - 1) / blockDim.x) & 7) == 0;
+    uint32_t pass = 0;
+    for (size_t vb = blockIdx.x; vb * (size_t)blockDim.x < g_count; vb += gridDim.x, pass++) {
+        const size_t bid = rot ? (vb & ~(size_t)7) | ((vb + (vb >> 3) + pass) & 7) : vb;
+        const size_t t = bid * (size_t)blockDim.x + threadIdx.x;
+        if (t >= g_count) continue;
         const size_t g = g_begin + t;
         uint32_t st[8];
         if (state_in) load8w(state_in + 32 * t, st);
@@ -1452,7 +1463,8 @@ int launch_leaf_chain_relay(hobbit_ctx *ctx, const F *tensor, size_t chunk_strid
                             const uint8_t *state_in, uint8_t *state_out, uint8_t *leaves, uint32_t zero_rows_from, int leaves_inout) {
     if (!g_count) return 0;
     ZeroDig zd; { uint32_t z[16] = {0}; blake3_compress64(z, zd.w); }
-    HB_LAUNCH(ctx, "k_leaf_chain_relay", k_leaf_chain_relay, dim3(grid_for(g_count, 256, 1 << 20)), dim3(256), 0, tensor, chunk_stride, K, cols, half_trs, g_begin,
+    const char *ge = getenv("HOBBIT_LEAF_GRID");
+    HB_LAUNCH(ctx, "k_leaf_chain_relay", k_leaf_chain_relay, dim3(grid_for(g_count, 256, ge ? atoi(ge) : 4096)), dim3(256), 0, tensor, chunk_stride, K, cols, half_trs, g_begin,
               g_count, state_in, state_out, leaves, (zero_rows_from + 3) / 4, zd, leaves_inout);
     return 0;
 }
@@ -1717,7 +1729,10 @@ int launch_leaf_chain(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, int
     ZeroDig zd; { uint32_t z[16] = {0}; blake3_compress64(z, zd.w); }
     const char *e = getenv("HOBBIT_LEAF_ZERO_SKIP");
     const uint32_t zero_from = (e && e[0] == '0') ? 0xFFFFFFFFu : (zero_rows_from + 3) / 4;
-    HB_LAUNCH(ctx, "k_leaf_chain", k_leaf_chain<NL>, dim3(grid_for((total + NL - 1) / NL, 256, 1 << 20)), dim3(256), 0, tensor, chunk_stride, K, cols,
+    // 4096 resident-ish workgroups walking the leaves instead of one workgroup per 256 leaves (32 768 at 2^28): 10.15 -> 9.65 ms, same call
+    // (2048: 9.7, 8192: 9.7; HOBBIT_LEAF_GRID for the A/B) -- fewer dispatches, and the per-pass rotation spreads the cheap all-zero groups evenly
+    const char *ge = getenv("HOBBIT_LEAF_GRID");
+    HB_LAUNCH(ctx, "k_leaf_chain", k_leaf_chain<NL>, dim3(grid_for((total + NL - 1) / NL, 256, ge ? atoi(ge) : 4096)), dim3(256), 0, tensor, chunk_stride, K, cols,
               half_trs, leaves, zero_from, zd);
     return 0;
 }
