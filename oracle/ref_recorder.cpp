@@ -28,6 +28,9 @@
 #ifndef OPENSTUB_ONLY
 static std::vector<uint64_t> g_rec;
 static bool g_on = false;
+// HOBBIT_REC_STREAM=<file>: every record is also appended to that file and flushed at once -- for runs of the reference that cannot return
+// (Our_PC's open_standard reaches SHA3 inside its first _whir_prove: the process dies on the unresolved symbol, the file keeps what ran before)
+static FILE *g_stream = nullptr;
 static pthread_t g_thread;
 static uint64_t g_other_threads = 0;
 
@@ -38,14 +41,21 @@ F mimc_hash(F input, F k) {
     if (!g_next) { fprintf(stderr, "[ref_recorder] rec_set_next() was not called\n"); abort(); }
     F out = g_next(input, k);
     if (g_on) {
-        if (pthread_equal(pthread_self(), g_thread)) { const uint64_t r[6] = {input.real, input.img, k.real, k.img, out.real, out.img}; g_rec.insert(g_rec.end(), r, r + 6); }
+        if (pthread_equal(pthread_self(), g_thread)) {
+            const uint64_t r[6] = {input.real, input.img, k.real, k.img, out.real, out.img}; g_rec.insert(g_rec.end(), r, r + 6);
+            if (g_stream) { fwrite(r, 8, 6, g_stream); fflush(g_stream); }
+        }
         else g_other_threads++;
     }
     return out;
 }
 extern "C" {
 void rec_set_next(void *fn) { g_next = (mimc_fn_t)fn; }
-void rec_start(void) { g_rec.clear(); g_thread = pthread_self(); g_other_threads = 0; g_on = true; }
+void rec_start(void) {
+    g_rec.clear(); g_thread = pthread_self(); g_other_threads = 0; g_on = true;
+    const char *f = getenv("HOBBIT_REC_STREAM");
+    if (f && !g_stream) g_stream = fopen(f, "wb");
+}
 void rec_stop(void) { g_on = false; }
 size_t rec_count(void) { return g_rec.size() / 6; }
 uint64_t rec_other_threads(void) { return g_other_threads; }

@@ -218,6 +218,23 @@ size_t ref_test_pc_commit(size_t N, int K, uint8_t *levels_out) {
     return flatten_levels(g_MT, levels_out);
 }
 
+// test_PC(N,4,K) from the same fresh generator state, commit AND open (src/Our_PC.cpp:757-826): commit_standard, x = generate_randomness(log2 N),
+// open_standard.  The opening reaches SHA3 (my_hhash, from the prebuilt lib/libXKCP.a that is never linked) inside its first shockwave_prove, so this
+// call does NOT return: the process dies on the unresolved symbol.  Used only under the transcript recorder with HOBBIT_REC_STREAM
+// (oracle/gen_open_transcript.py): what the reference's own P1..P4 and the first shockwave_prove's sumchecks hashed before that point is the fixture.
+void ref_test_pc_open(size_t N, int K) {
+    srandom(1);
+    vector<F> poly = generate_randomness((int)N);
+    linear_time = true; tensor_row_size = (int)(N / ((size_t)K << 11));
+    __encode_initialized = false;
+    expander_init_store(tensor_row_size);
+    _hash comm; g_MT.clear(); g_tensor.clear();
+    commit_standard(poly, comm, g_MT, g_tensor, K);
+    vector<F> x = generate_randomness((int)log2((double)N));
+    double vt = 0.0, ps = 0.0;
+    open_standard(poly, x, g_MT, g_tensor, K, vt, ps);
+}
+
 // aggregation axpy only (src/Our_PC.cpp:258-272): aggr[j] = sum_i beta[i]*poly[i*M+j].
 // The reference function continues into shockwave_commit; we call the real function and free
 // what it allocates.

@@ -739,6 +739,45 @@ def test_sharded_commit_result_goes_stale(hb, oracle):
     with pytest.raises(RuntimeError, match="one live commitment"):
         mod.parallel.sharded_open(ops, None, plan, 0, res_a, x, 64)
 
+@pytest.mark.parametrize("logn,K", [(20, 32), (22, 32), (21, 16)])
+def test_open_standard_transcript_vs_reference(hb, logn, K, monkeypatch):
+    """The orchestration of open_standard / recursive_prover_Spielman against the REAL reference, hash for hash: oracle/gen_open_transcript.py ran the
+    reference's own commit_standard + open_standard (test_PC's inputs and libc stream) under the call-through mimc_hash recorder until the process
+    died on the first SHA3 call (the prebuilt library is not linked, nothing stands in for it): 237-267 transcript hashes -- every round of P1..P4,
+    shockwave_prove(C_c)'s sumcheck and prove_fft, the first hashes of its _whir_prove (tests/golden/open_transcripts.json).  The library records its
+    own transcript of the same run here.  The reference runs shockwave_prove(C_c) BEFORE P5, the library (one thread) after it: the reference's
+    sequence must be the library's with exactly P5's block cut out."""
+    import json
+    fix = json.load(open(os.path.join(GOLD, "open_transcripts.json")))["test_pc_2e%d_K%d" % (logn, K)]
+    ref = np.array(fix["records"], np.uint64).reshape(-1, 6)
+    assert ref.shape[0] == fix["count"] > 200
+    monkeypatch.setenv("HOBBIT_OPEN_THREADS", "0")               # one thread: a deterministic order of the recorded hashes
+    N = 1 << logn; trs = N // (K << 11)
+    hb.rng_reset()
+    poly = hb.generate_randomness(N)                             # src/Our_PC.cpp:758
+    hb.expander_init_store(trs)                                  # :813
+    c = hb.commit_standard(poly, K, trs, 1)
+    x = hb.generate_randomness(logn)                             # :818
+    hb.lib.hobbit_transcript_record(1)
+    res = hb.open_standard(poly, c, x, 5900, want_paths=False)
+    hb.lib.hobbit_transcript_record(0)
+    n = hb.lib.hobbit_transcript_count()
+    mine = np.zeros((n, 6), np.uint64)
+    hb.lib.hobbit_transcript_read(mine.ctypes.data, n)
+    c.free()
+    assert res["checks"].tolist() == [1, 1, 1]
+    cols = 2 * (N // K) // trs
+    R1 = (2 * trs).bit_length() - 1; logc = cols.bit_length() - 1; R3 = R1 + logc
+    head = 3 * (R1 + logc + 2 * R3) + 2 * 4                      # P1..P4: three coefficients per round, two closing hashes per sumcheck
+    assert np.array_equal(mine[:head], ref[:head]), "P1..P4 differ from the reference at record %d" % int(np.nonzero((mine[:head] != ref[:head]).any(axis=1))[0][0])
+    rest = ref[head:]                                            # shockwave_prove(C_c) in the reference
+    hits = [j for j in range(head, n - len(rest) + 1) if np.array_equal(mine[j], rest[0])]
+    assert hits, "the reference's shockwave_prove(C_c) transcript does not start anywhere in the library's"
+    j0 = hits[0]
+    assert np.array_equal(mine[j0:j0 + len(rest)], rest), "shockwave_prove(C_c) differs from the reference"
+    assert j0 - head == 3 * logc + 2, "between P4 and shockwave_prove(C_c) the library hashes exactly P5 (prove_fft_matrix): %d records" % (j0 - head)
+
+
 def _two_rank_gpu_worker(rank, world, port, N, K, queries, seed, q):
     """one rank of test_two_process_relay_commit_and_open_on_one_gpu: real HipOps on cuda:0, gloo transport staged through the host"""
     import ctypes

@@ -146,3 +146,17 @@ def test_commit_standard_threaded_restatement_is_identical(oracle, logn, K, trs,
     for threads in (1, 3, 8):
         lv_mt, t_mt = oracle.commit_standard_mt(poly, K, trs, lin, threads, want_tensor=True)
         assert np.array_equal(lv, lv_mt) and np.array_equal(t, t_mt), threads
+
+
+def test_open_transcript_fixture_is_self_consistent():
+    """tests/golden/open_transcripts.json (the real reference's open_standard transcript up to its first SHA3 call, oracle/gen_open_transcript.py):
+    the records kept in full hash to the digest recorded beside them, the run ended on the unresolved SHA3 symbol and nowhere else"""
+    import hashlib, json, os
+    fix = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "open_transcripts.json")))
+    cases = [k for k in fix if k.startswith("test_pc_")]
+    assert len(cases) >= 3
+    for k in cases:
+        d = fix[k]
+        rec = np.array(d["records"], np.uint64).reshape(-1, 6)
+        assert rec.shape[0] == d["count"] > 200 and hashlib.sha256(rec.tobytes()).hexdigest() == d["sha256"], k
+        assert "undefined symbol: SHA3_256" in d["died_with"] and d["rc"] != 0, k
