@@ -70,8 +70,12 @@ static void stop_recording() {
 }
 #endif
 
+//   libref_recorder_mimc.so : (-DMIMC_ONLY) the mimc_hash recorder WITHOUT the `open` stand-in: for runs in which the reference's own Elastic_PC::open is
+//                             what is being recorded (oracle/gen_open_transcript.py; the run ends where the reference first needs SHA3, by itself)
+#ifndef MIMC_ONLY
 void open(stream_descriptor fd, vector<F> x, vector<vector<_hash>> &Commitment_MT, double &vt, double &ps) {
     (void)x; (void)Commitment_MT; (void)vt; (void)ps;
     stop_recording();
     printf("[ref_recorder] Elastic_PC::open(%s, %lld) not run: the transcript recording ends here\n", fd.name.c_str(), (long long)fd.size);
 }
+#endif

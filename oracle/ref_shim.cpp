@@ -71,6 +71,10 @@ static vector<vector<vector<F>>> g_tensor;
 
 extern bool has_lookups;            // src/main.cpp:70
 extern vector<F> lookup_rand;       // src/main.cpp:67
+// the reference's own drivers (C++ linkage; src/Our_PC.cpp:757, src/Elastic_PC.cpp:736)
+void test_PC(size_t N, int option, int K);
+void test_Elastic_PC(size_t N, int option);
+
 extern "C" {
 
 void ref_init(void) { init_hash(); }
@@ -233,6 +237,23 @@ void ref_test_pc_open(size_t N, int K) {
     vector<F> x = generate_randomness((int)log2((double)N));
     double vt = 0.0, ps = 0.0;
     open_standard(poly, x, g_MT, g_tensor, K, vt, ps);
+}
+
+// The reference's OWN drivers from a fresh generator state, for the transcript recorder (oracle/gen_open_transcript.py).  Neither returns: every
+// opening reaches SHA3 somewhere (first shockwave_prove / recursive_prover_RS / verify_claim_opt_blake) and the process dies on the unresolved symbol.
+//   test_PC(N, option, K)        src/Our_PC.cpp:757-826   (option 1: RS x RS, tensor_row_size = 128; option 4: RS x expander)
+//   test_Elastic_PC(N, option)   src/Elastic_PC.cpp:736-784  with BUFFER_SPACE = B   (option 1: RS x RS; option 2: RS x expander)
+void ref_run_test_pc(size_t N, int option, int K) {
+    srandom(1);
+    if (option == 1) linear_time = false;
+    __encode_initialized = false;
+    test_PC(N, option, K);
+}
+void ref_run_test_elastic(size_t N, size_t B, int option) {
+    srandom(1);
+    BUFFER_SPACE = B;
+    __encode_initialized = false;
+    test_Elastic_PC(N, option);
 }
 
 // aggregation axpy only (src/Our_PC.cpp:258-272): aggr[j] = sum_i beta[i]*poly[i*M+j].

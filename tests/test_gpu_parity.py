@@ -778,6 +778,41 @@ def test_open_standard_transcript_vs_reference(hb, logn, K, monkeypatch):
     assert j0 - head == 3 * logc + 2, "between P4 and shockwave_prove(C_c) the library hashes exactly P5 (prove_fft_matrix): %d records" % (j0 - head)
 
 
+@pytest.mark.parametrize("logn,K", [(20, 32), (22, 16)])
+def test_open_standard_rs_transcript_vs_reference(hb, logn, K, monkeypatch):
+    """The same pin for test_PC option 1 (RS x RS, tensor_row_size = 128; open_standard's !linear_time branch -> recursive_prover_RS): the REAL
+    reference's own test_PC(N, 1, K), called as it is, recorded until it died on its first SHA3 call -- 228 / 267 transcript hashes
+    (tests/golden/open_transcripts.json, driver_test_pc1_*).  Every one of them must appear, in order, in the library's own transcript of the same
+    run; the library may hash blocks in between that the reference only reaches later (at most one such block)."""
+    import json
+    fix = json.load(open(os.path.join(GOLD, "open_transcripts.json")))["driver_test_pc1_2e%d_K%d" % (logn, K)]
+    ref = np.array(fix["records"], np.uint64).reshape(-1, 6)
+    assert ref.shape[0] == fix["count"] > 200
+    monkeypatch.setenv("HOBBIT_OPEN_THREADS", "0")
+    N = 1 << logn
+    hb.rng_reset()
+    poly = hb.generate_randomness(N)                             # src/Our_PC.cpp:758
+    c = hb.commit_standard(poly, K, 128, 0)                      # :765-767
+    x = hb.generate_randomness(logn)                             # :775
+    hb.lib.hobbit_transcript_record(1)
+    hb.open_standard_rs(poly, c, x, 790, want_paths=False)
+    hb.lib.hobbit_transcript_record(0)
+    n = hb.lib.hobbit_transcript_count()
+    mine = np.zeros((n, 6), np.uint64)
+    hb.lib.hobbit_transcript_read(mine.ctypes.data, n)
+    c.free()
+    i = j = 0; gaps = []
+    while i < len(ref) and j < n:
+        if np.array_equal(ref[i], mine[j]):
+            i += 1; j += 1
+            continue
+        hit = [t for t in range(j + 1, n) if np.array_equal(mine[t], ref[i])]
+        assert hit, "reference record %d of %d is nowhere in the library's transcript (library record %d of %d)" % (i, len(ref), j, n)
+        gaps.append((j, hit[0] - j)); j = hit[0]
+    assert i == len(ref), "the library's transcript ends before the reference's recorded prefix (%d of %d matched)" % (i, len(ref))
+    assert len(gaps) <= 1, "more than one block out of order: %s" % gaps
+
+
 def _two_rank_gpu_worker(rank, world, port, N, K, queries, seed, q):
     """one rank of test_two_process_relay_commit_and_open_on_one_gpu: real HipOps on cuda:0, gloo transport staged through the host"""
     import ctypes

@@ -127,3 +127,37 @@ def test_transcript_matches_reference(name, want):
     assert got["sha256"] == want["sha256"] and got["first"] == want["first"] and got["last"] == want["last"]
     m = re.search(r"Ps : ([0-9.]+) KB", out)
     assert m and float(m.group(1)) == want["ps_truncated_run"], out[-500:]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_openstub.so")), reason="oracle/_ref is not built")
+def test_standard_prover_transcript_matches_reference(tmp_path):
+    """`./pigeon 11 18 18 1` (prove_circuit_standard, src/main.cpp:985-1087) against the REAL reference, hash for hash, as far as the reference can go:
+    oracle/gen_open_transcript.py ran the reference's own main() under the call-through mimc_hash recorder until it died on its first SHA3 call (inside
+    the first open_standard; the prebuilt library is not linked, nothing stands in for it) -- 1298 transcript hashes: both commitments' challenges,
+    prove_multiplication_tree_new over the memory fingerprints, prove_gate_consistency_standard, then the opening's P1..P4 and its first
+    shockwave_prove's sumchecks (tests/golden/standard_transcript.npz).  Here the same command runs with the device-backed mirror answering those
+    functions (one thread) and the library's own recorder on: every reference record must appear, in order, in the library's transcript, which may
+    hash at most one block in between that the reference only reaches later (P5 before shockwave_prove(C_c), as in the Our_PC opening tests)."""
+    import json
+    import numpy as np
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "standard_transcript.npz"), allow_pickle=False)["records"]
+    summ = json.load(open(os.path.join(ROOT, "tests", "golden", "open_transcripts.json")))["main_standard_11_18_18_1"]
+    assert ref.shape == (summ["count"], 6) and summ["count"] > 1000
+    dump = str(tmp_path / "mine.npy")
+    env = dict(os.environ, HOBBIT_E2E_TRANSCRIPT="1", HOBBIT_OPEN_THREADS="0", HOBBIT_TRANSCRIPT_DUMP=dump)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mlp_e2e.py")] + summ["cmd"].split(), capture_output=True, text=True, timeout=600, env=env)
+    out = p.stdout + p.stderr
+    assert p.returncode == 0 and os.path.exists(dump), out[-2000:]
+    mine = np.load(dump, allow_pickle=False)
+    n = mine.shape[0]
+    assert n > ref.shape[0]
+    i = j = 0; gaps = []
+    while i < len(ref) and j < n:
+        if np.array_equal(ref[i], mine[j]):
+            i += 1; j += 1
+            continue
+        hit = np.nonzero((mine[j + 1:] == ref[i]).all(axis=1))[0]
+        assert len(hit), "reference record %d of %d is nowhere in the library's transcript (library record %d of %d)" % (i, len(ref), j, n)
+        gaps.append((j, int(hit[0]) + 1)); j += int(hit[0]) + 1
+    assert i == len(ref), "the library's transcript ends before the reference's recorded prefix (%d of %d matched)" % (i, len(ref))
+    assert len(gaps) <= 1, "more than one block out of order: %s" % gaps
