@@ -15,7 +15,7 @@ import ctypes, hashlib, json, os, subprocess, sys, tempfile
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CASES = [(20, 32), (22, 32), (21, 16)]          # (log2 N, K): test_PC(N, 4, K), trs = N / (K 2^11)
+CASES = [(20, 32), (22, 32), (21, 16), (24, 32)]          # (log2 N, K): test_PC(N, 4, K), trs = N / (K 2^11)
 # the reference's own drivers, called as they are (ref_run_test_pc / ref_run_test_elastic in oracle/ref_shim.cpp): name -> (entry point, arguments)
 DRIVERS = {
     "driver_test_pc4_2e20_K32": ("ref_run_test_pc", (1 << 20, 4, 32)),                 # must equal test_pc_2e20_K32 above (hand-sequenced): checked below

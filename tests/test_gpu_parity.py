@@ -739,7 +739,7 @@ def test_sharded_commit_result_goes_stale(hb, oracle):
     with pytest.raises(RuntimeError, match="one live commitment"):
         mod.parallel.sharded_open(ops, None, plan, 0, res_a, x, 64)
 
-@pytest.mark.parametrize("logn,K", [(20, 32), (22, 32), (21, 16)])
+@pytest.mark.parametrize("logn,K", [(20, 32), (22, 32), (21, 16), (24, 32)])
 def test_open_standard_transcript_vs_reference(hb, logn, K, monkeypatch):
     """The orchestration of open_standard / recursive_prover_Spielman against the REAL reference, hash for hash: oracle/gen_open_transcript.py ran the
     reference's own commit_standard + open_standard (test_PC's inputs and libc stream) under the call-through mimc_hash recorder until the process
