@@ -1,6 +1,6 @@
 """tests/staged_dist.py -- TEST INFRASTRUCTURE.  A `torch.distributed`-shaped adapter that stages CUDA tensors through host memory, so that
 parallel.py's orchestration can run as real processes with the real per-rank GPU operations (HipOps) over the gloo backend -- several ranks on
-ONE GPU, where RCCL refuses to run (it wants one device per rank).  Only the calls parallel.py's relay commit and sharded open make."""
+ONE GPU, where RCCL refuses to run (it wants one device per rank).  The calls parallel.py's two commits (relay, all-to-all) and the sharded open make."""
 import torch
 import torch.distributed as dist
 
@@ -38,6 +38,16 @@ class StagedDist:
     def irecv(self, t, src):
         h = torch.empty(t.shape, dtype=t.dtype)
         return _RecvWork(dist.irecv(h, src), h, t)
+
+    class P2POp:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    def batch_isend_irecv(self, ops):
+        # sends first (each is already on its way when the receives are posted), as torch's own batch does not order them either
+        works = [o.op(o.tensor, o.peer) for o in ops if o.op == self.isend]
+        works += [o.op(o.tensor, o.peer) for o in ops if o.op == self.irecv]
+        return works
 
     def broadcast(self, t, src):
         h = self._host(t)

@@ -813,7 +813,7 @@ def test_open_standard_rs_transcript_vs_reference(hb, logn, K, monkeypatch):
     assert len(gaps) <= 1, "more than one block out of order: %s" % gaps
 
 
-def _two_rank_gpu_worker(rank, world, port, N, K, queries, seed, q):
+def _two_rank_gpu_worker(rank, world, port, N, K, queries, seed, q, exchange="relay"):
     """one rank of test_two_process_relay_commit_and_open_on_one_gpu: real HipOps on cuda:0, gloo transport staged through the host"""
     import ctypes
     import torch
@@ -831,15 +831,16 @@ def _two_rank_gpu_worker(rank, world, port, N, K, queries, seed, q):
     x = orc.generate_randomness(N.bit_length() - 1)
     hb = mod.Hobbit(0)
     hb.upload_graphs(trs, graphs_from(orc, trs))
-    plan = mod.parallel.ShardPlan(N, K, trs, world, contiguous=True)
+    plan = mod.parallel.ShardPlan(N, K, trs, world, contiguous=(exchange == "relay"))
     M = plan.M
     own = plan.chunks_of(rank)
     d_local = hb.to_device(np.concatenate([poly[i * M:(i + 1) * M] for i in own]))
     ops = mod.parallel.HipOps(hb, torch.device("cuda", 0))
     sd = StagedDist()
+    commit = mod.parallel.sharded_commit_relay if exchange == "relay" else mod.parallel.sharded_commit
     out = []
     for it in range(2):                                   # twice: the retained buffers of HipOps are re-used by the second commit
-        res = mod.parallel.sharded_commit_relay(ops, sd, plan, rank, (d_local.ptr, len(own)))
+        res = commit(ops, sd, plan, rank, (d_local.ptr, len(own)))
         ops.set_local_chunks((d_local.ptr, len(own)))
         ctypes.CDLL(None).srandom(seed)                   # (only rank 0's state matters: it draws the value every rank re-seeds with)
         o = mod.parallel.sharded_open(ops, sd, plan, rank, res, x, queries)
@@ -852,9 +853,10 @@ def _two_rank_gpu_worker(rank, world, port, N, K, queries, seed, q):
     hb.close()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_two_process_relay_commit_and_open_on_one_gpu(hb, oracle, world):
-    """parallel.py end to end as two / four real processes with the real per-rank GPU operations (HipOps, both on this one GPU) -- relay commit
+@pytest.mark.parametrize("world,exchange", [(2, "relay"), (4, "relay"), (2, "alltoall"), (4, "alltoall")])
+def test_two_process_relay_commit_and_open_on_one_gpu(hb, oracle, world, exchange):
+    """parallel.py end to end as two / four real processes with the real per-rank GPU operations (HipOps, all on this one GPU) -- the relay commit
+    or (exchange = "alltoall") SURVEY 8e's digest all-to-all with per-rank subtrees and the all-gather of their roots, then: relay commit
     (16 / 32 blocks handed from rank to rank), the integer all-reduce of the partial aggregates with its shift and fold kernels, the replicated
     open, replies all-gathered from the two tensor shards, paths broadcast from the tree's owner -- over gloo with the device tensors staged
     through the host (tests/staged_dist.py: RCCL wants one device per rank).  Equal, twice in a row, to the single-process commit_standard +
@@ -869,7 +871,7 @@ def test_two_process_relay_commit_and_open_on_one_gpu(hb, oracle, world):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_gpu_worker, args=(r, world, port, N, K, queries, seed, q)) for r in range(world)]
+    procs = [ctx.Process(target=_two_rank_gpu_worker, args=(r, world, port, N, K, queries, seed, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     got = []
