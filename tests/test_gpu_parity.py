@@ -902,6 +902,86 @@ def test_two_process_relay_commit_and_open_on_one_gpu(hb, oracle, world, exchang
             assert np.array_equal(o["sp_c_wq"], want["sp_c"]["wq"]) and np.array_equal(o["sp_f_q1"], want["sp_f"]["q1"]), (rank, it)
 
 
+def _elastic_rank_gpu_worker(rank, world, port, N, B, opt, q):
+    """one rank of test_two_process_sharded_elastic_commit_on_one_gpu"""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle
+    from staged_dist import StagedDist
+    from __graft_entry__ import load_package
+    mod = load_package()
+    orc = pyoracle.Oracle()
+    plan = mod.parallel.ElasticPlan(N, B, opt, world)
+    hb = mod.Hobbit(0)
+    orc.rng_reset()
+    if opt == 2:
+        orc.expander_init_store(plan.trs)
+        hb.upload_graphs(plan.trs, graphs_from(orc, plan.trs)) if plan.trs > 13 else hb.expander_init_store(plan.trs)
+    live = []
+
+    def source(c):
+        buf = hb.to_device(splitmix_field(B, 9000 + c)); live.append(buf); del live[:-2]
+        return buf.ptr
+    ops = mod.parallel.ElasticHipOps(hb, torch.device("cuda", 0), rank)
+    res = mod.parallel.sharded_commit(ops, StagedDist(), plan, rank, source)
+    q.put((rank, res["subtree"].cpu().numpy(), np.asarray(res["top"]), np.asarray(res["root"])))
+    dist.barrier()
+    dist.destroy_process_group()
+    hb.close()
+
+
+@pytest.mark.parametrize("opt", [1, 2])
+def test_two_process_sharded_elastic_commit_on_one_gpu(hb, oracle, opt):
+    """BASELINE config 5's shape in small: the streaming Elastic_PC commit sharded by groups of four chunks over TWO real processes with the real
+    per-rank GPU operations (ElasticHipOps: hobbit_elastic_push_inner per group, digest all-to-all, chain, per-rank subtree, all-gather of the
+    subtree roots) on a stream whose chunks all differ -- gloo transport staged through the host -- against the oracle's streaming commit."""
+    import ctypes
+    import multiprocessing as mp
+    import queue as _q
+    import socket
+    import time as _t
+    from __graft_entry__ import load_package
+    mod = load_package()
+    N, B, world = 1 << 20, 1 << 14, 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_elastic_rank_gpu_worker, args=(r, world, port, N, B, opt, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = []
+    deadline = _t.time() + 400
+    while len(got) < world:
+        try:
+            got.append(q.get(timeout=2))
+        except _q.Empty:
+            assert all(p.exitcode in (None, 0) for p in procs), "a rank died: exit codes %s" % [p.exitcode for p in procs]
+            assert _t.time() < deadline, "timeout waiting for the ranks"
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    plan = mod.parallel.ElasticPlan(N, B, opt, world)
+    oracle.rng_reset()
+    if opt == 2:
+        oracle.expander_init_store(plan.trs)
+    oracle.stream_config(1, 9000)
+    try:
+        want = np.zeros((8 * B, 32), np.uint8)
+        oracle.lib.orc_elastic_commit_model.restype = ctypes.c_size_t
+        cnt = oracle.lib.orc_elastic_commit_model(ctypes.c_size_t(N), ctypes.c_size_t(B), ctypes.c_int(opt), want.ctypes.data_as(ctypes.c_void_p))
+    finally:
+        oracle.stream_config(0, 0)
+    levels = mod.parallel.assemble_levels(plan, [g[1] for g in got], got[0][2])
+    T = 4 * B
+    assert np.array_equal(levels[:T - 1], want[:T - 1]) and np.array_equal(levels[T:], want[T:cnt])
+    for g in got:
+        assert np.array_equal(g[3], want[cnt - 1]) and np.array_equal(g[2], got[0][2])
+
+
 def test_sharded_open_hip_ops_world1(hb, oracle):
     """The per-rank GPU operations of the multi-GPU open (local aggregate, field sum of partials, open from the aggregate, replies
     from the tensor shard, subtree paths) at world size 1 against the single-process hobbit_open_standard and the oracle; the
