@@ -160,7 +160,9 @@ def algorithmic_bytes(N, K, world=1, sharded=False, nz=1.0):
         # remaining narrow steps read x_2 and write [x_3 .. z_1] (440 rows)
         "k_enc_fat_C1": f * (32 * N * r0 + 32 * N * (182.0 / 4096.0)),
         "k_encode_M2": f * (32 * N * (182.0 / 4096.0) + 32 * N * (440.0 / 4096.0)),
-        "k_enc_fat_D": f * (32 * N * (1486.0 / 4096.0) + 32 * N * ((4096.0 - 1486.0) / 4096.0)),
+        # D_0 writes z_0 (1463 rows) and the zero tail (1147 rows) -- or, in a commitment (not in the sharded path's raw shards), z_0 and the three
+        # rows up to the next leaf group only: the readers answer the rest as zeros (hobbit_commitment::rows_valid; HOBBIT_COMMIT_SKIP_TAIL=0 writes all)
+        "k_enc_fat_D": f * (32 * N * (1486.0 / 4096.0) + 32 * N * ((1466.0 if (not sharded and os.environ.get("HOBBIT_COMMIT_SKIP_TAIL", "1") != "0") else 2610.0) / 4096.0)),
         "k_leaf_chain": 64 * N * nz + 32 * M,           # read the non-zero rows of the tensor once (rows past the codeword length are zero), write the leaves once
         "k_inner_digests": f * (64 * N + 32 * N),       # read the local tensor shard, write its 32-byte digests
         "k_chain_digests": (32 * M * K + 64 * M) * (1.0 / world if sharded else 1.0),

@@ -25,6 +25,10 @@ struct hobbit_commitment {
     size_t N, M; int K, trs, lin; uint32_t cols, rows2;
     F *d_tensor; uint8_t *d_levels;
     size_t tensor_bytes, levels_bytes;
+    // Rows [rows_valid, rows2) of every column are zero by construction (an RS x expander codeword ends at `len`; rows_valid = len rounded up to the
+    // leaf group) and were NOT written: the leaf chain, the gathers and the row reads answer them as zeros; hobbit_commitment_tensor_dev fills them
+    // in before it hands the raw pointer out.  rows_valid == rows2: everything is in memory (RS x RS, shallow codes, HOBBIT_COMMIT_SKIP_TAIL=0).
+    uint32_t rows_valid;
 };
 
 // Scope of one library call for the staging arena (hobbit_ctx.hpp): the outermost scope resets the arena on entry and, in finish(),
@@ -884,7 +888,12 @@ static int commit_impl(hobbit_ctx *ctx, const hobbit_F *d_poly, size_t N, int K,
             }
         }
     }
+    const char *st_env = getenv("HOBBIT_COMMIT_SKIP_TAIL");
+    const char *zs_env = getenv("HOBBIT_LEAF_ZERO_SKIP");           // (a leaf chain told to hash the zero rows too needs them in memory)
+    ctx->enc_skip_tail = linear_time && !(st_env && st_env[0] == '0') && !(zs_env && zs_env[0] == '0'); ctx->enc_tail_skipped = false;
     int r = tensorcode_chunks(ctx, cF(d_poly), M, K, trs, linear_time, c->d_tensor, up);
+    c->rows_valid = (!r && ctx->enc_tail_skipped) ? std::min<uint32_t>((uint32_t)rows2, ((uint32_t)ctx->code.len + 3) & ~3u) : (uint32_t)rows2;
+    ctx->enc_skip_tail = false; ctx->enc_tail_skipped = false;
     // leaf chain over the K chunks (src/Our_PC.cpp:155-167), then the tree (src/Our_PC.cpp:169);
     // rows >= the codeword length are zero in every chunk of an RS x expander tensor (RS x RS fills all 2*trs rows)
     if (!r) r = launch_leaf_chain(ctx, c->d_tensor, cols * rows2, K, (uint32_t)cols, (uint32_t)(trs / 2), c->d_levels,
@@ -909,13 +918,20 @@ void hobbit_commitment_free(hobbit_commitment *c) {
 }
 size_t hobbit_commitment_num_leaves(const hobbit_commitment *c) { return c->M; }
 const uint8_t *hobbit_commitment_levels_dev(const hobbit_commitment *c) { return c->d_levels; }
-const hobbit_F *hobbit_commitment_tensor_dev(const hobbit_commitment *c) { return reinterpret_cast<const hobbit_F *>(c->d_tensor); }
+const hobbit_F *hobbit_commitment_tensor_dev(const hobbit_commitment *c) {
+    if (c->rows_valid < c->rows2) {                       // a raw pointer leaves the library: the implicit zeros become real ones, once
+        hobbit_commitment *m = const_cast<hobbit_commitment *>(c);
+        if (launch_zero_rows(m->ctx, m->d_tensor, (size_t)m->K * m->cols, m->rows2, m->rows_valid) != 0 || m->ctx->sync() != 0) return nullptr;
+        m->rows_valid = m->rows2;
+    }
+    return reinterpret_cast<const hobbit_F *>(c->d_tensor);
+}
 int hobbit_commitment_levels(hobbit_ctx *ctx, const hobbit_commitment *c, uint8_t *h_levels) { return hobbit_memcpy_d2h(ctx, h_levels, c->d_levels, 32 * (2 * c->M - 1)); }
 int hobbit_commitment_root(hobbit_ctx *ctx, const hobbit_commitment *c, uint8_t *h_root) { return hobbit_memcpy_d2h(ctx, h_root, c->d_levels + 32 * (2 * c->M - 2), 32); }
 int hobbit_commitment_tensor_row(hobbit_ctx *ctx, const hobbit_commitment *c, int chunk, int row, hobbit_F *h_out) {
     if (chunk < 0 || chunk >= c->K || row < 0 || (uint32_t)row >= c->rows2) return ctx->fail(HOBBIT_EINVAL, "tensor_row: index out of range");
     F *tmp; HB_TRY(ctx->workspace((size_t)c->cols * sizeof(F), (void **)&tmp));
-    HB_TRY(launch_tensor_row(ctx, c->d_tensor + (size_t)chunk * c->cols * c->rows2, c->rows2, c->cols, (uint32_t)row, tmp));
+    HB_TRY(launch_tensor_row(ctx, c->d_tensor + (size_t)chunk * c->cols * c->rows2, c->rows2, c->cols, (uint32_t)row, tmp, c->rows_valid));
     return hobbit_memcpy_d2h(ctx, h_out, tmp, (size_t)c->cols * sizeof(F));
 }
 int hobbit_commitment_gather(hobbit_ctx *ctx, const hobbit_commitment *c, const uint32_t *h_rows, const uint32_t *h_cols, size_t nq, hobbit_F *h_reply) {
@@ -927,7 +943,7 @@ int hobbit_commitment_gather(hobbit_ctx *ctx, const hobbit_commitment *c, const 
     F *d_reply = reinterpret_cast<F *>(buf); uint32_t *d_rows = reinterpret_cast<uint32_t *>(buf + rb), *d_cols = d_rows + nq;
     HB_TRY(h2d_staged(ctx, d_rows, h_rows, 4 * nq));
     HB_TRY(h2d_staged(ctx, d_cols, h_cols, 4 * nq));
-    HB_TRY(launch_gather(ctx, c->d_tensor, (size_t)c->cols * c->rows2, c->rows2, c->K, d_rows, d_cols, nq, d_reply));
+    HB_TRY(launch_gather(ctx, c->d_tensor, (size_t)c->cols * c->rows2, c->rows2, c->K, d_rows, d_cols, nq, d_reply, c->rows_valid));
     HB_TRY(d2h_staged(ctx, h_reply, d_reply, nq * c->K * sizeof(F)));
     return sc.finish();
 }
@@ -949,7 +965,7 @@ int hobbit_tensor_gather(hobbit_ctx *ctx, const hobbit_F *d_tensor, size_t M, in
     StageScope sc(ctx);
     HB_TRY(h2d_staged(ctx, d_rows, h_rows, 4 * nq));
     HB_TRY(h2d_staged(ctx, d_cols, h_cols, 4 * nq));
-    HB_TRY(launch_gather(ctx, cF(d_tensor), cols * rows2, (uint32_t)rows2, nchunks, d_rows, d_cols, nq, d_reply));
+    HB_TRY(launch_gather(ctx, cF(d_tensor), cols * rows2, (uint32_t)rows2, nchunks, d_rows, d_cols, nq, d_reply, (uint32_t)rows2));
     return hobbit_memcpy_d2h(ctx, h_reply, d_reply, nq * nchunks * sizeof(F));
 }
 int hobbit_commitment_paths(hobbit_ctx *ctx, const hobbit_commitment *c, const uint32_t *h_cols, const uint32_t *h_rows, size_t nq, uint8_t *h_paths) {

@@ -102,6 +102,8 @@ struct hobbit_ctx {
     // Event slots: [0, 56) the commit pipeline's chunk groups (tensorcode_chunks clamps its group count to 56), 60-63 open_impl's cross-stream
     // fences, 64/65 the pipeline's opening / closing brackets.
     hipStream_t side = nullptr; hipEvent_t side_ev[66] = {};
+    // commit_impl <-> launch_encode: "do not materialise the zero tail of the codewords" (asked / done); see hobbit_commitment::rows_valid
+    bool enc_skip_tail = false, enc_tail_skipped = false;
     // host -> device streaming of a caller's pageable polynomial (hobbit_commit_standard_host): copy stream, two pinned staging pieces, events
     hipStream_t up_stream = nullptr; void *up_pin[2] = {nullptr, nullptr}; hipEvent_t up_done[2] = {}; hipEvent_t up_ready[64] = {};
     static constexpr size_t UP_PIECE = (size_t)64 << 20;

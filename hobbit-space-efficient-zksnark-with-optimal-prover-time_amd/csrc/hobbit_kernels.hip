@@ -1221,7 +1221,11 @@ int launch_encode(hobbit_ctx *ctx, const F *src, size_t ld_src, F *dst, size_t l
             } else
                 HB_TRY(launch_encode_pass<true>(ctx, "k_encode_M", dst, ld_dst, dst, ld_dst, batch, pm, last.out_off - nn, block_for(c, 1, nsteps - 1, 8)));
             const char *wd_env = getenv("HOBBIT_ENC_FAT_WGS_D");
-            return launch_enc_fat<FAT_D_NOUT, FAT_D_CAP0, FAT_D_CAP1, FAT_D_CAP2, FAT_D_CONS, 1>(ctx, "k_enc_fat_D", c.fatD, dst, ld_dst, batch, (uint32_t)c.len, 2 * nn,
+            // the zero tail [len, 2n): a caller that answers those rows as zeros itself (commit_impl: leaf chain, gathers and row reads know the
+            // codeword length) asks for the rows up to the next multiple of four only -- the leaf group that straddles the codeword's end is read whole
+            uint32_t z_hi = 2 * nn;
+            if (ctx->enc_skip_tail) { z_hi = std::min<uint32_t>(2 * nn, ((uint32_t)c.len + 3) & ~3u); ctx->enc_tail_skipped = true; }
+            return launch_enc_fat<FAT_D_NOUT, FAT_D_CAP0, FAT_D_CAP1, FAT_D_CAP2, FAT_D_CONS, 1>(ctx, "k_enc_fat_D", c.fatD, dst, ld_dst, batch, (uint32_t)c.len, z_hi,
                                                                                                      wd_env ? (uint32_t)atoi(wd_env) : 256u);
         }
         return launch_encode_pass<true>(ctx, "k_encode_B", dst, ld_dst, dst, ld_dst, batch, pb, (uint32_t)c.len - nn, block_for(c, 1, nsteps, 8));
@@ -1856,27 +1860,41 @@ int launch_aggregate(hobbit_ctx *ctx, const F *poly, size_t M, int K, CHP h_beta
     return 0;
 }
 // reply[q*K + i] = tensor[i][col_q][row_q]   (src/Our_PC.cpp:291-305, codeword-major tensor)
+// rows >= rows_valid of a column are zero BY CONSTRUCTION and may never have been written (a commitment's RS x expander tensor past its codeword
+// length: commit_impl): they are answered as zero, not read
 __global__ void k_gather(const F *__restrict__ tensor, size_t chunk_stride, uint32_t rows2, int K, const uint32_t *__restrict__ rows,
-                         const uint32_t *__restrict__ cols, size_t nq, F *__restrict__ reply) {
+                         const uint32_t *__restrict__ cols, size_t nq, F *__restrict__ reply, uint32_t rows_valid) {
     size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (g >= nq * K) return;
     size_t q = g / K; int i = (int)(g % K);
-    stF(reply + g, ldF(tensor + (size_t)i * chunk_stride + (size_t)cols[q] * rows2 + rows[q]));
+    stF(reply + g, rows[q] < rows_valid ? ldF(tensor + (size_t)i * chunk_stride + (size_t)cols[q] * rows2 + rows[q]) : fmake(0));
 }
 int launch_gather(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, uint32_t rows2, int K, const uint32_t *d_rows, const uint32_t *d_cols,
-                  size_t nq, F *d_reply) {
+                  size_t nq, F *d_reply, uint32_t rows_valid) {
     size_t total = nq * K;
     if (!total) return 0;
-    HB_LAUNCH(ctx, "k_gather", k_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, tensor, chunk_stride, rows2, K, d_rows, d_cols, nq, d_reply);
+    HB_LAUNCH(ctx, "k_gather", k_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, tensor, chunk_stride, rows2, K, d_rows, d_cols, nq, d_reply,
+              rows_valid);
+    return 0;
+}
+// the unwritten tails made real: rows [rows_valid, rows2) of every column := 0 (before a raw pointer to the tensor leaves the library)
+__global__ void k_zero_rows(F *__restrict__ tensor, size_t ncols, uint32_t rows2, uint32_t rows_valid) {
+    const uint32_t span = rows2 - rows_valid;
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < ncols * span; g += (size_t)gridDim.x * blockDim.x)
+        stF(tensor + (g / span) * rows2 + rows_valid + (g % span), fmake(0));
+}
+int launch_zero_rows(hobbit_ctx *ctx, F *tensor, size_t ncols, uint32_t rows2, uint32_t rows_valid) {
+    if (rows_valid >= rows2 || !ncols) return 0;
+    HB_LAUNCH(ctx, "k_zero_rows", k_zero_rows, dim3(grid_for(ncols * (rows2 - rows_valid), 256, 8192)), dim3(256), 0, tensor, ncols, rows2, rows_valid);
     return 0;
 }
 // row `row` of one chunk in the reference's row-major order: out[c] = tensor[c*rows2 + row]
-__global__ void k_tensor_row(const F *__restrict__ chunk, uint32_t rows2, uint32_t cols, uint32_t row, F *__restrict__ out) {
+__global__ void k_tensor_row(const F *__restrict__ chunk, uint32_t rows2, uint32_t cols, uint32_t row, F *__restrict__ out, uint32_t rows_valid) {
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < cols) stF(out + c, ldF(chunk + (size_t)c * rows2 + row));
+    if (c < cols) stF(out + c, row < rows_valid ? ldF(chunk + (size_t)c * rows2 + row) : fmake(0));
 }
-int launch_tensor_row(hobbit_ctx *ctx, const F *chunk, uint32_t rows2, uint32_t cols, uint32_t row, F *d_out) {
-    HB_LAUNCH(ctx, "k_tensor_row", k_tensor_row, dim3((cols + 255) / 256), dim3(256), 0, chunk, rows2, cols, row, d_out);
+int launch_tensor_row(hobbit_ctx *ctx, const F *chunk, uint32_t rows2, uint32_t cols, uint32_t row, F *d_out, uint32_t rows_valid) {
+    HB_LAUNCH(ctx, "k_tensor_row", k_tensor_row, dim3((cols + 255) / 256), dim3(256), 0, chunk, rows2, cols, row, d_out, rows_valid);
     return 0;
 }
 // multilinear evaluation fold step of evaluate_vector (src/utils.cpp:789-802): v'[j] = (1-r) v[2j] + r v[2j+1]

@@ -31,8 +31,9 @@ int launch_merkle_paths(hobbit_ctx *ctx, const uint8_t *levels, size_t n, const 
 int launch_eq_table(hobbit_ctx *ctx, CHP h_r, int k, F *d_out);
 int launch_aggregate(hobbit_ctx *ctx, const F *poly, size_t M, int K, CHP h_beta, F *aggr);
 int launch_gather(hobbit_ctx *ctx, const F *tensor, size_t chunk_stride, uint32_t rows2, int K, const uint32_t *d_rows, const uint32_t *d_cols,
-                  size_t nq, F *d_reply);
-int launch_tensor_row(hobbit_ctx *ctx, const F *chunk, uint32_t rows2, uint32_t cols, uint32_t row, F *d_out);
+                  size_t nq, F *d_reply, uint32_t rows_valid);
+int launch_zero_rows(hobbit_ctx *ctx, F *tensor, size_t ncols, uint32_t rows2, uint32_t rows_valid);
+int launch_tensor_row(hobbit_ctx *ctx, const F *chunk, uint32_t rows2, uint32_t cols, uint32_t row, F *d_out, uint32_t rows_valid);
 int launch_eval_fold(hobbit_ctx *ctx, const F *v, F *o, size_t L, F r);
 int launch_eval_fold2(hobbit_ctx *ctx, const F *v, F *o, size_t L, F r0, F r1);
 int launch_eval_tail(hobbit_ctx *ctx, const F *v, F *o, size_t n, int levels, const F *r);

@@ -145,7 +145,9 @@ int hobbit_commit_standard_host(hobbit_ctx *ctx, const hobbit_F *h_poly, hobbit_
 void hobbit_commitment_free(hobbit_commitment *c);
 size_t hobbit_commitment_num_leaves(const hobbit_commitment *c);
 const uint8_t *hobbit_commitment_levels_dev(const hobbit_commitment *c);   /* flat levels, device */
-const hobbit_F *hobbit_commitment_tensor_dev(const hobbit_commitment *c);  /* K x cols x 2trs, device */
+/* K x cols x 2trs, device.  (An RS x expander commitment does not write the rows past the codeword's end -- they are zero by construction and
+ * every accessor answers them as zeros; this call writes them before it returns the raw pointer, once per commitment.) */
+const hobbit_F *hobbit_commitment_tensor_dev(const hobbit_commitment *c);
 int hobbit_commitment_levels(hobbit_ctx *ctx, const hobbit_commitment *c, uint8_t *h_levels); /* (2M-1)*32 B */
 int hobbit_commitment_root(hobbit_ctx *ctx, const hobbit_commitment *c, uint8_t *h_root);
 /* _tensor[chunk][row][0..cols) in the reference's row-major order (lazy materialisation) */

@@ -142,6 +142,49 @@ def test_fft_vs_golden(hb):
 
 
 @pytest.mark.gpu
+def test_commit_unwritten_zero_tail_on_a_dirty_buffer(hb):
+    """commit_standard does not write the zero tail of the RS x expander codewords (rows past the codeword length rounded up to the leaf group:
+    1144 of 8192 rows at trs = 4096); the leaf chain, the gathers and the row reads answer those rows as zeros, and hobbit_commitment_tensor_dev
+    fills them in before the raw pointer leaves the library.  Here the tensor buffer the commit re-uses is full of garbage: the commitment, every
+    accessor and the opening must be those of HOBBIT_COMMIT_SKIP_TAIL=0 (everything written)."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    N, K, trs = 1 << 24, 2, 4096
+    hb.rng_reset(); code_len = hb.expander_init_store(trs)
+    rv = (code_len + 3) & ~3
+    assert 4096 < code_len < rv < 8192
+    d = hb.fill_splitmix(N, 5151)
+    os.environ["HOBBIT_COMMIT_SKIP_TAIL"] = "0"
+    try:
+        c0 = hb.commit_standard((d, N), K, trs, 1)
+        want_levels = c0.levels()
+        probe_rows = [0, code_len - 1, code_len, rv - 1, rv, rv + 1, 8191]
+        want_rows = {r: c0.tensor_row(1, r) for r in probe_rows}
+        x = splitmix_field(24, 5)
+        libc.srandom(11); want_open = hb.open_standard((d, N), c0, x, 5900)
+        # dirty the whole buffer through the raw pointer, then park it for the next commit
+        ptr = hb.lib.hobbit_commitment_tensor_dev(c0.h)
+        hb._chk(hb.lib.hobbit_fill_splitmix(hb.ctx, ptr, 4 * N, 99)); hb.sync()
+        c0.free()
+    finally:
+        del os.environ["HOBBIT_COMMIT_SKIP_TAIL"]
+    c = hb.commit_standard((d, N), K, trs, 1)                # re-uses the dirty buffer; the tail stays unwritten
+    assert np.array_equal(c.levels(), want_levels)
+    for r in probe_rows:
+        assert np.array_equal(c.tensor_row(1, r), want_rows[r]), r
+    assert not want_rows[rv].any() and want_rows[code_len - 1].any()
+    libc.srandom(11); got = hb.open_standard((d, N), c, x, 5900)
+    assert (got["rows"] >= rv).sum() > 500                    # plenty of queries land in the unwritten rows
+    for k in ("cols", "rows", "reply", "paths", "poly", "r", "vr", "fin", "scalars", "roots", "checks"):
+        assert np.array_equal(got[k], want_open[k]), k
+    # the raw pointer: the tail is real zeros from here on
+    ptr = hb.lib.hobbit_commitment_tensor_dev(c.h)
+    col = np.zeros((8192, 2), np.uint64)
+    hb._chk(hb.lib.hobbit_memcpy_d2h(hb.ctx, col.ctypes.data, ptr + 16 * 8192 * (4096 + 77), 16 * 8192))      # column 77 of chunk 1
+    assert not col[rv:].any() and col[code_len - 1].any()
+    c.free()
+
+
 def test_evaluate_vector_all_fold_paths_vs_oracle(hb, oracle):
     """evaluate_vector folds two levels per launch above 4096 elements and the last (up to 12) levels in one workgroup: every split of the
     levels between the two kernels, against the oracle's level-by-level fold (src/utils.cpp:789-802)"""
